@@ -1,0 +1,255 @@
+/*
+ * dqnhip.h — C-ABI of the MI355X-native (gfx950) actor-critic learner.
+ *
+ * This is the drop-in boundary for ONE hot path of mhauskn/dqn-hfo: the
+ * dqn::DQN Update()/SelectAction(s)/AddTransition(s) surface declared in the
+ * reference's src/dqn.hpp:56-134.  The reference has no FFI of its own (it is
+ * a C++ class linked statically into bin/dqn, CMakeLists.txt:32-33); the
+ * entry points below are what a `dqn::DQN` adaptor class binds to (see
+ * INTEGRATION.md and dqn-hfo_amd/csrc/dqn_adaptor.hpp).  Every function cites
+ * the reference method it replaces.
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, ints, floats.  No torch, no HIP
+ *     types in signatures (streams / device memory travel as void*).
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from dqnhip_last_error() (thread-local).  The adaptor turns a
+ *     non-zero status into LOG(FATAL), which is the reference's error
+ *     convention (glog CHECK/abort, src/dqn.cpp:898,906 ...).
+ *   - one handle == one learner == one HIP stream on one device.  Handles are
+ *     not thread-safe (the reference uses one DQN per agent thread,
+ *     src/dqn_main.cpp:264).
+ *   - "host" pointers are ordinary CPU memory; "_device" variants take
+ *     pointers to HBM on the handle's device.
+ *   - ActorOutput layout (src/dqn.hpp:28, src/dqn.cpp:210-216): 10 floats
+ *     [dash, turn, tackle, kick | dashPow, dashAng, turnAng, tackleAng,
+ *      kickPow, kickAng].
+ *   - dense parameter order (Caffe learnable_params order):
+ *       actor : ip1.W[h1,S] ip1.b[h1] ... ip4.W ip4.b
+ *               action_layer.W[4,h4] .b[4]  actionpara_layer.W[6,h4] .b[6]
+ *       critic: ip1.W[h1,S+10] ip1.b ... ip4.W ip4.b  q_values_layer.W[1,h4] .b[1]
+ *     all weights row-major [num_output, K] as in Caffe InnerProduct.
+ */
+#ifndef DQNHIP_H_
+#define DQNHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DQNHIP_ACTION_SIZE 4        /* kActionSize       src/dqn.hpp:20 */
+#define DQNHIP_ACTION_PARAM_SIZE 6  /* kActionParamSize  src/dqn.hpp:21 */
+#define DQNHIP_ACTOR_OUT 10         /* ActorOutput       src/dqn.hpp:28 */
+#define DQNHIP_MAX_HIDDEN 8
+
+/* which network a call refers to */
+enum dqnhip_net {
+  DQNHIP_ACTOR = 0,         /* actor_net_          src/dqn.hpp:189 */
+  DQNHIP_CRITIC = 1,        /* critic_net_         src/dqn.hpp:191 */
+  DQNHIP_ACTOR_TARGET = 2,  /* actor_target_net_   src/dqn.hpp:193 */
+  DQNHIP_CRITIC_TARGET = 3  /* critic_target_net_  src/dqn.hpp:192 */
+};
+
+/* which per-parameter array: data, or Adam history (Caffe SolverState
+ * history = [m_0..m_P-1, v_0..v_P-1]), or last gradient */
+enum dqnhip_param_kind {
+  DQNHIP_KIND_W = 0,
+  DQNHIP_KIND_M = 1,
+  DQNHIP_KIND_V = 2,
+  DQNHIP_KIND_G = 3
+};
+
+/* Learner configuration.  Defaults in comments are the reference's.
+ * Replaces: the compile-time constants of src/dqn.hpp:18-21, the Tower()
+ * size list of src/dqn.cpp:425,449, the 11 learner gflags of
+ * src/dqn.cpp:21-31 and the solver fields set in src/dqn_main.cpp:249-262. */
+typedef struct dqnhip_config {
+  int32_t struct_size;       /* = sizeof(dqnhip_config); ABI check            */
+  int32_t minibatch;         /* kMinibatchSize (32); multiple of 32           */
+  int32_t state_size;        /* num_features = 50 + 9*players; >= 1           */
+  int32_t num_hidden;        /* tower depth (4); 1..DQNHIP_MAX_HIDDEN         */
+  int32_t hidden[DQNHIP_MAX_HIDDEN]; /* {1024,512,256,128}; multiples of 64   */
+  int32_t replay_capacity;   /* FLAGS_memory (500000)                         */
+  int32_t soft_update_freq;  /* FLAGS_soft_update_freq (1)                    */
+  double gamma;              /* FLAGS_gamma (.99) — double, as the reference  */
+  double beta;               /* FLAGS_beta  (.5)                              */
+  double tau;                /* FLAGS_tau   (.001); applied as float          */
+  float actor_lr;            /* FLAGS_actor_lr  (1e-5)                        */
+  float critic_lr;           /* FLAGS_critic_lr (1e-3)                        */
+  float momentum;            /* Adam beta1, FLAGS_momentum  (.95)             */
+  float momentum2;           /* Adam beta2, FLAGS_momentum2 (.999)            */
+  float delta;               /* Adam eps, Caffe SolverParameter.delta (1e-8)  */
+  float clip_gradients;      /* FLAGS_clip_grad (10); < 0 disables            */
+  int32_t device;            /* HIP device ordinal                            */
+  int32_t dp_world;          /* data-parallel world size (1 = single GPU)     */
+  int32_t dp_rank;           /* this learner's rank in the DP group           */
+  int32_t use_graph;         /* 1: replay the update as a captured hipGraph   */
+  uint64_t seed;             /* counter-based RNG key for on-device sampling  */
+  void* stream;              /* optional hipStream_t to run on (NULL: own)    */
+  void* grad_arena;          /* optional caller-owned device memory that will
+                                hold both gradient arenas (so torch.distributed
+                                can all-reduce it in place); NULL: library
+                                allocates.  Size: dqnhip_grad_arena_bytes().  */
+  size_t grad_arena_bytes;
+} dqnhip_config;
+
+typedef struct dqnhip_learner* dqnhip_handle;
+
+/* Fill *cfg with the reference defaults (B=32, tower 1024-512-256-128, replay
+ * 500k, gamma .99, beta .5, tau .001, Adam .95/.999, lr 1e-5/1e-3, clip 10). */
+void dqnhip_default_config(dqnhip_config* cfg, int32_t state_size);
+
+/* Bytes the caller must provide in cfg->grad_arena (0 on invalid config). */
+size_t dqnhip_grad_arena_bytes(const dqnhip_config* cfg);
+
+/* Thread-local message of the last failure in this thread. */
+const char* dqnhip_last_error(void);
+
+/* Replaces DQN::DQN + DQN::Initialize (src/dqn.cpp:457-483, 622-662):
+ * allocates nets (gaussian(0.01) weights, zero biases, src/dqn.cpp:350-352),
+ * Adam state, target nets as hard copies (CloneNet, :660-661) and the
+ * device-resident replay ring. */
+int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out);
+/* Replaces DQN::~DQN (src/dqn.cpp:485). */
+int dqnhip_destroy(dqnhip_handle h);
+
+/* ---- the hot path ------------------------------------------------------ */
+
+/* Replaces DQN::UpdateActorCritic (src/dqn.cpp:828-972): one full update —
+ * minibatch gather, target-net forward, TD target, critic Step (fwd, bwd,
+ * clip, Adam), actor forward, critic forward, critic input-gradient,
+ * inverting gradients, actor backward, clip, Adam, soft target update.
+ * idx_host: B logical replay indices in [0, memory_size) — the explicit form
+ * of SampleTransitionsFromMemory (src/dqn.cpp:501-509); NULL = sample on the
+ * device with the counter-based generator.  Blocks until the update is done
+ * and returns (critic_loss, avg_q) exactly as the reference's return value. */
+int dqnhip_update(dqnhip_handle h, const int32_t* idx_host,
+                  float* critic_loss, float* avg_q);
+
+/* Same update, enqueued on the stream without a host sync (the scalars stay
+ * on the device; read them with dqnhip_read_stats). */
+int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host);
+
+/* Data-parallel form of the same update, cut at its two exchange points:
+ *   phase 0: gather .. critic backward      -> critic gradients ready
+ *   phase 1: critic clip+Adam(+soft update), actor fwd, critic fwd, critic
+ *            input-gradient, inverting gradients, actor backward
+ *                                            -> actor gradients ready
+ *   phase 2: actor clip+Adam(+soft update), iteration counters
+ * Between phases the caller sum-all-reduces dqnhip_grad_buffer(net) across
+ * the DP group (RCCL).  With dp_world == 1 running 0,1,2 back to back is
+ * identical to dqnhip_update_async. */
+int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host);
+
+/* Device pointer + length (floats) of one net's gradient arena, including a
+ * 4-float tail [loss_sum, q_sum, 0, 0] so the two reported scalars ride in the
+ * same all-reduce.  net = DQNHIP_ACTOR or DQNHIP_CRITIC. */
+int dqnhip_grad_buffer(dqnhip_handle h, int32_t net, void** dptr, size_t* nfloats);
+
+/* Waits for the stream and returns the scalars of the last update. */
+int dqnhip_read_stats(dqnhip_handle h, float* critic_loss, float* avg_q);
+
+/* Replaces DQN::Benchmark (src/dqn.cpp:487-498): times `iterations` updates
+ * (after `warmup` untimed ones) with HIP events on the learner's stream and
+ * returns the average in milliseconds ("Average Update: X ms"). */
+int dqnhip_benchmark(dqnhip_handle h, int32_t warmup, int32_t iterations,
+                     float* avg_ms);
+
+/* Replaces the greedy branch of DQN::SelectActions -> SelectActionGreedily
+ * (src/dqn.cpp:695-711, 734-766): actor forward on n states [n, S] (host),
+ * returns [n, 10] ActorOutputs (host).  n is not capped at kMinibatchSize.
+ * The epsilon draw and GetRandomActorOutput stay in the caller so the
+ * reference's std::mt19937 call order is preserved (src/dqn.cpp:700). */
+int dqnhip_select_actions(dqnhip_handle h, const float* states_host, int32_t n,
+                          float* actor_out_host);
+/* Same with states / outputs in HBM ([n,S] and [n,10], dense). */
+int dqnhip_select_actions_device(dqnhip_handle h, const float* states_dev,
+                                 int32_t n, float* actor_out_dev);
+/* Target-actor variant (SelectActionGreedily(*actor_target_net_, ...)). */
+int dqnhip_select_actions_net(dqnhip_handle h, int32_t net,
+                              const float* states_host, int32_t n,
+                              float* actor_out_host);
+
+/* Replaces DQN::CriticForward / EvaluateAction (src/dqn.cpp:982-1020,
+ * 688-693): Q(s, a) for n host rows using `net` (CRITIC or CRITIC_TARGET). */
+int dqnhip_critic_forward(dqnhip_handle h, int32_t net, const float* states_host,
+                          const float* actor_out_host, int32_t n, float* q_host);
+
+/* Replaces DQN::AddTransitions (src/dqn.cpp:775-781): FIFO-evicts while
+ * size + n >= capacity, then appends n transitions.  terminal[i] != 0 means
+ * next_state == boost::none (src/dqn.cpp:878); next_states rows of terminal
+ * transitions are ignored. */
+int dqnhip_add_transitions(dqnhip_handle h, const float* states, const float* actor_out,
+                           const float* rewards, const float* on_policy_targets,
+                           const float* next_states, const uint8_t* terminal, int32_t n);
+/* Replaces DQN::AddTransition (src/dqn.cpp:768-773): evicts one iff size ==
+ * capacity, then appends one. */
+int dqnhip_add_transition(dqnhip_handle h, const float* state, const float* actor_out,
+                          float reward, float on_policy_target,
+                          const float* next_state, uint8_t terminal);
+/* AddTransitions with all arrays already in HBM (batched env workers). */
+int dqnhip_add_transitions_device(dqnhip_handle h, const float* states, const float* actor_out,
+                                  const float* rewards, const float* on_policy_targets,
+                                  const float* next_states, const uint8_t* terminal, int32_t n);
+
+/* Replaces DQN::LabelTransitions (src/dqn.cpp:783-797) for one episode held in
+ * host arrays: on_policy_target[last] = r[last]; [i] = r[i] + gamma*[i+1]
+ * (gamma double, result rounded to float). */
+int dqnhip_label_transitions(double gamma, const float* rewards, int32_t n,
+                             float* on_policy_targets);
+
+/* DQN::memory_size / ClearReplayMemory (src/dqn.hpp:106,112). */
+int dqnhip_memory_size(dqnhip_handle h, int32_t* size);
+int dqnhip_clear_memory(dqnhip_handle h);
+/* Read logical transitions [first, first+n) back to host arrays (for
+ * DQN::SnapshotReplayMemory, src/dqn.cpp:1146-1178).  Any pointer may be NULL. */
+int dqnhip_read_memory(dqnhip_handle h, int32_t first, int32_t n, float* states,
+                       float* actor_out, float* rewards, float* on_policy_targets,
+                       float* next_states, uint8_t* terminal);
+
+/* ---- parameters, iterations, targets ----------------------------------- */
+
+/* number of learnable parameters of a net in the dense order above */
+int dqnhip_param_count(dqnhip_handle h, int32_t net, size_t* count);
+/* Copy a whole net's dense parameter vector out / in.  Used by Snapshot /
+ * Restore / LoadWeights (src/dqn.cpp:525-557, 586-620).  kind M/V/G only for
+ * ACTOR and CRITIC. */
+int dqnhip_get_params(dqnhip_handle h, int32_t net, int32_t kind, float* host, size_t count);
+int dqnhip_set_params(dqnhip_handle h, int32_t net, int32_t kind, const float* host, size_t count);
+/* CloneNet (src/dqn.cpp:1022-1035): hard copy online -> target.
+ * net = DQNHIP_ACTOR or DQNHIP_CRITIC (the source). */
+int dqnhip_clone_to_target(dqnhip_handle h, int32_t net);
+/* Solver::iter / set_iter (src/dqn.hpp:129-130, src/dqn.cpp:965). */
+int dqnhip_get_iters(dqnhip_handle h, int32_t* actor_iter, int32_t* critic_iter);
+int dqnhip_set_iters(dqnhip_handle h, int32_t actor_iter, int32_t critic_iter);
+
+/* ---- introspection for parity tests ------------------------------------ */
+
+/* Copy a named [B, *] intermediate of the last update to the host:
+ * "q_target" [B] (Q'(s',mu'(s'))), "y" [B] (TD target), "q_train" [B],
+ * "q_policy" [B], "actor_out" [B,10] (mu(s)), "dq_da" [B,10] (post
+ * inverting-gradients), "idx" [B] (as float), "terminal" [B].
+ * count = floats the caller's buffer holds; fails if too small. */
+int dqnhip_debug_read(dqnhip_handle h, const char* name, float* host, size_t count);
+
+/* The HIP stream (hipStream_t) the learner enqueues on. */
+int dqnhip_get_stream(dqnhip_handle h, void** stream);
+/* Average duration (ms) of the dominant kernel family over the launches since
+ * the last call with reset != 0; measured with HIP events when profiling is
+ * enabled via dqnhip_set_kernel_timing.  Used by bench.py's roofline leg. */
+int dqnhip_set_kernel_timing(dqnhip_handle h, int32_t enable);
+int dqnhip_get_kernel_timing(dqnhip_handle h, const char* family, float* avg_ms,
+                             int64_t* launches, int32_t reset);
+
+/* ---- batched env front-end (HFOGameState reward shaping, N workers) ----- */
+
+/* Replaces HFOGameState::update + reward (src/hfo_game.cpp:122-236) for n
+ * synthetic workers whose state vectors are in HBM: see dqnhip_env.h. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQNHIP_H_ */
