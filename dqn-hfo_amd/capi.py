@@ -1,0 +1,86 @@
+"""ctypes declarations of include/dqnhip.h (one entry per exported symbol)."""
+import ctypes as C
+import os
+
+from ._build import LIB, build
+
+MAX_HIDDEN = 8
+ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET = 0, 1, 2, 3
+KIND_W, KIND_M, KIND_V, KIND_G = 0, 1, 2, 3
+
+
+class Config(C.Structure):
+    """struct dqnhip_config (include/dqnhip.h)."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("minibatch", C.c_int32), ("state_size", C.c_int32),
+        ("num_hidden", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
+        ("replay_capacity", C.c_int32), ("soft_update_freq", C.c_int32),
+        ("gamma", C.c_double), ("beta", C.c_double), ("tau", C.c_double),
+        ("actor_lr", C.c_float), ("critic_lr", C.c_float), ("momentum", C.c_float),
+        ("momentum2", C.c_float), ("delta", C.c_float), ("clip_gradients", C.c_float),
+        ("device", C.c_int32), ("dp_world", C.c_int32), ("dp_rank", C.c_int32), ("use_graph", C.c_int32),
+        ("seed", C.c_uint64), ("stream", C.c_void_p), ("grad_arena", C.c_void_p),
+        ("grad_arena_bytes", C.c_size_t),
+    ]
+
+
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int32)
+up = C.POINTER(C.c_uint8)
+H = C.c_void_p
+
+# name -> (restype, argtypes): every function include/dqnhip.h declares
+SIGNATURES = {
+    "dqnhip_default_config": (None, [C.POINTER(Config), C.c_int32]),
+    "dqnhip_grad_arena_bytes": (C.c_size_t, [C.POINTER(Config)]),
+    "dqnhip_last_error": (C.c_char_p, []),
+    "dqnhip_create": (C.c_int, [C.POINTER(Config), C.POINTER(H)]),
+    "dqnhip_destroy": (C.c_int, [H]),
+    "dqnhip_update": (C.c_int, [H, ip, fp, fp]),
+    "dqnhip_update_async": (C.c_int, [H, ip]),
+    "dqnhip_update_phase": (C.c_int, [H, C.c_int32, ip]),
+    "dqnhip_grad_buffer": (C.c_int, [H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "dqnhip_read_stats": (C.c_int, [H, fp, fp]),
+    "dqnhip_benchmark": (C.c_int, [H, C.c_int32, C.c_int32, fp]),
+    "dqnhip_select_actions": (C.c_int, [H, fp, C.c_int32, fp]),
+    "dqnhip_select_actions_device": (C.c_int, [H, C.c_void_p, C.c_int32, C.c_void_p]),
+    "dqnhip_select_actions_net": (C.c_int, [H, C.c_int32, fp, C.c_int32, fp]),
+    "dqnhip_critic_forward": (C.c_int, [H, C.c_int32, fp, fp, C.c_int32, fp]),
+    "dqnhip_add_transitions": (C.c_int, [H, fp, fp, fp, fp, fp, up, C.c_int32]),
+    "dqnhip_add_transition": (C.c_int, [H, fp, fp, C.c_float, C.c_float, fp, C.c_uint8]),
+    "dqnhip_add_transitions_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_int32]),
+    "dqnhip_label_transitions": (C.c_int, [C.c_double, fp, C.c_int32, fp]),
+    "dqnhip_memory_size": (C.c_int, [H, ip]),
+    "dqnhip_clear_memory": (C.c_int, [H]),
+    "dqnhip_read_memory": (C.c_int, [H, C.c_int32, C.c_int32, fp, fp, fp, fp, fp, up]),
+    "dqnhip_param_count": (C.c_int, [H, C.c_int32, C.POINTER(C.c_size_t)]),
+    "dqnhip_get_params": (C.c_int, [H, C.c_int32, C.c_int32, fp, C.c_size_t]),
+    "dqnhip_set_params": (C.c_int, [H, C.c_int32, C.c_int32, fp, C.c_size_t]),
+    "dqnhip_clone_to_target": (C.c_int, [H, C.c_int32]),
+    "dqnhip_get_iters": (C.c_int, [H, ip, ip]),
+    "dqnhip_set_iters": (C.c_int, [H, C.c_int32, C.c_int32]),
+    "dqnhip_debug_read": (C.c_int, [H, C.c_char_p, fp, C.c_size_t]),
+    "dqnhip_get_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
+    "dqnhip_set_kernel_timing": (C.c_int, [H, C.c_int32]),
+    "dqnhip_get_kernel_timing": (C.c_int, [H, C.c_char_p, fp, C.POINTER(C.c_int64), C.c_int32]),
+}
+
+_lib = None
+
+
+def load(rebuild=False):
+    """dlopen the in-tree libdqnhip.so (building it first if needed).  There is no
+    fallback: a missing or unloadable HIP library is a hard error."""
+    global _lib
+    if _lib is None or rebuild:
+        build()
+        if not os.path.exists(LIB):
+            raise RuntimeError("libdqnhip.so is missing: the HIP extension is mandatory")
+        lib = C.CDLL(LIB)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

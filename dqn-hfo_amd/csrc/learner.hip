@@ -1,0 +1,1031 @@
+// learner.hip — the device-resident actor-critic learner behind include/dqnhip.h.
+//
+// Host-side orchestration of DQN::UpdateActorCritic (reference src/dqn.cpp:828-972)
+// as a fixed sequence of gfx950 kernels on one HIP stream with no host sync:
+// nothing crosses PCIe per update except (optionally) B sampled indices in and
+// two floats out.  See DESIGN.md for the data layout and the kernel list.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/dqnhip.h"
+#include "gemm_mfma.hip.h"
+#include "small_kernels.hip.h"
+
+using namespace dqnhip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return 1;
+}
+
+#define HIPCHK(expr)                                                                  \
+  do {                                                                                \
+    hipError_t e__ = (expr);                                                          \
+    if (e__ != hipSuccess)                                                            \
+      return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+#define RC(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t round_up_z(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+constexpr int kMaxL = DQNHIP_MAX_HIDDEN;
+
+// Internal parameter arena of one net: tower layer l has W_l[dims[l+1]][kp[l]] (K
+// padded to a multiple of 64 so every GEMM tile is whole) and b_l[dims[l+1]];
+// the head(s) are stored as one [NH][H] matrix (action_layer rows 0-3,
+// actionpara_layer rows 4-9: the Split layer disappears) and bh[16].
+struct NetLayout {
+  int L = 0, in_dim = 0, NH = 0;
+  int dims[kMaxL + 1] = {0};   // logical widths: dims[0] = in_dim
+  int kp[kMaxL + 1] = {0};     // padded widths of each activation panel
+  size_t w_off[kMaxL] = {0}, b_off[kMaxL] = {0}, hw_off = 0, hb_off = 0;
+  size_t arena = 0;            // floats, multiple of 64
+  size_t dense = 0;            // dense (Caffe-order) parameter count
+  // sum-of-squares partial slots
+  int part_off[kMaxL + 1] = {0};  // per tower layer, then head
+  int n_part = 0;
+};
+
+void layout_init(NetLayout& l, int in_dim, const dqnhip_config& c, bool actor) {
+  l.L = c.num_hidden; l.in_dim = in_dim; l.NH = actor ? kNO : 1;
+  l.dims[0] = in_dim; l.kp[0] = round_up(in_dim, 64);
+  for (int i = 0; i < l.L; ++i) { l.dims[i + 1] = c.hidden[i]; l.kp[i + 1] = c.hidden[i]; }
+  size_t off = 0, dense = 0;
+  int part = 0;
+  for (int i = 0; i < l.L; ++i) {
+    l.w_off[i] = off; off += (size_t)l.dims[i + 1] * l.kp[i];
+    l.b_off[i] = off; off += round_up(l.dims[i + 1], 64);
+    dense += (size_t)l.dims[i + 1] * l.dims[i] + l.dims[i + 1];
+    l.part_off[i] = part; part += (l.kp[i] / 64) * (l.dims[i + 1] / 64);
+  }
+  const int H = l.dims[l.L];
+  l.hw_off = off; off += round_up_z((size_t)l.NH * H, 64);
+  l.hb_off = off; off += 64;
+  dense += (size_t)l.NH * H + l.NH;
+  l.part_off[l.L] = part; part += H / 64;
+  l.arena = round_up_z(off, 64);
+  l.dense = dense;
+  l.n_part = part;
+}
+
+struct TimingRec { int family; hipEvent_t a, b; };
+
+}  // namespace
+
+struct dqnhip_learner {
+  dqnhip_config cfg;
+  int B = 0, S = 0, L = 0;
+  NetLayout la, lc;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // parameter arenas
+  float* w[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* m[2] = {nullptr, nullptr};
+  float* v[2] = {nullptr, nullptr};
+  float* g[2] = {nullptr, nullptr};     // inside grad_base
+  float* grad_base = nullptr; bool own_grad = false;
+  // replay
+  Ring ring{};
+  DevState* st = nullptr;
+  int* done_counter = nullptr;
+  long long h_head = 0, h_size = 0;     // host mirror of (head,size)
+  int h_actor_iter = 0, h_critic_iter = 0;
+  // minibatch panels / activations: pass 0 AT, 1 A, 2 CT, 3 C1, 4 C2
+  float* Xa_s = nullptr; float* Xa_n = nullptr; float* Xc_tr = nullptr; float* Xc_pl = nullptr; float* Xc_nx = nullptr;
+  float* act[5][kMaxL + 1] = {{nullptr}};
+  float* dZa[kMaxL + 1] = {nullptr};
+  float* dZc[kMaxL + 1] = {nullptr};
+  float *mb_reward = nullptr, *mb_mc = nullptr, *mb_term = nullptr;
+  int* mb_idx = nullptr;
+  int* idx_dev = nullptr; int* idx_pinned = nullptr;
+  float *aout_t16 = nullptr, *aout16 = nullptr, *dA16 = nullptr;
+  float *q_t = nullptr, *q1 = nullptr, *q2 = nullptr, *y = nullptr, *dq = nullptr;
+  float* loss_partial = nullptr; double* q_partial = nullptr; int n_head_blocks = 0;
+  float* part[2] = {nullptr, nullptr};  // GEMM-epilogue sumsq partials per net
+  float* part_dp = nullptr; int n_part_dp = 0;
+  // host-staging for add_transitions / acting
+  void* stage_dev = nullptr; size_t stage_bytes = 0;
+  float* act_buf = nullptr; size_t act_floats = 0;
+  float* pinned_stats = nullptr;
+  // timing
+  bool timing = false;
+  std::vector<TimingRec> recs;
+  // graph
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // [0]: device-sampled, [1]: explicit idx
+  bool graph_failed = false;
+};
+
+namespace {
+
+using H = dqnhip_learner;
+
+const char* kFamily[] = {"gemm_fwd", "gemm_dgrad", "gemm_wgrad", "adam"};
+
+struct ScopedTiming {
+  H* h; int fam; hipEvent_t a = nullptr, b = nullptr;
+  ScopedTiming(H* h_, int f) : h(h_), fam(f) {
+    if (h->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, h->stream); }
+  }
+  ~ScopedTiming() {
+    if (h->timing) { hipEventRecord(b, h->stream); h->recs.push_back({fam, a, b}); }
+  }
+};
+
+// ---- dense (Caffe order) <-> internal arena ----------------------------------
+void dense_to_arena(const NetLayout& l, const float* dense, std::vector<float>& arena) {
+  arena.assign(l.arena, 0.0f);
+  size_t d = 0;
+  for (int i = 0; i < l.L; ++i) {
+    const int N = l.dims[i + 1], K = l.dims[i], KP = l.kp[i];
+    for (int n = 0; n < N; ++n) memcpy(&arena[l.w_off[i] + (size_t)n * KP], dense + d + (size_t)n * K, K * sizeof(float));
+    d += (size_t)N * K;
+    memcpy(&arena[l.b_off[i]], dense + d, N * sizeof(float)); d += N;
+  }
+  const int Hh = l.dims[l.L];
+  if (l.NH == kNO) {  // action_layer.W[4,H] .b[4] actionpara_layer.W[6,H] .b[6]
+    memcpy(&arena[l.hw_off], dense + d, (size_t)kNA * Hh * sizeof(float)); d += (size_t)kNA * Hh;
+    memcpy(&arena[l.hb_off], dense + d, kNA * sizeof(float)); d += kNA;
+    memcpy(&arena[l.hw_off + (size_t)kNA * Hh], dense + d, (size_t)kNP * Hh * sizeof(float)); d += (size_t)kNP * Hh;
+    memcpy(&arena[l.hb_off + kNA], dense + d, kNP * sizeof(float)); d += kNP;
+  } else {
+    memcpy(&arena[l.hw_off], dense + d, (size_t)Hh * sizeof(float)); d += Hh;
+    arena[l.hb_off] = dense[d]; d += 1;
+  }
+}
+void arena_to_dense(const NetLayout& l, const std::vector<float>& arena, float* dense) {
+  size_t d = 0;
+  for (int i = 0; i < l.L; ++i) {
+    const int N = l.dims[i + 1], K = l.dims[i], KP = l.kp[i];
+    for (int n = 0; n < N; ++n) memcpy(dense + d + (size_t)n * K, &arena[l.w_off[i] + (size_t)n * KP], K * sizeof(float));
+    d += (size_t)N * K;
+    memcpy(dense + d, &arena[l.b_off[i]], N * sizeof(float)); d += N;
+  }
+  const int Hh = l.dims[l.L];
+  if (l.NH == kNO) {
+    memcpy(dense + d, &arena[l.hw_off], (size_t)kNA * Hh * sizeof(float)); d += (size_t)kNA * Hh;
+    memcpy(dense + d, &arena[l.hb_off], kNA * sizeof(float)); d += kNA;
+    memcpy(dense + d, &arena[l.hw_off + (size_t)kNA * Hh], (size_t)kNP * Hh * sizeof(float)); d += (size_t)kNP * Hh;
+    memcpy(dense + d, &arena[l.hb_off + kNA], kNP * sizeof(float)); d += kNP;
+  } else {
+    memcpy(dense + d, &arena[l.hw_off], (size_t)Hh * sizeof(float)); d += Hh;
+    dense[d] = arena[l.hb_off]; d += 1;
+  }
+}
+
+const NetLayout& layout_of(const H* h, int net) { return (net & 1) ? h->lc : h->la; }
+
+int validate(const dqnhip_config* c) {
+  if (!c) return fail("config is null");
+  if (c->struct_size != (int32_t)sizeof(dqnhip_config)) return fail("dqnhip_config.struct_size %d != %zu (ABI mismatch)", c->struct_size, sizeof(dqnhip_config));
+  if (c->minibatch <= 0 || c->minibatch % 32) return fail("minibatch must be a positive multiple of 32 (got %d)", c->minibatch);
+  if (c->state_size < 1) return fail("state_size must be >= 1");
+  if (c->num_hidden < 1 || c->num_hidden > kMaxL) return fail("num_hidden out of range");
+  for (int i = 0; i < c->num_hidden; ++i)
+    if (c->hidden[i] <= 0 || c->hidden[i] % 64) return fail("hidden[%d]=%d must be a positive multiple of 64", i, c->hidden[i]);
+  if (c->replay_capacity < 2) return fail("replay_capacity must be >= 2");
+  if (c->soft_update_freq < 1) return fail("soft_update_freq must be >= 1");
+  if (c->dp_world < 1 || c->dp_rank < 0 || c->dp_rank >= c->dp_world) return fail("bad dp_world/dp_rank");
+  return 0;
+}
+
+size_t grad_arena_floats(const NetLayout& la, const NetLayout& lc) { return la.arena + 64 + lc.arena + 64; }
+
+// ---- forward / backward building blocks ----------------------------------------
+
+struct FwdPass { const float* w; const NetLayout* l; float** act; };
+
+// Tower forward for up to kMaxGroup independent passes of identical shape
+// (grouped launch per layer).  act[0] of every pass must already hold the input panel.
+int tower_forward(H* h, const FwdPass* passes, int n, int rows) {
+  const NetLayout& l = *passes[0].l;
+  for (int i = 0; i < l.L; ++i) {
+    GemmBatch b{}; b.n = n;
+    for (int j = 0; j < n; ++j) {
+      GemmProblem& p = b.prob[j];
+      p.P = passes[j].w + l.w_off[i]; p.ldp = l.kp[i];
+      p.Q = passes[j].act[i]; p.ldq = l.kp[i];
+      p.C = passes[j].act[i + 1]; p.ldc = l.kp[i + 1];
+      p.Pdim = l.dims[i + 1]; p.Qdim = rows; p.Kred = l.kp[i];
+      p.bias = passes[j].w + l.b_off[i]; p.relu = 1;
+    }
+    ScopedTiming t(h, 0);
+    HIPCHK((gemm_launch<GEMM_FWD, 64, 32, 2, 2>(b, h->stream)));
+  }
+  return 0;
+}
+
+// Tower backward from dZ[L] (gradient wrt the last tower pre-activation) down.
+// want_w: produce dW/db (+sumsq partials) into garena; input_grad: also dZ[0].
+int tower_backward(H* h, const NetLayout& l, const float* w, float* garena, float* partial,
+                   float** act, float** dZ, int rows, bool want_w, bool input_grad) {
+  for (int i = l.L - 1; i >= 0; --i) {
+    if (want_w) {
+      GemmBatch b{}; b.n = 1;
+      GemmProblem& p = b.prob[0];
+      p.P = act[i]; p.ldp = l.kp[i];
+      p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
+      p.C = garena + l.w_off[i]; p.ldc = l.kp[i];
+      p.Pdim = l.kp[i]; p.Qdim = l.dims[i + 1]; p.Kred = rows;
+      p.db = garena + l.b_off[i];
+      p.partial = partial ? partial + l.part_off[i] : nullptr;
+      ScopedTiming t(h, 2);
+      HIPCHK((gemm_launch<GEMM_WGRAD, 64, 64, 2, 2>(b, h->stream)));
+    }
+    if (i > 0 || input_grad) {
+      GemmBatch b{}; b.n = 1;
+      GemmProblem& p = b.prob[0];
+      p.P = w + l.w_off[i]; p.ldp = l.kp[i];
+      p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
+      p.C = dZ[i]; p.ldc = l.kp[i];
+      p.Pdim = l.kp[i]; p.Qdim = rows; p.Kred = l.dims[i + 1];
+      p.mask = i > 0 ? act[i] : nullptr; p.ldm = l.kp[i];
+      ScopedTiming t(h, 1);
+      HIPCHK((gemm_launch<GEMM_DGRAD, 64, 32, 2, 2>(b, h->stream)));
+    }
+  }
+  return 0;
+}
+
+template <int NH, int MODE>
+int head_forward(H* h, HeadArgs& a) {
+  const int blocks = (a.rows + 3) / 4;
+  hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(blocks), dim3(256), 0, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int adam_launch(H* h, int net, const float* partial, int n_partial) {
+  const NetLayout& l = layout_of(h, net);
+  AdamArgs a{};
+  a.w = h->w[net]; a.g = h->g[net]; a.m = h->m[net]; a.v = h->v[net]; a.wt = h->w[net + 2];
+  a.n4 = l.arena / 4; a.partial = partial; a.n_partial = n_partial;
+  a.lr = net == DQNHIP_ACTOR ? h->cfg.actor_lr : h->cfg.critic_lr;
+  a.beta1 = h->cfg.momentum; a.beta2 = h->cfg.momentum2; a.eps = h->cfg.delta;
+  a.clip = h->cfg.clip_gradients; a.tau = (float)h->cfg.tau;
+  a.soft_update_freq = h->cfg.soft_update_freq; a.which = net; a.st = h->st;
+  int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, 2048);
+  ScopedTiming t(h, 3);
+  hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sumsq_launch(H* h, int net) {
+  const NetLayout& l = layout_of(h, net);
+  hipLaunchKernelGGL(k_sumsq, dim3(h->n_part_dp), dim3(256), 0, h->stream, h->g[net], l.arena / 4, h->part_dp);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- the update, in three phases (see dqnhip.h) ---------------------------------
+int run_phase(H* h, int phase, const int* idx_dev) {
+  const int B = h->B, L = h->L;
+  const NetLayout &la = h->la, &lc = h->lc;
+  const bool dp = h->cfg.dp_world > 1;
+  const float inv_batch = 1.0f / (float)(B * h->cfg.dp_world);
+  float* actor_tail = h->g[0] + la.arena;
+  float* critic_tail = h->g[1] + lc.arena;
+  const int Hh = la.dims[L];
+  if (phase == 0) {
+    // 1-2: sample + gather (src/dqn.cpp:846-887)
+    GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
+                 h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
+    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->ring, h->st, idx_dev,
+                       (uint64_t)h->cfg.seed, go, B);
+    HIPCHK(hipGetLastError());
+    // actor_target(s') [:979] and actor(s) [:910-911, pre-update weights] share launches
+    FwdPass ap[2] = {{h->w[DQNHIP_ACTOR_TARGET], &la, h->act[0]}, {h->w[DQNHIP_ACTOR], &la, h->act[1]}};
+    RC(tower_forward(h, ap, 2, B));
+    {
+      HeadArgs a{}; a.X = h->act[0][L]; a.ldx = Hh; a.H = Hh; a.rows = B;
+      a.W = h->w[DQNHIP_ACTOR_TARGET] + la.hw_off; a.b = h->w[DQNHIP_ACTOR_TARGET] + la.hb_off;
+      a.out16 = h->aout_t16; a.xc = h->Xc_nx; a.ldxc = lc.kp[0]; a.xc_col = h->S;
+      RC((head_forward<kNO, HEAD_ACTOR>(h, a)));
+      HeadArgs c{}; c.X = h->act[1][L]; c.ldx = Hh; c.H = Hh; c.rows = B;
+      c.W = h->w[DQNHIP_ACTOR] + la.hw_off; c.b = h->w[DQNHIP_ACTOR] + la.hb_off;
+      c.out16 = h->aout16; c.xc = h->Xc_pl; c.ldxc = lc.kp[0]; c.xc_col = h->S;
+      RC((head_forward<kNO, HEAD_ACTOR>(h, c)));
+    }
+    // critic_target(s', mu'(s')) [:889-891] and critic(s, a) train forward [:904]
+    FwdPass cp[2] = {{h->w[DQNHIP_CRITIC_TARGET], &lc, h->act[2]}, {h->w[DQNHIP_CRITIC], &lc, h->act[3]}};
+    RC(tower_forward(h, cp, 2, B));
+    const int Hc = lc.dims[L];
+    {
+      HeadArgs a{}; a.X = h->act[2][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
+      a.W = h->w[DQNHIP_CRITIC_TARGET] + lc.hw_off; a.b = h->w[DQNHIP_CRITIC_TARGET] + lc.hb_off; a.q = h->q_t;
+      RC((head_forward<1, HEAD_Q>(h, a)));
+      HeadArgs c{}; c.X = h->act[3][L]; c.ldx = Hc; c.H = Hc; c.rows = B;
+      c.W = h->w[DQNHIP_CRITIC] + lc.hw_off; c.b = h->w[DQNHIP_CRITIC] + lc.hb_off; c.q = h->q1;
+      c.q_target = h->q_t; c.reward = h->mb_reward; c.mc = h->mb_mc; c.term = h->mb_term;
+      c.y = h->y; c.dq = h->dq; c.loss_partial = h->loss_partial;
+      c.gamma = h->cfg.gamma; c.beta = h->cfg.beta; c.inv_batch = inv_batch;
+      RC((head_forward<1, HEAD_Q_TRAIN>(h, c)));
+    }
+    // critic backward (rest of Step(1)): head, then tower; wgrad writes (beta=0)
+    // so ClearParamDiffs/ZeroGradParameters (src/dqn.cpp:63-78, 908-909) vanish
+    hipLaunchKernelGGL((k_head_bwd_dx<1>), dim3(std::min(1024, (B * Hc / 4 + 255) / 256)), dim3(256), 0, h->stream,
+                       (const float*)h->dq, 1, (const float*)(h->w[DQNHIP_CRITIC] + lc.hw_off),
+                       (const float*)h->act[3][L], Hc, B, h->dZc[L]);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL((k_head_wgrad<1>), dim3(Hc / 64), dim3(256), 0, h->stream, (const float*)h->dq, 1,
+                       (const float*)h->act[3][L], Hc, B, h->g[1] + lc.hw_off, h->g[1] + lc.hb_off,
+                       h->part[1] + lc.part_off[L]);
+    HIPCHK(hipGetLastError());
+    RC(tower_backward(h, lc, h->w[DQNHIP_CRITIC], h->g[1], h->part[1], h->act[3], h->dZc, B, true, false));
+    if (dp) {
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, h->stream, (const float*)h->loss_partial,
+                         h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }
+  if (phase == 1) {
+    // ClipGradients + Adam + Net::Update of the critic, soft update of critic_target fused
+    if (dp) { RC(sumsq_launch(h, 1)); RC(adam_launch(h, 1, h->part_dp, h->n_part_dp)); }
+    else RC(adam_launch(h, 1, h->part[1], lc.n_part));
+    // critic(s, mu(s)) with the UPDATED critic (src/dqn.cpp:913-916)
+    FwdPass cp[1] = {{h->w[DQNHIP_CRITIC], &lc, h->act[4]}};
+    h->act[4][0] = h->Xc_pl;
+    RC(tower_forward(h, cp, 1, B));
+    const int Hc = lc.dims[L];
+    {
+      HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
+      a.W = h->w[DQNHIP_CRITIC] + lc.hw_off; a.b = h->w[DQNHIP_CRITIC] + lc.hb_off; a.q = h->q2;
+      a.qsum_partial = h->q_partial;
+      RC((head_forward<1, HEAD_Q_POLICY>(h, a)));
+    }
+    // q diff = -1 per row, BackwardFrom(q_values_layer) — input gradient only; the
+    // reference's discarded critic dW is never computed
+    hipLaunchKernelGGL((k_head_bwd_dx<1>), dim3(std::min(1024, (B * Hc / 4 + 255) / 256)), dim3(256), 0, h->stream,
+                       (const float*)nullptr, 1, (const float*)(h->w[DQNHIP_CRITIC] + lc.hw_off),
+                       (const float*)h->act[4][L], Hc, B, h->dZc[L]);
+    HIPCHK(hipGetLastError());
+    RC(tower_backward(h, lc, h->w[DQNHIP_CRITIC], nullptr, nullptr, h->act[4], h->dZc, B, false, true));
+    // inverting gradients (src/dqn.cpp:924-957)
+    hipLaunchKernelGGL(k_invert_grad, dim3((B * kAP + 255) / 256), dim3(256), 0, h->stream,
+                       (const float*)h->dZc[0], lc.kp[0], h->S, (const float*)h->aout16, h->dA16, B);
+    HIPCHK(hipGetLastError());
+    // actor backward from both heads (src/dqn.cpp:960-963)
+    hipLaunchKernelGGL((k_head_bwd_dx<kNO>), dim3(std::min(1024, (B * Hh / 4 + 255) / 256)), dim3(256), 0, h->stream,
+                       (const float*)h->dA16, kAP, (const float*)(h->w[DQNHIP_ACTOR] + la.hw_off),
+                       (const float*)h->act[1][L], Hh, B, h->dZa[L]);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL((k_head_wgrad<kNO>), dim3(Hh / 64), dim3(256), 0, h->stream, (const float*)h->dA16, kAP,
+                       (const float*)h->act[1][L], Hh, B, h->g[0] + la.hw_off, h->g[0] + la.hb_off,
+                       h->part[0] + la.part_off[L]);
+    HIPCHK(hipGetLastError());
+    RC(tower_backward(h, la, h->w[DQNHIP_ACTOR], h->g[0], h->part[0], h->act[1], h->dZa, B, true, false));
+    if (dp) {
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, h->stream, (const float*)nullptr, 0,
+                         (const double*)h->q_partial, h->n_head_blocks, inv_batch, (float*)nullptr, actor_tail);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }
+  if (phase == 2) {
+    if (dp) { RC(sumsq_launch(h, 0)); RC(adam_launch(h, 0, h->part_dp, h->n_part_dp)); }
+    else {
+      RC(adam_launch(h, 0, h->part[0], la.n_part));
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, h->stream, (const float*)h->loss_partial, h->n_head_blocks,
+                         (const double*)h->q_partial, h->n_head_blocks, inv_batch, critic_tail, actor_tail);
+      HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(64), 0, h->stream, h->st, (const float*)critic_tail,
+                       (const float*)actor_tail, dp ? (const double*)nullptr : (const double*)h->q_partial,
+                       h->n_head_blocks, (float)(B * h->cfg.dp_world));
+    HIPCHK(hipGetLastError());
+    h->h_actor_iter += 1; h->h_critic_iter += 1;
+    return 0;
+  }
+  return fail("phase must be 0, 1 or 2 (got %d)", phase);
+}
+
+int stage_indices(H* h, const int32_t* idx_host, const int** idx_dev) {
+  *idx_dev = nullptr;
+  if (h->h_size < 1) return fail("replay memory is empty");
+  if (idx_host) {
+    for (int i = 0; i < h->B; ++i)
+      if (idx_host[i] < 0 || idx_host[i] >= h->h_size)
+        return fail("sampled index %d = %d out of range [0,%lld)", i, idx_host[i], h->h_size);
+    // the pinned staging buffer may still be in flight from the previous update
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(h->idx_pinned, idx_host, h->B * sizeof(int));
+    HIPCHK(hipMemcpyAsync(h->idx_dev, h->idx_pinned, h->B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    *idx_dev = h->idx_dev;
+  }
+  return 0;
+}
+
+int ensure_stage(H* h, size_t bytes) {
+  if (bytes <= h->stage_bytes) return 0;
+  if (h->stage_dev) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipFree(h->stage_dev)); h->stage_dev = nullptr; }
+  bytes = round_up_z(bytes, 1 << 20);
+  HIPCHK(hipMalloc(&h->stage_dev, bytes));
+  h->stage_bytes = bytes;
+  return 0;
+}
+
+// acting-time activation scratch for `rows` rows of the widest net
+int ensure_act(H* h, int rows) {
+  size_t need = 0;
+  for (int i = 0; i <= h->L; ++i) need += (size_t)rows * std::max(h->la.kp[i], h->lc.kp[i]);
+  need += (size_t)rows * (kAP + 1);
+  if (need <= h->act_floats) return 0;
+  if (h->act_buf) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipFree(h->act_buf)); h->act_buf = nullptr; }
+  HIPCHK(hipMalloc(&h->act_buf, need * sizeof(float)));
+  h->act_floats = need;
+  return 0;
+}
+
+}  // namespace
+
+// ================================ C ABI =========================================
+extern "C" {
+
+void dqnhip_default_config(dqnhip_config* c, int32_t state_size) {
+  memset(c, 0, sizeof *c);
+  c->struct_size = (int32_t)sizeof *c;
+  c->minibatch = 32;                       // src/dqn.hpp:19
+  c->state_size = state_size;
+  c->num_hidden = 4;                       // src/dqn.cpp:425,449
+  c->hidden[0] = 1024; c->hidden[1] = 512; c->hidden[2] = 256; c->hidden[3] = 128;
+  c->replay_capacity = 500000;             // src/dqn.cpp:25
+  c->soft_update_freq = 1;                 // :23
+  c->gamma = .99; c->beta = .5; c->tau = .001;   // :24, :31, :22
+  c->actor_lr = 0.00001f; c->critic_lr = 0.001f; // src/dqn_main.cpp:33-34
+  c->momentum = .95f; c->momentum2 = .999f;      // src/dqn_main.cpp:31-32
+  c->delta = 1e-8f;                        // Caffe SolverParameter.delta default
+  c->clip_gradients = 10.f;                // src/dqn_main.cpp:35
+  c->device = 0; c->dp_world = 1; c->dp_rank = 0; c->use_graph = 0; c->seed = 1;
+}
+
+const char* dqnhip_last_error(void) { return g_err.c_str(); }
+
+size_t dqnhip_grad_arena_bytes(const dqnhip_config* cfg) {
+  if (validate(cfg)) return 0;
+  NetLayout la, lc;
+  layout_init(la, cfg->state_size, *cfg, true);
+  layout_init(lc, cfg->state_size + kNO, *cfg, false);
+  return grad_arena_floats(la, lc) * sizeof(float);
+}
+
+int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
+  if (!out) return fail("out is null");
+  *out = nullptr;
+  RC(validate(cfg));
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail("device %d not available (%d visible)", cfg->device, ndev);
+  HIPCHK(hipSetDevice(cfg->device));
+  H* h = new H();
+  h->cfg = *cfg; h->B = cfg->minibatch; h->S = cfg->state_size; h->L = cfg->num_hidden;
+  layout_init(h->la, h->S, *cfg, true);
+  layout_init(h->lc, h->S + kNO, *cfg, false);
+  if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
+  else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+  const int B = h->B, L = h->L;
+  auto dalloc = [&](float** p, size_t n) -> int {
+    HIPCHK(hipMalloc(p, n * sizeof(float)));
+    HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(float), h->stream));
+    return 0;
+  };
+  for (int i = 0; i < 4; ++i) RC(dalloc(&h->w[i], layout_of(h, i).arena));
+  for (int i = 0; i < 2; ++i) { RC(dalloc(&h->m[i], layout_of(h, i).arena)); RC(dalloc(&h->v[i], layout_of(h, i).arena)); }
+  const size_t gfl = grad_arena_floats(h->la, h->lc);
+  if (cfg->grad_arena) {
+    if (cfg->grad_arena_bytes < gfl * sizeof(float)) return fail("grad_arena too small: %zu < %zu", cfg->grad_arena_bytes, gfl * sizeof(float));
+    h->grad_base = (float*)cfg->grad_arena;
+    HIPCHK(hipMemsetAsync(h->grad_base, 0, gfl * sizeof(float), h->stream));
+  } else { RC(dalloc(&h->grad_base, gfl)); h->own_grad = true; }
+  h->g[0] = h->grad_base; h->g[1] = h->grad_base + h->la.arena + 64;
+  // replay ring
+  Ring& r = h->ring;
+  r.cap = cfg->replay_capacity; r.S = h->S; r.SP = round_up(h->S, 64);
+  RC(dalloc(&r.state, (size_t)r.cap * r.SP)); RC(dalloc(&r.next, (size_t)r.cap * r.SP));
+  RC(dalloc(&r.act, (size_t)r.cap * kAP)); RC(dalloc(&r.reward, r.cap)); RC(dalloc(&r.mc, r.cap));
+  HIPCHK(hipMalloc(&r.term, r.cap)); HIPCHK(hipMemsetAsync(r.term, 0, r.cap, h->stream));
+  HIPCHK(hipMalloc(&h->st, sizeof(DevState))); HIPCHK(hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream));
+  HIPCHK(hipMalloc(&h->done_counter, sizeof(int))); HIPCHK(hipMemsetAsync(h->done_counter, 0, sizeof(int), h->stream));
+  // panels and activations
+  RC(dalloc(&h->Xa_s, (size_t)B * h->la.kp[0])); RC(dalloc(&h->Xa_n, (size_t)B * h->la.kp[0]));
+  RC(dalloc(&h->Xc_tr, (size_t)B * h->lc.kp[0])); RC(dalloc(&h->Xc_pl, (size_t)B * h->lc.kp[0]));
+  RC(dalloc(&h->Xc_nx, (size_t)B * h->lc.kp[0]));
+  h->act[0][0] = h->Xa_n; h->act[1][0] = h->Xa_s; h->act[2][0] = h->Xc_nx; h->act[3][0] = h->Xc_tr; h->act[4][0] = h->Xc_pl;
+  for (int p = 0; p < 5; ++p)
+    for (int i = 1; i <= L; ++i) RC(dalloc(&h->act[p][i], (size_t)B * layout_of(h, p >= 2).kp[i]));
+  for (int i = 0; i <= L; ++i) { RC(dalloc(&h->dZa[i], (size_t)B * h->la.kp[i])); RC(dalloc(&h->dZc[i], (size_t)B * h->lc.kp[i])); }
+  RC(dalloc(&h->mb_reward, B)); RC(dalloc(&h->mb_mc, B)); RC(dalloc(&h->mb_term, B));
+  HIPCHK(hipMalloc(&h->mb_idx, B * sizeof(int))); HIPCHK(hipMalloc(&h->idx_dev, B * sizeof(int)));
+  HIPCHK(hipHostMalloc((void**)&h->idx_pinned, B * sizeof(int), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&h->pinned_stats, 64, hipHostMallocDefault));
+  RC(dalloc(&h->aout_t16, (size_t)B * kAP)); RC(dalloc(&h->aout16, (size_t)B * kAP)); RC(dalloc(&h->dA16, (size_t)B * kAP));
+  RC(dalloc(&h->q_t, B)); RC(dalloc(&h->q1, B)); RC(dalloc(&h->q2, B)); RC(dalloc(&h->y, B)); RC(dalloc(&h->dq, B));
+  h->n_head_blocks = (B + 3) / 4;
+  RC(dalloc(&h->loss_partial, h->n_head_blocks));
+  HIPCHK(hipMalloc(&h->q_partial, h->n_head_blocks * sizeof(double)));
+  HIPCHK(hipMemsetAsync(h->q_partial, 0, h->n_head_blocks * sizeof(double), h->stream));
+  RC(dalloc(&h->part[0], h->la.n_part)); RC(dalloc(&h->part[1], h->lc.n_part));
+  h->n_part_dp = 1024; RC(dalloc(&h->part_dp, h->n_part_dp));
+  // weights: gaussian(std 0.01), zero bias (src/dqn.cpp:350-352); targets = hard copy (:660-661)
+  {
+    std::mt19937_64 rng(cfg->seed * 0x9E3779B97F4A7C15ull + 12345);
+    std::normal_distribution<float> nd(0.0f, 0.01f);
+    for (int net = 0; net < 2; ++net) {
+      const NetLayout& l = layout_of(h, net);
+      std::vector<float> dense(l.dense, 0.0f), arena;
+      size_t d = 0;
+      for (int i = 0; i < l.L; ++i) {
+        const size_t nw = (size_t)l.dims[i + 1] * l.dims[i];
+        for (size_t e = 0; e < nw; ++e) dense[d + e] = nd(rng);
+        d += nw + l.dims[i + 1];
+      }
+      const int Hh = l.dims[l.L];
+      if (net == 0) {
+        for (size_t e = 0; e < (size_t)kNA * Hh; ++e) dense[d + e] = nd(rng);
+        d += (size_t)kNA * Hh + kNA;
+        for (size_t e = 0; e < (size_t)kNP * Hh; ++e) dense[d + e] = nd(rng);
+      } else {
+        for (size_t e = 0; e < (size_t)Hh; ++e) dense[d + e] = nd(rng);
+      }
+      dense_to_arena(l, dense.data(), arena);
+      HIPCHK(hipMemcpyAsync(h->w[net], arena.data(), l.arena * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      HIPCHK(hipMemcpyAsync(h->w[net + 2], h->w[net], l.arena * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    }
+  }
+  HIPCHK((gemm_prepare<GEMM_FWD, 64, 32, 2, 2>()));
+  HIPCHK((gemm_prepare<GEMM_DGRAD, 64, 32, 2, 2>()));
+  HIPCHK((gemm_prepare<GEMM_WGRAD, 64, 64, 2, 2>()));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *out = h;
+  return 0;
+}
+
+int dqnhip_destroy(dqnhip_handle h) {
+  if (!h) return 0;
+  hipSetDevice(h->cfg.device);
+  hipStreamSynchronize(h->stream);
+  for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (int i = 0; i < 2; ++i) if (h->graph_exec[i]) hipGraphExecDestroy(h->graph_exec[i]);
+  for (int i = 0; i < 4; ++i) hipFree(h->w[i]);
+  for (int i = 0; i < 2; ++i) { hipFree(h->m[i]); hipFree(h->v[i]); hipFree(h->part[i]); }
+  if (h->own_grad) hipFree(h->grad_base);
+  hipFree(h->ring.state); hipFree(h->ring.next); hipFree(h->ring.act); hipFree(h->ring.reward);
+  hipFree(h->ring.mc); hipFree(h->ring.term); hipFree(h->st); hipFree(h->done_counter);
+  hipFree(h->Xa_s); hipFree(h->Xa_n); hipFree(h->Xc_tr); hipFree(h->Xc_pl); hipFree(h->Xc_nx);
+  for (int p = 0; p < 5; ++p) for (int i = 1; i <= h->L; ++i) hipFree(h->act[p][i]);
+  for (int i = 0; i <= h->L; ++i) { hipFree(h->dZa[i]); hipFree(h->dZc[i]); }
+  hipFree(h->mb_reward); hipFree(h->mb_mc); hipFree(h->mb_term); hipFree(h->mb_idx); hipFree(h->idx_dev);
+  hipHostFree(h->idx_pinned); hipHostFree(h->pinned_stats);
+  hipFree(h->aout_t16); hipFree(h->aout16); hipFree(h->dA16);
+  hipFree(h->q_t); hipFree(h->q1); hipFree(h->q2); hipFree(h->y); hipFree(h->dq);
+  hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp);
+  if (h->stage_dev) hipFree(h->stage_dev);
+  if (h->act_buf) hipFree(h->act_buf);
+  if (h->own_stream) hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+// ---- update -----------------------------------------------------------------------
+
+static int capture_graph(H* h, int which) {
+  // Capture phases 0,1,2 once; replays re-read every changing scalar from DevState
+  // and (which == 1) the indices from the fixed pinned buffer through a memcpy node.
+  hipGraph_t graph = nullptr;
+  HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  const int* idx_dev = nullptr;
+  if (which == 1) {
+    hipError_t e = hipMemcpyAsync(h->idx_dev, h->idx_pinned, h->B * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) rc = fail("capture memcpy: %s", hipGetErrorString(e));
+    idx_dev = h->idx_dev;
+  }
+  const int it_a = h->h_actor_iter, it_c = h->h_critic_iter;
+  for (int p = 0; p < 3 && !rc; ++p) rc = run_phase(h, p, idx_dev);
+  h->h_actor_iter = it_a; h->h_critic_iter = it_c;   // capture does not execute
+  hipError_t e = hipStreamEndCapture(h->stream, &graph);
+  if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
+  e = hipGraphInstantiate(&h->graph_exec[which], graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->cfg.dp_world > 1) return fail("dqnhip_update_async: dp_world > 1 requires dqnhip_update_phase + all-reduce");
+  if (h->cfg.use_graph && !h->timing && !h->graph_failed) {
+    if (h->h_size < 1) return fail("replay memory is empty");
+    const int which = idx_host ? 1 : 0;
+    if (idx_host) {
+      for (int i = 0; i < h->B; ++i)
+        if (idx_host[i] < 0 || idx_host[i] >= h->h_size) return fail("sampled index out of range");
+      HIPCHK(hipStreamSynchronize(h->stream));
+      memcpy(h->idx_pinned, idx_host, h->B * sizeof(int));
+    }
+    if (!h->graph_exec[which]) {
+      if (capture_graph(h, which)) { h->graph_failed = true; }
+    }
+    if (h->graph_exec[which]) {
+      HIPCHK(hipGraphLaunch(h->graph_exec[which], h->stream));
+      h->h_actor_iter += 1; h->h_critic_iter += 1;
+      return 0;
+    }
+  }
+  const int* idx_dev = nullptr;
+  RC(stage_indices(h, idx_host, &idx_dev));
+  for (int p = 0; p < 3; ++p) RC(run_phase(h, p, idx_dev));
+  return 0;
+}
+
+int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int* idx_dev = nullptr;
+  if (phase == 0) RC(stage_indices(h, idx_host, &idx_dev));
+  return run_phase(h, phase, idx_dev);
+}
+
+int dqnhip_read_stats(dqnhip_handle h, float* critic_loss, float* avg_q) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipMemcpyAsync(h->pinned_stats, &h->st->critic_loss, 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (critic_loss) *critic_loss = h->pinned_stats[0];
+  if (avg_q) *avg_q = h->pinned_stats[1];
+  // CHECK(std::isfinite(critic_loss)) (src/dqn.cpp:906) — reported as an error code
+  if (!std::isfinite(h->pinned_stats[0])) return fail("Critic loss not finite!");
+  return 0;
+}
+
+int dqnhip_update(dqnhip_handle h, const int32_t* idx_host, float* critic_loss, float* avg_q) {
+  RC(dqnhip_update_async(h, idx_host));
+  return dqnhip_read_stats(h, critic_loss, avg_q);
+}
+
+int dqnhip_grad_buffer(dqnhip_handle h, int32_t net, void** dptr, size_t* nfloats) {
+  if (!h) return fail("null handle");
+  if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return fail("net must be ACTOR or CRITIC");
+  if (dptr) *dptr = h->g[net];
+  if (nfloats) *nfloats = layout_of(h, net).arena + 4;
+  return 0;
+}
+
+int dqnhip_benchmark(dqnhip_handle h, int32_t warmup, int32_t iterations, float* avg_ms) {
+  if (!h) return fail("null handle");
+  if (iterations < 1) return fail("iterations must be >= 1");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  for (int i = 0; i < warmup; ++i) RC(dqnhip_update_async(h, nullptr));
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipEventRecord(a, h->stream));
+  for (int i = 0; i < iterations; ++i) RC(dqnhip_update_async(h, nullptr));
+  HIPCHK(hipEventRecord(b, h->stream));
+  HIPCHK(hipEventSynchronize(b));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, a, b));
+  hipEventDestroy(a); hipEventDestroy(b);
+  if (avg_ms) *avg_ms = ms / iterations;
+  return 0;
+}
+
+// ---- acting ------------------------------------------------------------------------
+
+static int actor_forward_dev(H* h, int net, const float* states_dev, int n, float* out_dev) {
+  if (n < 1) return fail("n must be >= 1");
+  if (net != DQNHIP_ACTOR && net != DQNHIP_ACTOR_TARGET) return fail("net must be an actor");
+  const int rows = round_up(n, 32);
+  RC(ensure_act(h, rows));
+  const NetLayout& l = h->la;
+  float* acts[kMaxL + 1];
+  float* p = h->act_buf;
+  for (int i = 0; i <= l.L; ++i) { acts[i] = p; p += (size_t)rows * std::max(h->la.kp[i], h->lc.kp[i]); }
+  float* out16 = p;
+  hipLaunchKernelGGL(k_pack_rows, dim3((rows * l.kp[0] + 255) / 256), dim3(256), 0, h->stream, states_dev, n,
+                     h->S, acts[0], rows, l.kp[0]);
+  HIPCHK(hipGetLastError());
+  FwdPass fp[1] = {{h->w[net], &l, acts}};
+  RC(tower_forward(h, fp, 1, rows));
+  HeadArgs a{}; a.X = acts[l.L]; a.ldx = l.dims[l.L]; a.H = l.dims[l.L]; a.rows = rows;
+  a.W = h->w[net] + l.hw_off; a.b = h->w[net] + l.hb_off; a.out16 = out16;
+  RC((head_forward<kNO, HEAD_ACTOR>(h, a)));
+  hipLaunchKernelGGL(k_unpack_out, dim3((n * kNO + 255) / 256), dim3(256), 0, h->stream, (const float*)out16, n, out_dev);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int dqnhip_select_actions_device(dqnhip_handle h, const float* states_dev, int32_t n, float* actor_out_dev) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  return actor_forward_dev(h, DQNHIP_ACTOR, states_dev, n, actor_out_dev);
+}
+
+int dqnhip_select_actions_net(dqnhip_handle h, int32_t net, const float* states_host, int32_t n, float* actor_out_host) {
+  if (!h) return fail("null handle");
+  if (n < 1) return fail("n must be >= 1");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t sb = (size_t)n * h->S * sizeof(float), ob = (size_t)n * kNO * sizeof(float);
+  RC(ensure_stage(h, round_up_z(sb, 256) + ob));
+  float* sdev = (float*)h->stage_dev;
+  float* odev = (float*)((char*)h->stage_dev + round_up_z(sb, 256));
+  HIPCHK(hipMemcpyAsync(sdev, states_host, sb, hipMemcpyHostToDevice, h->stream));
+  RC(actor_forward_dev(h, net, sdev, n, odev));
+  HIPCHK(hipMemcpyAsync(actor_out_host, odev, ob, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int dqnhip_select_actions(dqnhip_handle h, const float* states_host, int32_t n, float* actor_out_host) {
+  return dqnhip_select_actions_net(h, DQNHIP_ACTOR, states_host, n, actor_out_host);
+}
+
+int dqnhip_critic_forward(dqnhip_handle h, int32_t net, const float* states_host, const float* actor_out_host,
+                          int32_t n, float* q_host) {
+  if (!h) return fail("null handle");
+  if (n < 1) return fail("n must be >= 1");
+  if (net != DQNHIP_CRITIC && net != DQNHIP_CRITIC_TARGET) return fail("net must be a critic");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int rows = round_up(n, 32);
+  const size_t sb = round_up_z((size_t)n * h->S * sizeof(float), 256), ab = round_up_z((size_t)n * kNO * sizeof(float), 256);
+  RC(ensure_stage(h, sb + ab + (size_t)rows * sizeof(float)));
+  float* sdev = (float*)h->stage_dev;
+  float* adev = (float*)((char*)h->stage_dev + sb);
+  float* qdev = (float*)((char*)h->stage_dev + sb + ab);
+  HIPCHK(hipMemcpyAsync(sdev, states_host, (size_t)n * h->S * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(adev, actor_out_host, (size_t)n * kNO * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  RC(ensure_act(h, rows));
+  const NetLayout& l = h->lc;
+  float* acts[kMaxL + 1];
+  float* p = h->act_buf;
+  for (int i = 0; i <= l.L; ++i) { acts[i] = p; p += (size_t)rows * std::max(h->la.kp[i], h->lc.kp[i]); }
+  hipLaunchKernelGGL(k_pack_critic, dim3((rows * l.kp[0] + 255) / 256), dim3(256), 0, h->stream, (const float*)sdev,
+                     (const float*)adev, n, h->S, acts[0], rows, l.kp[0]);
+  HIPCHK(hipGetLastError());
+  FwdPass fp[1] = {{h->w[net], &l, acts}};
+  RC(tower_forward(h, fp, 1, rows));
+  HeadArgs a{}; a.X = acts[l.L]; a.ldx = l.dims[l.L]; a.H = l.dims[l.L]; a.rows = rows;
+  a.W = h->w[net] + l.hw_off; a.b = h->w[net] + l.hb_off; a.q = qdev;
+  RC((head_forward<1, HEAD_Q>(h, a)));
+  HIPCHK(hipMemcpyAsync(q_host, qdev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---- replay memory -------------------------------------------------------------------
+
+static int add_dev(H* h, const float* s, const float* a, const float* r, const float* mc, const float* nx,
+                   const uint8_t* term, int n, int single) {
+  if (n < 1) return fail("n must be >= 1");
+  const long long cap = h->ring.cap;
+  if (!single && n >= cap) return fail("AddTransitions: batch of %d does not fit capacity %lld (the reference would pop an empty deque)", n, cap);
+  hipLaunchKernelGGL(k_add_transitions, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->ring, h->st, s, a, r, mc, nx,
+                     term, n, single, h->done_counter);
+  HIPCHK(hipGetLastError());
+  // host mirror of the same deque arithmetic (src/dqn.cpp:768-781)
+  if (single) { if (h->h_size == cap) { h->h_head = (h->h_head + 1) % cap; h->h_size -= 1; } }
+  else {
+    long long pops = h->h_size + n - cap + 1;
+    pops = std::max(0LL, std::min(pops, h->h_size));
+    h->h_head = (h->h_head + pops) % cap; h->h_size -= pops;
+  }
+  h->h_size += n;
+  return 0;
+}
+
+int dqnhip_add_transitions_device(dqnhip_handle h, const float* states, const float* actor_out, const float* rewards,
+                                  const float* on_policy_targets, const float* next_states, const uint8_t* terminal,
+                                  int32_t n) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  return add_dev(h, states, actor_out, rewards, on_policy_targets, next_states, terminal, n, 0);
+}
+
+static int add_host(H* h, const float* s, const float* a, const float* r, const float* mc, const float* nx,
+                    const uint8_t* term, int n, int single) {
+  if (!h) return fail("null handle");
+  if (n < 1) return fail("n must be >= 1");
+  if (!s || !a || !r || !mc || !term) return fail("null input array");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t sb = round_up_z((size_t)n * h->S * 4, 256), ab = round_up_z((size_t)n * kNO * 4, 256), vb = round_up_z((size_t)n * 4, 256);
+  // staging is reused: wait for the previous scatter to drain before overwriting
+  HIPCHK(hipStreamSynchronize(h->stream));
+  RC(ensure_stage(h, 2 * sb + ab + 3 * vb));
+  char* base = (char*)h->stage_dev;
+  float* ds = (float*)base; float* dn = (float*)(base + sb); float* da = (float*)(base + 2 * sb);
+  float* dr = (float*)(base + 2 * sb + ab); float* dm = (float*)(base + 2 * sb + ab + vb);
+  uint8_t* dt = (uint8_t*)(base + 2 * sb + ab + 2 * vb);
+  HIPCHK(hipMemcpyAsync(ds, s, (size_t)n * h->S * 4, hipMemcpyHostToDevice, h->stream));
+  if (nx) HIPCHK(hipMemcpyAsync(dn, nx, (size_t)n * h->S * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(da, a, (size_t)n * kNO * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dr, r, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dm, mc, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dt, term, (size_t)n, hipMemcpyHostToDevice, h->stream));
+  return add_dev(h, ds, da, dr, dm, nx ? dn : nullptr, dt, n, single);
+}
+
+int dqnhip_add_transitions(dqnhip_handle h, const float* states, const float* actor_out, const float* rewards,
+                           const float* on_policy_targets, const float* next_states, const uint8_t* terminal, int32_t n) {
+  return add_host(h, states, actor_out, rewards, on_policy_targets, next_states, terminal, n, 0);
+}
+
+int dqnhip_add_transition(dqnhip_handle h, const float* state, const float* actor_out, float reward,
+                          float on_policy_target, const float* next_state, uint8_t terminal) {
+  return add_host(h, state, actor_out, &reward, &on_policy_target, next_state, &terminal, 1, 1);
+}
+
+int dqnhip_label_transitions(double gamma, const float* rewards, int32_t n, float* mc) {
+  if (n < 1) return fail("Need at least one transition to label.");   // CHECK_GT, src/dqn.cpp:784
+  if (!rewards || !mc) return fail("null array");
+  mc[n - 1] = rewards[n - 1];
+  for (int i = n - 2; i >= 0; --i) mc[i] = (float)((double)rewards[i] + gamma * (double)mc[i + 1]);
+  return 0;
+}
+
+int dqnhip_memory_size(dqnhip_handle h, int32_t* size) {
+  if (!h || !size) return fail("null argument");
+  *size = (int32_t)h->h_size;
+  return 0;
+}
+
+int dqnhip_clear_memory(dqnhip_handle h) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipMemsetAsync(h->st, 0, 2 * sizeof(int), h->stream));   // ring_head, ring_size
+  h->h_head = 0; h->h_size = 0;
+  return 0;
+}
+
+int dqnhip_read_memory(dqnhip_handle h, int32_t first, int32_t n, float* states, float* actor_out, float* rewards,
+                       float* on_policy_targets, float* next_states, uint8_t* terminal) {
+  if (!h) return fail("null handle");
+  if (n < 1 || first < 0 || (long long)first + n > h->h_size) return fail("read_memory range [%d,%d) outside [0,%lld)", first, first + n, h->h_size);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t sb = round_up_z((size_t)n * h->S * 4, 256), ab = round_up_z((size_t)n * kNO * 4, 256), vb = round_up_z((size_t)n * 4, 256);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  RC(ensure_stage(h, 2 * sb + ab + 3 * vb));
+  char* base = (char*)h->stage_dev;
+  float* ds = (float*)base; float* dn = (float*)(base + sb); float* da = (float*)(base + 2 * sb);
+  float* dr = (float*)(base + 2 * sb + ab); float* dm = (float*)(base + 2 * sb + ab + vb);
+  uint8_t* dt = (uint8_t*)(base + 2 * sb + ab + 2 * vb);
+  hipLaunchKernelGGL(k_read_memory, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->ring, (const DevState*)h->st, first, n,
+                     ds, da, dr, dm, dn, dt);
+  HIPCHK(hipGetLastError());
+  if (states) HIPCHK(hipMemcpyAsync(states, ds, (size_t)n * h->S * 4, hipMemcpyDeviceToHost, h->stream));
+  if (next_states) HIPCHK(hipMemcpyAsync(next_states, dn, (size_t)n * h->S * 4, hipMemcpyDeviceToHost, h->stream));
+  if (actor_out) HIPCHK(hipMemcpyAsync(actor_out, da, (size_t)n * kNO * 4, hipMemcpyDeviceToHost, h->stream));
+  if (rewards) HIPCHK(hipMemcpyAsync(rewards, dr, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+  if (on_policy_targets) HIPCHK(hipMemcpyAsync(on_policy_targets, dm, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+  if (terminal) HIPCHK(hipMemcpyAsync(terminal, dt, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---- parameters ----------------------------------------------------------------------
+
+static float* arena_ptr(H* h, int net, int kind) {
+  if (kind == DQNHIP_KIND_W) return (net >= 0 && net < 4) ? h->w[net] : nullptr;
+  if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return nullptr;
+  return kind == DQNHIP_KIND_M ? h->m[net] : kind == DQNHIP_KIND_V ? h->v[net] : kind == DQNHIP_KIND_G ? h->g[net] : nullptr;
+}
+
+int dqnhip_param_count(dqnhip_handle h, int32_t net, size_t* count) {
+  if (!h || !count) return fail("null argument");
+  if (net < 0 || net > 3) return fail("bad net %d", net);
+  *count = layout_of(h, net).dense;
+  return 0;
+}
+
+int dqnhip_get_params(dqnhip_handle h, int32_t net, int32_t kind, float* host, size_t count) {
+  if (!h || !host) return fail("null argument");
+  float* p = arena_ptr(h, net, kind);
+  if (!p) return fail("bad (net,kind) = (%d,%d)", net, kind);
+  const NetLayout& l = layout_of(h, net);
+  if (count != l.dense) return fail("count %zu != parameter count %zu", count, l.dense);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  std::vector<float> arena(l.arena);
+  HIPCHK(hipMemcpyAsync(arena.data(), p, l.arena * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  arena_to_dense(l, arena, host);
+  return 0;
+}
+
+int dqnhip_set_params(dqnhip_handle h, int32_t net, int32_t kind, const float* host, size_t count) {
+  if (!h || !host) return fail("null argument");
+  float* p = arena_ptr(h, net, kind);
+  if (!p) return fail("bad (net,kind) = (%d,%d)", net, kind);
+  const NetLayout& l = layout_of(h, net);
+  if (count != l.dense) return fail("count %zu != parameter count %zu", count, l.dense);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  std::vector<float> arena;
+  dense_to_arena(l, host, arena);
+  HIPCHK(hipMemcpyAsync(p, arena.data(), l.arena * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int dqnhip_clone_to_target(dqnhip_handle h, int32_t net) {
+  if (!h) return fail("null handle");
+  if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return fail("net must be ACTOR or CRITIC");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipMemcpyAsync(h->w[net + 2], h->w[net], layout_of(h, net).arena * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  return 0;
+}
+
+int dqnhip_get_iters(dqnhip_handle h, int32_t* actor_iter, int32_t* critic_iter) {
+  if (!h) return fail("null handle");
+  if (actor_iter) *actor_iter = h->h_actor_iter;
+  if (critic_iter) *critic_iter = h->h_critic_iter;
+  return 0;
+}
+
+int dqnhip_set_iters(dqnhip_handle h, int32_t actor_iter, int32_t critic_iter) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int v[2] = {actor_iter, critic_iter};
+  HIPCHK(hipMemcpy(&h->st->actor_iter, v, sizeof v, hipMemcpyHostToDevice));
+  h->h_actor_iter = actor_iter; h->h_critic_iter = critic_iter;
+  return 0;
+}
+
+// ---- introspection ----------------------------------------------------------------------
+
+int dqnhip_debug_read(dqnhip_handle h, const char* name, float* host, size_t count) {
+  if (!h || !name || !host) return fail("null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t B = h->B;
+  const float* src = nullptr; size_t n = B; bool pad16 = false; bool is_int = false;
+  if (!strcmp(name, "q_target")) src = h->q_t;
+  else if (!strcmp(name, "y")) src = h->y;
+  else if (!strcmp(name, "q_train")) src = h->q1;
+  else if (!strcmp(name, "q_policy")) src = h->q2;
+  else if (!strcmp(name, "terminal")) src = h->mb_term;
+  else if (!strcmp(name, "actor_out")) { src = h->aout16; pad16 = true; n = B * kNO; }
+  else if (!strcmp(name, "dq_da")) { src = h->dA16; pad16 = true; n = B * kNO; }
+  else if (!strcmp(name, "idx")) { src = (const float*)h->mb_idx; is_int = true; }
+  else return fail("unknown debug buffer '%s'", name);
+  if (count < n) return fail("buffer too small for '%s': %zu < %zu", name, count, n);
+  std::vector<float> tmp(pad16 ? B * kAP : B);
+  HIPCHK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (pad16) { for (size_t r = 0; r < B; ++r) for (int c = 0; c < kNO; ++c) host[r * kNO + c] = tmp[r * kAP + c]; }
+  else if (is_int) { for (size_t r = 0; r < B; ++r) host[r] = (float)reinterpret_cast<const int*>(tmp.data())[r]; }
+  else memcpy(host, tmp.data(), B * sizeof(float));
+  return 0;
+}
+
+int dqnhip_get_stream(dqnhip_handle h, void** stream) {
+  if (!h || !stream) return fail("null argument");
+  *stream = (void*)h->stream;
+  return 0;
+}
+
+int dqnhip_set_kernel_timing(dqnhip_handle h, int32_t enable) {
+  if (!h) return fail("null handle");
+  h->timing = enable != 0;
+  return 0;
+}
+
+int dqnhip_get_kernel_timing(dqnhip_handle h, const char* family, float* avg_ms, int64_t* launches, int32_t reset) {
+  if (!h || !family) return fail("null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  int fam = -1;
+  for (int i = 0; i < 4; ++i) if (!strcmp(family, kFamily[i])) fam = i;
+  if (fam < 0) return fail("unknown kernel family '%s' (gemm_fwd|gemm_dgrad|gemm_wgrad|adam)", family);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double total = 0; int64_t cnt = 0;
+  for (auto& r : h->recs) {
+    if (r.family != fam) continue;
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+    total += ms; cnt += 1;
+  }
+  if (avg_ms) *avg_ms = cnt ? (float)(total / cnt) : 0.0f;
+  if (launches) *launches = cnt;
+  if (reset) {
+    for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    h->recs.clear();
+  }
+  return 0;
+}
+
+}  // extern "C"

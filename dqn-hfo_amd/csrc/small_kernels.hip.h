@@ -1,0 +1,505 @@
+// small_kernels.hip.h — the HBM/latency-bound kernels around the MFMA GEMMs:
+// replay gather/scatter, skinny head layers, TD target + Euclidean loss,
+// inverting gradients, fused clip+Adam+soft-update, bookkeeping.
+// Each kernel cites the reference lines it replaces (paths under /root/reference).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_mfma.hip.h"
+
+namespace dqnhip {
+
+constexpr int kNA = 4;    // kActionSize       src/dqn.hpp:20
+constexpr int kNP = 6;    // kActionParamSize  src/dqn.hpp:21
+constexpr int kNO = 10;   // ActorOutput       src/dqn.hpp:28
+constexpr int kAP = 16;   // padded ActorOutput row (64 B)
+
+// Device-resident scalars of one learner (graph-replayable: nothing that
+// changes per update is a kernel argument).
+struct DevState {
+  int ring_head;        // physical slot of logical transition 0
+  int ring_size;        // std::deque::size()
+  int actor_iter;       // actor_solver_->iter()
+  int critic_iter;      // critic_solver_->iter()
+  unsigned long long update_counter;  // Philox counter for on-device sampling
+  float critic_loss;    // last update's return value .first
+  float avg_q;          // .second
+  int pad;
+};
+
+// ---- counter-based RNG (Philox-4x32-10) for SampleTransitionsFromMemory ------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t ctr, uint32_t lane) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), lane, 0x9E3779B9u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  return c[0];
+}
+
+// ---- replay ring -------------------------------------------------------------
+// SoA ring in HBM: state[cap][SP], next[cap][SP] (rows padded to SP = roundup(S,64)
+// floats so every row is whole 256-B lines), act[cap][16], reward[cap], mc[cap],
+// term[cap].  Logical index i (what the reference's deque exposes) lives in
+// physical slot (head + i) % cap.
+struct Ring {
+  float* state; float* next; float* act; float* reward; float* mc; uint8_t* term;
+  int cap, S, SP;
+};
+
+// DQN::AddTransitions / AddTransition (src/dqn.cpp:768-781): the eviction
+// arithmetic runs on one thread and publishes (head,size); rows are scattered
+// by the rest of the grid from the values BEFORE the update (old_head/old_size
+// are recomputed identically by every block).
+__global__ void k_add_transitions(Ring ring, DevState* st, const float* __restrict__ s,
+                                  const float* __restrict__ a, const float* __restrict__ r,
+                                  const float* __restrict__ mc, const float* __restrict__ nx,
+                                  const uint8_t* __restrict__ term, int n, int single_mode,
+                                  int* done_counter) {
+  // every block derives the same post-eviction (head,size)
+  int head = st->ring_head, size = st->ring_size;
+  if (single_mode) {           // AddTransition: pop iff size == capacity
+    if (size == ring.cap) { head = (head + 1) % ring.cap; size -= 1; }
+  } else {                     // AddTransitions: while (size + n >= capacity) pop_front
+    int pops = size + n - ring.cap + 1;
+    if (pops < 0) pops = 0;
+    if (pops > size) pops = size;
+    head = (int)(((long long)head + pops) % ring.cap); size -= pops;
+  }
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row < n) {
+    const long long slot = ((long long)head + size + row) % ring.cap;
+    const uint8_t t = term[row];
+    for (int c = lane; c < ring.SP; c += 64) {
+      ring.state[slot * ring.SP + c] = c < ring.S ? s[(size_t)row * ring.S + c] : 0.0f;
+      ring.next[slot * ring.SP + c] = (c < ring.S && !t && nx != nullptr) ? nx[(size_t)row * ring.S + c] : 0.0f;
+    }
+    if (lane < kAP) ring.act[slot * kAP + lane] = lane < kNO ? a[(size_t)row * kNO + lane] : 0.0f;
+    if (lane == 0) { ring.reward[slot] = r[row]; ring.mc[slot] = mc[row]; ring.term[slot] = t ? 1 : 0; }
+  }
+  // last block to finish publishes the new (head,size)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int prev = atomicAdd(done_counter, 1);
+    if (prev == (int)gridDim.x - 1) {
+      st->ring_head = head; st->ring_size = size + n; *done_counter = 0;
+      __threadfence();
+    }
+  }
+}
+
+__global__ void k_read_memory(Ring ring, const DevState* st, int first, int n, float* s, float* a,
+                              float* r, float* mc, float* nx, uint8_t* term) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const long long slot = ((long long)st->ring_head + first + row) % ring.cap;
+  for (int c = lane; c < ring.S; c += 64) {
+    if (s) s[(size_t)row * ring.S + c] = ring.state[slot * ring.SP + c];
+    if (nx) nx[(size_t)row * ring.S + c] = ring.next[slot * ring.SP + c];
+  }
+  if (a && lane < kNO) a[(size_t)row * kNO + lane] = ring.act[slot * kAP + lane];
+  if (lane == 0) {
+    if (r) r[row] = ring.reward[slot];
+    if (mc) mc[row] = ring.mc[slot];
+    if (term) term[row] = ring.term[slot];
+  }
+}
+
+// Minibatch gather (src/dqn.cpp:846-887): one wave per sampled transition; each
+// row of the ring is whole 256-B lines so the reads are fully coalesced.  Writes
+// the five network input panels directly (Concat layer, src/dqn.cpp:446-448,
+// folded in):  Xa_s=[s|0]  Xa_n=[s'|0]  Xc_tr=[s|a|0]  Xc_pl=[s|0..]  Xc_nx=[s'|0..]
+struct GatherOut {
+  float* Xa_s; float* Xa_n; int KaP;
+  float* Xc_tr; float* Xc_pl; float* Xc_nx; int KcP;
+  float* reward; float* mc; float* term; int* idx;
+};
+__global__ void k_gather(Ring ring, const DevState* st, const int* __restrict__ idx_in,
+                         uint64_t seed, GatherOut o, int B) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= B) return;
+  const int size = st->ring_size;
+  int li;
+  if (idx_in != nullptr) li = idx_in[row];
+  else {
+    // SampleTransitionsFromMemory (src/dqn.cpp:501-509): uniform in [0,size-1] with
+    // replacement; counter-based so the draw depends only on (seed, update, row)
+    const uint32_t u = philox_u32(seed, st->update_counter, (uint32_t)row);
+    li = (int)(((uint64_t)u * (uint64_t)size) >> 32);
+  }
+  li = li < 0 ? 0 : (li >= size ? size - 1 : li);
+  const long long slot = ((long long)st->ring_head + li) % ring.cap;
+  const float* sp = ring.state + slot * ring.SP;
+  const float* np = ring.next + slot * ring.SP;
+  const float* ap = ring.act + slot * kAP;
+  const int S = ring.S;
+  for (int c = lane; c < o.KcP; c += 64) {
+    const float sv = c < S ? sp[c] : 0.0f;
+    const float nv = c < S ? np[c] : 0.0f;
+    if (c < o.KaP) { o.Xa_s[(size_t)row * o.KaP + c] = sv; o.Xa_n[(size_t)row * o.KaP + c] = nv; }
+    const float av = (c >= S && c < S + kNO) ? ap[c - S] : 0.0f;
+    o.Xc_tr[(size_t)row * o.KcP + c] = c < S ? sv : av;
+    o.Xc_pl[(size_t)row * o.KcP + c] = sv;
+    o.Xc_nx[(size_t)row * o.KcP + c] = nv;
+  }
+  if (lane == 0) {
+    o.reward[row] = ring.reward[slot]; o.mc[row] = ring.mc[slot];
+    o.term[row] = ring.term[slot] ? 1.0f : 0.0f; o.idx[row] = li;
+  }
+}
+
+// ---- skinny head layers ------------------------------------------------------
+// action_layer(4) + actionpara_layer(6) of the actor and q_values_layer(1) of
+// the critic (src/dqn.cpp:426-427, 450) are K=H4 dot products per row: one wave
+// per row, float4 strips over k, butterfly reduce.
+enum HeadMode { HEAD_ACTOR = 0, HEAD_Q = 1, HEAD_Q_TRAIN = 2, HEAD_Q_POLICY = 3 };
+struct HeadArgs {
+  const float* X; int ldx; int H;      // [rows][H] tower top
+  const float* W; const float* b;      // [NH][H], [NH]
+  int rows;
+  // HEAD_ACTOR
+  float* out16;                        // [rows][16]
+  float* xc; int ldxc; int xc_col;     // also written into a critic input panel (may be null)
+  // HEAD_Q*
+  float* q;                            // [rows]
+  // HEAD_Q_TRAIN: TD target + Euclidean loss
+  const float* q_target; const float* reward; const float* mc; const float* term;
+  float* y; float* dq; float* loss_partial;   // loss_partial[gridDim.x]
+  double gamma, beta; float inv_batch;
+  // HEAD_Q_POLICY
+  double* qsum_partial;                // [gridDim.x]
+};
+
+template <int NH, int MODE>
+__global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  __shared__ float s_part[4];
+  __shared__ double s_q[4];
+  float acc[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
+  if (row < a.rows) {
+    const float* x = a.X + (size_t)row * a.ldx;
+    for (int k = lane * 4; k < a.H; k += 256) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
+#pragma unroll
+      for (int j = 0; j < NH; ++j) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k);
+        acc[j] = fmaf(xv.x, wv.x, acc[j]); acc[j] = fmaf(xv.y, wv.y, acc[j]);
+        acc[j] = fmaf(xv.z, wv.z, acc[j]); acc[j] = fmaf(xv.w, wv.w, acc[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
+    acc[j] += a.b[j];
+  }
+  if constexpr (MODE == HEAD_ACTOR) {
+    if (row < a.rows && lane < kAP) {
+      float v = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NH; ++j) if (lane == j) v = acc[j];
+      a.out16[(size_t)row * kAP + lane] = v;
+      if (a.xc != nullptr && lane < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + lane] = v;
+    }
+  } else {
+    const float q = acc[0];
+    float d2 = 0.0f;
+    if (row < a.rows && lane == 0) {
+      a.q[row] = q;
+      if constexpr (MODE == HEAD_Q_TRAIN) {
+        // TD target (src/dqn.cpp:892-900), doubles where the reference has them
+        const float r = a.reward[row];
+        const float off_policy = a.term[row] != 0.0f
+            ? r : (float)((double)r + a.gamma * (double)a.q_target[row]);
+        const float target = (float)(a.beta * (double)a.mc[row] + (1 - a.beta) * (double)off_policy);
+        a.y[row] = target;
+        // EuclideanLoss: diff = q - y; bottom diff = diff / num
+        const float d = q - target;
+        a.dq[row] = a.inv_batch * d;
+        d2 = d * d;
+      }
+    }
+    if constexpr (MODE == HEAD_Q_TRAIN) {
+      if (lane == 0) s_part[wave] = d2;
+      __syncthreads();
+      if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+    }
+    if constexpr (MODE == HEAD_Q_POLICY) {
+      if (lane == 0) s_q[wave] = row < a.rows ? (double)q : 0.0;
+      __syncthreads();
+      if (threadIdx.x == 0) a.qsum_partial[blockIdx.x] = ((s_q[0] + s_q[1]) + s_q[2]) + s_q[3];
+    }
+  }
+}
+
+// Head backward wrt the tower top, with the tower's last ReLU backward fused:
+//   dZ4[m][k] = (sum_j dYh[m][j] * Wh[j][k]) * lrelu'(X4[m][k])
+// NH == 10 (actor): the two IP layers' bottom diffs are formed separately and
+// added by the Split layer: (4-term sum) + (6-term sum).
+// dyh == nullptr means dY = -1 for every row (src/dqn.cpp:918-921).
+template <int NH>
+__global__ __launch_bounds__(256) void k_head_bwd_dx(const float* __restrict__ dyh, int lddy,
+                                                     const float* __restrict__ W,
+                                                     const float* __restrict__ X4, int H, int rows,
+                                                     float* __restrict__ dZ) {
+  const int total4 = rows * H / 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+    const int m = (i * 4) / H, k = (i * 4) % H;
+    float dy[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) dy[j] = dyh ? dyh[(size_t)m * lddy + j] : -1.0f;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(W + (size_t)j * H + k);
+      if (NH == kNO && j >= kNA) {
+        s1.x = fmaf(dy[j], wv.x, s1.x); s1.y = fmaf(dy[j], wv.y, s1.y);
+        s1.z = fmaf(dy[j], wv.z, s1.z); s1.w = fmaf(dy[j], wv.w, s1.w);
+      } else {
+        s0.x = fmaf(dy[j], wv.x, s0.x); s0.y = fmaf(dy[j], wv.y, s0.y);
+        s0.z = fmaf(dy[j], wv.z, s0.z); s0.w = fmaf(dy[j], wv.w, s0.w);
+      }
+    }
+    if (NH == kNO) { s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w; }
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(X4 + (size_t)m * H + k);
+    s0.x *= lrelu_mask(xv.x); s0.y *= lrelu_mask(xv.y); s0.z *= lrelu_mask(xv.z); s0.w *= lrelu_mask(xv.w);
+    *reinterpret_cast<f32x4*>(dZ + (size_t)m * H + k) = s0;
+  }
+}
+
+// Head weight/bias gradient: dWh[j][k] = sum_m dYh[m][j] X4[m][k]; dbh[j] = sum_m dYh[m][j].
+// Block = 64 k-columns x 4 row-quarters; quarters are added in fixed order.
+template <int NH>
+__global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ dyh, int lddy,
+                                                    const float* __restrict__ X4, int H, int rows,
+                                                    float* __restrict__ dW, float* __restrict__ db,
+                                                    float* __restrict__ partial) {
+  __shared__ float s_acc[4][NH][64];
+  __shared__ float s_b[4][NH];
+  __shared__ float s_red[4];
+  const int kc = threadIdx.x & 63, mq = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kc;
+  const int per = (rows + 3) / 4;
+  const int m0 = mq * per, m1 = min(rows, m0 + per);
+  float acc[NH], bs[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) { acc[j] = 0.0f; bs[j] = 0.0f; }
+  for (int m = m0; m < m1; ++m) {
+    const float xv = X4[(size_t)m * H + k];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const float d = dyh[(size_t)m * lddy + j];
+      acc[j] = fmaf(d, xv, acc[j]);
+      bs[j] += d;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NH; ++j) { s_acc[mq][j][kc] = acc[j]; if (kc == 0) s_b[mq][j] = bs[j]; }
+  __syncthreads();
+  float ssq = 0.0f;
+  if (mq == 0) {
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const float v = ((s_acc[0][j][kc] + s_acc[1][j][kc]) + s_acc[2][j][kc]) + s_acc[3][j][kc];
+      dW[(size_t)j * H + k] = v;
+      ssq = fmaf(v, v, ssq);
+    }
+    if (blockIdx.x == 0 && kc < NH) {
+      const float v = ((s_b[0][kc] + s_b[1][kc]) + s_b[2][kc]) + s_b[3][kc];
+      db[kc] = v;
+      ssq = fmaf(v, v, ssq);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
+    if (kc == 0 && partial != nullptr) partial[blockIdx.x] = ssq;
+  }
+  (void)s_red;
+}
+
+// Inverting gradients (src/dqn.cpp:924-957) on the critic's input gradient
+// columns [S, S+10): bounds logits [-1,1]; params h in {0,4}: [0,100], else
+// [-180,180].  Also the place where critic_iter's consumer-side bookkeeping is
+// not needed: counters are advanced by k_tick.
+__global__ void k_invert_grad(const float* __restrict__ dXc, int ldx, int S,
+                              const float* __restrict__ aout16, float* __restrict__ dA16, int rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * kAP) return;
+  const int m = i / kAP, h = i % kAP;
+  float diff = 0.0f;
+  if (h < kNO) {
+    diff = dXc[(size_t)m * ldx + S + h];
+    const float out = aout16[(size_t)m * kAP + h];
+    float mn, mx;
+    if (h < kNA) { mn = -1.0f; mx = 1.0f; }
+    else { const int p = h - kNA; if (p == 0 || p == 4) { mn = 0.0f; mx = 100.0f; } else { mn = -180.0f; mx = 180.0f; } }
+    if (diff < 0) diff *= (mx - out) / (mx - mn);
+    else if (diff > 0) diff *= (out - mn) / (mx - mn);
+  }
+  dA16[(size_t)m * kAP + h] = diff;
+}
+
+// ---- optimiser -----------------------------------------------------------------
+// Sum of squares of a gradient arena -> per-block partials (used after an
+// all-reduce, where the GEMM-epilogue partials no longer describe the reduced
+// gradient).
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, size_t n4,
+                                               float* __restrict__ partial) {
+  __shared__ float s[4];
+  float acc = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// SGDSolver::ClipGradients + AdamSolver::ComputeUpdateValue + Net::Update +
+// DQN::SoftUpdateNet in ONE pass over (w, g, m, v, w_target)
+// (Caffe sgd_solver.cpp/adam_solver.cpp @2ef5847; src/dqn.cpp:
+// 904, 964, 967-970, 1085-1096).  36 B/param of HBM traffic instead of Caffe's
+// ~7 separate param-sized passes plus the separate soft-update pass.
+struct AdamArgs {
+  float* w; float* g; float* m; float* v; float* wt;
+  size_t n4;                      // arena length / 4
+  const float* partial; int n_partial;
+  float lr, beta1, beta2, eps, clip, tau;
+  int soft_update_freq;
+  int which;                      // 0 actor, 1 critic (selects the iter counter)
+  const DevState* st;
+};
+__global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
+  __shared__ float s[4];
+  __shared__ float s_scale;
+  // every block re-derives the same global L2 norm from the partials, in the
+  // same order -> bit-identical scale everywhere, no extra launch
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < a.n_partial; i += 256) acc += a.partial[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float sumsq = (s[0] + s[1]) + (s[2] + s[3]);
+    const float l2 = sqrtf(sumsq);
+    s_scale = (a.clip >= 0.0f && l2 > a.clip) ? a.clip / l2 : 1.0f;
+  }
+  __syncthreads();
+  const float scale = s_scale;
+  const int it_a = a.st->actor_iter, it_c = a.st->critic_iter;
+  const int t = (a.which == 0 ? it_a : it_c) + 1;      // t = iter_ + 1 (before increment)
+  // correction = sqrt(1 - beta2^t) / (1 - beta1^t), evaluated in double, rounded once
+  const float correction = (float)(sqrt(1.0 - pow((double)a.beta2, (double)t)) /
+                                   (1.0 - pow((double)a.beta1, (double)t)));
+  const float step = a.lr * correction;
+  const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
+  // soft update condition uses max_iter() AFTER both increments (src/dqn.cpp:967)
+  const int mx = (it_a + 1) > (it_c + 1) ? (it_a + 1) : (it_c + 1);
+  const bool soft = (mx % a.soft_update_freq) == 0;
+  const float tau = a.tau, omt = 1 - a.tau;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) {
+    f32x4 g = reinterpret_cast<f32x4*>(a.g)[i];
+    f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
+    f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
+    f32x4 w = reinterpret_cast<f32x4*>(a.w)[i];
+    f32x4 wt = reinterpret_cast<f32x4*>(a.wt)[i];
+    float* gp = reinterpret_cast<float*>(&g); float* mp = reinterpret_cast<float*>(&m);
+    float* vp = reinterpret_cast<float*>(&v); float* wp = reinterpret_cast<float*>(&w);
+    float* tp = reinterpret_cast<float*>(&wt);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gi = gp[e] * scale;
+      const float mi = fmaf(omb1, gi, a.beta1 * mp[e]);
+      const float vi = fmaf(omb2, gi * gi, a.beta2 * vp[e]);
+      const float upd = step * (mi / (sqrtf(vi) + a.eps));
+      const float wi = wp[e] - upd;
+      mp[e] = mi; vp[e] = vi; wp[e] = wi;
+      if (soft) tp[e] = fmaf(tau, wi, omt * tp[e]);
+    }
+    reinterpret_cast<f32x4*>(a.m)[i] = m;
+    reinterpret_cast<f32x4*>(a.v)[i] = v;
+    reinterpret_cast<f32x4*>(a.w)[i] = w;
+    if (soft) reinterpret_cast<f32x4*>(a.wt)[i] = wt;
+  }
+}
+
+// Reduce the per-block loss / q partials into the gradient-arena tails
+// ([loss_sum, q_sum, 0, 0]) so they ride in the gradient all-reduce.
+__global__ void k_tails(const float* loss_partial, int n_loss, const double* q_partial, int n_q,
+                        float inv_batch, float* critic_tail, float* actor_tail) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (critic_tail != nullptr) {
+    float dot = 0.0f;
+    for (int i = 0; i < n_loss; ++i) dot += loss_partial[i];
+    critic_tail[0] = dot * inv_batch / 2.0f;   // EuclideanLoss: dot / num / 2
+    critic_tail[1] = 0.f; critic_tail[2] = 0.f; critic_tail[3] = 0.f;
+  }
+  if (actor_tail != nullptr) {
+    double qs = 0.0;
+    for (int i = 0; i < n_q; ++i) qs += q_partial[i];
+    actor_tail[0] = 0.f; actor_tail[1] = (float)qs; actor_tail[2] = 0.f; actor_tail[3] = 0.f;
+  }
+}
+
+// End of update: publish (critic_loss, avg_q), advance both solver iterations
+// (Step's ++iter_, set_iter(iter+1): src/dqn.cpp:904, 965) and the sampling counter.
+// avg_q = std::accumulate(q, 0.0) / float(B) (src/dqn.cpp:915-916): the double sum
+// is taken from the per-block double partials when they are local (single GPU),
+// from the all-reduced float tail under data parallelism.
+__global__ void k_tick(DevState* st, const float* critic_tail, const float* actor_tail,
+                       const double* q_partial, int n_q, float batch) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->critic_loss = critic_tail[0];
+  double qs = 0.0;
+  if (q_partial != nullptr) { for (int i = 0; i < n_q; ++i) qs += q_partial[i]; }
+  else qs = (double)actor_tail[1];
+  st->avg_q = (float)(qs / (double)batch);
+  st->actor_iter += 1; st->critic_iter += 1; st->update_counter += 1;
+}
+
+// ---- acting-time helpers ---------------------------------------------------------
+// dense [n][S] -> padded panel [npad][SP] (pad rows/cols zero)
+__global__ void k_pack_rows(const float* __restrict__ src, int n, int S, float* __restrict__ dst,
+                            int npad, int SP) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad * SP) return;
+  const int r = i / SP, c = i % SP;
+  dst[i] = (r < n && c < S) ? src[(size_t)r * S + c] : 0.0f;
+}
+// critic input panel from dense states + dense actor outputs
+__global__ void k_pack_critic(const float* __restrict__ s, const float* __restrict__ a, int n, int S,
+                              float* __restrict__ dst, int npad, int KP) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad * KP) return;
+  const int r = i / KP, c = i % KP;
+  float v = 0.0f;
+  if (r < n) { if (c < S) v = s[(size_t)r * S + c]; else if (c < S + kNO) v = a[(size_t)r * kNO + (c - S)]; }
+  dst[i] = v;
+}
+__global__ void k_unpack_out(const float* __restrict__ out16, int n, float* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * kNO) return;
+  dst[i] = out16[(size_t)(i / kNO) * kAP + (i % kNO)];
+}
+
+}  // namespace dqnhip

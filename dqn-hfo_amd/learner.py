@@ -1,0 +1,379 @@
+"""Host-side mirror of the reference's `dqn::DQN` (src/dqn.hpp:56-134) for the hot
+path, over the C-ABI of include/dqnhip.h.  Method names, argument meaning and error
+behaviour follow the reference; where the reference aborts through glog CHECK /
+LOG(FATAL) this raises `DQNFatal`.
+
+PyTorch is not used here at all — device memory and streams live inside the native
+library; torch only appears in parallel.py (torch.distributed over RCCL).
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import capi
+from .capi import ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET, KIND_W, KIND_M, KIND_V, KIND_G
+
+kActionSize = 4          # src/dqn.hpp:20
+kActionParamSize = 6     # src/dqn.hpp:21
+kStateInputCount = 1     # src/dqn.hpp:18
+DASH, TURN, TACKLE, KICK = 0, 1, 2, 3   # hfo::action_t values pinned by src/dqn.cpp:181-186
+
+Action = namedtuple("Action", "action arg1 arg2")          # src/hfo_game.hpp:7-11
+Transition = namedtuple("Transition", "state actor_output reward on_policy_target next_state")
+# next_state is None for terminal transitions (boost::none, src/dqn.cpp:878)
+
+
+class DQNFatal(RuntimeError):
+    """The reference's CHECK/LOG(FATAL) abort, as an exception."""
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(capi.fp)
+
+
+def GetParamOffset(action, arg_num=0):
+    """src/dqn.cpp:162-178."""
+    if arg_num < 0 or arg_num > 1:
+        return -1
+    if action == DASH:
+        return arg_num
+    if action == TURN:
+        return 2 if arg_num == 0 else -1
+    if action == TACKLE:
+        return 3 if arg_num == 0 else -1
+    if action == KICK:
+        return 4 + arg_num
+    raise DQNFatal("Unrecognized action: %r" % (action,))
+
+
+def GetAction(actor_output):
+    """src/dqn.cpp:196-208: argmax over the 4 logits with TACKLE masked to -99999
+    (std::max_element: the first maximum wins), then the chosen action's parameters."""
+    ao = np.asarray(actor_output, dtype=np.float32)
+    copy = ao[:kActionSize].copy()
+    copy[TACKLE] = -99999
+    act = int(np.argmax(copy))                 # np.argmax also returns the first maximum
+    o1 = GetParamOffset(act, 0)
+    assert o1 >= 0
+    o2 = GetParamOffset(act, 1)
+    return Action(act, float(ao[kActionSize + o1]), 0.0 if o2 < 0 else float(ao[kActionSize + o2]))
+
+
+def PrintActorOutput(ao):
+    """src/dqn.cpp:210-216."""
+    f = lambda v: "%f" % v
+    return ("Dash(" + f(ao[4]) + ", " + f(ao[5]) + ")=" + f(ao[0]) + ", Turn(" + f(ao[6]) + ")=" + f(ao[1])
+            + ", Tackle(" + f(ao[7]) + ")=" + f(ao[2]) + ", Kick(" + f(ao[8]) + ", " + f(ao[9]) + ")=" + f(ao[3]))
+
+
+class DQN:
+    """Device-resident learner with the reference's method surface.
+
+    Constructor arguments replace the reference's SolverParameter pair + gflags
+    (src/dqn.cpp:21-31, src/dqn_main.cpp:249-262); defaults are the reference's.
+    """
+
+    def __init__(self, state_size, minibatch=32, hidden=(1024, 512, 256, 128), memory=500000,
+                 gamma=0.99, beta=0.5, tau=0.001, soft_update_freq=1, actor_lr=1e-5, critic_lr=1e-3,
+                 momentum=0.95, momentum2=0.999, clip_grad=10.0, memory_threshold=1000, seed=1,
+                 device=0, dp_world=1, dp_rank=0, use_graph=False, stream=None, grad_arena=None,
+                 grad_arena_bytes=0, tid=0, save_path="state/dqn"):
+        self.lib = capi.load()
+        cfg = capi.Config()
+        self.lib.dqnhip_default_config(C.byref(cfg), state_size)
+        cfg.minibatch = minibatch
+        cfg.num_hidden = len(hidden)
+        for i in range(capi.MAX_HIDDEN):
+            cfg.hidden[i] = hidden[i] if i < len(hidden) else 0
+        cfg.replay_capacity = memory
+        cfg.soft_update_freq = soft_update_freq
+        cfg.gamma, cfg.beta, cfg.tau = gamma, beta, tau
+        cfg.actor_lr, cfg.critic_lr = actor_lr, critic_lr
+        cfg.momentum, cfg.momentum2, cfg.clip_gradients = momentum, momentum2, clip_grad
+        cfg.device, cfg.dp_world, cfg.dp_rank, cfg.use_graph = device, dp_world, dp_rank, int(use_graph)
+        cfg.seed = seed
+        cfg.stream = stream
+        cfg.grad_arena = grad_arena
+        cfg.grad_arena_bytes = grad_arena_bytes
+        self.cfg = cfg
+        self.h = capi.H()
+        self._ck(self.lib.dqnhip_create(C.byref(cfg), C.byref(self.h)))
+        self.state_size_ = state_size
+        self.kMinibatchSize = minibatch
+        self.memory_threshold = memory_threshold        # FLAGS_memory_threshold, src/dqn.cpp:26
+        self.gamma_ = gamma
+        self.tid_ = tid
+        self.save_path_ = save_path
+        self.unum_ = 0
+        self.random_engine = np.random.default_rng(seed)   # stands in for std::mt19937
+        self.smoothed_critic_loss_ = 0.0
+        self.smoothed_actor_loss_ = 0.0
+
+    # -- plumbing -----------------------------------------------------------------
+    @staticmethod
+    def grad_arena_bytes(state_size, minibatch, hidden):
+        lib = capi.load()
+        cfg = capi.Config()
+        lib.dqnhip_default_config(C.byref(cfg), state_size)
+        cfg.minibatch = minibatch
+        cfg.num_hidden = len(hidden)
+        for i, hsz in enumerate(hidden):
+            cfg.hidden[i] = hsz
+        return lib.dqnhip_grad_arena_bytes(C.byref(cfg))
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise DQNFatal(self.lib.dqnhip_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.dqnhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- accessors (src/dqn.hpp:112, 127-134) ------------------------------------------
+    def memory_size(self):
+        n = C.c_int32()
+        self._ck(self.lib.dqnhip_memory_size(self.h, C.byref(n)))
+        return n.value
+
+    def _iters(self):
+        a, c = C.c_int32(), C.c_int32()
+        self._ck(self.lib.dqnhip_get_iters(self.h, C.byref(a), C.byref(c)))
+        return a.value, c.value
+
+    def actor_iter(self):
+        return self._iters()[0]
+
+    def critic_iter(self):
+        return self._iters()[1]
+
+    def max_iter(self):
+        return max(self._iters())
+
+    def min_iter(self):
+        return min(self._iters())
+
+    def set_iters(self, actor_iter, critic_iter):
+        self._ck(self.lib.dqnhip_set_iters(self.h, actor_iter, critic_iter))
+
+    def state_size(self):
+        return self.state_size_
+
+    def save_path(self):
+        return self.save_path_
+
+    def unum(self):
+        return self.unum_
+
+    def set_unum(self, unum):
+        self.unum_ = unum
+
+    # -- replay memory -------------------------------------------------------------------
+    def ClearReplayMemory(self):
+        self._ck(self.lib.dqnhip_clear_memory(self.h))
+
+    def LabelTransitions(self, transitions):
+        """src/dqn.cpp:783-797: fills on_policy_target by the reverse discounted scan;
+        returns the relabelled list (the reference mutates in place)."""
+        if len(transitions) == 0:
+            raise DQNFatal("Need at least one transition to label.")
+        r = _f32([t.reward for t in transitions])
+        mc = np.empty_like(r)
+        self._ck(self.lib.dqnhip_label_transitions(self.gamma_, _p(r), r.size, _p(mc)))
+        return [t._replace(on_policy_target=float(m)) for t, m in zip(transitions, mc)]
+
+    def _pack(self, transitions):
+        S = self.state_size_
+        n = len(transitions)
+        s = np.empty((n, S), np.float32); nx = np.zeros((n, S), np.float32)
+        a = np.empty((n, 10), np.float32); r = np.empty(n, np.float32); mc = np.empty(n, np.float32)
+        term = np.zeros(n, np.uint8)
+        for i, t in enumerate(transitions):
+            if len(t.state) != S:
+                raise DQNFatal("state size %d != %d" % (len(t.state), S))
+            s[i] = t.state; a[i] = t.actor_output; r[i] = t.reward; mc[i] = t.on_policy_target
+            if t.next_state is None:
+                term[i] = 1
+            else:
+                nx[i] = t.next_state
+        return s, a, r, mc, nx, term
+
+    def AddTransition(self, transition):
+        """src/dqn.cpp:768-773."""
+        s, a, r, mc, nx, term = self._pack([transition])
+        self._ck(self.lib.dqnhip_add_transition(self.h, _p(s), _p(a), float(r[0]), float(mc[0]), _p(nx), int(term[0])))
+
+    def AddTransitions(self, transitions):
+        """src/dqn.cpp:775-781."""
+        s, a, r, mc, nx, term = self._pack(transitions)
+        self.add_transitions_arrays(s, a, r, mc, nx, term)
+
+    def add_transitions_arrays(self, s, a, r, mc, nx, term):
+        """AddTransitions on already-packed arrays ([n,S], [n,10], [n], [n], [n,S], [n] u8)."""
+        s, a, r, mc, nx = _f32(s), _f32(a), _f32(r), _f32(mc), _f32(nx)
+        term = np.ascontiguousarray(term, dtype=np.uint8)
+        self._ck(self.lib.dqnhip_add_transitions(self.h, _p(s), _p(a), _p(r), _p(mc), _p(nx),
+                                                 term.ctypes.data_as(capi.up), r.size))
+
+    def read_memory(self, first, n):
+        S = self.state_size_
+        s = np.empty((n, S), np.float32); nx = np.empty((n, S), np.float32)
+        a = np.empty((n, 10), np.float32); r = np.empty(n, np.float32); mc = np.empty(n, np.float32)
+        t = np.empty(n, np.uint8)
+        self._ck(self.lib.dqnhip_read_memory(self.h, first, n, _p(s), _p(a), _p(r), _p(mc), _p(nx),
+                                             t.ctypes.data_as(capi.up)))
+        return s, a, r, mc, nx, t
+
+    # -- acting (src/dqn.cpp:664-711) -------------------------------------------------------
+    def GetRandomActorOutput(self):
+        g = self.random_engine
+        ao = np.empty(10, np.float32)
+        ao[0:4] = g.uniform(-1.0, 1.0, 4)
+        ao[4] = g.uniform(-100.0, 100.0)
+        ao[5] = g.uniform(-180.0, 180.0); ao[6] = g.uniform(-180.0, 180.0); ao[7] = g.uniform(-180.0, 180.0)
+        ao[8] = g.uniform(0.0, 100.0)
+        ao[9] = g.uniform(-180.0, 180.0)
+        return ao
+
+    def SelectActionGreedily(self, states_batch, net=ACTOR):
+        s = _f32(states_batch).reshape(-1, self.state_size_)
+        out = np.empty((s.shape[0], 10), np.float32)
+        self._ck(self.lib.dqnhip_select_actions_net(self.h, net, _p(s), s.shape[0], _p(out)))
+        return out
+
+    def SelectActions(self, states_batch, epsilon):
+        """src/dqn.cpp:695-711: ONE epsilon draw for the whole batch."""
+        if not (0.0 <= epsilon <= 1.0):
+            raise DQNFatal("CHECK failed: epsilon >= 0.0 && epsilon <= 1.0")
+        s = _f32(states_batch).reshape(-1, self.state_size_)
+        if self.random_engine.uniform(0.0, 1.0) < epsilon:
+            return np.stack([self.GetRandomActorOutput() for _ in range(s.shape[0])])
+        return self.SelectActionGreedily(s)
+
+    def SelectAction(self, input_states, epsilon):
+        return self.SelectActions(np.asarray(input_states, np.float32).reshape(1, -1), epsilon)[0]
+
+    def CriticForward(self, states_batch, action_batch, net=CRITIC):
+        s = _f32(states_batch).reshape(-1, self.state_size_)
+        a = _f32(action_batch).reshape(-1, 10)
+        if s.shape[0] != a.shape[0]:
+            raise DQNFatal("CHECK_EQ(states_batch.size(), action_batch.size())")
+        q = np.empty(s.shape[0], np.float32)
+        self._ck(self.lib.dqnhip_critic_forward(self.h, net, _p(s), _p(a), s.shape[0], _p(q)))
+        return q
+
+    def EvaluateAction(self, input_states, action):
+        """src/dqn.cpp:688-693."""
+        return float(self.CriticForward(np.asarray(input_states).reshape(1, -1), np.asarray(action).reshape(1, -1))[0])
+
+    # -- the update (src/dqn.cpp:799-972) ---------------------------------------------------------
+    def UpdateActorCritic(self, idx=None):
+        """One update; idx = explicit sampled indices or None for on-device
+        sampling.  Returns (critic_loss, avg_q) like the reference."""
+        loss, avgq = C.c_float(), C.c_float()
+        ip = None
+        if idx is not None:
+            i = np.ascontiguousarray(idx, dtype=np.int32)
+            if i.size != self.kMinibatchSize:
+                raise DQNFatal("need %d indices" % self.kMinibatchSize)
+            ip = i.ctypes.data_as(capi.ip)
+        self._ck(self.lib.dqnhip_update(self.h, ip, C.byref(loss), C.byref(avgq)))
+        return loss.value, avgq.value
+
+    def update_async(self, idx=None):
+        ip = None
+        if idx is not None:
+            i = np.ascontiguousarray(idx, dtype=np.int32)
+            ip = i.ctypes.data_as(capi.ip)
+        self._ck(self.lib.dqnhip_update_async(self.h, ip))
+
+    def update_phase(self, phase, idx=None):
+        ip = None
+        if idx is not None:
+            i = np.ascontiguousarray(idx, dtype=np.int32)
+            ip = i.ctypes.data_as(capi.ip)
+        self._ck(self.lib.dqnhip_update_phase(self.h, phase, ip))
+
+    def read_stats(self):
+        loss, avgq = C.c_float(), C.c_float()
+        self._ck(self.lib.dqnhip_read_stats(self.h, C.byref(loss), C.byref(avgq)))
+        return loss.value, avgq.value
+
+    def Update(self, loss_display_iter=1000):
+        """src/dqn.cpp:799-826 (snapshotting is in snapshot.py)."""
+        if self.memory_size() < self.memory_threshold:
+            return None
+        critic_loss, avg_q = self.UpdateActorCritic()
+        logs = []
+        if self.critic_iter() % loss_display_iter == 0:
+            logs.append("[Agent%d] Critic Iteration %d, loss = %g" % (self.tid_, self.critic_iter(), self.smoothed_critic_loss_))
+            self.smoothed_critic_loss_ = 0.0
+        self.smoothed_critic_loss_ += critic_loss / float(loss_display_iter)
+        if self.actor_iter() % loss_display_iter == 0:
+            logs.append("[Agent%d] Actor Iteration %d, avg_q_value = %g" % (self.tid_, self.actor_iter(), self.smoothed_actor_loss_))
+            self.smoothed_actor_loss_ = 0.0
+        self.smoothed_actor_loss_ += avg_q / float(loss_display_iter)
+        for line in logs:
+            print(line)
+        return critic_loss, avg_q
+
+    def Benchmark(self, iterations=1000, warmup=0):
+        """src/dqn.cpp:487-498; returns the average update time in ms."""
+        ms = C.c_float()
+        self._ck(self.lib.dqnhip_benchmark(self.h, warmup, iterations, C.byref(ms)))
+        return ms.value
+
+    # -- parameters ------------------------------------------------------------------------------------
+    def param_count(self, net):
+        n = C.c_size_t()
+        self._ck(self.lib.dqnhip_param_count(self.h, net, C.byref(n)))
+        return n.value
+
+    def get_params(self, net, kind=KIND_W):
+        out = np.empty(self.param_count(net), np.float32)
+        self._ck(self.lib.dqnhip_get_params(self.h, net, kind, _p(out), out.size))
+        return out
+
+    def set_params(self, net, arr, kind=KIND_W):
+        a = _f32(arr)
+        self._ck(self.lib.dqnhip_set_params(self.h, net, kind, _p(a), a.size))
+
+    def CloneNet(self, net):
+        """src/dqn.cpp:1022-1035: hard copy online -> target."""
+        self._ck(self.lib.dqnhip_clone_to_target(self.h, net))
+
+    def debug_read(self, name):
+        B = self.kMinibatchSize
+        wide = name in ("actor_out", "dq_da")
+        out = np.empty(B * (10 if wide else 1), np.float32)
+        self._ck(self.lib.dqnhip_debug_read(self.h, name.encode(), _p(out), out.size))
+        return out.reshape(B, 10) if wide else out
+
+    def grad_buffer(self, net):
+        ptr, n = C.c_void_p(), C.c_size_t()
+        self._ck(self.lib.dqnhip_grad_buffer(self.h, net, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def stream(self):
+        s = C.c_void_p()
+        self._ck(self.lib.dqnhip_get_stream(self.h, C.byref(s)))
+        return s.value
+
+    def set_kernel_timing(self, enable):
+        self._ck(self.lib.dqnhip_set_kernel_timing(self.h, int(enable)))
+
+    def kernel_timing(self, family, reset=False):
+        ms, n = C.c_float(), C.c_int64()
+        self._ck(self.lib.dqnhip_get_kernel_timing(self.h, family.encode(), C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value

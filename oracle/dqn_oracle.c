@@ -243,11 +243,26 @@ static void net_backward(const orc_layout *l, const float *w, float *g, float **
  * Reached from critic_solver_->Step(1) (src/dqn.cpp:904) and
  * actor_solver_->ApplyUpdate() (src/dqn.cpp:964).  iter is the value BEFORE
  * the increment (t = iter + 1). */
-static void solver_apply(size_t P, float *w, float *g, float *m, float *v, int iter,
+static void solver_apply(const orc_layout *l, float *w, float *g, float *m, float *v, int iter,
                          float lr, const orc_config *c) {
+  const size_t P = l->count;
   if (c->clip >= 0.0f) {
+    /* ClipGradients: sumsq_diff += net_params[i]->sumsq_diff() — one cblas_sdot per
+     * param blob, accumulated over blobs in Dtype.  The summation order inside sdot
+     * is BLAS-implementation-defined, so each blob's sum is taken in double (the
+     * limit every reasonable order converges to) and rounded to float once. */
     float sumsq = 0.0f;
-    for (size_t i = 0; i < P; ++i) sumsq = fmaf(g[i], g[i], sumsq);
+    const int nblob = l->L + l->n_heads;
+    for (int i = 0; i < nblob; ++i) {
+      const int rows = i < l->L ? l->dims[i + 1] : l->head_out[i - l->L];
+      const int cols = i < l->L ? l->dims[i] : l->dims[l->L];
+      double sw = 0.0, sb = 0.0;
+      const float *gw = g + l->w_off[i], *gb = g + l->b_off[i];
+      for (size_t e = 0; e < (size_t)rows * cols; ++e) sw += (double)gw[e] * (double)gw[e];
+      for (int e = 0; e < rows; ++e) sb += (double)gb[e] * (double)gb[e];
+      sumsq += (float)sw;
+      sumsq += (float)sb;
+    }
     const float l2 = sqrtf(sumsq);
     if (l2 > c->clip) {
       const float s = c->clip / l2;
@@ -491,7 +506,7 @@ static inline float invert_grad(float diff, float output, float mn, float mx) {
  * SampleTransitionsFromMemory, src/dqn.cpp:501-509). */
 int orc_update_phase(orc *o, int phase, const int32_t *idx) {
   const orc_config *c = &o->cfg;
-  const int B = c->B, S = c->S, L = c->L;
+  const int B = c->B, S = c->S;
   const orc_layout *la = &o->la, *lc = &o->lc;
   const int Kc = lc->in_dim;
   if (phase == 0) {
@@ -547,7 +562,7 @@ int orc_update_phase(orc *o, int phase, const int32_t *idx) {
   }
   if (phase == 1) {
     /* rest of Step(1): clip, Adam, update, ++iter */
-    solver_apply(lc->count, o->w[1], o->g[1], o->m[1], o->v[1], o->iter[1], c->lr_critic, c);
+    solver_apply(lc, o->w[1], o->g[1], o->m[1], o->v[1], o->iter[1], c->lr_critic, c);
     o->iter[1] += 1;
     o->last_loss = o->tail[1][0];
     if (!isfinite(o->last_loss)) return 4; /* CHECK(isfinite(critic_loss)) :906 */
@@ -595,7 +610,7 @@ int orc_update_phase(orc *o, int phase, const int32_t *idx) {
   }
   if (phase == 2) {
     /* actor_solver_->ApplyUpdate(); set_iter(iter+1) (src/dqn.cpp:964-965) */
-    solver_apply(la->count, o->w[0], o->g[0], o->m[0], o->v[0], o->iter[0], c->lr_actor, c);
+    solver_apply(la, o->w[0], o->g[0], o->m[0], o->v[0], o->iter[0], c->lr_actor, c);
     o->iter[0] += 1;
     /* soft target update (src/dqn.cpp:967-970) */
     const int mx = o->iter[0] > o->iter[1] ? o->iter[0] : o->iter[1];
