@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py — DQN updates/sec on MI355X (BASELINE.json metric), with the kernel roofline
+and the CPU baseline timed beside it.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one DQN::UpdateActorCritic (reference src/dqn.cpp:828-972): on-device sampling
++ minibatch gather from the device-resident replay, 5 tower forwards, 3 backwards, TD
+target, 2x (clip + Adam), 2x soft target update.  Workload = BASELINE.json configs[1]:
+1v0 HFO, 4x1024 actor/critic MLP, minibatch 256, replay 1M transitions resident in HBM,
+58-dim synthetic states.  N > 1: data-parallel weak scaling — every rank keeps its own
+replay shard and a 256-row local minibatch (global minibatch 256*N), gradients summed by
+RCCL all-reduce; value is reported in minibatch-256 updates/s (= N x global updates/s).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from __graft_entry__ import load_package  # noqa: E402
+
+HIDDEN = (1024, 1024, 1024, 1024)
+B = 256
+S = 58
+REPLAY = 1_000_000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+
+def tower_weights(in_dim, hidden):
+    dims = (in_dim,) + tuple(hidden)
+    return [dims[i] * dims[i + 1] for i in range(len(hidden))]
+
+
+def family_flops(B, S, hidden):
+    """Algorithmic GEMM FLOPs per update, per kernel family (tower layers only; the skinny
+    heads are separate kernels).  See DESIGN.md §roofline."""
+    wa = tower_weights(S, hidden)
+    wc = tower_weights(S + 10, hidden)
+    h1 = hidden[0]
+    fwd = 2 * B * (2 * sum(wa) + 3 * sum(wc))
+    wgrad = 2 * B * (sum(wa) + sum(wc))
+    dgrad = 2 * B * (sum(wc[1:])            # critic train: dX down to layer 2's input
+                     + sum(wc[1:]) + 10 * h1  # critic dQ/da: layer 1 needs only the 10 action columns
+                     + sum(wa[1:]))         # actor
+    return {"gemm_fwd": fwd, "gemm_dgrad": dgrad, "gemm_wgrad": wgrad}
+
+
+def prefill(dqn, n, seed, chunk=131072):
+    from synth import synth_replay
+    rng = np.random.default_rng(seed)
+    done = 0
+    while done < n:
+        m = min(chunk, n - done)
+        dqn.add_transitions_arrays(*synth_replay(rng, m, S))
+        done += m
+
+
+def cpu_baseline(budget_s=12.0):
+    """CPU stand-ins for 'the reference Caffe CPU solver' (which cannot be built here:
+    Caffe/HFO/boost/glog/gflags/protobuf are absent): (A) the C restatement
+    executing the reference's op sequence incl. its wasted work, OpenMP on all cores;
+    (B) the same sequence in PyTorch-CPU fp32 (MKL/oneDNN GEMMs).  Bounded sample."""
+    from oracle import c_oracle, torch_ref
+    from synth import synth_replay
+    import torch
+    rng = np.random.default_rng(11)
+    cores = os.cpu_count() or 1
+    n_rep = 8192
+    data = synth_replay(rng, n_rep, S)
+    wts = [torch_ref.init_params_np(rng, S, HIDDEN, a) for a in (True, False)]
+    res = {}
+    # (A) C port
+    orc = c_oracle.Oracle(B=B, S=S, hidden=HIDDEN, capacity=n_rep + 1, mirror_waste=1)
+    for net in (0, 1):
+        orc.set_params(net, wts[net]); orc.clone_to_target(net)
+    orc.add_transitions(*data)
+    orc.update(rng.integers(0, n_rep, size=B))      # warm-up
+    t0 = time.perf_counter(); n = 0
+    while n < 3 or time.perf_counter() - t0 < budget_s / 2:
+        orc.update(rng.integers(0, n_rep, size=B)); n += 1
+    res["c_port_openmp"] = n / (time.perf_counter() - t0)
+    orc.close()
+    # (B) torch fp32
+    torch.set_num_threads(cores)
+    t = torch_ref.TorchRef(B=B, S=S, hidden=HIDDEN, dtype=torch.float32)
+    for net in (0, 1):
+        t.set_params(net, wts[net]); t.set_params(net + 2, wts[net])
+    s, a, r, mc, nx, term = data
+    def one():
+        idx = rng.integers(0, n_rep, size=B)
+        t.update(s[idx], a[idx], r[idx], mc[idx], nx[idx], term[idx])
+    one()
+    t0 = time.perf_counter(); n = 0
+    while n < 3 or time.perf_counter() - t0 < budget_s / 2:
+        one(); n += 1
+    res["torch_cpu_fp32"] = n / (time.perf_counter() - t0)
+    best = max(res, key=res.get)
+    return {"value": round(res[best], 3), "unit": "updates/s", "cores": cores, "kind": "port",
+            "sample": "%s: ~%.0f s of B=256 4x1024 updates on an 8192-transition replay, reference op "
+                      "sequence incl. its discarded critic wgrad; faster of %s" % (
+                          best, budget_s / 2, json.dumps({k: round(v, 3) for k, v in res.items()})),
+            "note": "stand-in: the reference's Caffe CPU solver cannot be built in this image"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--replay", type=int, default=REPLAY)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],
+                    help="N>1: dp = gradient all-reduce (weak scaling), replicas = independent learners")
+    args = ap.parse_args()
+
+    import torch
+    pkg = load_package()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    use_dp = world > 1 and args.mode == "dp"
+    if use_dp:
+        from importlib import import_module
+        par = import_module("dqn_hfo_amd.parallel")
+        dqn, dp = par.make_hip_data_parallel(pkg, S, rank, world, local_rank, minibatch=B, hidden=HIDDEN,
+                                             memory=args.replay, seed=1 + rank)
+        step = lambda: dp.update(None)
+    else:
+        dqn = pkg.DQN(S, minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1 + rank, device=local_rank,
+                      use_graph=not args.no_graph)
+        step = lambda: dqn.update_async(None)
+    prefill(dqn, args.replay - 1, seed=100 + rank)     # AddTransitions keeps <= capacity-1 (src/dqn.cpp:776)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    loss, avgq = dqn.read_stats()
+
+    # roofline of the dominant kernel family, timed live with HIP events on the learner's stream
+    roof = None
+    if rank == 0:
+        fam_flops = family_flops(B, S, HIDDEN)
+        dqn.set_kernel_timing(True)
+        n_t = 20
+        for _ in range(n_t):
+            step()
+        stats = {}
+        for fam in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "adam"):
+            ms, cnt = dqn.kernel_timing(fam)
+            stats[fam] = (ms, cnt)
+        dqn.kernel_timing("adam", reset=True)
+        dqn.set_kernel_timing(False)
+        dom = max(("gemm_fwd", "gemm_dgrad", "gemm_wgrad"), key=lambda f: stats[f][0] * stats[f][1])
+        ms, cnt = stats[dom]
+        per_update_launches = cnt / n_t
+        flops_per_launch = fam_flops[dom] / per_update_launches
+        ach = flops_per_launch / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                "avg_launch_us": round(ms * 1e3, 2), "launches_per_update": per_update_launches,
+                "flops_per_launch": flops_per_launch,
+                "families_us": {f: [round(stats[f][0] * 1e3, 2), stats[f][1] / n_t] for f in stats}}
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        ups = args.steps / elapsed
+        value = ups * (world if world > 1 else 1)
+        fl = sum(family_flops(B, S, HIDDEN).values())
+        out = {
+            "metric": "DQN updates/sec, 1v0 HFO, 4x1024 MLP, minibatch 256",
+            "value": round(value, 2), "unit": "updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: 1v0 HFO, 1 MI355X, 4x1024 actor-critic MLP, "
+                                   "minibatch 256, device-resident replay %d transitions, 58-dim synthetic states"
+                                   % args.replay,
+                       "minibatch_per_gpu": B, "global_minibatch": B * (world if use_dp else 1),
+                       "parallelism": ("dp%d (RCCL all-reduce of critic then actor gradients); value counts "
+                                       "minibatch-256 updates" % world) if use_dp else
+                                      ("replicas x%d" % world if world > 1 else "single"),
+                       "hip_graph": (not args.no_graph) and not use_dp,
+                       "sampling": "on-device Philox, uniform with replacement"},
+            "update_gflop": round(fl / 1e9, 3),
+            "update_mfma_frac": round(fl * ups / 1e12 / MFMA_F32_PEAK_TF, 4),
+            "last_critic_loss": loss, "last_avg_q": avgq,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    dqn.close()
+
+
+if __name__ == "__main__":
+    main()

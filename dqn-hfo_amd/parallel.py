@@ -1,0 +1,56 @@
+"""Data-parallel form of the update: one process per GPU, gradients summed with
+torch.distributed (backend "nccl" == RCCL over xGMI on ROCm).
+
+The reference has no collective at all (threads + a mutex, src/dqn_main.cpp:62-63,
+359-363); this is the MI355X-native addition of SURVEY.md §8e.  The update has exactly
+two exchange points — after the critic backward and after the actor backward — because
+the actor step reads the UPDATED critic (src/dqn.cpp:904 -> 914).  Each rank gathers its
+own minibatch slice from its own replay shard, so no data-path collective exists; the
+EuclideanLoss normaliser is the GLOBAL batch, the actor gradient is an un-normalised sum
+(src/dqn.cpp:918-921), hence a plain sum all-reduce reproduces the single-GPU update up
+to summation order.  The clip norm is taken on the reduced gradient, so every rank
+applies the identical Adam step and the replicas never diverge.
+
+`backend` is anything with update_phase(phase, idx) — the HIP learner on the GPU, a
+stand-in in the CPU/gloo tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallelUpdate:
+    def __init__(self, backend, critic_grad, actor_grad, group=None):
+        self.backend = backend
+        self.critic_grad = critic_grad      # flat view: critic gradient arena + [loss_sum, q_sum, 0, 0]
+        self.actor_grad = actor_grad
+        self.group = group
+
+    def update(self, idx=None):
+        b = self.backend
+        b.update_phase(0, idx)
+        dist.all_reduce(self.critic_grad, op=dist.ReduceOp.SUM, group=self.group)
+        b.update_phase(1, None)
+        dist.all_reduce(self.actor_grad, op=dist.ReduceOp.SUM, group=self.group)
+        b.update_phase(2, None)
+
+
+def make_hip_data_parallel(pkg, state_size, rank, world, device, group=None, **dqn_kwargs):
+    """Build a HIP learner whose gradient arenas live in a torch tensor (so RCCL can reduce
+    them in place) and which enqueues on torch's current stream (so collectives and kernels
+    are ordered by the stream, no host sync)."""
+    torch.cuda.set_device(device)
+    hidden = dqn_kwargs.get("hidden", (1024, 512, 256, 128))
+    B = dqn_kwargs.get("minibatch", 32)
+    nbytes = pkg.DQN.grad_arena_bytes(state_size, B, hidden)
+    arena = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda:%d" % device)
+    stream = torch.cuda.current_stream().cuda_stream
+    dqn = pkg.DQN(state_size, device=device, dp_world=world, dp_rank=rank, stream=stream,
+                  grad_arena=arena.data_ptr(), grad_arena_bytes=nbytes, **dqn_kwargs)
+    views = []
+    for net in (pkg.ACTOR, pkg.CRITIC):
+        ptr, n = dqn.grad_buffer(net)
+        off = (ptr - arena.data_ptr()) // 4
+        views.append(arena[off:off + n])
+    dp = DataParallelUpdate(dqn, critic_grad=views[1], actor_grad=views[0], group=group)
+    dp.arena = arena       # keep the storage alive
+    return dqn, dp
