@@ -1,0 +1,205 @@
+// gemm_bench.hip — dqnhip_test_gemm: correctness + timing harness for the GEMM kernel
+// families (include/dqnhip_internal.h).  Test/tuning infrastructure, not on the hot path.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#include "../../include/dqnhip_internal.h"
+#include "gemm_direct.hip.h"
+#include "gemm_mfma.hip.h"
+
+using namespace dqnhip;
+
+namespace {
+
+__global__ void k_fill(float* p, size_t n, uint32_t seed, float lo, float hi) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = lo + (hi - lo) * (float)(x >> 8) * (1.0f / 16777216.0f);
+  }
+}
+__global__ void k_ref_fwd(const float* X, const float* W, const float* b, float* Y, int M, int N, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int m = i / N, n = i % N;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf(X[(size_t)m * K + k], W[(size_t)n * K + k], acc);
+  Y[i] = lrelu_fwd(acc + b[n]);
+}
+__global__ void k_ref_dgrad(const float* dY, const float* W, const float* A, float* dX, int M, int N, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * K) return;
+  const int m = i / K, k = i % K;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) acc = fmaf(dY[(size_t)m * N + n], W[(size_t)n * K + k], acc);
+  dX[i] = acc * lrelu_mask(A[i]);
+}
+__global__ void k_ref_wgrad(const float* dY, const float* X, float* dW, float* db, int M, int N, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * K) return;
+  const int n = i / K, k = i % K;
+  float acc = 0.f, bs = 0.f;
+  for (int m = 0; m < M; ++m) { acc = fmaf(dY[(size_t)m * N + n], X[(size_t)m * K + k], acc); bs += dY[(size_t)m * N + n]; }
+  dW[i] = acc;
+  if (k == 0) db[n] = bs;
+}
+__global__ void k_maxdiff(const float* a, const float* b, size_t n, float* out /*[2]*/) {
+  __shared__ float sd[256], sr[256];
+  float d = 0.f, r = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 256) { d = fmaxf(d, fabsf(a[i] - b[i])); r = fmaxf(r, fabsf(b[i])); }
+  sd[threadIdx.x] = d; sr[threadIdx.x] = r;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sd[threadIdx.x] = fmaxf(sd[threadIdx.x], sd[threadIdx.x + s]); sr[threadIdx.x] = fmaxf(sr[threadIdx.x], sr[threadIdx.x + s]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = fmaxf(out[0], sd[0]); out[1] = fmaxf(out[1], sr[0]); }
+}
+
+// pure MFMA issue-rate probe: NACC independent accumulators, no memory traffic in the loop
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_peak(float* out, int iters, float a0, float b0) {
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float a = a0 + threadIdx.x * 1e-3f, b = b0 - threadIdx.x * 1e-3f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < NACC; ++e) acc[e] = DQN_MFMA(a, b, acc[e]);
+  }
+  f32x4 r = acc[0];
+#pragma unroll
+  for (int e = 1; e < NACC; ++e) { r.x += acc[e].x; r.y += acc[e].y; r.z += acc[e].z; r.w += acc[e].w; }
+  reinterpret_cast<f32x4*>(out)[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+#define CK(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { fprintf(stderr, "dqnhip_test_gemm: %s -> %s\n", #e, hipGetErrorString(e__)); return 2; } } while (0)
+
+hipError_t launch_variant(int mode, int variant, GemmBatch& b, hipStream_t s) {
+  // variant 0: LDS-staged family (gemm_mfma.hip.h); 1..: direct family (gemm_direct.hip.h)
+  if (mode == GEMM_FWD) {
+    switch (variant) {
+      case 0: return gemm_launch<GEMM_FWD, 64, 32, 2, 2>(b, s);
+      case 1: return fwd_direct_launch<2, 2>(b, s);   // 32x32
+      case 2: return fwd_direct_launch<4, 2>(b, s);   // 64x32
+      case 3: return fwd_direct_launch<2, 1>(b, s);   // 32x16
+      case 4: return fwd_direct_launch<4, 4>(b, s);   // 64x64
+      case 5: return direct_launch(gemm_fwd_direct<2, 2, 1>, b, 32, 32, 4 * 4 * 64 * 16, s);  // ablation: no loads in loop
+      case 6: return direct_launch(gemm_fwd_direct<2, 2, 2>, b, 32, 32, 4 * 4 * 64 * 16, s);  // ablation: no MFMA
+      case 7: return direct_launch(gemm_fwd_direct<4, 4, 1>, b, 64, 64, 4 * 16 * 64 * 16, s);
+      case 8: return direct_launch(gemm_fwd_direct<4, 4, 2>, b, 64, 64, 4 * 16 * 64 * 16, s);
+    }
+  } else if (mode == GEMM_DGRAD) {
+    switch (variant) {
+      case 0: return gemm_launch<GEMM_DGRAD, 64, 32, 2, 2>(b, s);
+      case 1: return dgrad_direct_launch<1, 1>(b, s);  // 64x16
+      case 2: return dgrad_direct_launch<1, 2>(b, s);  // 64x32
+      case 3: return dgrad_direct_launch<2, 1>(b, s);  // 128x16
+      case 4: return dgrad_direct_launch<1, 4>(b, s);  // 64x64
+    }
+  } else {
+    switch (variant) {
+      case 0: return gemm_launch<GEMM_WGRAD, 64, 64, 2, 2>(b, s);
+      case 1: return wgrad_direct_launch<1, 1>(b, s);  // 64x64
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+extern "C" int dqnhip_test_gemm(int32_t mode, int32_t variant, int32_t rows, int32_t n_out, int32_t k_in,
+                                int32_t groups, int32_t iters, float* avg_us, float* max_abs_err, float* max_ref) {
+  if (mode == 99) {   // MFMA peak probe: variant = accumulators per wave, rows = blocks, n_out = loop iterations
+    hipStream_t s; CK(hipStreamCreate(&s));
+    float* out; CK(hipMalloc(&out, (size_t)rows * 256 * 16));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0, s));
+      for (int i = 0; i < iters; ++i) {
+        if (variant == 1) hipLaunchKernelGGL(k_mfma_peak<1>, dim3(rows), dim3(256), 0, s, out, n_out, 0.5f, 0.25f);
+        else if (variant == 2) hipLaunchKernelGGL(k_mfma_peak<2>, dim3(rows), dim3(256), 0, s, out, n_out, 0.5f, 0.25f);
+        else hipLaunchKernelGGL(k_mfma_peak<4>, dim3(rows), dim3(256), 0, s, out, n_out, 0.5f, 0.25f);
+      }
+      CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    }
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (avg_us) *avg_us = ms * 1000.0f / iters;
+    hipFree(out); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+    return 0;
+  }
+  if (groups < 1 || groups > kMaxGroup || iters < 1) return 1;
+  static bool prepared = false;
+  if (!prepared) {
+    CK((gemm_prepare<GEMM_FWD, 64, 32, 2, 2>())); CK((gemm_prepare<GEMM_DGRAD, 64, 32, 2, 2>()));
+    CK((gemm_prepare<GEMM_WGRAD, 64, 64, 2, 2>()));
+    CK(direct_prepare(gemm_wgrad_direct<1, 1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
+    CK(direct_prepare(gemm_fwd_direct<4, 4>, 4 * 16 * 64 * 16));
+    CK(direct_prepare(gemm_fwd_direct<4, 4, 1>, 4 * 16 * 64 * 16)); CK(direct_prepare(gemm_fwd_direct<4, 4, 2>, 4 * 16 * 64 * 16));
+    CK(direct_prepare(gemm_dgrad_direct<1, 4>, 4 * 16 * 64 * 16));
+    prepared = true;
+  }
+  hipStream_t s; CK(hipStreamCreate(&s));
+  const int M = rows, N = n_out, K = k_in;
+  const size_t nX = (size_t)M * K, nW = (size_t)N * K, nY = (size_t)M * N;
+  std::vector<float*> X(groups), W(groups), Yv(groups), bias(groups), out(groups), ref(groups), db(groups), dbref(groups), part(groups);
+  const size_t nOut = mode == GEMM_FWD ? nY : mode == GEMM_DGRAD ? nX : nW;
+  for (int g = 0; g < groups; ++g) {
+    CK(hipMalloc(&X[g], nX * 4)); CK(hipMalloc(&W[g], nW * 4)); CK(hipMalloc(&Yv[g], nY * 4));
+    CK(hipMalloc(&bias[g], N * 4)); CK(hipMalloc(&out[g], nOut * 4)); CK(hipMalloc(&ref[g], nOut * 4));
+    CK(hipMalloc(&db[g], N * 4)); CK(hipMalloc(&dbref[g], N * 4)); CK(hipMalloc(&part[g], 65536 * 4));
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, X[g], nX, 11u + g, -1.f, 1.f);
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, W[g], nW, 23u + g, -1.f, 1.f);
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, Yv[g], nY, 37u + g, -1.f, 1.f);
+    hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, s, bias[g], (size_t)N, 41u + g, -1.f, 1.f);
+    CK(hipMemsetAsync(out[g], 0xff, nOut * 4, s));
+  }
+  GemmBatch b{}; b.n = groups;
+  for (int g = 0; g < groups; ++g) {
+    GemmProblem& p = b.prob[g];
+    if (mode == GEMM_FWD) {
+      p.P = W[g]; p.ldp = K; p.Q = X[g]; p.ldq = K; p.C = out[g]; p.ldc = N; p.Pdim = N; p.Qdim = M; p.Kred = K;
+      p.bias = bias[g]; p.relu = 1;
+    } else if (mode == GEMM_DGRAD) {
+      p.P = W[g]; p.ldp = K; p.Q = Yv[g]; p.ldq = N; p.C = out[g]; p.ldc = K; p.Pdim = K; p.Qdim = M; p.Kred = N;
+      p.mask = X[g]; p.ldm = K;
+    } else {
+      p.P = X[g]; p.ldp = K; p.Q = Yv[g]; p.ldq = N; p.C = out[g]; p.ldc = K; p.Pdim = K; p.Qdim = N; p.Kred = M;
+      p.db = db[g]; p.partial = part[g];
+    }
+  }
+  for (int i = 0; i < 3; ++i) CK(launch_variant(mode, variant, b, s));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipStreamSynchronize(s));
+  CK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) CK(launch_variant(mode, variant, b, s));
+  CK(hipEventRecord(e1, s));
+  CK(hipEventSynchronize(e1));
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+  if (avg_us) *avg_us = ms * 1000.0f / iters;
+  // reference + compare
+  float* dres; CK(hipMalloc(&dres, 8)); CK(hipMemsetAsync(dres, 0, 8, s));
+  for (int g = 0; g < groups; ++g) {
+    const int threads = 256;
+    if (mode == GEMM_FWD) hipLaunchKernelGGL(k_ref_fwd, dim3((nOut + 255) / 256), dim3(threads), 0, s, X[g], W[g], bias[g], ref[g], M, N, K);
+    else if (mode == GEMM_DGRAD) hipLaunchKernelGGL(k_ref_dgrad, dim3((nOut + 255) / 256), dim3(threads), 0, s, Yv[g], W[g], X[g], ref[g], M, N, K);
+    else hipLaunchKernelGGL(k_ref_wgrad, dim3((nOut + 255) / 256), dim3(threads), 0, s, Yv[g], X[g], ref[g], dbref[g], M, N, K);
+    hipLaunchKernelGGL(k_maxdiff, dim3(1), dim3(256), 0, s, out[g], ref[g], nOut, dres);
+    if (mode == GEMM_WGRAD) hipLaunchKernelGGL(k_maxdiff, dim3(1), dim3(256), 0, s, db[g], dbref[g], (size_t)N, dres);
+  }
+  float hres[2] = {0, 0};
+  CK(hipMemcpyAsync(hres, dres, 8, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  if (max_abs_err) *max_abs_err = hres[0];
+  if (max_ref) *max_ref = hres[1];
+  for (int g = 0; g < groups; ++g) {
+    hipFree(X[g]); hipFree(W[g]); hipFree(Yv[g]); hipFree(bias[g]); hipFree(out[g]); hipFree(ref[g]);
+    hipFree(db[g]); hipFree(dbref[g]); hipFree(part[g]);
+  }
+  hipFree(dres); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+  return 0;
+}

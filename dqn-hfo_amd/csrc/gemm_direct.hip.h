@@ -1,0 +1,400 @@
+// gemm_direct.hip.h — "direct-to-register, split-K-across-waves" fp32 MFMA GEMMs
+// for the small-M (minibatch 32..4096) layers of the actor/critic towers.
+//
+// Why a second family: at M = 256 a 1024x1024 layer is only 0.54 GFLOP.  An
+// LDS-staged tile kernel (gemm_mfma.hip.h) needs one workgroup barrier per K
+// tile and can only offer 128-256 workgroups; measured 16-25 us per layer
+// (profiles/r01_v1_*).  Here instead:
+//   * every output tile is computed by ONE workgroup of 4 waves, each wave
+//     accumulating the WHOLE tile over its own quarter of the reduction
+//     range (in-workgroup split-K).  The waves never synchronise in the main
+//     loop — four independent load->MFMA pipelines per CU, one per SIMD;
+//   * operands go global/L2 -> VGPR directly in MFMA fragment layout with
+//     16-byte loads, no LDS round trip: a "k-contiguous" operand (KC) is read
+//     as float4 along k (4 consecutive k-steps of one row per lane); a
+//     "k-strided" operand (KS) is read as float4 along the free dimension
+//     (whole 256-B rows per 16 lanes) and its four components feed four
+//     interleaved MFMAs (output columns 4i+c);
+//   * a 4-deep register ring keeps >= 2048 MFMA-cycles of loads in flight;
+//   * one LDS pass at the end adds the four waves' partial tiles in fixed order
+//     (w0+w1)+(w2+w3) -> deterministic, no atomics; the epilogue (bias +
+//     leaky ReLU / ReLU' mask / bias-gradient + sum-of-squares partial) is
+//     applied by the wave that reduces the accumulator.
+// The smallest tiles (32x32 fwd, 64x16 dgrad, 64x64 wgrad) give 256
+// workgroups for ONE 256x1024x1024 layer, i.e. a single layer fills the chip.
+//
+// Same GemmProblem/GemmBatch interface and the same three modes as
+// gemm_mfma.hip.h (C[q][p] = sum_k P(p,k) Q(q,k), p contiguous).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gemm_mfma.hip.h"
+
+namespace dqnhip {
+
+// ---- shared pieces ----------------------------------------------------------------
+
+__device__ __forceinline__ void tile_of_block(const GemmBatch& batch, int& pi, int& tile_p, int& tile_q) {
+  int b = blockIdx.x;
+  pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < batch.n && b >= batch.prob[i].tile_base) pi = i;
+  const GemmProblem& pr = batch.prob[pi];
+  b -= pr.tile_base;
+  if ((pr.tiles_p & 7) == 0) {       // same P panel (weight slice) -> same XCD L2 (b % 8)
+    const int xcd = b & 7, j = b >> 3;
+    tile_q = j % pr.tiles_q;
+    tile_p = (j / pr.tiles_q) * 8 + xcd;
+  } else {
+    tile_q = b % pr.tiles_q;
+    tile_p = b / pr.tiles_q;
+  }
+}
+
+// Each wave parks its NACC accumulators in LDS (lane-linear: conflict free), then wave w
+// returns, for every accumulator e with (e & 3) == w, the fixed-order sum over the 4 waves.
+template <int NACC>
+__device__ __forceinline__ void park_accumulators(float* smem, const f32x4 (&acc)[NACC], int wave, int lane) {
+  f32x4* s = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) s[(wave * NACC + e) * 64 + lane] = acc[e];
+}
+template <int NACC>
+__device__ __forceinline__ f32x4 reduce_accumulator(const float* smem, int e, int lane) {
+  const f32x4* s = reinterpret_cast<const f32x4*>(smem);
+  const f32x4 a0 = s[(0 * NACC + e) * 64 + lane], a1 = s[(1 * NACC + e) * 64 + lane];
+  const f32x4 a2 = s[(2 * NACC + e) * 64 + lane], a3 = s[(3 * NACC + e) * 64 + lane];
+  f32x4 r;
+  r.x = (a0.x + a1.x) + (a2.x + a3.x); r.y = (a0.y + a1.y) + (a2.y + a3.y);
+  r.z = (a0.z + a1.z) + (a2.z + a3.z); r.w = (a0.w + a1.w) + (a2.w + a3.w);
+  return r;
+}
+
+#define DQN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// hipcc otherwise sinks every prefetch load below the whole MFMA block of an iteration
+// (collapsing the register ring: measured); pin the COMPUTE/LOAD interleave.
+#define DQN_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// ================================ FWD ================================================
+// Y[m][n] = lrelu(sum_k X[m][k] W[n][k] + b[n]).  P = W (KC, 16-row blocks), Q = X (KC).
+// Tile = (16*TP) x (16*TQ).  Kred % 64 == 0.
+template <int TP, int TQ, int ABL = 0>
+__global__ __launch_bounds__(256) void gemm_fwd_direct(const GemmBatch batch) {
+  constexpr int NACC = TP * TQ;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  const GemmProblem& pr = batch.prob[pi];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int p0 = tile_p * 16 * TP, q0 = tile_q * 16 * TQ;
+  const int Kw = pr.Kred >> 2;              // this wave's share of the reduction
+  const int nkb = Kw >> 4;                  // 16-wide k blocks
+  const float* pp[TP];
+  const float* qp[TQ];
+#pragma unroll
+  for (int c = 0; c < TP; ++c) pp[c] = pr.P + (size_t)(p0 + c * 16 + li) * pr.ldp + wave * Kw + lg * 4;
+#pragma unroll
+  for (int a = 0; a < TQ; ++a) qp[a] = pr.Q + (size_t)(q0 + a * 16 + li) * pr.ldq + wave * Kw + lg * 4;
+
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 rp[4][TP], rq[4][TQ];
+
+#define FWD_LOAD(slot, kb)                                                              \
+  if (ABL != 1 || (kb) < 4) {                                                           \
+    _Pragma("unroll") for (int c = 0; c < TP; ++c)                                      \
+        rp[slot][c] = *reinterpret_cast<const f32x4*>(pp[c] + ((kb) << 4));            \
+    _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
+        rq[slot][a] = *reinterpret_cast<const f32x4*>(qp[a] + ((kb) << 4));            \
+  }
+#define FWD_COMPUTE(slot)                                                               \
+  if (ABL != 2) {                                                                       \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
+    _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
+    _Pragma("unroll") for (int c = 0; c < TP; ++c)                                      \
+        acc[a * TP + c] = DQN_MFMA(rp[slot][c][s], rq[slot][a][s], acc[a * TP + c]);    \
+  } else {                                                                              \
+    _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
+    _Pragma("unroll") for (int c = 0; c < TP; ++c) {                                    \
+        acc[a * TP + c].x += rp[slot][c].x + rq[slot][a].y;                             \
+        acc[a * TP + c].y += rp[slot][c].z + rq[slot][a].w; }                           \
+  }
+
+  const int nkb4 = nkb & ~3;
+  if (nkb4 > 0) {
+    FWD_LOAD(0, 0) FWD_LOAD(1, 1) FWD_LOAD(2, 2) FWD_LOAD(3, 3)
+    int kb = 0;
+    for (; kb + 4 < nkb4; kb += 4) {
+      FWD_COMPUTE(0) DQN_PIN(); FWD_LOAD(0, kb + 4) DQN_PIN();
+      FWD_COMPUTE(1) DQN_PIN(); FWD_LOAD(1, kb + 5) DQN_PIN();
+      FWD_COMPUTE(2) DQN_PIN(); FWD_LOAD(2, kb + 6) DQN_PIN();
+      FWD_COMPUTE(3) DQN_PIN(); FWD_LOAD(3, kb + 7) DQN_PIN();
+    }
+    FWD_COMPUTE(0) FWD_COMPUTE(1) FWD_COMPUTE(2) FWD_COMPUTE(3)
+  }
+  for (int kb = nkb4; kb < nkb; ++kb) { FWD_LOAD(0, kb) FWD_COMPUTE(0) }
+#undef FWD_LOAD
+#undef FWD_COMPUTE
+
+  park_accumulators<NACC>(smem, acc, wave, lane);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) {
+    if ((e & 3) == wave) {
+      const int a = e / TP, c = e % TP;
+      f32x4 v = reduce_accumulator<NACC>(smem, e, lane);
+      const int q = q0 + a * 16 + li, p = p0 + c * 16 + (lg << 2);
+      if (pr.bias != nullptr) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(pr.bias + p);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      }
+      if (pr.relu) { v.x = lrelu_fwd(v.x); v.y = lrelu_fwd(v.y); v.z = lrelu_fwd(v.z); v.w = lrelu_fwd(v.w); }
+      *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
+    }
+  }
+}
+
+// ================================ DGRAD ==============================================
+// dX[m][j] = (sum_n dY[m][n] W[n][j]) * lrelu'(act[m][j]).  P = W (KS, 64-wide blocks of j),
+// Q = dY (KC, 16-row blocks of m).  Tile = (64*TPB) x (16*TQ).  Kred (= n) % 64 == 0.
+template <int TPB, int TQ>
+__global__ __launch_bounds__(256) void gemm_dgrad_direct(const GemmBatch batch) {
+  constexpr int NACC = TPB * 4 * TQ;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  const GemmProblem& pr = batch.prob[pi];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int p0 = tile_p * 64 * TPB, q0 = tile_q * 16 * TQ;
+  const int Kw = pr.Kred >> 2;
+  const int nkb = Kw >> 4;
+  // P rows are reduction indices: lane group lg owns n = base + kb*16 + 4*lg + s at step s
+  const float* pp = pr.P + (size_t)(wave * Kw + lg * 4) * pr.ldp + p0 + li * 4;
+  const float* qp[TQ];
+#pragma unroll
+  for (int a = 0; a < TQ; ++a) qp[a] = pr.Q + (size_t)(q0 + a * 16 + li) * pr.ldq + wave * Kw + lg * 4;
+  const size_t ldp = pr.ldp;
+
+  f32x4 acc[NACC];   // index ((a*TPB + b)*4 + pc)
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 rp[4][4][TPB], rq[4][TQ];
+
+#define DG_LOAD(slot, kb)                                                               \
+  {                                                                                     \
+    _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
+        rq[slot][a] = *reinterpret_cast<const f32x4*>(qp[a] + ((kb) << 4));            \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
+    _Pragma("unroll") for (int b = 0; b < TPB; ++b)                                     \
+        rp[slot][s][b] = *reinterpret_cast<const f32x4*>(pp + (size_t)(((kb) << 4) + s) * ldp + b * 64); \
+  }
+#define DG_COMPUTE(slot)                                                                \
+  {                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
+    _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
+    _Pragma("unroll") for (int b = 0; b < TPB; ++b)                                     \
+    _Pragma("unroll") for (int pc = 0; pc < 4; ++pc)                                    \
+        acc[(a * TPB + b) * 4 + pc] =                                                   \
+            DQN_MFMA(rp[slot][s][b][pc], rq[slot][a][s], acc[(a * TPB + b) * 4 + pc]);  \
+  }
+
+  const int nkb4 = nkb & ~3;
+  if (nkb4 > 0) {
+    DG_LOAD(0, 0) DG_LOAD(1, 1) DG_LOAD(2, 2) DG_LOAD(3, 3)
+    int kb = 0;
+    for (; kb + 4 < nkb4; kb += 4) {
+      DG_COMPUTE(0) DQN_PIN(); DG_LOAD(0, kb + 4) DQN_PIN();
+      DG_COMPUTE(1) DQN_PIN(); DG_LOAD(1, kb + 5) DQN_PIN();
+      DG_COMPUTE(2) DQN_PIN(); DG_LOAD(2, kb + 6) DQN_PIN();
+      DG_COMPUTE(3) DQN_PIN(); DG_LOAD(3, kb + 7) DQN_PIN();
+    }
+    DG_COMPUTE(0) DG_COMPUTE(1) DG_COMPUTE(2) DG_COMPUTE(3)
+  }
+  for (int kb = nkb4; kb < nkb; ++kb) { DG_LOAD(0, kb) DG_COMPUTE(0) }
+#undef DG_LOAD
+#undef DG_COMPUTE
+
+  park_accumulators<NACC>(smem, acc, wave, lane);
+  __syncthreads();
+  // accumulators (a,b,pc=0..3) form float4s over pc: reduce them as a group of 4
+#pragma unroll
+  for (int ab = 0; ab < TQ * TPB; ++ab) {
+    if ((ab & 3) == wave) {
+      const int a = ab / TPB, b = ab % TPB;
+      f32x4 r0 = reduce_accumulator<NACC>(smem, ab * 4 + 0, lane);
+      f32x4 r1 = reduce_accumulator<NACC>(smem, ab * 4 + 1, lane);
+      f32x4 r2 = reduce_accumulator<NACC>(smem, ab * 4 + 2, lane);
+      f32x4 r3 = reduce_accumulator<NACC>(smem, ab * 4 + 3, lane);
+      const int q = q0 + a * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = p0 + b * 64 + (lg << 4) + (r << 2);
+        f32x4 v = f32x4{r0[r], r1[r], r2[r], r3[r]};
+        if (pr.mask != nullptr) {
+          const f32x4 mv = *reinterpret_cast<const f32x4*>(pr.mask + (size_t)q * pr.ldm + p);
+          v.x *= lrelu_mask(mv.x); v.y *= lrelu_mask(mv.y); v.z *= lrelu_mask(mv.z); v.w *= lrelu_mask(mv.w);
+        }
+        *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
+      }
+    }
+  }
+}
+
+// ================================ WGRAD ==============================================
+// dW[n][j] = sum_m dY[m][n] X[m][j];  db[n] = sum_m dY[m][n].  P = X (KS, 64-wide blocks of
+// j), Q = dY (KS, 64-wide blocks of n).  Tile = (64*TPB) x (64*TQB).  Kred (= rows m) % 16 == 0.
+template <int TPB, int TQB>
+__global__ __launch_bounds__(256) void gemm_wgrad_direct(const GemmBatch batch) {
+  constexpr int NACC = TPB * 4 * TQB * 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  const GemmProblem& pr = batch.prob[pi];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int p0 = tile_p * 64 * TPB, q0 = tile_q * 64 * TQB;
+  const int Kw = pr.Kred >> 2;
+  const int nst = Kw >> 2;                 // steps of 4 rows
+  const float* pp = pr.P + (size_t)(wave * Kw + lg) * pr.ldp + p0 + li * 4;
+  const float* qp = pr.Q + (size_t)(wave * Kw + lg) * pr.ldq + q0 + li * 4;
+  const size_t ldp = pr.ldp, ldq = pr.ldq;
+  const bool want_db = (pr.db != nullptr) && (tile_p == 0);
+
+  f32x4 acc[NACC];   // index (((d*4 + qc)*TPB + b)*4 + pc)
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dbacc[TQB];
+#pragma unroll
+  for (int d = 0; d < TQB; ++d) dbacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 rp[4][TPB], rq[4][TQB];
+
+#define WG_LOAD(slot, st)                                                               \
+  {                                                                                     \
+    _Pragma("unroll") for (int b = 0; b < TPB; ++b)                                     \
+        rp[slot][b] = *reinterpret_cast<const f32x4*>(pp + (size_t)((st) << 2) * ldp + b * 64); \
+    _Pragma("unroll") for (int d = 0; d < TQB; ++d)                                     \
+        rq[slot][d] = *reinterpret_cast<const f32x4*>(qp + (size_t)((st) << 2) * ldq + d * 64); \
+  }
+#define WG_COMPUTE(slot)                                                                \
+  {                                                                                     \
+    _Pragma("unroll") for (int d = 0; d < TQB; ++d) {                                   \
+      dbacc[d].x += rq[slot][d].x; dbacc[d].y += rq[slot][d].y;                         \
+      dbacc[d].z += rq[slot][d].z; dbacc[d].w += rq[slot][d].w;                         \
+      _Pragma("unroll") for (int qc = 0; qc < 4; ++qc)                                  \
+      _Pragma("unroll") for (int b = 0; b < TPB; ++b)                                   \
+      _Pragma("unroll") for (int pc = 0; pc < 4; ++pc)                                  \
+          acc[((d * 4 + qc) * TPB + b) * 4 + pc] = DQN_MFMA(                            \
+              rp[slot][b][pc], rq[slot][d][qc], acc[((d * 4 + qc) * TPB + b) * 4 + pc]); \
+    }                                                                                   \
+  }
+
+  const int nst4 = nst & ~3;
+  if (nst4 > 0) {
+    WG_LOAD(0, 0) WG_LOAD(1, 1) WG_LOAD(2, 2) WG_LOAD(3, 3)
+    int st = 0;
+    for (; st + 4 < nst4; st += 4) {
+      WG_COMPUTE(0) DQN_PIN(); WG_LOAD(0, st + 4) DQN_PIN();
+      WG_COMPUTE(1) DQN_PIN(); WG_LOAD(1, st + 5) DQN_PIN();
+      WG_COMPUTE(2) DQN_PIN(); WG_LOAD(2, st + 6) DQN_PIN();
+      WG_COMPUTE(3) DQN_PIN(); WG_LOAD(3, st + 7) DQN_PIN();
+    }
+    WG_COMPUTE(0) WG_COMPUTE(1) WG_COMPUTE(2) WG_COMPUTE(3)
+  }
+  for (int st = nst4; st < nst; ++st) { WG_LOAD(0, st) WG_COMPUTE(0) }
+#undef WG_LOAD
+#undef WG_COMPUTE
+
+  park_accumulators<NACC>(smem, acc, wave, lane);
+  float* sdb = smem + 4 * NACC * 64 * 4;      // [4 waves][TQB][16 li] float4
+  if (want_db) {
+#pragma unroll
+    for (int d = 0; d < TQB; ++d) {
+      f32x4 v = dbacc[d];
+      // add the 4 lane groups (rows m+0..3): lanes l, l^16, l^32, l^48
+      v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
+      v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+      if (lg == 0) reinterpret_cast<f32x4*>(sdb)[(wave * TQB + d) * 16 + li] = v;
+    }
+  }
+  __syncthreads();
+  float ssq = 0.0f;
+  // accumulators (d,qc,b,pc=0..3) form float4s over pc
+#pragma unroll
+  for (int g4 = 0; g4 < TQB * 4 * TPB; ++g4) {
+    if ((g4 & 3) == wave) {
+      const int b = g4 % TPB, dq = g4 / TPB, qc = dq & 3, d = dq >> 2;
+      f32x4 r0 = reduce_accumulator<NACC>(smem, g4 * 4 + 0, lane);
+      f32x4 r1 = reduce_accumulator<NACC>(smem, g4 * 4 + 1, lane);
+      f32x4 r2 = reduce_accumulator<NACC>(smem, g4 * 4 + 2, lane);
+      f32x4 r3 = reduce_accumulator<NACC>(smem, g4 * 4 + 3, lane);
+      const int n = q0 + d * 64 + (li << 2) + qc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = p0 + b * 64 + (lg << 4) + (r << 2);
+        const f32x4 v = f32x4{r0[r], r1[r], r2[r], r3[r]};
+        ssq = fmaf(v.x, v.x, ssq); ssq = fmaf(v.y, v.y, ssq); ssq = fmaf(v.z, v.z, ssq); ssq = fmaf(v.w, v.w, ssq);
+        *reinterpret_cast<f32x4*>(pr.C + (size_t)n * pr.ldc + p) = v;
+      }
+    }
+  }
+  if (want_db && wave == 0 && lane < 16 * TQB) {
+    const int d = lane >> 4, l16 = lane & 15;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(sdb);
+    const f32x4 a0 = s4[(0 * TQB + d) * 16 + l16], a1 = s4[(1 * TQB + d) * 16 + l16];
+    const f32x4 a2 = s4[(2 * TQB + d) * 16 + l16], a3 = s4[(3 * TQB + d) * 16 + l16];
+    f32x4 v;
+    v.x = (a0.x + a1.x) + (a2.x + a3.x); v.y = (a0.y + a1.y) + (a2.y + a3.y);
+    v.z = (a0.z + a1.z) + (a2.z + a3.z); v.w = (a0.w + a1.w) + (a2.w + a3.w);
+    *reinterpret_cast<f32x4*>(pr.db + q0 + d * 64 + (l16 << 2)) = v;
+    ssq = fmaf(v.x, v.x, ssq); ssq = fmaf(v.y, v.y, ssq); ssq = fmaf(v.z, v.z, ssq); ssq = fmaf(v.w, v.w, ssq);
+  }
+  if (pr.partial != nullptr) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
+    __syncthreads();                       // every wave is done reading the parked tiles
+    if (lane == 0) smem[wave] = ssq;
+    __syncthreads();
+    if (threadIdx.x == 0) pr.partial[tile_q * pr.tiles_p + tile_p] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+  }
+}
+
+// ---- launchers ------------------------------------------------------------------------
+
+template <typename K>
+inline hipError_t direct_launch(K kernel, GemmBatch& batch, int BP, int BQ, int lds_bytes, hipStream_t stream) {
+  int base = 0;
+  for (int i = 0; i < batch.n; ++i) {
+    GemmProblem& p = batch.prob[i];
+    p.tiles_p = p.Pdim / BP;
+    p.tiles_q = p.Qdim / BQ;
+    p.tile_base = base;
+    base += p.tiles_p * p.tiles_q;
+  }
+  batch.total_tiles = base;
+  hipLaunchKernelGGL(kernel, dim3(base), dim3(256), lds_bytes, stream, batch);
+  return hipGetLastError();
+}
+
+template <int TP, int TQ>
+inline hipError_t fwd_direct_launch(GemmBatch& b, hipStream_t s) {
+  return direct_launch(gemm_fwd_direct<TP, TQ>, b, 16 * TP, 16 * TQ, 4 * TP * TQ * 64 * 16, s);
+}
+template <int TPB, int TQ>
+inline hipError_t dgrad_direct_launch(GemmBatch& b, hipStream_t s) {
+  return direct_launch(gemm_dgrad_direct<TPB, TQ>, b, 64 * TPB, 16 * TQ, 4 * TPB * 4 * TQ * 64 * 16, s);
+}
+template <int TPB, int TQB>
+inline hipError_t wgrad_direct_launch(GemmBatch& b, hipStream_t s) {
+  return direct_launch(gemm_wgrad_direct<TPB, TQB>, b, 64 * TPB, 64 * TQB,
+                       4 * TPB * 4 * TQB * 4 * 64 * 16 + 4 * TQB * 16 * 16, s);
+}
+template <typename K>
+inline hipError_t direct_prepare(K kernel, int lds_bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+}
+
+}  // namespace dqnhip

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/dqnhip.h"
+#include "gemm_direct.hip.h"
 #include "gemm_mfma.hip.h"
 #include "small_kernels.hip.h"
 
@@ -224,7 +225,9 @@ int tower_forward(H* h, const FwdPass* passes, int n, int rows) {
       p.bias = passes[j].w + l.b_off[i]; p.relu = 1;
     }
     ScopedTiming t(h, 0);
-    HIPCHK((gemm_launch<GEMM_FWD, 64, 32, 2, 2>(b, h->stream)));
+    // one problem: 32x32 tiles (256 workgroups for a 256x1024 layer); grouped: 64x32
+    if (n == 1) HIPCHK((fwd_direct_launch<2, 2>(b, h->stream)));
+    else HIPCHK((fwd_direct_launch<4, 2>(b, h->stream)));
   }
   return 0;
 }
@@ -244,7 +247,7 @@ int tower_backward(H* h, const NetLayout& l, const float* w, float* garena, floa
       p.db = garena + l.b_off[i];
       p.partial = partial ? partial + l.part_off[i] : nullptr;
       ScopedTiming t(h, 2);
-      HIPCHK((gemm_launch<GEMM_WGRAD, 64, 64, 2, 2>(b, h->stream)));
+      HIPCHK((wgrad_direct_launch<1, 1>(b, h->stream)));
     }
     if (i > 0 || input_grad) {
       GemmBatch b{}; b.n = 1;
@@ -255,7 +258,7 @@ int tower_backward(H* h, const NetLayout& l, const float* w, float* garena, floa
       p.Pdim = l.kp[i]; p.Qdim = rows; p.Kred = l.dims[i + 1];
       p.mask = i > 0 ? act[i] : nullptr; p.ldm = l.kp[i];
       ScopedTiming t(h, 1);
-      HIPCHK((gemm_launch<GEMM_DGRAD, 64, 32, 2, 2>(b, h->stream)));
+      HIPCHK((dgrad_direct_launch<1, 1>(b, h->stream)));
     }
   }
   return 0;
@@ -568,9 +571,7 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
       HIPCHK(hipMemcpyAsync(h->w[net + 2], h->w[net], l.arena * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     }
   }
-  HIPCHK((gemm_prepare<GEMM_FWD, 64, 32, 2, 2>()));
-  HIPCHK((gemm_prepare<GEMM_DGRAD, 64, 32, 2, 2>()));
-  HIPCHK((gemm_prepare<GEMM_WGRAD, 64, 64, 2, 2>()));
+  HIPCHK(direct_prepare(gemm_wgrad_direct<1, 1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(hipStreamSynchronize(h->stream));
   *out = h;
   return 0;

@@ -1,0 +1,45 @@
+"""Every MFMA GEMM kernel variant against a naive one-thread-per-output fp32 reference on
+uniform [-1,1) data (asymmetric operands: a transposed tile or a swapped fragment shows up as
+an O(1) error).  Tolerance: fp32 summation-order noise only."""
+import ctypes as C
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FWD, DGRAD, WGRAD = 0, 1, 2
+
+
+def _run(pkg, mode, variant, rows, n_out, k_in, groups=1):
+    lib = pkg.capi.load()
+    fn = lib.dqnhip_test_gemm
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 3
+    us, err, ref = C.c_float(), C.c_float(), C.c_float()
+    rc = fn(mode, variant, rows, n_out, k_in, groups, 2, C.byref(us), C.byref(err), C.byref(ref))
+    assert rc == 0
+    return err.value, ref.value
+
+
+# (rows, n_out, k_in): BASELINE layer, reference-default layers, padded first layers, B=32
+SHAPES = [(256, 1024, 1024), (32, 512, 1024), (32, 128, 256), (64, 1024, 64), (256, 1024, 128),
+          (32, 64, 64), (96, 192, 320)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mode,variant", [(FWD, 1), (FWD, 2), (DGRAD, 1), (DGRAD, 2), (WGRAD, 1),
+                                          (FWD, 0), (DGRAD, 0), (WGRAD, 0)])
+def test_gemm_variant_vs_naive(pkg, gpu, mode, variant, shape):
+    rows, n_out, k_in = shape
+    # tile divisibility of each variant (the learner only launches shapes that satisfy them)
+    if mode == FWD and variant == 2 and n_out % 64:
+        pytest.skip("64-wide P tile")
+    if variant == 0 and (n_out % 64 or k_in % 64):
+        pytest.skip("LDS-staged family needs 64-multiples")
+    if mode == DGRAD and variant == 2 and rows % 32:
+        pytest.skip("32-row Q tile")
+    for groups in (1, 2):
+        err, ref = _run(pkg, mode, variant, rows, n_out, k_in, groups)
+        red = {FWD: k_in, DGRAD: n_out, WGRAD: rows}[mode]
+        assert ref > 1.0
+        assert err <= 4e-7 * red ** 0.5 * ref + 1e-6, (mode, variant, shape, groups, err, ref)
