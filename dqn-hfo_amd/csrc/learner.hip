@@ -265,9 +265,19 @@ int tower_backward(H* h, const NetLayout& l, const float* w, float* garena, floa
 }
 
 template <int NH, int MODE>
-int head_forward(H* h, HeadArgs& a) {
+int head_forward(H* h, const HeadArgs& a, const HeadArgs* b = nullptr) {
+  HeadArgs2 a2{}; a2.p[0] = a; if (b) a2.p[1] = *b;
   const int blocks = (a.rows + 3) / 4;
-  hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(blocks), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(blocks, b ? 2 : 1), dim3(256), 0, h->stream, a2);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <int NH>
+int head_backward(H* h, const HeadBwdArgs& a) {
+  const size_t lds = ((size_t)a.rows * NH + 16 * NH * 64 + 16) * sizeof(float);
+  if (lds > 160 * 1024) return fail("minibatch %d too large for the fused head-backward kernel (LDS %zu B)", a.rows, lds);
+  hipLaunchKernelGGL((k_head_bwd<NH>), dim3(a.H / 64), dim3(1024), lds, h->stream, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -318,37 +328,33 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       HeadArgs a{}; a.X = h->act[0][L]; a.ldx = Hh; a.H = Hh; a.rows = B;
       a.W = h->w[DQNHIP_ACTOR_TARGET] + la.hw_off; a.b = h->w[DQNHIP_ACTOR_TARGET] + la.hb_off;
       a.out16 = h->aout_t16; a.xc = h->Xc_nx; a.ldxc = lc.kp[0]; a.xc_col = h->S;
-      RC((head_forward<kNO, HEAD_ACTOR>(h, a)));
       HeadArgs c{}; c.X = h->act[1][L]; c.ldx = Hh; c.H = Hh; c.rows = B;
       c.W = h->w[DQNHIP_ACTOR] + la.hw_off; c.b = h->w[DQNHIP_ACTOR] + la.hb_off;
       c.out16 = h->aout16; c.xc = h->Xc_pl; c.ldxc = lc.kp[0]; c.xc_col = h->S;
-      RC((head_forward<kNO, HEAD_ACTOR>(h, c)));
+      RC((head_forward<kNO, HEAD_ACTOR>(h, a, &c)));     // both actors' heads in one launch
     }
     // critic_target(s', mu'(s')) [:889-891] and critic(s, a) train forward [:904]
     FwdPass cp[2] = {{h->w[DQNHIP_CRITIC_TARGET], &lc, h->act[2]}, {h->w[DQNHIP_CRITIC], &lc, h->act[3]}};
     RC(tower_forward(h, cp, 2, B));
     const int Hc = lc.dims[L];
     {
-      HeadArgs a{}; a.X = h->act[2][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
-      a.W = h->w[DQNHIP_CRITIC_TARGET] + lc.hw_off; a.b = h->w[DQNHIP_CRITIC_TARGET] + lc.hb_off; a.q = h->q_t;
-      RC((head_forward<1, HEAD_Q>(h, a)));
-      HeadArgs c{}; c.X = h->act[3][L]; c.ldx = Hc; c.H = Hc; c.rows = B;
-      c.W = h->w[DQNHIP_CRITIC] + lc.hw_off; c.b = h->w[DQNHIP_CRITIC] + lc.hb_off; c.q = h->q1;
-      c.q_target = h->q_t; c.reward = h->mb_reward; c.mc = h->mb_mc; c.term = h->mb_term;
-      c.y = h->y; c.dq = h->dq; c.loss_partial = h->loss_partial;
-      c.gamma = h->cfg.gamma; c.beta = h->cfg.beta; c.inv_batch = inv_batch;
-      RC((head_forward<1, HEAD_Q_TRAIN>(h, c)));
+      HeadTrainArgs t{};
+      t.Xt = h->act[2][L]; t.Wt = h->w[DQNHIP_CRITIC_TARGET] + lc.hw_off; t.bt = h->w[DQNHIP_CRITIC_TARGET] + lc.hb_off;
+      t.X = h->act[3][L]; t.W = h->w[DQNHIP_CRITIC] + lc.hw_off; t.b = h->w[DQNHIP_CRITIC] + lc.hb_off;
+      t.H = Hc; t.rows = B; t.reward = h->mb_reward; t.mc = h->mb_mc; t.term = h->mb_term;
+      t.q_target = h->q_t; t.q = h->q1; t.y = h->y; t.dq = h->dq; t.loss_partial = h->loss_partial;
+      t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch;
+      hipLaunchKernelGGL(k_head_q_train, dim3((B + 3) / 4), dim3(256), 0, h->stream, t);
+      HIPCHK(hipGetLastError());
     }
-    // critic backward (rest of Step(1)): head, then tower; wgrad writes (beta=0)
-    // so ClearParamDiffs/ZeroGradParameters (src/dqn.cpp:63-78, 908-909) vanish
-    hipLaunchKernelGGL((k_head_bwd_dx<1>), dim3(std::min(1024, (B * Hc / 4 + 255) / 256)), dim3(256), 0, h->stream,
-                       (const float*)h->dq, 1, (const float*)(h->w[DQNHIP_CRITIC] + lc.hw_off),
-                       (const float*)h->act[3][L], Hc, B, h->dZc[L]);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL((k_head_wgrad<1>), dim3(Hc / 64), dim3(256), 0, h->stream, (const float*)h->dq, 1,
-                       (const float*)h->act[3][L], Hc, B, h->g[1] + lc.hw_off, h->g[1] + lc.hb_off,
-                       h->part[1] + lc.part_off[L]);
-    HIPCHK(hipGetLastError());
+    // critic backward (rest of Step(1)): head (dgrad + ReLU' + wgrad fused), then tower; wgrad
+    // writes (beta=0) so ClearParamDiffs/ZeroGradParameters (src/dqn.cpp:63-78, 908-909) vanish
+    {
+      HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = h->w[DQNHIP_CRITIC] + lc.hw_off; a.X4 = h->act[3][L];
+      a.H = Hc; a.rows = B; a.dZ = h->dZc[L]; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
+      a.partial = h->part[1] + lc.part_off[L];
+      RC(head_backward<1>(h, a));
+    }
     RC(tower_backward(h, lc, h->w[DQNHIP_CRITIC], h->g[1], h->part[1], h->act[3], h->dZc, B, true, false));
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, h->stream, (const float*)h->loss_partial,
@@ -374,24 +380,19 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     }
     // q diff = -1 per row, BackwardFrom(q_values_layer) — input gradient only; the
     // reference's discarded critic dW is never computed
-    hipLaunchKernelGGL((k_head_bwd_dx<1>), dim3(std::min(1024, (B * Hc / 4 + 255) / 256)), dim3(256), 0, h->stream,
-                       (const float*)nullptr, 1, (const float*)(h->w[DQNHIP_CRITIC] + lc.hw_off),
-                       (const float*)h->act[4][L], Hc, B, h->dZc[L]);
-    HIPCHK(hipGetLastError());
+    {
+      HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = h->w[DQNHIP_CRITIC] + lc.hw_off; a.X4 = h->act[4][L];
+      a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
+      RC(head_backward<1>(h, a));
+    }
     RC(tower_backward(h, lc, h->w[DQNHIP_CRITIC], nullptr, nullptr, h->act[4], h->dZc, B, false, true));
-    // inverting gradients (src/dqn.cpp:924-957)
-    hipLaunchKernelGGL(k_invert_grad, dim3((B * kAP + 255) / 256), dim3(256), 0, h->stream,
-                       (const float*)h->dZc[0], lc.kp[0], h->S, (const float*)h->aout16, h->dA16, B);
-    HIPCHK(hipGetLastError());
-    // actor backward from both heads (src/dqn.cpp:960-963)
-    hipLaunchKernelGGL((k_head_bwd_dx<kNO>), dim3(std::min(1024, (B * Hh / 4 + 255) / 256)), dim3(256), 0, h->stream,
-                       (const float*)h->dA16, kAP, (const float*)(h->w[DQNHIP_ACTOR] + la.hw_off),
-                       (const float*)h->act[1][L], Hh, B, h->dZa[L]);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL((k_head_wgrad<kNO>), dim3(Hh / 64), dim3(256), 0, h->stream, (const float*)h->dA16, kAP,
-                       (const float*)h->act[1][L], Hh, B, h->g[0] + la.hw_off, h->g[0] + la.hb_off,
-                       h->part[0] + la.part_off[L]);
-    HIPCHK(hipGetLastError());
+    // inverting gradients (src/dqn.cpp:924-957) + actor heads backward (src/dqn.cpp:960-963)
+    {
+      HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;
+      a.W = h->w[DQNHIP_ACTOR] + la.hw_off; a.X4 = h->act[1][L]; a.H = Hh; a.rows = B; a.dZ = h->dZa[L];
+      a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
+      RC(head_backward<kNO>(h, a));
+    }
     RC(tower_backward(h, la, h->w[DQNHIP_ACTOR], h->g[0], h->part[0], h->act[1], h->dZa, B, true, false));
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, h->stream, (const float*)nullptr, 0,
@@ -402,15 +403,11 @@ int run_phase(H* h, int phase, const int* idx_dev) {
   }
   if (phase == 2) {
     if (dp) { RC(sumsq_launch(h, 0)); RC(adam_launch(h, 0, h->part_dp, h->n_part_dp)); }
-    else {
-      RC(adam_launch(h, 0, h->part[0], la.n_part));
-      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, h->stream, (const float*)h->loss_partial, h->n_head_blocks,
-                         (const double*)h->q_partial, h->n_head_blocks, inv_batch, critic_tail, actor_tail);
-      HIPCHK(hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(64), 0, h->stream, h->st, (const float*)critic_tail,
-                       (const float*)actor_tail, dp ? (const double*)nullptr : (const double*)h->q_partial,
-                       h->n_head_blocks, (float)(B * h->cfg.dp_world));
+    else RC(adam_launch(h, 0, h->part[0], la.n_part));
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(64), 0, h->stream, h->st, critic_tail, actor_tail,
+                       (const float*)h->loss_partial, h->n_head_blocks,
+                       dp ? (const double*)nullptr : (const double*)h->q_partial, h->n_head_blocks,
+                       (float)(B * h->cfg.dp_world));
     HIPCHK(hipGetLastError());
     h->h_actor_iter += 1; h->h_critic_iter += 1;
     return 0;
@@ -572,6 +569,8 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
     }
   }
   HIPCHK(direct_prepare(gemm_wgrad_direct<1, 1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
+  HIPCHK(direct_prepare(k_head_bwd<1>, 160 * 1024));
+  HIPCHK(direct_prepare(k_head_bwd<kNO>, 160 * 1024));
   HIPCHK(hipStreamSynchronize(h->stream));
   *out = h;
   return 0;

@@ -183,11 +183,13 @@ struct HeadArgs {
   double* qsum_partial;                // [gridDim.x]
 };
 
+struct HeadArgs2 { HeadArgs p[2]; };
+
 template <int NH, int MODE>
-__global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
+__global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
+  const HeadArgs& a = a2.p[blockIdx.y];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
-  __shared__ float s_part[4];
   __shared__ double s_q[4];
   float acc[NH];
 #pragma unroll
@@ -220,27 +222,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
     }
   } else {
     const float q = acc[0];
-    float d2 = 0.0f;
-    if (row < a.rows && lane == 0) {
-      a.q[row] = q;
-      if constexpr (MODE == HEAD_Q_TRAIN) {
-        // TD target (src/dqn.cpp:892-900), doubles where the reference has them
-        const float r = a.reward[row];
-        const float off_policy = a.term[row] != 0.0f
-            ? r : (float)((double)r + a.gamma * (double)a.q_target[row]);
-        const float target = (float)(a.beta * (double)a.mc[row] + (1 - a.beta) * (double)off_policy);
-        a.y[row] = target;
-        // EuclideanLoss: diff = q - y; bottom diff = diff / num
-        const float d = q - target;
-        a.dq[row] = a.inv_batch * d;
-        d2 = d * d;
-      }
-    }
-    if constexpr (MODE == HEAD_Q_TRAIN) {
-      if (lane == 0) s_part[wave] = d2;
-      __syncthreads();
-      if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
-    }
+    if (row < a.rows && lane == 0) a.q[row] = q;
     if constexpr (MODE == HEAD_Q_POLICY) {
       if (lane == 0) s_q[wave] = row < a.rows ? (double)q : 0.0;
       __syncthreads();
@@ -249,110 +231,144 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
   }
 }
 
-// Head backward wrt the tower top, with the tower's last ReLU backward fused:
-//   dZ4[m][k] = (sum_j dYh[m][j] * Wh[j][k]) * lrelu'(X4[m][k])
-// NH == 10 (actor): the two IP layers' bottom diffs are formed separately and
-// added by the Split layer: (4-term sum) + (6-term sum).
-// dyh == nullptr means dY = -1 for every row (src/dqn.cpp:918-921).
-template <int NH>
-__global__ __launch_bounds__(256) void k_head_bwd_dx(const float* __restrict__ dyh, int lddy,
-                                                     const float* __restrict__ W,
-                                                     const float* __restrict__ X4, int H, int rows,
-                                                     float* __restrict__ dZ) {
-  const int total4 = rows * H / 4;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
-    const int m = (i * 4) / H, k = (i * 4) % H;
-    float dy[NH];
-#pragma unroll
-    for (int j = 0; j < NH; ++j) dy[j] = dyh ? dyh[(size_t)m * lddy + j] : -1.0f;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(W + (size_t)j * H + k);
-      if (NH == kNO && j >= kNA) {
-        s1.x = fmaf(dy[j], wv.x, s1.x); s1.y = fmaf(dy[j], wv.y, s1.y);
-        s1.z = fmaf(dy[j], wv.z, s1.z); s1.w = fmaf(dy[j], wv.w, s1.w);
-      } else {
-        s0.x = fmaf(dy[j], wv.x, s0.x); s0.y = fmaf(dy[j], wv.y, s0.y);
-        s0.z = fmaf(dy[j], wv.z, s0.z); s0.w = fmaf(dy[j], wv.w, s0.w);
-      }
+// Both critic heads of the training step in one launch: q' = q_values(critic_target tower
+// top), q = q_values(critic tower top), then the TD target (src/dqn.cpp:892-900, doubles where
+// the reference has them) and the EuclideanLoss diff.  One wave per row.
+struct HeadTrainArgs {
+  const float* Xt; const float* Wt; const float* bt;   // target critic top / head
+  const float* X; const float* W; const float* b;      // online critic top / head
+  int H, rows;
+  const float* reward; const float* mc; const float* term;
+  float* q_target; float* q; float* y; float* dq; float* loss_partial;
+  double gamma, beta; float inv_batch;
+};
+__global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  __shared__ float s_part[4];
+  float at = 0.0f, ao = 0.0f;
+  if (row < a.rows) {
+    const float* xt = a.Xt + (size_t)row * a.H;
+    const float* x = a.X + (size_t)row * a.H;
+    for (int k = lane * 4; k < a.H; k += 256) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(xt + k), w0 = *reinterpret_cast<const f32x4*>(a.Wt + k);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + k), w1 = *reinterpret_cast<const f32x4*>(a.W + k);
+      at = fmaf(v0.x, w0.x, at); at = fmaf(v0.y, w0.y, at); at = fmaf(v0.z, w0.z, at); at = fmaf(v0.w, w0.w, at);
+      ao = fmaf(v1.x, w1.x, ao); ao = fmaf(v1.y, w1.y, ao); ao = fmaf(v1.z, w1.z, ao); ao = fmaf(v1.w, w1.w, ao);
     }
-    if (NH == kNO) { s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w; }
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(X4 + (size_t)m * H + k);
-    s0.x *= lrelu_mask(xv.x); s0.y *= lrelu_mask(xv.y); s0.z *= lrelu_mask(xv.z); s0.w *= lrelu_mask(xv.w);
-    *reinterpret_cast<f32x4*>(dZ + (size_t)m * H + k) = s0;
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { at += __shfl_xor(at, off, 64); ao += __shfl_xor(ao, off, 64); }
+  float d2 = 0.0f;
+  if (row < a.rows && lane == 0) {
+    const float qt = at + a.bt[0], q = ao + a.b[0];
+    a.q_target[row] = qt; a.q[row] = q;
+    const float r = a.reward[row];
+    const float off_policy = a.term[row] != 0.0f ? r : (float)((double)r + a.gamma * (double)qt);
+    const float target = (float)(a.beta * (double)a.mc[row] + (1 - a.beta) * (double)off_policy);
+    a.y[row] = target;
+    const float d = q - target;
+    a.dq[row] = a.inv_batch * d;
+    d2 = d * d;
+  }
+  if (lane == 0) s_part[wave] = d2;
+  __syncthreads();
+  if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
 }
 
-// Head weight/bias gradient: dWh[j][k] = sum_m dYh[m][j] X4[m][k]; dbh[j] = sum_m dYh[m][j].
-// Block = 64 k-columns x 4 row-quarters; quarters are added in fixed order.
+// Fused head backward: in one pass over the tower top X4[rows][H]
+//   (actor only) inverting gradients (src/dqn.cpp:924-957) on the critic's input-gradient
+//                columns -> dYh[m][0..9]
+//   dZ4[m][k]  = (sum_j dYh[m][j] Wh[j][k]) * lrelu'(X4[m][k])       (head dgrad + ReLU bwd)
+//   dWh[j][k]  = sum_m dYh[m][j] X4[m][k] ;  dbh[j] = sum_m dYh[m][j]  (head wgrad)
+//   + one sum-of-squares partial per block.
+// Block = 64 columns x 16 row groups (1024 threads); row groups are added in fixed order.
+// Replaces three launches (invert, head dgrad, head wgrad) and 16x the parallelism of the
+// old column-strip wgrad.
+struct HeadBwdArgs {
+  const float* dyh; int lddy;          // NH==1: dq[rows] (null: -1 per row, no wgrad)
+  const float* dXc; int ldx; int S;    // actor: critic input gradient (invert source)
+  const float* aout16;                 // actor: mu(s) for the inverting bounds
+  float* dA16;                         // actor: post-invert head diffs (debug / parity)
+  const float* W; const float* X4; int H; int rows;
+  float* dZ; float* dW; float* db; float* partial;
+};
 template <int NH>
-__global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ dyh, int lddy,
-                                                    const float* __restrict__ X4, int H, int rows,
-                                                    float* __restrict__ dW, float* __restrict__ db,
-                                                    float* __restrict__ partial) {
-  __shared__ float s_acc[4][NH][64];
-  __shared__ float s_b[4][NH];
-  __shared__ float s_red[4];
-  const int kc = threadIdx.x & 63, mq = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_dy = sm;                              // [rows][NH]
+  float* s_acc = sm + a.rows * NH;               // [16][NH][64]
+  float* s_red = s_acc + 16 * NH * 64;           // [16]
+  const int tid = threadIdx.x;
+  const bool want_w = a.dW != nullptr;
+  // ---- head diffs for every row into LDS
+  for (int i = tid; i < a.rows * NH; i += 1024) {
+    const int m = i / NH, j = i % NH;
+    float d;
+    if constexpr (NH == kNO) {
+      d = a.dXc[(size_t)m * a.ldx + a.S + j];
+      const float out = a.aout16[(size_t)m * kAP + j];
+      float mn, mx;
+      if (j < kNA) { mn = -1.0f; mx = 1.0f; }
+      else { const int p = j - kNA; if (p == 0 || p == 4) { mn = 0.0f; mx = 100.0f; } else { mn = -180.0f; mx = 180.0f; } }
+      if (d < 0) d *= (mx - out) / (mx - mn);
+      else if (d > 0) d *= (out - mn) / (mx - mn);
+      if (blockIdx.x == 0) a.dA16[(size_t)m * kAP + j] = d;
+    } else {
+      d = a.dyh ? a.dyh[(size_t)m * a.lddy + j] : -1.0f;
+    }
+    s_dy[i] = d;
+  }
+  __syncthreads();
+  const int kc = tid & 63, rg = tid >> 6;          // 16 row groups
   const int k = blockIdx.x * 64 + kc;
-  const int per = (rows + 3) / 4;
-  const int m0 = mq * per, m1 = min(rows, m0 + per);
-  float acc[NH], bs[NH];
+  float w[NH];
 #pragma unroll
-  for (int j = 0; j < NH; ++j) { acc[j] = 0.0f; bs[j] = 0.0f; }
+  for (int j = 0; j < NH; ++j) w[j] = a.W[(size_t)j * a.H + k];
+  float acc[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
+  const int per = (a.rows + 15) / 16;
+  const int m0 = rg * per, m1 = min(a.rows, m0 + per);
   for (int m = m0; m < m1; ++m) {
-    const float xv = X4[(size_t)m * H + k];
+    const float xv = a.X4[(size_t)m * a.H + k];
+    float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
-      const float d = dyh[(size_t)m * lddy + j];
+      const float d = s_dy[m * NH + j];
+      // Split layer: action_layer's and actionpara_layer's bottom diffs are
+      // formed separately and added
+      if (NH == kNO && j >= kNA) s1 = fmaf(d, w[j], s1); else s0 = fmaf(d, w[j], s0);
       acc[j] = fmaf(d, xv, acc[j]);
-      bs[j] += d;
     }
+    if (NH == kNO) s0 += s1;
+    a.dZ[(size_t)m * a.H + k] = s0 * lrelu_mask(xv);
   }
+  if (!want_w) return;
 #pragma unroll
-  for (int j = 0; j < NH; ++j) { s_acc[mq][j][kc] = acc[j]; if (kc == 0) s_b[mq][j] = bs[j]; }
+  for (int j = 0; j < NH; ++j) s_acc[(rg * NH + j) * 64 + kc] = acc[j];
   __syncthreads();
   float ssq = 0.0f;
-  if (mq == 0) {
+  if (rg == 0) {
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
-      const float v = ((s_acc[0][j][kc] + s_acc[1][j][kc]) + s_acc[2][j][kc]) + s_acc[3][j][kc];
-      dW[(size_t)j * H + k] = v;
+      float v = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) v += s_acc[(g * NH + j) * 64 + kc];
+      a.dW[(size_t)j * a.H + k] = v;
       ssq = fmaf(v, v, ssq);
     }
     if (blockIdx.x == 0 && kc < NH) {
-      const float v = ((s_b[0][kc] + s_b[1][kc]) + s_b[2][kc]) + s_b[3][kc];
-      db[kc] = v;
+      float v = 0.0f;
+      for (int m = 0; m < a.rows; ++m) v += s_dy[m * NH + kc];
+      a.db[kc] = v;
       ssq = fmaf(v, v, ssq);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
-    if (kc == 0 && partial != nullptr) partial[blockIdx.x] = ssq;
+    if (kc == 0 && a.partial != nullptr) a.partial[blockIdx.x] = ssq;
   }
   (void)s_red;
-}
-
-// Inverting gradients (src/dqn.cpp:924-957) on the critic's input gradient
-// columns [S, S+10): bounds logits [-1,1]; params h in {0,4}: [0,100], else
-// [-180,180].  Also the place where critic_iter's consumer-side bookkeeping is
-// not needed: counters are advanced by k_tick.
-__global__ void k_invert_grad(const float* __restrict__ dXc, int ldx, int S,
-                              const float* __restrict__ aout16, float* __restrict__ dA16, int rows) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * kAP) return;
-  const int m = i / kAP, h = i % kAP;
-  float diff = 0.0f;
-  if (h < kNO) {
-    diff = dXc[(size_t)m * ldx + S + h];
-    const float out = aout16[(size_t)m * kAP + h];
-    float mn, mx;
-    if (h < kNA) { mn = -1.0f; mx = 1.0f; }
-    else { const int p = h - kNA; if (p == 0 || p == 4) { mn = 0.0f; mx = 100.0f; } else { mn = -180.0f; mx = 180.0f; } }
-    if (diff < 0) diff *= (mx - out) / (mx - mn);
-    else if (diff > 0) diff *= (out - mn) / (mx - mn);
-  }
-  dA16[(size_t)m * kAP + h] = diff;
 }
 
 // ---- optimiser -----------------------------------------------------------------
@@ -466,13 +482,18 @@ __global__ void k_tails(const float* loss_partial, int n_loss, const double* q_p
 // avg_q = std::accumulate(q, 0.0) / float(B) (src/dqn.cpp:915-916): the double sum
 // is taken from the per-block double partials when they are local (single GPU),
 // from the all-reduced float tail under data parallelism.
-__global__ void k_tick(DevState* st, const float* critic_tail, const float* actor_tail,
-                       const double* q_partial, int n_q, float batch) {
+__global__ void k_tick(DevState* st, float* critic_tail, float* actor_tail, const float* loss_partial,
+                       int n_loss, const double* q_partial, int n_q, float batch) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  st->critic_loss = critic_tail[0];
   double qs = 0.0;
-  if (q_partial != nullptr) { for (int i = 0; i < n_q; ++i) qs += q_partial[i]; }
-  else qs = (double)actor_tail[1];
+  if (q_partial != nullptr) {          // single GPU: reduce the per-block partials here
+    float dot = 0.0f;
+    for (int i = 0; i < n_loss; ++i) dot += loss_partial[i];
+    critic_tail[0] = dot / batch / 2.0f;              // EuclideanLoss: dot / num / 2
+    for (int i = 0; i < n_q; ++i) qs += q_partial[i];
+    actor_tail[1] = (float)qs;
+  } else qs = (double)actor_tail[1];   // data parallel: tails were all-reduced
+  st->critic_loss = critic_tail[0];
   st->avg_q = (float)(qs / (double)batch);
   st->actor_iter += 1; st->critic_iter += 1; st->update_counter += 1;
 }
