@@ -54,7 +54,9 @@ def family_flops(B, S, hidden):
     dgrad = 2 * B * (sum(wc[1:])            # critic train: dX down to layer 2's input
                      + sum(wc[1:]) + 10 * h1  # critic dQ/da: layer 1 needs only the 10 action columns
                      + sum(wa[1:]))         # actor
-    return {"gemm_fwd": fwd, "gemm_dgrad": dgrad, "gemm_wgrad": wgrad}
+    pair = 2 * B * (2 * sum(wc[1:]) + 2 * sum(wa[1:]))      # dgrad+wgrad of layers 2..L, critic train + actor
+    return {"gemm_fwd": fwd, "gemm_dgrad": dgrad - 2 * B * (sum(wc[1:]) + sum(wa[1:])),
+            "gemm_wgrad": wgrad - 2 * B * (sum(wc[1:]) + sum(wa[1:])), "gemm_bwd_pair": pair}
 
 
 def prefill(dqn, n, seed, chunk=131072):
@@ -183,12 +185,12 @@ def main():
         for _ in range(n_t):
             step()
         stats = {}
-        for fam in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "adam"):
+        for fam in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_bwd_pair", "adam"):
             ms, cnt = dqn.kernel_timing(fam)
             stats[fam] = (ms, cnt)
         dqn.kernel_timing("adam", reset=True)
         dqn.set_kernel_timing(False)
-        dom = max(("gemm_fwd", "gemm_dgrad", "gemm_wgrad"), key=lambda f: stats[f][0] * stats[f][1])
+        dom = max(("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_bwd_pair"), key=lambda f: stats[f][0] * stats[f][1])
         ms, cnt = stats[dom]
         per_update_launches = cnt / n_t
         flops_per_launch = fam_flops[dom] / per_update_launches

@@ -80,12 +80,8 @@ __device__ __forceinline__ f32x4 reduce_accumulator(const float* smem, int e, in
 // Y[m][n] = lrelu(sum_k X[m][k] W[n][k] + b[n]).  P = W (KC, 16-row blocks), Q = X (KC).
 // Tile = (16*TP) x (16*TQ).  Kred % 64 == 0.
 template <int TP, int TQ, int ABL = 0>
-__global__ __launch_bounds__(256) void gemm_fwd_direct(const GemmBatch batch) {
+__device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
   constexpr int NACC = TP * TQ;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  int pi, tile_p, tile_q;
-  tile_of_block(batch, pi, tile_p, tile_q);
-  const GemmProblem& pr = batch.prob[pi];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int p0 = tile_p * 16 * TP, q0 = tile_q * 16 * TQ;
@@ -97,6 +93,13 @@ __global__ __launch_bounds__(256) void gemm_fwd_direct(const GemmBatch batch) {
   for (int c = 0; c < TP; ++c) pp[c] = pr.P + (size_t)(p0 + c * 16 + li) * pr.ldp + wave * Kw + lg * 4;
 #pragma unroll
   for (int a = 0; a < TQ; ++a) qp[a] = pr.Q + (size_t)(q0 + a * 16 + li) * pr.ldq + wave * Kw + lg * 4;
+  if (ABL == 3) {   // ablation: same bytes, but 8 rows x 128 B per wave instruction (full lines)
+#pragma unroll
+    for (int c = 0; c < TP; ++c) pp[c] = pr.P + (size_t)(p0 + c * 16 + (lane >> 3)) * pr.ldp + wave * Kw + (lane & 7) * 4;
+#pragma unroll
+    for (int a = 0; a < TQ; ++a) qp[a] = pr.Q + (size_t)(q0 + a * 16 + (lane >> 3)) * pr.ldq + wave * Kw + (lane & 7) * 4;
+  }
+  const size_t abl_p8 = (size_t)8 * pr.ldp, abl_q8 = (size_t)8 * pr.ldq;
 
   f32x4 acc[NACC];
 #pragma unroll
@@ -104,14 +107,19 @@ __global__ __launch_bounds__(256) void gemm_fwd_direct(const GemmBatch batch) {
   f32x4 rp[4][TP], rq[4][TQ];
 
 #define FWD_LOAD(slot, kb)                                                              \
-  if (ABL != 1 || (kb) < 4) {                                                           \
+  if (ABL == 3) {                                                                       \
+    _Pragma("unroll") for (int c = 0; c < TP; ++c)                                      \
+        rp[slot][c] = *reinterpret_cast<const f32x4*>(pp[c] + ((kb) & 1) * abl_p8 + (((kb) >> 1) << 5)); \
+    _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
+        rq[slot][a] = *reinterpret_cast<const f32x4*>(qp[a] + ((kb) & 1) * abl_q8 + (((kb) >> 1) << 5)); \
+  } else if (ABL != 1 || (kb) < 4) {                                                    \
     _Pragma("unroll") for (int c = 0; c < TP; ++c)                                      \
         rp[slot][c] = *reinterpret_cast<const f32x4*>(pp[c] + ((kb) << 4));            \
     _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
         rq[slot][a] = *reinterpret_cast<const f32x4*>(qp[a] + ((kb) << 4));            \
   }
 #define FWD_COMPUTE(slot)                                                               \
-  if (ABL != 2) {                                                                       \
+  if (ABL != 2 && ABL != 3) {                                                           \
     _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
     _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
     _Pragma("unroll") for (int c = 0; c < TP; ++c)                                      \
@@ -161,12 +169,8 @@ __global__ __launch_bounds__(256) void gemm_fwd_direct(const GemmBatch batch) {
 // dX[m][j] = (sum_n dY[m][n] W[n][j]) * lrelu'(act[m][j]).  P = W (KS, 64-wide blocks of j),
 // Q = dY (KC, 16-row blocks of m).  Tile = (64*TPB) x (16*TQ).  Kred (= n) % 64 == 0.
 template <int TPB, int TQ>
-__global__ __launch_bounds__(256) void gemm_dgrad_direct(const GemmBatch batch) {
+__device__ __forceinline__ void dgrad_direct_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
   constexpr int NACC = TPB * 4 * TQ;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  int pi, tile_p, tile_q;
-  tile_of_block(batch, pi, tile_p, tile_q);
-  const GemmProblem& pr = batch.prob[pi];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int p0 = tile_p * 64 * TPB, q0 = tile_q * 16 * TQ;
@@ -248,12 +252,8 @@ __global__ __launch_bounds__(256) void gemm_dgrad_direct(const GemmBatch batch) 
 // dW[n][j] = sum_m dY[m][n] X[m][j];  db[n] = sum_m dY[m][n].  P = X (KS, 64-wide blocks of
 // j), Q = dY (KS, 64-wide blocks of n).  Tile = (64*TPB) x (64*TQB).  Kred (= rows m) % 16 == 0.
 template <int TPB, int TQB>
-__global__ __launch_bounds__(256) void gemm_wgrad_direct(const GemmBatch batch) {
+__device__ __forceinline__ void wgrad_direct_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
   constexpr int NACC = TPB * 4 * TQB * 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  int pi, tile_p, tile_q;
-  tile_of_block(batch, pi, tile_p, tile_q);
-  const GemmProblem& pr = batch.prob[pi];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int p0 = tile_p * 64 * TPB, q0 = tile_q * 64 * TQB;
@@ -362,6 +362,161 @@ __global__ __launch_bounds__(256) void gemm_wgrad_direct(const GemmBatch batch) 
   }
 }
 
+// ================================ FWD, coalesced =====================================
+// Same tile / split-K structure as fwd_direct_body, but the k-contiguous operands are
+// fetched as WHOLE 128-byte lines (8 rows x 128 B per wave instruction) and transposed into
+// MFMA fragment layout through a wave-private LDS image — the fragment-shaped loads of
+// fwd_direct_body (sixteen 64-B pieces per instruction) run the texture addresser at 1/4
+// rate: measured 8.5 TB/s vs 20 TB/s for the same bytes (ablation v6/v9).
+//   global (coalesced)  lane l -> row l>>3, 16-B chunk l&7          [2 loads / 16 rows / 32 k]
+//   LDS image per 16-row block: [16 rows][8 chunks], chunk ^= row&7 (ds_write_b128: 8 lanes
+//   of a row hit 8 distinct chunks; ds_read_b128 in MFMA layout is conflict-free, see
+//   DESIGN.md for the lane-group check)
+//   fragment            lane (i=l&15, g=l>>4), kb -> row i, chunk kb*4+g
+// The LDS image is private to the wave (no barrier anywhere in the main loop); two images
+// ping-pong, global loads run two 32-k steps ahead in registers.
+// Requires Kred % 256 == 0 and Kred >= 512 (>= 4 steps of 32 k per wave, even count).
+template <int TP, int TQ, bool PIN>
+__device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
+  constexpr int NB = TP + TQ;
+  constexpr int NACC = TP * TQ;
+  constexpr int SLOT = NB * 512;                 // floats per LDS image (NB blocks x 16 rows x 32 k)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int lr = lane >> 3, lc = lane & 7;
+  const int p0 = tile_p * 16 * TP, q0 = tile_q * 16 * TQ;
+  const int Kw = pr.Kred >> 2;
+  const int T = Kw >> 5;                         // steps of 32 k
+  float* wsm = smem + wave * (2 * SLOT);
+  const float* gp[NB];
+  size_t ld8[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b < TP) { gp[b] = pr.P + (size_t)(p0 + b * 16 + lr) * pr.ldp + wave * Kw + lc * 4; ld8[b] = (size_t)8 * pr.ldp; }
+    else { gp[b] = pr.Q + (size_t)(q0 + (b - TP) * 16 + lr) * pr.ldq + wave * Kw + lc * 4; ld8[b] = (size_t)8 * pr.ldq; }
+  }
+  const int woff = lr * 32 + ((lc ^ lr) << 2);                 // + h*256 + b*512
+  int roff[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) roff[kb] = li * 32 + ((((kb << 2) + lg) ^ (li & 7)) << 2);
+
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 G0[NB][2], G1[NB][2], F[NB][2], Fn[NB][2];
+
+#define L_GLOAD(G, t)                                                                   \
+  { _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                    \
+      G[b][0] = *reinterpret_cast<const f32x4*>(gp[b] + ((t) << 5));                   \
+      G[b][1] = *reinterpret_cast<const f32x4*>(gp[b] + ld8[b] + ((t) << 5)); } }
+#define L_SWRITE(slot, G)                                                               \
+  { _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                    \
+      *reinterpret_cast<f32x4*>(wsm + (slot) * SLOT + b * 512 + woff) = G[b][0];        \
+      *reinterpret_cast<f32x4*>(wsm + (slot) * SLOT + b * 512 + 256 + woff) = G[b][1]; } }
+#define L_SREAD(FF, slot)                                                               \
+  { _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                    \
+      FF[b][0] = *reinterpret_cast<const f32x4*>(wsm + (slot) * SLOT + b * 512 + roff[0]); \
+      FF[b][1] = *reinterpret_cast<const f32x4*>(wsm + (slot) * SLOT + b * 512 + roff[1]); } }
+#define L_MFMA(FF)                                                                      \
+  { _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                    \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
+    _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
+    _Pragma("unroll") for (int c = 0; c < TP; ++c)                                      \
+        acc[a * TP + c] = DQN_MFMA(FF[c][kb][s], FF[TP + a][kb][s], acc[a * TP + c]); }
+#define L_PIN() { if (PIN) DQN_PIN(); }
+
+  L_GLOAD(G0, 0) L_GLOAD(G1, 1)
+  L_SWRITE(0, G0) L_GLOAD(G0, 2) L_SREAD(F, 0)
+  int t = 0;
+  for (; t + 4 < T; t += 2) {
+    L_SWRITE(1, G1) L_GLOAD(G1, t + 3) L_SREAD(Fn, 1) L_PIN()
+    L_MFMA(F) L_PIN()
+    L_SWRITE(0, G0) L_GLOAD(G0, t + 4) L_SREAD(F, 0) L_PIN()
+    L_MFMA(Fn) L_PIN()
+  }
+  // t == T-4
+  L_SWRITE(1, G1) L_GLOAD(G1, T - 1) L_SREAD(Fn, 1) L_PIN()
+  L_MFMA(F) L_PIN()
+  L_SWRITE(0, G0) L_SREAD(F, 0) L_PIN()
+  L_MFMA(Fn) L_PIN()
+  L_SWRITE(1, G1) L_SREAD(Fn, 1) L_PIN()
+  L_MFMA(F) L_PIN()
+  L_MFMA(Fn)
+#undef L_GLOAD
+#undef L_SWRITE
+#undef L_SREAD
+#undef L_MFMA
+#undef L_PIN
+
+  // park into this wave's own (now idle) staging region, reduce across waves in fixed order
+  f32x4* park = reinterpret_cast<f32x4*>(wsm);
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) park[e * 64 + lane] = acc[e];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) {
+    if ((e & 3) == wave) {
+      const int a = e / TP, c = e % TP;
+      const f32x4 a0 = reinterpret_cast<const f32x4*>(smem + 0 * (2 * SLOT))[e * 64 + lane];
+      const f32x4 a1 = reinterpret_cast<const f32x4*>(smem + 1 * (2 * SLOT))[e * 64 + lane];
+      const f32x4 a2 = reinterpret_cast<const f32x4*>(smem + 2 * (2 * SLOT))[e * 64 + lane];
+      const f32x4 a3 = reinterpret_cast<const f32x4*>(smem + 3 * (2 * SLOT))[e * 64 + lane];
+      f32x4 v;
+      v.x = (a0.x + a1.x) + (a2.x + a3.x); v.y = (a0.y + a1.y) + (a2.y + a3.y);
+      v.z = (a0.z + a1.z) + (a2.z + a3.z); v.w = (a0.w + a1.w) + (a2.w + a3.w);
+      const int q = q0 + a * 16 + li, p = p0 + c * 16 + (lg << 2);
+      if (pr.bias != nullptr) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(pr.bias + p);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      }
+      if (pr.relu) { v.x = lrelu_fwd(v.x); v.y = lrelu_fwd(v.y); v.z = lrelu_fwd(v.z); v.w = lrelu_fwd(v.w); }
+      *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
+    }
+  }
+}
+
+// ---- kernels: thin wrappers over the bodies --------------------------------------------
+template <int TP, int TQ, int ABL = 0>
+__global__ __launch_bounds__(256) void gemm_fwd_direct(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  fwd_direct_body<TP, TQ, ABL>(batch.prob[pi], tile_p, tile_q, smem);
+}
+template <int TP, int TQ, bool PIN>
+__global__ __launch_bounds__(256) void gemm_fwd_lds(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  fwd_lds_body<TP, TQ, PIN>(batch.prob[pi], tile_p, tile_q, smem);
+}
+template <int TPB, int TQ>
+__global__ __launch_bounds__(256) void gemm_dgrad_direct(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  dgrad_direct_body<TPB, TQ>(batch.prob[pi], tile_p, tile_q, smem);
+}
+template <int TPB, int TQB>
+__global__ __launch_bounds__(256) void gemm_wgrad_direct(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  wgrad_direct_body<TPB, TQB>(batch.prob[pi], tile_p, tile_q, smem);
+}
+// One layer's backward in ONE launch: problems with mode GEMM_DGRAD (64x16 tiles) and
+// GEMM_WGRAD (64x64 tiles) side by side.  dX_{l-1} = dZ_l W_l and dW_l = dZ_l^T X_{l-1} only
+// share their input dZ_l, so a 256x1024x1024 layer offers 256 + 256 workgroups = 2 per CU.
+template <int TQD = 1>
+__global__ __launch_bounds__(256) void gemm_bwd_pair_direct(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  const GemmProblem& pr = batch.prob[pi];
+  if (pr.mode == GEMM_WGRAD) wgrad_direct_body<1, 1>(pr, tile_p, tile_q, smem);
+  else dgrad_direct_body<1, TQD>(pr, tile_p, tile_q, smem);
+}
+
 // ---- launchers ------------------------------------------------------------------------
 
 template <typename K>
@@ -383,6 +538,10 @@ template <int TP, int TQ>
 inline hipError_t fwd_direct_launch(GemmBatch& b, hipStream_t s) {
   return direct_launch(gemm_fwd_direct<TP, TQ>, b, 16 * TP, 16 * TQ, 4 * TP * TQ * 64 * 16, s);
 }
+template <int TP, int TQ, bool PIN>
+inline hipError_t fwd_lds_launch(GemmBatch& b, hipStream_t s) {
+  return direct_launch(gemm_fwd_lds<TP, TQ, PIN>, b, 16 * TP, 16 * TQ, 4 * 2 * (TP + TQ) * 512 * 4, s);
+}
 template <int TPB, int TQ>
 inline hipError_t dgrad_direct_launch(GemmBatch& b, hipStream_t s) {
   return direct_launch(gemm_dgrad_direct<TPB, TQ>, b, 64 * TPB, 16 * TQ, 4 * TPB * 4 * TQ * 64 * 16, s);
@@ -391,6 +550,21 @@ template <int TPB, int TQB>
 inline hipError_t wgrad_direct_launch(GemmBatch& b, hipStream_t s) {
   return direct_launch(gemm_wgrad_direct<TPB, TQB>, b, 64 * TPB, 64 * TQB,
                        4 * TPB * 4 * TQB * 4 * 64 * 16 + 4 * TQB * 16 * 16, s);
+}
+// mixed dgrad(64x16)/wgrad(64x64) launch; every problem carries its own mode
+template <int TQD>
+inline hipError_t bwd_pair_direct_launch(GemmBatch& batch, hipStream_t stream) {
+  int base = 0;
+  for (int i = 0; i < batch.n; ++i) {
+    GemmProblem& p = batch.prob[i];
+    p.tiles_p = p.Pdim / 64;
+    p.tiles_q = p.Qdim / (p.mode == GEMM_WGRAD ? 64 : 16 * TQD);
+    p.tile_base = base;
+    base += p.tiles_p * p.tiles_q;
+  }
+  batch.total_tiles = base;
+  hipLaunchKernelGGL(gemm_bwd_pair_direct<TQD>, dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, batch);
+  return hipGetLastError();
 }
 template <typename K>
 inline hipError_t direct_prepare(K kernel, int lds_bytes) {

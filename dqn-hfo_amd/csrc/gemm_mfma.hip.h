@@ -55,6 +55,7 @@ struct GemmProblem {
   float* db;                 // WGRAD: bias gradient [q] (null: skip)
   float* partial;            // WGRAD: one sum-of-squares partial per tile (null: skip)
   int relu;                  // FWD: apply leaky ReLU
+  int mode;                  // mixed-mode launches (gemm_bwd_pair_direct): GEMM_DGRAD / GEMM_WGRAD
   int tiles_p, tiles_q, tile_base;
 };
 

@@ -135,7 +135,7 @@ namespace {
 
 using H = dqnhip_learner;
 
-const char* kFamily[] = {"gemm_fwd", "gemm_dgrad", "gemm_wgrad", "adam"};
+const char* kFamily[] = {"gemm_fwd", "gemm_dgrad", "gemm_wgrad", "adam", "gemm_bwd_pair"};
 
 struct ScopedTiming {
   H* h; int fam; hipEvent_t a = nullptr, b = nullptr;
@@ -226,8 +226,11 @@ int tower_forward(H* h, const FwdPass* passes, int n, int rows) {
     }
     ScopedTiming t(h, 0);
     // one problem: 32x32 tiles (256 workgroups for a 256x1024 layer); grouped: 64x32
-    if (n == 1) HIPCHK((fwd_direct_launch<2, 2>(b, h->stream)));
-    else HIPCHK((fwd_direct_launch<4, 2>(b, h->stream)));
+    // K >= 512 and K % 256 == 0: full-line loads + wave-private LDS transpose; else (first
+    // layer, narrow towers) the plain direct kernel
+    const bool lds_ok = (l.kp[i] >= 512) && (l.kp[i] % 256 == 0);
+    if (n == 1) { if (lds_ok) HIPCHK((fwd_lds_launch<2, 2, false>(b, h->stream))); else HIPCHK((fwd_direct_launch<2, 2>(b, h->stream))); }
+    else { if (lds_ok) HIPCHK((fwd_lds_launch<4, 2, false>(b, h->stream))); else HIPCHK((fwd_direct_launch<4, 2>(b, h->stream))); }
   }
   return 0;
 }
@@ -237,29 +240,31 @@ int tower_forward(H* h, const FwdPass* passes, int n, int rows) {
 int tower_backward(H* h, const NetLayout& l, const float* w, float* garena, float* partial,
                    float** act, float** dZ, int rows, bool want_w, bool input_grad) {
   for (int i = l.L - 1; i >= 0; --i) {
-    if (want_w) {
-      GemmBatch b{}; b.n = 1;
-      GemmProblem& p = b.prob[0];
+    GemmBatch b{}; b.n = 0;
+    const bool need_dx = (i > 0 || input_grad);
+    if (need_dx) {                         // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
+      GemmProblem& p = b.prob[b.n++];
+      p.mode = GEMM_DGRAD;
+      p.P = w + l.w_off[i]; p.ldp = l.kp[i];
+      p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
+      p.C = dZ[i]; p.ldc = l.kp[i];
+      p.Pdim = l.kp[i]; p.Qdim = rows; p.Kred = l.dims[i + 1];
+      p.mask = i > 0 ? act[i] : nullptr; p.ldm = l.kp[i];
+    }
+    if (want_w) {                          // dW_i = dZ[i+1]^T . act[i] ; db_i = colsum(dZ[i+1])
+      GemmProblem& p = b.prob[b.n++];
+      p.mode = GEMM_WGRAD;
       p.P = act[i]; p.ldp = l.kp[i];
       p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
       p.C = garena + l.w_off[i]; p.ldc = l.kp[i];
       p.Pdim = l.kp[i]; p.Qdim = l.dims[i + 1]; p.Kred = rows;
       p.db = garena + l.b_off[i];
       p.partial = partial ? partial + l.part_off[i] : nullptr;
-      ScopedTiming t(h, 2);
-      HIPCHK((wgrad_direct_launch<1, 1>(b, h->stream)));
     }
-    if (i > 0 || input_grad) {
-      GemmBatch b{}; b.n = 1;
-      GemmProblem& p = b.prob[0];
-      p.P = w + l.w_off[i]; p.ldp = l.kp[i];
-      p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
-      p.C = dZ[i]; p.ldc = l.kp[i];
-      p.Pdim = l.kp[i]; p.Qdim = rows; p.Kred = l.dims[i + 1];
-      p.mask = i > 0 ? act[i] : nullptr; p.ldm = l.kp[i];
-      ScopedTiming t(h, 1);
-      HIPCHK((dgrad_direct_launch<1, 1>(b, h->stream)));
-    }
+    ScopedTiming t(h, (need_dx && want_w) ? 4 : need_dx ? 1 : 2);
+    if (need_dx && want_w) HIPCHK(bwd_pair_direct_launch<1>(b, h->stream));   // 64x32 dgrad tiles measured slower here (27 vs 19 us)
+    else if (need_dx) HIPCHK((dgrad_direct_launch<1, 1>(b, h->stream)));
+    else HIPCHK((wgrad_direct_launch<1, 1>(b, h->stream)));
   }
   return 0;
 }
@@ -569,6 +574,8 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
     }
   }
   HIPCHK(direct_prepare(gemm_wgrad_direct<1, 1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
+  HIPCHK(direct_prepare(gemm_bwd_pair_direct<1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
+  HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4));
   HIPCHK(direct_prepare(k_head_bwd<1>, 160 * 1024));
   HIPCHK(direct_prepare(k_head_bwd<kNO>, 160 * 1024));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1009,8 +1016,8 @@ int dqnhip_get_kernel_timing(dqnhip_handle h, const char* family, float* avg_ms,
   if (!h || !family) return fail("null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
   int fam = -1;
-  for (int i = 0; i < 4; ++i) if (!strcmp(family, kFamily[i])) fam = i;
-  if (fam < 0) return fail("unknown kernel family '%s' (gemm_fwd|gemm_dgrad|gemm_wgrad|adam)", family);
+  for (int i = 0; i < 5; ++i) if (!strcmp(family, kFamily[i])) fam = i;
+  if (fam < 0) return fail("unknown kernel family '%s' (gemm_fwd|gemm_dgrad|gemm_wgrad|gemm_bwd_pair|adam)", family);
   HIPCHK(hipStreamSynchronize(h->stream));
   double total = 0; int64_t cnt = 0;
   for (auto& r : h->recs) {
