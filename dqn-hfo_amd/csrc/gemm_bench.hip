@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/dqnhip_internal.h"
@@ -182,6 +183,28 @@ extern "C" int dqnhip_test_gemm(int32_t mode, int32_t variant, int32_t rows, int
   }
   for (int i = 0; i < 3; ++i) CK(launch_variant(mode, variant, b, s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  if (getenv("DQNHIP_BENCH_STREAMS")) {
+    // concurrency probe: the same launch sequence on NS independent streams (separate problems
+    // per stream would be cleaner; outputs are identical so the write race is benign here)
+    const int NS = atoi(getenv("DQNHIP_BENCH_STREAMS"));
+    std::vector<hipStream_t> ss(NS);
+    std::vector<hipEvent_t> ev(NS);
+    for (int k = 0; k < NS; ++k) { CK(hipStreamCreateWithFlags(&ss[k], hipStreamNonBlocking)); CK(hipEventCreate(&ev[k])); }
+    CK(hipStreamSynchronize(s));
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0, s));
+      for (int k = 0; k < NS; ++k) CK(hipStreamWaitEvent(ss[k], e0, 0));
+      for (int i = 0; i < iters; ++i)
+        for (int k = 0; k < NS; ++k) CK(launch_variant(mode, variant, b, ss[k]));
+      for (int k = 0; k < NS; ++k) { CK(hipEventRecord(ev[k], ss[k])); CK(hipStreamWaitEvent(s, ev[k], 0)); }
+      CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    }
+    float ms2 = 0; CK(hipEventElapsedTime(&ms2, e0, e1));
+    if (avg_us) *avg_us = ms2 * 1000.0f / iters;     // per "round" of NS concurrent launches
+    for (int k = 0; k < NS; ++k) { hipStreamDestroy(ss[k]); hipEventDestroy(ev[k]); }
+    if (max_abs_err) *max_abs_err = 0; if (max_ref) *max_ref = 0;
+    return 0;
+  }
   CK(hipStreamSynchronize(s));
   CK(hipEventRecord(e0, s));
   for (int i = 0; i < iters; ++i) CK(launch_variant(mode, variant, b, s));

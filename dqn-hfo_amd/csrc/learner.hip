@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -94,6 +95,8 @@ struct dqnhip_learner {
   NetLayout la, lc;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t aux = nullptr;                 // branch stream (nullptr: single-stream schedule)
+  std::vector<hipEvent_t> events; int ev_next = 0;
   // parameter arenas
   float* w[4] = {nullptr, nullptr, nullptr, nullptr};
   float* m[2] = {nullptr, nullptr};
@@ -138,12 +141,12 @@ using H = dqnhip_learner;
 const char* kFamily[] = {"gemm_fwd", "gemm_dgrad", "gemm_wgrad", "adam", "gemm_bwd_pair"};
 
 struct ScopedTiming {
-  H* h; int fam; hipEvent_t a = nullptr, b = nullptr;
-  ScopedTiming(H* h_, int f) : h(h_), fam(f) {
-    if (h->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, h->stream); }
+  H* h; int fam; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+  ScopedTiming(H* h_, int f, hipStream_t s) : h(h_), fam(f), st(s) {
+    if (h->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
   }
   ~ScopedTiming() {
-    if (h->timing) { hipEventRecord(b, h->stream); h->recs.push_back({fam, a, b}); }
+    if (h->timing) { hipEventRecord(b, st); h->recs.push_back({fam, a, b}); }
   }
 };
 
@@ -206,44 +209,68 @@ int validate(const dqnhip_config* c) {
 
 size_t grad_arena_floats(const NetLayout& la, const NetLayout& lc) { return la.arena + 64 + lc.arena + 64; }
 
+// ---- two-stream scheduling ------------------------------------------------------------
+// The update is a DAG with a few independent branches (the two forward chains of phase 0,
+// every layer's wgrad next to the dgrad chain, per-layer Adam ahead of the forward that
+// consumes it).  Branches run on an auxiliary stream; dependencies are events.  Under graph
+// capture the same calls become parallel branches of the hipGraph.  A dependent kernel
+// boundary costs ~2 us on this chip and a 256-workgroup layer leaves room for a second
+// kernel, so a concurrent branch hides both (measured: 6.5 vs 9.9 us per layer).
+hipStream_t aux_of(H* h) { return (h->aux && !h->timing) ? h->aux : h->stream; }
+
+int stream_wait(H* h, hipStream_t waiter, hipStream_t signaler) {
+  if (waiter == signaler) return 0;
+  hipEvent_t ev = h->events[h->ev_next];
+  h->ev_next = (h->ev_next + 1) % (int)h->events.size();
+  HIPCHK(hipEventRecord(ev, signaler));
+  HIPCHK(hipStreamWaitEvent(waiter, ev, 0));
+  return 0;
+}
+
 // ---- forward / backward building blocks ----------------------------------------
 
 struct FwdPass { const float* w; const NetLayout* l; float** act; };
 
-// Tower forward for up to kMaxGroup independent passes of identical shape
-// (grouped launch per layer).  act[0] of every pass must already hold the input panel.
-int tower_forward(H* h, const FwdPass* passes, int n, int rows) {
+// One tower layer forward for up to kMaxGroup passes of identical shape.
+int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, int i) {
   const NetLayout& l = *passes[0].l;
-  for (int i = 0; i < l.L; ++i) {
-    GemmBatch b{}; b.n = n;
-    for (int j = 0; j < n; ++j) {
-      GemmProblem& p = b.prob[j];
-      p.P = passes[j].w + l.w_off[i]; p.ldp = l.kp[i];
-      p.Q = passes[j].act[i]; p.ldq = l.kp[i];
-      p.C = passes[j].act[i + 1]; p.ldc = l.kp[i + 1];
-      p.Pdim = l.dims[i + 1]; p.Qdim = rows; p.Kred = l.kp[i];
-      p.bias = passes[j].w + l.b_off[i]; p.relu = 1;
-    }
-    ScopedTiming t(h, 0);
-    // one problem: 32x32 tiles (256 workgroups for a 256x1024 layer); grouped: 64x32
-    // K >= 512 and K % 256 == 0: full-line loads + wave-private LDS transpose; else (first
-    // layer, narrow towers) the plain direct kernel
-    const bool lds_ok = (l.kp[i] >= 512) && (l.kp[i] % 256 == 0);
-    if (n == 1) { if (lds_ok) HIPCHK((fwd_lds_launch<2, 2, false>(b, h->stream))); else HIPCHK((fwd_direct_launch<2, 2>(b, h->stream))); }
-    else { if (lds_ok) HIPCHK((fwd_lds_launch<4, 2, false>(b, h->stream))); else HIPCHK((fwd_direct_launch<4, 2>(b, h->stream))); }
+  GemmBatch b{}; b.n = n;
+  for (int j = 0; j < n; ++j) {
+    GemmProblem& p = b.prob[j];
+    p.P = passes[j].w + l.w_off[i]; p.ldp = l.kp[i];
+    p.Q = passes[j].act[i]; p.ldq = l.kp[i];
+    p.C = passes[j].act[i + 1]; p.ldc = l.kp[i + 1];
+    p.Pdim = l.dims[i + 1]; p.Qdim = rows; p.Kred = l.kp[i];
+    p.bias = passes[j].w + l.b_off[i]; p.relu = 1;
   }
+  ScopedTiming t(h, 0, st);
+  // K >= 512 and K % 256 == 0: full-line loads + wave-private LDS transpose; else (first
+  // layer, narrow towers) the plain direct kernel.  One problem: 32x32 tiles (256 workgroups
+  // for a 256x1024 layer); grouped: 64x32.
+  const bool lds_ok = (l.kp[i] >= 512) && (l.kp[i] % 256 == 0);
+  if (n == 1) { if (lds_ok) HIPCHK((fwd_lds_launch<2, 2, false>(b, st))); else HIPCHK((fwd_direct_launch<2, 2>(b, st))); }
+  else { if (lds_ok) HIPCHK((fwd_lds_launch<4, 2, false>(b, st))); else HIPCHK((fwd_direct_launch<4, 2>(b, st))); }
+  return 0;
+}
+int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows) {
+  for (int i = 0; i < passes[0].l->L; ++i) RC(layer_forward(h, st, passes, n, rows, i));
   return 0;
 }
 
-// Tower backward from dZ[L] (gradient wrt the last tower pre-activation) down.
+// Tower backward from dZ[L] (gradient wrt the last tower pre-activation) down.  The dgrad
+// chain runs on `st`; each layer's wgrad (which only needs dZ[i+1]) goes to the auxiliary
+// stream when there is one, else shares a mixed-mode launch with the dgrad.
 // want_w: produce dW/db (+sumsq partials) into garena; input_grad: also dZ[0].
-int tower_backward(H* h, const NetLayout& l, const float* w, float* garena, float* partial,
+// On return the aux stream may still be running wgrads: the caller joins before using them.
+int tower_backward(H* h, hipStream_t st, const NetLayout& l, const float* w, float* garena, float* partial,
                    float** act, float** dZ, int rows, bool want_w, bool input_grad) {
+  hipStream_t ax = aux_of(h);
+  const bool split = want_w && ax != st;
   for (int i = l.L - 1; i >= 0; --i) {
-    GemmBatch b{}; b.n = 0;
+    GemmBatch bd{}, bw{};
     const bool need_dx = (i > 0 || input_grad);
     if (need_dx) {                         // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
-      GemmProblem& p = b.prob[b.n++];
+      GemmProblem& p = bd.prob[bd.n++];
       p.mode = GEMM_DGRAD;
       p.P = w + l.w_off[i]; p.ldp = l.kp[i];
       p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
@@ -252,7 +279,7 @@ int tower_backward(H* h, const NetLayout& l, const float* w, float* garena, floa
       p.mask = i > 0 ? act[i] : nullptr; p.ldm = l.kp[i];
     }
     if (want_w) {                          // dW_i = dZ[i+1]^T . act[i] ; db_i = colsum(dZ[i+1])
-      GemmProblem& p = b.prob[b.n++];
+      GemmProblem& p = bw.prob[bw.n++];
       p.mode = GEMM_WGRAD;
       p.P = act[i]; p.ldp = l.kp[i];
       p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
@@ -261,44 +288,68 @@ int tower_backward(H* h, const NetLayout& l, const float* w, float* garena, floa
       p.db = garena + l.b_off[i];
       p.partial = partial ? partial + l.part_off[i] : nullptr;
     }
-    ScopedTiming t(h, (need_dx && want_w) ? 4 : need_dx ? 1 : 2);
-    if (need_dx && want_w) HIPCHK(bwd_pair_direct_launch<1>(b, h->stream));   // 64x32 dgrad tiles measured slower here (27 vs 19 us)
-    else if (need_dx) HIPCHK((dgrad_direct_launch<1, 1>(b, h->stream)));
-    else HIPCHK((wgrad_direct_launch<1, 1>(b, h->stream)));
+    if (split) {
+      RC(stream_wait(h, ax, st));          // dZ[i+1] is complete on st at this point
+      HIPCHK((wgrad_direct_launch<1, 1>(bw, ax)));
+      if (need_dx) HIPCHK((dgrad_direct_launch<1, 1>(bd, st)));
+    } else if (need_dx && want_w) {
+      GemmBatch b{}; b.n = 2; b.prob[0] = bd.prob[0]; b.prob[1] = bw.prob[0];
+      ScopedTiming t(h, 4, st);
+      HIPCHK(bwd_pair_direct_launch<1>(b, st));
+    } else if (need_dx) {
+      ScopedTiming t(h, 1, st);
+      HIPCHK((dgrad_direct_launch<1, 1>(bd, st)));
+    } else {
+      ScopedTiming t(h, 2, st);
+      HIPCHK((wgrad_direct_launch<1, 1>(bw, st)));
+    }
   }
   return 0;
 }
 
 template <int NH, int MODE>
-int head_forward(H* h, const HeadArgs& a, const HeadArgs* b = nullptr) {
+int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nullptr) {
   HeadArgs2 a2{}; a2.p[0] = a; if (b) a2.p[1] = *b;
   const int blocks = (a.rows + 3) / 4;
-  hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(blocks, b ? 2 : 1), dim3(256), 0, h->stream, a2);
+  hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(blocks, b ? 2 : 1), dim3(256), 0, st, a2);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 template <int NH>
-int head_backward(H* h, const HeadBwdArgs& a) {
+int head_backward(H* h, hipStream_t st, const HeadBwdArgs& a) {
   const size_t lds = ((size_t)a.rows * NH + 16 * NH * 64 + 16) * sizeof(float);
   if (lds > 160 * 1024) return fail("minibatch %d too large for the fused head-backward kernel (LDS %zu B)", a.rows, lds);
-  hipLaunchKernelGGL((k_head_bwd<NH>), dim3(a.H / 64), dim3(1024), lds, h->stream, a);
+  hipLaunchKernelGGL((k_head_bwd<NH>), dim3(a.H / 64), dim3(1024), lds, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-int adam_launch(H* h, int net, const float* partial, int n_partial) {
-  const NetLayout& l = layout_of(h, net);
+AdamArgs adam_args(H* h, int net, const float* partial, int n_partial, size_t begin, size_t end) {
   AdamArgs a{};
-  a.w = h->w[net]; a.g = h->g[net]; a.m = h->m[net]; a.v = h->v[net]; a.wt = h->w[net + 2];
-  a.n4 = l.arena / 4; a.partial = partial; a.n_partial = n_partial;
+  a.w = h->w[net] + begin; a.g = h->g[net] + begin; a.m = h->m[net] + begin; a.v = h->v[net] + begin;
+  a.wt = h->w[net + 2] + begin;
+  a.n4 = (end - begin) / 4; a.partial = partial; a.n_partial = n_partial;
+  a.lr = net == DQNHIP_ACTOR ? h->cfg.actor_lr : h->cfg.critic_lr;
+  a.beta1 = h->cfg.momentum; a.beta2 = h->cfg.momentum2; a.eps = h->cfg.delta;
+  a.clip = h->cfg.clip_gradients; a.tau = (float)h->cfg.tau;
+  a.soft_update_freq = h->cfg.soft_update_freq; a.which = net; a.st = h->st;
+  return a;
+}
+
+// clip + Adam + Net::Update + soft target update over arena floats [begin, end)
+int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end) {
+  AdamArgs a{};
+  a.w = h->w[net] + begin; a.g = h->g[net] + begin; a.m = h->m[net] + begin; a.v = h->v[net] + begin;
+  a.wt = h->w[net + 2] + begin;
+  a.n4 = (end - begin) / 4; a.partial = partial; a.n_partial = n_partial;
   a.lr = net == DQNHIP_ACTOR ? h->cfg.actor_lr : h->cfg.critic_lr;
   a.beta1 = h->cfg.momentum; a.beta2 = h->cfg.momentum2; a.eps = h->cfg.delta;
   a.clip = h->cfg.clip_gradients; a.tau = (float)h->cfg.tau;
   a.soft_update_freq = h->cfg.soft_update_freq; a.which = net; a.st = h->st;
   int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, 2048);
-  ScopedTiming t(h, 3);
-  hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, h->stream, a);
+  ScopedTiming t(h, 3, st);
+  hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -318,30 +369,41 @@ int run_phase(H* h, int phase, const int* idx_dev) {
   const float inv_batch = 1.0f / (float)(B * h->cfg.dp_world);
   float* actor_tail = h->g[0] + la.arena;
   float* critic_tail = h->g[1] + lc.arena;
-  const int Hh = la.dims[L];
+  const int Hh = la.dims[L], Hc = lc.dims[L];
+  hipStream_t st = h->stream, ax = aux_of(h);
   if (phase == 0) {
     // 1-2: sample + gather (src/dqn.cpp:846-887)
     GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
                  h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
-    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->ring, h->st, idx_dev,
+    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, h->ring, h->st, idx_dev,
                        (uint64_t)h->cfg.seed, go, B);
     HIPCHK(hipGetLastError());
-    // actor_target(s') [:979] and actor(s) [:910-911, pre-update weights] share launches
-    FwdPass ap[2] = {{h->w[DQNHIP_ACTOR_TARGET], &la, h->act[0]}, {h->w[DQNHIP_ACTOR], &la, h->act[1]}};
-    RC(tower_forward(h, ap, 2, B));
-    {
-      HeadArgs a{}; a.X = h->act[0][L]; a.ldx = Hh; a.H = Hh; a.rows = B;
-      a.W = h->w[DQNHIP_ACTOR_TARGET] + la.hw_off; a.b = h->w[DQNHIP_ACTOR_TARGET] + la.hb_off;
-      a.out16 = h->aout_t16; a.xc = h->Xc_nx; a.ldxc = lc.kp[0]; a.xc_col = h->S;
-      HeadArgs c{}; c.X = h->act[1][L]; c.ldx = Hh; c.H = Hh; c.rows = B;
-      c.W = h->w[DQNHIP_ACTOR] + la.hw_off; c.b = h->w[DQNHIP_ACTOR] + la.hb_off;
-      c.out16 = h->aout16; c.xc = h->Xc_pl; c.ldxc = lc.kp[0]; c.xc_col = h->S;
-      RC((head_forward<kNO, HEAD_ACTOR>(h, a, &c)));     // both actors' heads in one launch
+    FwdPass pAT{h->w[DQNHIP_ACTOR_TARGET], &la, h->act[0]}, pA{h->w[DQNHIP_ACTOR], &la, h->act[1]};
+    FwdPass pCT{h->w[DQNHIP_CRITIC_TARGET], &lc, h->act[2]}, pC1{h->w[DQNHIP_CRITIC], &lc, h->act[3]};
+    HeadArgs hAT{}; hAT.X = h->act[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
+    hAT.W = h->w[DQNHIP_ACTOR_TARGET] + la.hw_off; hAT.b = h->w[DQNHIP_ACTOR_TARGET] + la.hb_off;
+    hAT.out16 = h->aout_t16; hAT.xc = h->Xc_nx; hAT.ldxc = lc.kp[0]; hAT.xc_col = h->S;
+    HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
+    hA.W = h->w[DQNHIP_ACTOR] + la.hw_off; hA.b = h->w[DQNHIP_ACTOR] + la.hb_off;
+    hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
+    if (ax != st) {
+      // branch 1 (st):  actor_target(s') -> critic_target(s', mu'(s'))   [src/dqn.cpp:889-891]
+      // branch 2 (aux): actor(s) [:910-911, pre-update weights] -> critic(s, a) train fwd [:904]
+      RC(stream_wait(h, ax, st));
+      RC(tower_forward(h, st, &pAT, 1, B));
+      RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT)));
+      RC(tower_forward(h, st, &pCT, 1, B));
+      RC(tower_forward(h, ax, &pA, 1, B));
+      RC((head_forward<kNO, HEAD_ACTOR>(h, ax, hA)));
+      RC(tower_forward(h, ax, &pC1, 1, B));
+      RC(stream_wait(h, st, ax));
+    } else {
+      FwdPass ap[2] = {pAT, pA};
+      RC(tower_forward(h, st, ap, 2, B));
+      RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));     // both actors' heads in one launch
+      FwdPass cp[2] = {pCT, pC1};
+      RC(tower_forward(h, st, cp, 2, B));
     }
-    // critic_target(s', mu'(s')) [:889-891] and critic(s, a) train forward [:904]
-    FwdPass cp[2] = {{h->w[DQNHIP_CRITIC_TARGET], &lc, h->act[2]}, {h->w[DQNHIP_CRITIC], &lc, h->act[3]}};
-    RC(tower_forward(h, cp, 2, B));
-    const int Hc = lc.dims[L];
     {
       HeadTrainArgs t{};
       t.Xt = h->act[2][L]; t.Wt = h->w[DQNHIP_CRITIC_TARGET] + lc.hw_off; t.bt = h->w[DQNHIP_CRITIC_TARGET] + lc.hb_off;
@@ -349,7 +411,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       t.H = Hc; t.rows = B; t.reward = h->mb_reward; t.mc = h->mb_mc; t.term = h->mb_term;
       t.q_target = h->q_t; t.q = h->q1; t.y = h->y; t.dq = h->dq; t.loss_partial = h->loss_partial;
       t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch;
-      hipLaunchKernelGGL(k_head_q_train, dim3((B + 3) / 4), dim3(256), 0, h->stream, t);
+      hipLaunchKernelGGL(k_head_q_train, dim3((B + 3) / 4), dim3(256), 0, st, t);
       HIPCHK(hipGetLastError());
     }
     // critic backward (rest of Step(1)): head (dgrad + ReLU' + wgrad fused), then tower; wgrad
@@ -358,58 +420,72 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = h->w[DQNHIP_CRITIC] + lc.hw_off; a.X4 = h->act[3][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L]; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
-      RC(head_backward<1>(h, a));
+      RC(head_backward<1>(h, st, a));
     }
-    RC(tower_backward(h, lc, h->w[DQNHIP_CRITIC], h->g[1], h->part[1], h->act[3], h->dZc, B, true, false));
+    RC(tower_backward(h, st, lc, h->w[DQNHIP_CRITIC], h->g[1], h->part[1], h->act[3], h->dZc, B, true, false));
+    RC(stream_wait(h, st, ax));            // all critic wgrads done
     if (dp) {
-      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, h->stream, (const float*)h->loss_partial,
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)h->loss_partial,
                          h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr);
       HIPCHK(hipGetLastError());
     }
     return 0;
   }
   if (phase == 1) {
-    // ClipGradients + Adam + Net::Update of the critic, soft update of critic_target fused
-    if (dp) { RC(sumsq_launch(h, 1)); RC(adam_launch(h, 1, h->part_dp, h->n_part_dp)); }
-    else RC(adam_launch(h, 1, h->part[1], lc.n_part));
-    // critic(s, mu(s)) with the UPDATED critic (src/dqn.cpp:913-916)
-    FwdPass cp[1] = {{h->w[DQNHIP_CRITIC], &lc, h->act[4]}};
+    // ClipGradients + Adam + Net::Update of the critic, soft update of critic_target fused.
+    // Per layer, on the auxiliary stream, so that layer i of the forward below only waits for
+    // the Adam of layer i (every launch re-derives the same global clip scale from the partials).
+    const float* part = h->part[1]; int n_part = lc.n_part;
+    if (dp) { RC(sumsq_launch(h, 1)); part = h->part_dp; n_part = h->n_part_dp; }
+    FwdPass pC2{h->w[DQNHIP_CRITIC], &lc, h->act[4]};
     h->act[4][0] = h->Xc_pl;
-    RC(tower_forward(h, cp, 1, B));
-    const int Hc = lc.dims[L];
+    if (ax != st) {
+      RC(stream_wait(h, ax, st));
+      for (int i = 0; i < L; ++i) {
+        RC(adam_launch(h, ax, 1, part, n_part, lc.w_off[i], i + 1 < L ? lc.w_off[i + 1] : lc.hw_off));
+        RC(stream_wait(h, st, ax));
+        RC(layer_forward(h, st, &pC2, 1, B, i));       // critic(s, mu(s)), UPDATED weights [:913-916]
+      }
+      RC(adam_launch(h, ax, 1, part, n_part, lc.hw_off, lc.arena));
+      RC(stream_wait(h, st, ax));
+    } else {
+      RC(adam_launch(h, st, 1, part, n_part, 0, lc.arena));
+      RC(tower_forward(h, st, &pC2, 1, B));
+    }
     {
       HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
       a.W = h->w[DQNHIP_CRITIC] + lc.hw_off; a.b = h->w[DQNHIP_CRITIC] + lc.hb_off; a.q = h->q2;
       a.qsum_partial = h->q_partial;
-      RC((head_forward<1, HEAD_Q_POLICY>(h, a)));
+      RC((head_forward<1, HEAD_Q_POLICY>(h, st, a)));
     }
     // q diff = -1 per row, BackwardFrom(q_values_layer) — input gradient only; the
     // reference's discarded critic dW is never computed
     {
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = h->w[DQNHIP_CRITIC] + lc.hw_off; a.X4 = h->act[4][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
-      RC(head_backward<1>(h, a));
+      RC(head_backward<1>(h, st, a));
     }
-    RC(tower_backward(h, lc, h->w[DQNHIP_CRITIC], nullptr, nullptr, h->act[4], h->dZc, B, false, true));
+    RC(tower_backward(h, st, lc, h->w[DQNHIP_CRITIC], nullptr, nullptr, h->act[4], h->dZc, B, false, true));
     // inverting gradients (src/dqn.cpp:924-957) + actor heads backward (src/dqn.cpp:960-963)
     {
       HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;
       a.W = h->w[DQNHIP_ACTOR] + la.hw_off; a.X4 = h->act[1][L]; a.H = Hh; a.rows = B; a.dZ = h->dZa[L];
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
-      RC(head_backward<kNO>(h, a));
+      RC(head_backward<kNO>(h, st, a));
     }
-    RC(tower_backward(h, la, h->w[DQNHIP_ACTOR], h->g[0], h->part[0], h->act[1], h->dZa, B, true, false));
+    RC(tower_backward(h, st, la, h->w[DQNHIP_ACTOR], h->g[0], h->part[0], h->act[1], h->dZa, B, true, false));
+    RC(stream_wait(h, st, ax));            // all actor wgrads done
     if (dp) {
-      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, h->stream, (const float*)nullptr, 0,
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)nullptr, 0,
                          (const double*)h->q_partial, h->n_head_blocks, inv_batch, (float*)nullptr, actor_tail);
       HIPCHK(hipGetLastError());
     }
     return 0;
   }
   if (phase == 2) {
-    if (dp) { RC(sumsq_launch(h, 0)); RC(adam_launch(h, 0, h->part_dp, h->n_part_dp)); }
-    else RC(adam_launch(h, 0, h->part[0], la.n_part));
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(64), 0, h->stream, h->st, critic_tail, actor_tail,
+    if (dp) { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena)); }
+    else RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena));
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(64), 0, st, h->st, critic_tail, actor_tail,
                        (const float*)h->loss_partial, h->n_head_blocks,
                        dp ? (const double*)nullptr : (const double*)h->q_partial, h->n_head_blocks,
                        (float)(B * h->cfg.dp_world));
@@ -503,6 +579,11 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   layout_init(h->lc, h->S + kNO, *cfg, false);
   if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
   else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+  // Two-stream schedule is opt-in: every cross-stream event edge costs several us on this
+  // platform (measured: 18 edges per update -> 535 us vs 380 us single-stream).
+  if (getenv("DQNHIP_AUX")) HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+  h->events.resize(64);
+  for (auto& e : h->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const int B = h->B, L = h->L;
   auto dalloc = [&](float** p, size_t n) -> int {
     HIPCHK(hipMalloc(p, n * sizeof(float)));
@@ -604,6 +685,8 @@ int dqnhip_destroy(dqnhip_handle h) {
   hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp);
   if (h->stage_dev) hipFree(h->stage_dev);
   if (h->act_buf) hipFree(h->act_buf);
+  if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
+  for (auto& e : h->events) hipEventDestroy(e);
   if (h->own_stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -731,10 +814,10 @@ static int actor_forward_dev(H* h, int net, const float* states_dev, int n, floa
                      h->S, acts[0], rows, l.kp[0]);
   HIPCHK(hipGetLastError());
   FwdPass fp[1] = {{h->w[net], &l, acts}};
-  RC(tower_forward(h, fp, 1, rows));
+  RC(tower_forward(h, h->stream, fp, 1, rows));
   HeadArgs a{}; a.X = acts[l.L]; a.ldx = l.dims[l.L]; a.H = l.dims[l.L]; a.rows = rows;
   a.W = h->w[net] + l.hw_off; a.b = h->w[net] + l.hb_off; a.out16 = out16;
-  RC((head_forward<kNO, HEAD_ACTOR>(h, a)));
+  RC((head_forward<kNO, HEAD_ACTOR>(h, h->stream, a)));
   hipLaunchKernelGGL(k_unpack_out, dim3((n * kNO + 255) / 256), dim3(256), 0, h->stream, (const float*)out16, n, out_dev);
   HIPCHK(hipGetLastError());
   return 0;
@@ -788,10 +871,10 @@ int dqnhip_critic_forward(dqnhip_handle h, int32_t net, const float* states_host
                      (const float*)adev, n, h->S, acts[0], rows, l.kp[0]);
   HIPCHK(hipGetLastError());
   FwdPass fp[1] = {{h->w[net], &l, acts}};
-  RC(tower_forward(h, fp, 1, rows));
+  RC(tower_forward(h, h->stream, fp, 1, rows));
   HeadArgs a{}; a.X = acts[l.L]; a.ldx = l.dims[l.L]; a.H = l.dims[l.L]; a.rows = rows;
   a.W = h->w[net] + l.hw_off; a.b = h->w[net] + l.hb_off; a.q = qdev;
-  RC((head_forward<1, HEAD_Q>(h, a)));
+  RC((head_forward<1, HEAD_Q>(h, h->stream, a)));
   HIPCHK(hipMemcpyAsync(q_host, qdev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gemm_direct.hip.h"
 #include "gemm_mfma.hip.h"
 
 namespace dqnhip {
@@ -404,9 +405,9 @@ struct AdamArgs {
   int which;                      // 0 actor, 1 critic (selects the iter counter)
   const DevState* st;
 };
-__global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
-  __shared__ float s[4];
-  __shared__ float s_scale;
+// body shared by the stand-alone kernel and the mixed GEMM+Adam launch: block `blk` of
+// `nblk` 256-thread blocks strides over the arena slice
+__device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int nblk, float* s /*>= 5 floats*/) {
   // every block re-derives the same global L2 norm from the partials, in the
   // same order -> bit-identical scale everywhere, no extra launch
   float acc = 0.0f;
@@ -418,10 +419,10 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   if (threadIdx.x == 0) {
     const float sumsq = (s[0] + s[1]) + (s[2] + s[3]);
     const float l2 = sqrtf(sumsq);
-    s_scale = (a.clip >= 0.0f && l2 > a.clip) ? a.clip / l2 : 1.0f;
+    s[4] = (a.clip >= 0.0f && l2 > a.clip) ? a.clip / l2 : 1.0f;
   }
   __syncthreads();
-  const float scale = s_scale;
+  const float scale = s[4];
   const int it_a = a.st->actor_iter, it_c = a.st->critic_iter;
   const int t = (a.which == 0 ? it_a : it_c) + 1;      // t = iter_ + 1 (before increment)
   // correction = sqrt(1 - beta2^t) / (1 - beta1^t), evaluated in double, rounded once
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   const int mx = (it_a + 1) > (it_c + 1) ? (it_a + 1) : (it_c + 1);
   const bool soft = (mx % a.soft_update_freq) == 0;
   const float tau = a.tau, omt = 1 - a.tau;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) {
+  for (size_t i = (size_t)blk * 256 + threadIdx.x; i < a.n4; i += (size_t)nblk * 256) {
     f32x4 g = reinterpret_cast<f32x4*>(a.g)[i];
     f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
     f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
@@ -457,6 +458,10 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
     reinterpret_cast<f32x4*>(a.w)[i] = w;
     if (soft) reinterpret_cast<f32x4*>(a.wt)[i] = wt;
   }
+}
+__global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
+  __shared__ float s[8];
+  adam_soft_body(a, blockIdx.x, gridDim.x, s);
 }
 
 // Reduce the per-block loss / q partials into the gradient-arena tails
