@@ -1,0 +1,68 @@
+"""The C-ABI library loads (no GPU needed: hipcc cross-compiles, dlopen works without a device)
+and exports every symbol that include/*.h declares; the ctypes table in capi.py covers the same
+set.  No compute calls."""
+import ctypes as C
+import glob
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = set()
+    for hdr in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = open(hdr).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        for m in re.finditer(r"\b(dqnhip_[a-z_0-9]+)\s*\(", src):
+            names.add(m.group(1))
+    return names
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    lib_path = pkg.build()
+    decl = declared_functions()
+    assert len(decl) >= 30
+    lib = C.CDLL(lib_path)
+    missing = [n for n in sorted(decl) if not hasattr(lib, n)]
+    assert not missing, missing
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\b(dqnhip_[a-z_0-9]+)\b", out))
+    assert decl <= exported
+
+
+def test_ctypes_table_matches_header(pkg):
+    decl = {n for n in declared_functions() if n != "dqnhip_test_gemm"}
+    assert set(pkg.capi.SIGNATURES) == decl
+
+
+def test_config_struct_size_and_defaults(pkg):
+    """dqnhip_default_config is pure host code: the defaults are the reference's
+    (src/dqn.hpp:19, src/dqn.cpp:21-31, 425, src/dqn_main.cpp:30-37)."""
+    lib = pkg.capi.load()
+    cfg = pkg.capi.Config()
+    lib.dqnhip_default_config(C.byref(cfg), 59)
+    assert cfg.struct_size == C.sizeof(pkg.capi.Config)
+    assert (cfg.minibatch, cfg.state_size, cfg.num_hidden) == (32, 59, 4)
+    assert list(cfg.hidden)[:4] == [1024, 512, 256, 128]
+    assert cfg.replay_capacity == 500000 and cfg.soft_update_freq == 1
+    assert (cfg.gamma, cfg.beta, cfg.tau) == (0.99, 0.5, 0.001)
+    assert abs(cfg.actor_lr - 1e-5) < 1e-12 and abs(cfg.critic_lr - 1e-3) < 1e-10
+    assert abs(cfg.momentum - 0.95) < 1e-7 and abs(cfg.momentum2 - 0.999) < 1e-7
+    assert abs(cfg.delta - 1e-8) < 1e-15 and cfg.clip_gradients == 10.0
+    assert lib.dqnhip_grad_arena_bytes(C.byref(cfg)) > 4 * (751754 + 760833)
+    cfg.minibatch = 33                                   # not a multiple of 32 -> rejected
+    assert lib.dqnhip_grad_arena_bytes(C.byref(cfg)) == 0
+    assert b"multiple of 32" in lib.dqnhip_last_error()
+
+
+def test_create_fails_loudly_without_gpu(pkg):
+    """On a box with no HIP device the product path must error, never fall back."""
+    import pytest
+    from conftest import _gpu_present
+    if _gpu_present():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.DQNFatal):
+        pkg.DQN(59)

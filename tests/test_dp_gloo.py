@@ -1,0 +1,109 @@
+"""The data-parallel update (dqn-hfo_amd/parallel.py) on CPU: world_size 2, gloo backend, the C
+oracle standing in for the HIP learner behind the same update_phase() interface.  Each rank
+holds its own replay shard and half of the minibatch; the result must match ONE learner fed the
+concatenated minibatch (EuclideanLoss normalised by the global batch, actor gradient an
+un-normalised sum: src/dqn.cpp:918-921)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B_LOCAL, S, HIDDEN, N_REP = 32, 59, (64, 64), 512
+
+
+class OracleBackend:
+    """oracle with the learner's phase interface; gradients + tail in one flat tensor per net"""
+
+    def __init__(self, orc):
+        self.orc = orc
+        self.flat = [torch.zeros(orc.param_count(n) + 4) for n in (0, 1)]
+
+    def update_phase(self, phase, idx):
+        o = self.orc
+        if phase == 1:                       # critic grads/tail were all-reduced
+            self._scatter(1)
+        if phase == 2:
+            self._scatter(0)
+            o.set_stats_from_tails()
+        o.update_phase(phase, self.idx if idx is None else idx)
+        if idx is not None:
+            self.idx = np.asarray(idx)
+        if phase == 0:
+            self._gather(1)
+        if phase == 1:
+            self._gather(0)
+
+    def _gather(self, net):
+        g, t = self.orc.grad_view(net), self.orc.tail_view(net)
+        self.flat[net][:g.size] = torch.from_numpy(g.copy()); self.flat[net][g.size:] = torch.from_numpy(t.copy())
+
+    def _scatter(self, net):
+        g, t = self.orc.grad_view(net), self.orc.tail_view(net)
+        g[:] = self.flat[net][:g.size].numpy(); t[:] = self.flat[net][g.size:].numpy()
+
+
+def _setup(world, rank):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import c_oracle, torch_ref
+    from synth import synth_replay
+    rng = np.random.default_rng(3)
+    w = [torch_ref.init_params_np(rng, S, HIDDEN, a) * 8 for a in (True, False)]
+    shards = [synth_replay(np.random.default_rng(10 + r), N_REP, S, mean_len=10) for r in range(world)]
+    idx = [np.random.default_rng(20 + r).integers(0, N_REP, size=(3, B_LOCAL)) for r in range(world)]
+    return c_oracle, w, shards, idx
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c_oracle, w, shards, idx = _setup(world, rank)
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    load_package()
+    from importlib import import_module
+    par = import_module("dqn_hfo_amd.parallel")
+    orc = c_oracle.Oracle(B=B_LOCAL, S=S, hidden=HIDDEN, capacity=N_REP + 1, global_B=B_LOCAL * world)
+    for net in (0, 1):
+        orc.set_params(net, w[net]); orc.clone_to_target(net)
+    orc.add_transitions(*shards[rank])
+    be = OracleBackend(orc)
+    dp = par.DataParallelUpdate(be, critic_grad=be.flat[1], actor_grad=be.flat[0])
+    stats = []
+    for u in range(3):
+        dp.update(idx[rank][u])
+        stats.append(orc.last_stats())
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), stats=np.array(stats),
+             **{"w%d" % n: orc.get_params(n) for n in range(4)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_dp_matches_single_learner(tmp_path):
+    world = 2
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world))
+    # replicas stay bit-identical (same reduced gradient, same Adam)
+    for n in range(4):
+        np.testing.assert_array_equal(r0["w%d" % n], r1["w%d" % n])
+    np.testing.assert_array_equal(r0["stats"], r1["stats"])
+    # single learner on the concatenated minibatch
+    c_oracle, w, shards, idx = _setup(world, 0)
+    cat = [np.concatenate([shards[r][k] for r in range(world)]) for k in range(6)]
+    one = c_oracle.Oracle(B=B_LOCAL * world, S=S, hidden=HIDDEN, capacity=N_REP * world + 1)
+    for net in (0, 1):
+        one.set_params(net, w[net]); one.clone_to_target(net)
+    one.add_transitions(*cat)
+    for u in range(3):
+        gi = np.concatenate([idx[r][u] + r * N_REP for r in range(world)])
+        loss, avgq = one.update(gi)
+        assert abs(loss - r0["stats"][u][0]) <= 1e-5 * max(1, abs(loss))
+        assert abs(avgq - r0["stats"][u][1]) <= 1e-5
+    for n in range(4):
+        np.testing.assert_allclose(r0["w%d" % n], one.get_params(n), rtol=1e-4, atol=2e-6)
+    one.close()
