@@ -44,19 +44,42 @@ def tower_weights(in_dim, hidden):
 
 
 def family_flops(B, S, hidden):
-    """Algorithmic GEMM FLOPs per update, per kernel family (tower layers only; the skinny
-    heads are separate kernels).  See DESIGN.md §roofline."""
+    """Algorithmic GEMM FLOPs per update, per kernel (tower layers only; the skinny heads are
+    separate kernels).  See DESIGN.md §5.  Keys are the learner's timing families."""
     wa = tower_weights(S, hidden)
     wc = tower_weights(S + 10, hidden)
     h1 = hidden[0]
-    fwd = 2 * B * (2 * sum(wa) + 3 * sum(wc))
-    wgrad = 2 * B * (sum(wa) + sum(wc))
-    dgrad = 2 * B * (sum(wc[1:])            # critic train: dX down to layer 2's input
-                     + sum(wc[1:]) + 10 * h1  # critic dQ/da: layer 1 needs only the 10 action columns
-                     + sum(wa[1:]))         # actor
-    pair = 2 * B * (2 * sum(wc[1:]) + 2 * sum(wa[1:]))      # dgrad+wgrad of layers 2..L, critic train + actor
-    return {"gemm_fwd": fwd, "gemm_dgrad": dgrad - 2 * B * (sum(wc[1:]) + sum(wa[1:])),
-            "gemm_wgrad": wgrad - 2 * B * (sum(wc[1:]) + sum(wa[1:])), "gemm_bwd_pair": pair}
+    return {
+        # {actor_target, actor} and {critic_target, critic} layers 2..L, two layers per launch
+        "gemm_fwd_lds_4x2": 2 * B * (2 * sum(wa[1:]) + 2 * sum(wc[1:])),
+        # critic(s, mu(s)) layers 2..L
+        "gemm_fwd_lds_2x2": 2 * B * sum(wc[1:]),
+        # first layers (K = 58 / 68): 2 actor + 3 critic passes
+        "gemm_fwd_direct": 2 * B * (2 * wa[0] + 3 * wc[0]),
+        # dgrad+wgrad of layers 2..L: critic train + actor
+        "gemm_bwd_pair": 2 * B * (2 * sum(wc[1:]) + 2 * sum(wa[1:])),
+        # critic dQ/da chain: layers 2..L plus the 10 action columns of layer 1
+        "gemm_dgrad": 2 * B * (sum(wc[1:]) + 10 * h1),
+        # first-layer wgrads: critic + actor
+        "gemm_wgrad": 2 * B * (wc[0] + wa[0]),
+    }
+
+
+KERNEL_NAMES = {"gemm_fwd_lds_4x2": "gemm_fwd_lds<4,2,false>", "gemm_fwd_lds_2x2": "gemm_fwd_lds<2,2,false>",
+                "gemm_fwd_direct": "gemm_fwd_direct<*>", "gemm_bwd_pair": "gemm_bwd_pair_direct<1>",
+                "gemm_dgrad": "gemm_dgrad_direct<1,1>", "gemm_wgrad": "gemm_wgrad_direct<1,1>"}
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/): separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE is doubled as MI355X_MICROARCH.md
+    §HBM prescribes for wide coalesced reads on gfx950.  None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        d = json.load(open(path))["kernels"][kernel]
+        return int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
+    except Exception:
+        return None
 
 
 def prefill(dqn, n, seed, chunk=131072):
@@ -72,13 +95,14 @@ def prefill(dqn, n, seed, chunk=131072):
 def cpu_baseline(budget_s=12.0):
     """CPU stand-ins for 'the reference Caffe CPU solver' (which cannot be built here:
     Caffe/HFO/boost/glog/gflags/protobuf are absent): (A) the C restatement
-    executing the reference's op sequence incl. its wasted work, OpenMP on all cores;
+    executing the reference's op sequence incl. its wasted work, OpenMP on all usable cores;
     (B) the same sequence in PyTorch-CPU fp32 (MKL/oneDNN GEMMs).  Bounded sample."""
     from oracle import c_oracle, torch_ref
     from synth import synth_replay
     import torch
     rng = np.random.default_rng(11)
-    cores = os.cpu_count() or 1
+    cores = c_oracle.usable_cores()          # affinity capped by the cgroup quota (16 on the GPU box)
+    c_oracle.set_threads(cores)
     n_rep = 8192
     data = synth_replay(rng, n_rep, S)
     wts = [torch_ref.init_params_np(rng, S, HIDDEN, a) for a in (True, False)]
@@ -109,11 +133,15 @@ def cpu_baseline(budget_s=12.0):
         one(); n += 1
     res["torch_cpu_fp32"] = n / (time.perf_counter() - t0)
     best = max(res, key=res.get)
+    what = {"c_port_openmp": "C restatement (oracle/dqn_oracle.c), the reference's op sequence incl. the critic "
+                             "wgrad it computes and discards, OpenMP",
+            "torch_cpu_fp32": "PyTorch-CPU fp32 restatement (oracle/torch_ref.py, MKL/oneDNN GEMMs, autograd: "
+                              "necessary work only)"}
     return {"value": round(res[best], 3), "unit": "updates/s", "cores": cores, "kind": "port",
-            "sample": "%s: ~%.0f s of B=256 4x1024 updates on an 8192-transition replay, reference op "
-                      "sequence incl. its discarded critic wgrad; faster of %s" % (
-                          best, budget_s / 2, json.dumps({k: round(v, 3) for k, v in res.items()})),
-            "note": "stand-in: the reference's Caffe CPU solver cannot be built in this image"}
+            "sample": "%s; ~%.0f s of B=256 4x1024 updates on an 8192-transition replay; faster of %s" % (
+                what[best], budget_s / 2, json.dumps({k: round(v, 3) for k, v in res.items()})),
+            "note": "stand-in: the reference's Caffe CPU solver cannot be built in this image; cores = CPU "
+                    "affinity capped by the cgroup quota"}
 
 
 def main():
@@ -185,18 +213,18 @@ def main():
         for _ in range(n_t):
             step()
         stats = {}
-        for fam in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_bwd_pair", "adam"):
+        for fam in list(fam_flops) + ["adam"]:
             ms, cnt = dqn.kernel_timing(fam)
             stats[fam] = (ms, cnt)
         dqn.kernel_timing("adam", reset=True)
         dqn.set_kernel_timing(False)
-        dom = max(("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_bwd_pair"), key=lambda f: stats[f][0] * stats[f][1])
+        dom = max(fam_flops, key=lambda f: stats[f][0] * stats[f][1])
         ms, cnt = stats[dom]
         per_update_launches = cnt / n_t
         flops_per_launch = fam_flops[dom] / per_update_launches
         ach = flops_per_launch / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
-                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None,
+        roof = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": pmc_traffic(KERNEL_NAMES[dom]),
                 "avg_launch_us": round(ms * 1e3, 2), "launches_per_update": per_update_launches,
                 "flops_per_launch": flops_per_launch,
                 "families_us": {f: [round(stats[f][0] * 1e3, 2), stats[f][1] / n_t] for f in stats}}

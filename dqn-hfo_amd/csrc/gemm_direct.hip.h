@@ -27,6 +27,7 @@
 // gemm_mfma.hip.h (C[q][p] = sum_k P(p,k) Q(q,k), p contiguous).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdlib>
 
@@ -521,6 +522,12 @@ __global__ __launch_bounds__(256) void gemm_bwd_pair_direct(const GemmBatch batc
 
 // ---- launchers ------------------------------------------------------------------------
 
+// When set (by the learner's timing mode), the next launch is bracketed by these events through
+// hipExtLaunchKernelGGL: they carry the dispatch packet's own start/stop timestamps, i.e. the
+// same kernel duration rocprofv3 reports, without the cost of separate event records.
+struct LaunchTimer { hipEvent_t start = nullptr, stop = nullptr; };
+inline LaunchTimer& launch_timer() { static thread_local LaunchTimer t; return t; }
+
 // DQNHIP_LDS_PAD (bytes, env, tuning only): over-allocate dynamic LDS to cap workgroups per CU
 inline int lds_pad_bytes() {
   static int pad = -1;
@@ -542,7 +549,9 @@ inline hipError_t direct_launch(K kernel, GemmBatch& batch, int BP, int BQ, int 
     base += p.tiles_p * p.tiles_q;
   }
   batch.total_tiles = base;
-  hipLaunchKernelGGL(kernel, dim3(base), dim3(256), lds_bytes, stream, batch);
+  LaunchTimer& lt = launch_timer();
+  if (lt.start) { hipExtLaunchKernelGGL(kernel, dim3(base), dim3(256), lds_bytes, stream, lt.start, lt.stop, 0, batch); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL(kernel, dim3(base), dim3(256), lds_bytes, stream, batch);
   return hipGetLastError();
 }
 
@@ -575,7 +584,9 @@ inline hipError_t bwd_pair_direct_launch(GemmBatch& batch, hipStream_t stream) {
     base += p.tiles_p * p.tiles_q;
   }
   batch.total_tiles = base;
-  hipLaunchKernelGGL(gemm_bwd_pair_direct<TQD>, dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, batch);
+  LaunchTimer& lt = launch_timer();
+  if (lt.start) { hipExtLaunchKernelGGL(gemm_bwd_pair_direct<TQD>, dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, lt.start, lt.stop, 0, batch); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL(gemm_bwd_pair_direct<TQD>, dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, batch);
   return hipGetLastError();
 }
 template <typename K>

@@ -138,15 +138,19 @@ namespace {
 
 using H = dqnhip_learner;
 
-const char* kFamily[] = {"gemm_fwd", "gemm_dgrad", "gemm_wgrad", "adam", "gemm_bwd_pair"};
+const char* kFamily[] = {"gemm_fwd_lds_4x2", "gemm_dgrad", "gemm_wgrad", "adam", "gemm_bwd_pair", "gemm_fwd_lds_2x2", "gemm_fwd_direct"};
+constexpr int kNumFamily = 7;
 
+// Timing mode: the NEXT kernel launch (through direct_launch / adam_launch) is bracketed by the
+// dispatch packet's own timestamps (hipExtLaunchKernelGGL start/stop events).
 struct ScopedTiming {
-  H* h; int fam; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
-  ScopedTiming(H* h_, int f, hipStream_t s) : h(h_), fam(f), st(s) {
-    if (h->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
-  }
-  ~ScopedTiming() {
-    if (h->timing) { hipEventRecord(b, st); h->recs.push_back({fam, a, b}); }
+  ScopedTiming(H* h, int fam, hipStream_t) {
+    if (h->timing) {
+      hipEvent_t a = nullptr, b = nullptr;
+      hipEventCreate(&a); hipEventCreate(&b);
+      launch_timer().start = a; launch_timer().stop = b;
+      h->recs.push_back({fam, a, b});
+    }
   }
 };
 
@@ -243,11 +247,11 @@ int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, 
     p.Pdim = l.dims[i + 1]; p.Qdim = rows; p.Kred = l.kp[i];
     p.bias = passes[j].w + l.b_off[i]; p.relu = 1;
   }
-  ScopedTiming t(h, 0, st);
   // K >= 512 and K % 256 == 0: full-line loads + wave-private LDS transpose; else (first
   // layer, narrow towers) the plain direct kernel.  One problem: 32x32 tiles (256 workgroups
   // for a 256x1024 layer); grouped: 64x32.
   const bool lds_ok = (l.kp[i] >= 512) && (l.kp[i] % 256 == 0);
+  ScopedTiming t(h, !lds_ok ? 6 : (n == 1 ? 5 : 0), st);
   if (n == 1) { if (lds_ok) HIPCHK((fwd_lds_launch<2, 2, false>(b, st))); else HIPCHK((fwd_direct_launch<2, 2>(b, st))); }
   else { if (lds_ok) HIPCHK((fwd_lds_launch<4, 2, false>(b, st))); else HIPCHK((fwd_direct_launch<4, 2>(b, st))); }
   return 0;
@@ -349,7 +353,9 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   a.soft_update_freq = h->cfg.soft_update_freq; a.which = net; a.st = h->st;
   int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, 2048);
   ScopedTiming t(h, 3, st);
-  hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, a);
+  LaunchTimer& lt = launch_timer();
+  if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1099,8 +1105,8 @@ int dqnhip_get_kernel_timing(dqnhip_handle h, const char* family, float* avg_ms,
   if (!h || !family) return fail("null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
   int fam = -1;
-  for (int i = 0; i < 5; ++i) if (!strcmp(family, kFamily[i])) fam = i;
-  if (fam < 0) return fail("unknown kernel family '%s' (gemm_fwd|gemm_dgrad|gemm_wgrad|gemm_bwd_pair|adam)", family);
+  for (int i = 0; i < kNumFamily; ++i) if (!strcmp(family, kFamily[i])) fam = i;
+  if (fam < 0) return fail("unknown kernel family '%s' (gemm_fwd_lds_4x2|gemm_fwd_lds_2x2|gemm_fwd_direct|gemm_dgrad|gemm_wgrad|gemm_bwd_pair|adam)", family);
   HIPCHK(hipStreamSynchronize(h->stream));
   double total = 0; int64_t cnt = 0;
   for (auto& r : h->recs) {

@@ -92,6 +92,7 @@ def lib():
         L.orc_set_stats_from_tails.argtypes = [C.c_void_p]
         L.orc_last_stats.argtypes = [C.c_void_p, fp, fp]
         L.orc_debug_read.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_size_t]
+        L.orc_set_threads.argtypes = [C.c_int]
         L.orc_game_update.argtypes = [C.POINTER(OrcGame), fp, C.c_int, C.c_int]
         L.orc_game_reward.restype = C.c_float
         L.orc_game_reward.argtypes = [C.POINTER(OrcGame)]
@@ -247,6 +248,28 @@ class Oracle:
         rc = self.L.orc_debug_read(self.h, name.encode(), _fp(out), n)
         assert rc == 0, (name, rc)
         return out.reshape(self.B, -1) if name in ("actor_out", "dq_da") else out
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def usable_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
 
 
 def label_transitions(gamma, rewards):

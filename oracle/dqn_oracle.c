@@ -31,6 +31,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define ORC_MAXL 8
 #define ORC_NA 4   /* kActionSize      src/dqn.hpp:20 */
 #define ORC_NP 6   /* kActionParamSize src/dqn.hpp:21 */
@@ -79,6 +83,15 @@ typedef struct {
   float last_loss, last_avgq;
   float tail[2][4];           /* per-net [loss_sum, q_sum, 0, 0] for DP all-reduce */
 } orc;
+
+/* number of OpenMP threads used by the dense kernels (CPU-baseline timing) */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 
 /* ------------------------------------------------------------------ layout */
 
