@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--replay", type=int, default=REPLAY)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="use the data-parallel path even with one rank (testing)")
     ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],
                     help="N>1: dp = gradient all-reduce (weak scaling), replicas = independent learners")
     args = ap.parse_args()
@@ -165,12 +166,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dp
+    if dist_on:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    use_dp = world > 1 and args.mode == "dp"
+    use_dp = dist_on and args.mode == "dp"
     if use_dp:
         from importlib import import_module
         par = import_module("dqn_hfo_amd.parallel")
@@ -184,7 +187,7 @@ def main():
     prefill(dqn, args.replay - 1, seed=100 + rank)     # AddTransitions keeps <= capacity-1 (src/dqn.cpp:776)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -197,12 +200,13 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     loss, avgq = dqn.read_stats()
+    final_line = None
 
     # roofline of the dominant kernel family, timed live with HIP events on the learner's stream
     roof = None
@@ -258,12 +262,23 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
+        final_line = json.dumps(out)
+    if dist_on:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
     dqn.close()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio, which is flushed only at exit: push it out
+        # now so that the JSON line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(final_line, flush=True)       # the ONE JSON line
+        os._exit(0) if dist_on else None    # nothing after it (atexit output of the comm libraries)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,73 @@
+"""The data-parallel plumbing on one real GPU: world_size 1, backend nccl (= RCCL).  Exercises
+what N > 1 uses — gradient arenas inside a torch tensor, the learner enqueuing on torch's
+current stream, the three-phase update with all-reduces in between — and checks it against the
+single-GPU path (a 1-rank sum all-reduce is the identity)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch, torch.distributed as dist
+from __graft_entry__ import load_package
+from importlib import import_module
+pkg = load_package()
+par = import_module("dqn_hfo_amd.parallel")
+from oracle import torch_ref
+from synth import synth_replay
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29631")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+B, S, hid = 64, 59, (256, 128, 64, 64)
+rng = np.random.default_rng(5)
+w = [torch_ref.init_params_np(rng, S, hid, a) * 5 for a in (True, False)]
+data = synth_replay(rng, 1024, S, mean_len=10)
+idx = rng.integers(0, 1024, size=(4, B))
+dqn_dp, dp = par.make_hip_data_parallel(pkg, S, 0, 1, 0, minibatch=B, hidden=hid, memory=4096, seed=2)
+ref = pkg.DQN(S, minibatch=B, hidden=hid, memory=4096, seed=2)
+for d in (dqn_dp, ref):
+    for net in (0, 1):
+        d.set_params(net, w[net]); d.CloneNet(net)
+    d.add_transitions_arrays(*data)
+for u in range(4):
+    dp.update(idx[u]); s_dp = dqn_dp.read_stats()
+    s_ref = ref.UpdateActorCritic(idx[u])
+    assert abs(s_dp[0] - s_ref[0]) <= 1e-5 * max(1, abs(s_ref[0])), (s_dp, s_ref)
+    assert abs(s_dp[1] - s_ref[1]) <= 1e-5, (s_dp, s_ref)
+for net in range(4):
+    a, b = dqn_dp.get_params(net), ref.get_params(net)
+    assert np.abs(a - b).max() <= 1e-6, (net, np.abs(a - b).max())
+for u in range(3):                       # on-device sampling through the DP path
+    dp.update(None)
+l, q = dqn_dp.read_stats()
+assert np.isfinite(l) and np.isfinite(q)
+dist.barrier(); dist.destroy_process_group()
+print("DP-1 OK")
+'''
+
+
+def test_dp_plumbing_world_size_one(pkg, gpu):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "DP-1 OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_bench_runs_under_torchrun_one_rank(pkg, gpu):
+    """The exact launch line the driver uses for N > 1, with N = 1."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "20", "--warmup", "5", "--replay", "20000", "--no-cpu-baseline", "--force-dp"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 100 and d["config"]["parallelism"].startswith("dp1")
