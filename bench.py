@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--replay", type=int, default=REPLAY)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-env", action="store_true", help="skip the env-steps/sec leg")
+    ap.add_argument("--frames-per-trial", type=int, default=500)
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel path even with one rank (testing)")
     ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],
                     help="N>1: dp = gradient all-reduce (weak scaling), replicas = independent learners")
@@ -234,6 +236,36 @@ def main():
                 "families_us": {f: [round(stats[f][0] * 1e3, 2), stats[f][1] / n_t] for f in stats}}
         torch.cuda.synchronize()
 
+    # env-steps/sec (the other half of BASELINE.json's metric): N synthetic workers -> batched
+    # SelectActions + GetAction + HFOGameState reward + LabelTransitions/AddTransitions, all on device
+    env_res = None
+    if rank == 0 and not args.no_env:
+        env_res = {}
+        for workers in (64, 1024):            # workers * frames_per_trial must stay below the replay capacity
+            env = pkg.EnvFrontEnd(dqn, workers, max_steps=args.frames_per_trial, p_end=0.01, seed=5)
+            env.step(0.1, 20)
+            env.stats()
+            t1 = time.perf_counter()
+            n_env = 200 if workers <= 64 else 100
+            env.step(0.1, n_env)
+            st = env.stats()          # blocks
+            dt = time.perf_counter() - t1
+            env_res["workers_%d" % workers] = {"env_steps_per_s": round(workers * n_env / dt, 1),
+                                               "us_per_batched_step": round(dt / n_env * 1e6, 2),
+                                               "episodes": st[1]}
+            env.close()
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import c_oracle, torch_ref
+            orc = c_oracle.Oracle(B=B, S=S, hidden=HIDDEN, capacity=200000)
+            c_oracle.set_threads(c_oracle.usable_cores())
+            rngw = np.random.default_rng(3)
+            orc.set_params(0, torch_ref.init_params_np(rngw, S, HIDDEN, True))
+            oenv = c_oracle.OracleEnv(orc, 64, max_steps=args.frames_per_trial, p_end=0.01, seed=5)
+            oenv.step(0.1, 1)
+            t1 = time.perf_counter(); oenv.step(0.1, 10); dt = time.perf_counter() - t1
+            env_res["cpu_port_workers_64"] = {"env_steps_per_s": round(64 * 10 / dt, 1), "cores": c_oracle.usable_cores()}
+            oenv.close(); orc.close()
+
     if rank == 0:
         ups = args.steps / elapsed
         value = ups * (world if world > 1 else 1)
@@ -257,6 +289,7 @@ def main():
             "update_mfma_frac": round(fl * ups / 1e12 / MFMA_F32_PEAK_TF, 4),
             "last_critic_loss": loss, "last_avg_q": avgq,
             "roofline": roof,
+            "env_steps": env_res,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

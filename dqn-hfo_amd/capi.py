@@ -66,6 +66,21 @@ SIGNATURES = {
     "dqnhip_get_kernel_timing": (C.c_int, [H, C.c_char_p, fp, C.POINTER(C.c_int64), C.c_int32]),
 }
 
+class EnvConfig(C.Structure):
+    """struct dqnhip_env_config (include/dqnhip_env.h)."""
+    _fields_ = [("struct_size", C.c_int32), ("workers", C.c_int32), ("max_steps", C.c_int32), ("unum", C.c_int32),
+                ("p_end", C.c_float), ("p_goal", C.c_float), ("seed", C.c_uint64)]
+
+
+SIGNATURES.update({
+    "dqnhip_env_create": (C.c_int, [H, C.POINTER(EnvConfig), C.POINTER(C.c_void_p)]),
+    "dqnhip_env_destroy": (C.c_int, [C.c_void_p]),
+    "dqnhip_env_step": (C.c_int, [C.c_void_p, C.c_float, C.c_int32]),
+    "dqnhip_env_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int64)]),
+    "dqnhip_env_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, fp, C.c_size_t]),
+})
+
 _lib = None
 
 

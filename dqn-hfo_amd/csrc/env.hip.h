@@ -1,0 +1,262 @@
+// env.hip.h — device side of the batched env front-end (include/dqnhip_env.h): per-worker
+// epsilon-greedy selection + GetAction, synthetic HFO state stream, HFOGameState reward
+// shaping, per-episode buffers, LabelTransitions + AddTransitions at episode end.
+// Reference lines: src/dqn_main.cpp:97-153, src/dqn.cpp:162-208, 664-711, 768-797,
+// src/hfo_game.cpp:109-236.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "small_kernels.hip.h"
+
+namespace dqnhip {
+
+// HFOGameState (src/hfo_game.hpp:29-60), one per worker, SoA-free for clarity (N is small)
+struct GameState {
+  float old_ball_prox, ball_prox_delta, old_kickable, kickable_delta, old_ball_dist_goal, ball_dist_goal_delta;
+  int steps, episode_over, got_kickable_reward, pass_active, pob, old_pob, status, pad;
+};
+
+struct EnvDev {
+  int N, S, SP, T;                 // workers, state size, padded state size, max steps per episode
+  int unum;
+  float p_end, p_goal;
+  unsigned long long seed;
+  float* cur;                      // [Npad][SP] current states == actor input panel
+  float* out16;                    // [Npad][16] greedy actor outputs of this step
+  float* ep_s;                     // [N][T][SP]
+  float* ep_a;                     // [N][T][16]
+  float* ep_r;                     // [N][T]
+  GameState* game;                 // [N]
+  int* len;                        // [N] transitions in the open episode
+  int* done;                       // [N] length of the episode that finished in this step, 0 if none
+  unsigned long long* g;           // [N] per-worker draw counter
+  // per-worker last-step values (debug / parity)
+  int* act; float* arg1; float* arg2; float* rew;
+  // totals
+  unsigned long long* n_steps; unsigned long long* n_episodes; unsigned long long* n_goals; double* reward_sum;
+};
+
+__device__ __forceinline__ float env_u01(unsigned long long seed, unsigned long long g, int w, int k) {
+  return (float)(philox_u32(seed, g, (uint32_t)(w * 256 + k)) >> 8) * (1.0f / 16777216.0f);
+}
+
+// synthetic low-level feature f of worker w at draw counter g
+__device__ __forceinline__ float env_feature(const EnvDev& e, unsigned long long g, int w, int f) {
+  const float kPi = 3.14159265358979323846f;
+  if (f == 13 || f == 14) { const float th = fmaf(2.0f, env_u01(e.seed, g, w, 16 + 13), -1.0f) * kPi; return f == 13 ? sinf(th) : cosf(th); }
+  if (f == 51 || f == 52) { const float th = fmaf(2.0f, env_u01(e.seed, g, w, 16 + 51), -1.0f) * kPi; return f == 51 ? sinf(th) : cosf(th); }
+  const float u = env_u01(e.seed, g, w, 16 + f);
+  if (f == 12 || f == 54) return u < 0.5f ? -1.0f : 1.0f;
+  return fmaf(2.0f, u, -1.0f);
+}
+
+// HFOGameState::update (src/hfo_game.cpp:122-173) minus hfo.step(): status / player_on_ball given
+__device__ __forceinline__ void game_update(GameState& g, const float* st, int status, int pob) {
+  g.status = status;
+  if (status != 0) g.episode_over = 1;
+  const float ball_proximity = st[53], goal_proximity = st[15];
+  const float ball_dist = (float)(1.0 - (double)ball_proximity), goal_dist = (float)(1.0 - (double)goal_proximity);
+  const float kickable = st[12];
+  float ball_ang_rad = (float)acos((double)st[52]);
+  if (st[51] < 0) ball_ang_rad = (float)((double)ball_ang_rad * -1.);
+  float goal_ang_rad = (float)acos((double)st[14]);
+  if (st[13] < 0) goal_ang_rad = (float)((double)goal_ang_rad * -1.);
+  const float alpha = fmaxf(ball_ang_rad, goal_ang_rad) - fminf(ball_ang_rad, goal_ang_rad);
+  const float ball_dist_goal = (float)sqrt((double)(ball_dist * ball_dist + goal_dist * goal_dist) -
+                                           2. * (double)ball_dist * (double)goal_dist * cos((double)alpha));
+  const float ball_vel_valid = st[54], ball_vel = st[55];
+  if (ball_vel_valid != 0.0f && (double)ball_vel > -.5) g.pass_active = 1;   // kPassVelThreshold, src/hfo_game.hpp:18
+  if (g.steps > 0) {
+    g.ball_prox_delta = ball_proximity - g.old_ball_prox;
+    g.kickable_delta = kickable - g.old_kickable;
+    g.ball_dist_goal_delta = ball_dist_goal - g.old_ball_dist_goal;
+  }
+  g.old_ball_prox = ball_proximity; g.old_kickable = kickable; g.old_ball_dist_goal = ball_dist_goal;
+  if (g.episode_over) { g.ball_prox_delta = 0; g.kickable_delta = 0; g.ball_dist_goal_delta = 0; }
+  g.old_pob = g.pob; g.pob = pob;
+  g.steps++;
+}
+
+// HFOGameState::reward (src/hfo_game.cpp:175-236): moveToBall + 3*kickToGoal + EOT; pass_reward()
+// is evaluated for its side effect on pass_active but not added (:178-180)
+__device__ __forceinline__ float game_reward(GameState& g, int our_unum, int* goal) {
+  float mtb = 0;
+  if (g.pob < 0 || g.pob == our_unum) mtb += g.ball_prox_delta;
+  if (g.kickable_delta >= 1 && !g.got_kickable_reward) { mtb = (float)((double)mtb + 1.0); g.got_kickable_reward = 1; }
+  float ktg = 0;
+  if (g.pob == our_unum) ktg = -g.ball_dist_goal_delta;
+  else if (g.got_kickable_reward) ktg = (float)(0.2 * (double)(-g.ball_dist_goal_delta));
+  const float kickToGoal = (float)(3. * (double)ktg);
+  if (g.pass_active && g.pob > 0 && g.pob != g.old_pob) g.pass_active = 0;
+  float eot = 0;
+  if (g.status == 1) { eot = (g.pob == our_unum) ? 5 : 1; *goal = 1; }
+  return mtb + kickToGoal + eot;
+}
+
+__device__ __forceinline__ void game_reset(GameState& g) {
+  g.old_ball_prox = 0; g.ball_prox_delta = 0; g.old_kickable = 0; g.kickable_delta = 0;
+  g.old_ball_dist_goal = 0; g.ball_dist_goal_delta = 0; g.steps = 0; g.episode_over = 0;
+  g.got_kickable_reward = 0; g.pass_active = 0; g.pob = 0; g.old_pob = 0; g.status = 0; g.pad = 0;
+}
+
+// new episode for worker w: first state, HFOGameState() and the initial update after the forced
+// DASH(0,0) (src/dqn_main.cpp:103-105).  One wave; s_state is a [SP] LDS row.
+__device__ __forceinline__ void env_reset_worker(const EnvDev& e, int w, int lane, float* s_state) {
+  const unsigned long long g = e.g[w];
+  for (int f = lane; f < e.SP; f += 64) {
+    const float v = f < e.S ? env_feature(e, g, w, f) : 0.0f;
+    s_state[f] = v; e.cur[(size_t)w * e.SP + f] = v;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    GameState gs; game_reset(gs);
+    game_update(gs, s_state, 0, 0);
+    e.game[w] = gs; e.len[w] = 0; e.g[w] = g + 1;
+  }
+}
+
+__global__ void k_env_init(EnvDev e) {
+  extern __shared__ float s_state[];
+  env_reset_worker(e, blockIdx.x, threadIdx.x, s_state);
+}
+
+// one environment step of every worker (block = one wave = one worker)
+__global__ void k_env_step(EnvDev e, float epsilon) {
+  extern __shared__ float s_next[];
+  __shared__ float s_ao[16];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int len = e.len[w];
+  const unsigned long long g = e.g[w];
+  // SelectAction(state, epsilon): ONE epsilon draw per call (src/dqn.cpp:700)
+  const bool rnd = env_u01(e.seed, g, w, 0) < epsilon;
+  if (lane < kAP) {
+    float v = 0.0f;
+    if (lane < kNO) {
+      if (rnd) {                                   // GetRandomActorOutput (src/dqn.cpp:664-682)
+        const float u = env_u01(e.seed, g, w, 1 + lane);
+        if (lane < kNA) v = fmaf(2.0f, u, -1.0f);
+        else if (lane == kNA + 0) v = fmaf(200.0f, u, -100.0f);
+        else if (lane == kNA + 4) v = 100.0f * u;
+        else v = fmaf(360.0f, u, -180.0f);
+      } else v = e.out16[(size_t)w * kAP + lane];
+    }
+    s_ao[lane] = v;
+    e.ep_a[((size_t)w * e.T + len) * kAP + lane] = v;
+  }
+  float* eps_row = e.ep_s + ((size_t)w * e.T + len) * e.SP;
+  float* cur = e.cur + (size_t)w * e.SP;
+  for (int f = lane; f < e.SP; f += 64) {
+    eps_row[f] = cur[f];
+    const float v = f < e.S ? env_feature(e, g, w, f) : 0.0f;
+    s_next[f] = v;
+  }
+  __syncthreads();
+  for (int f = lane; f < e.SP; f += 64) cur[f] = s_next[f];
+  if (lane == 0) {
+    // GetAction (src/dqn.cpp:196-208)
+    float c0 = s_ao[0], c1 = s_ao[1], c3 = s_ao[3];
+    const float c2 = -99999.0f;
+    int best = 0; float bv = c0;
+    if (c1 > bv) { best = 1; bv = c1; }
+    if (c2 > bv) { best = 2; bv = c2; }
+    if (c3 > bv) { best = 3; bv = c3; }
+    const int o1 = best == 0 ? 0 : best == 1 ? 2 : best == 2 ? 3 : 4;
+    const int o2 = best == 0 ? 1 : best == 3 ? 5 : -1;
+    e.act[w] = best; e.arg1[w] = s_ao[kNA + o1]; e.arg2[w] = o2 < 0 ? 0.0f : s_ao[kNA + o2];
+    // synthetic server: does the episode end on this step, and how
+    int status = 0;
+    if (env_u01(e.seed, g, w, 11) < e.p_end) status = env_u01(e.seed, g, w, 12) < e.p_goal ? 1 : 2;   // GOAL / CAPTURED_BY_DEFENSE
+    if (status == 0 && len + 1 >= e.T) status = 4;                                                   // OUT_OF_TIME
+    const int pob = env_u01(e.seed, g, w, 13) < 0.5f ? e.unum : -1;
+    GameState gs = e.game[w];
+    game_update(gs, s_next, status, pob);
+    int goal = 0;
+    const float r = game_reward(gs, e.unum, &goal);
+    e.game[w] = gs;
+    e.ep_r[(size_t)w * e.T + len] = r; e.rew[w] = r;
+    e.len[w] = len + 1; e.g[w] = g + 1;
+    e.done[w] = status != 0 ? len + 1 : 0;           // length of the finished episode (0: still open)
+    e.n_steps[w] += 1; e.reward_sum[w] += (double)r; e.n_goals[w] += goal;
+  }
+}
+
+// the reference's deque arithmetic of AddTransitions(n) (src/dqn.cpp:775-781)
+__device__ __forceinline__ void ring_add_plan(int cap, int n, int& head, int& size) {
+  int pops = size + n - cap + 1;
+  if (pops < 0) pops = 0;
+  if (pops > size) pops = size;
+  head = (int)(((long long)head + pops) % cap); size -= pops;
+}
+
+// finished episodes: LabelTransitions + AddTransitions, in worker order; then reset the worker
+__global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const DevState* st, double gamma) {
+  extern __shared__ float sm[];          // [T] mc labels, then [SP] reset row
+  __shared__ int s_start;
+  const int w = blockIdx.x;
+  const int len = e.done[w];
+  if (len == 0) return;
+  if (threadIdx.x == 0) {
+    int head = st->ring_head, size = st->ring_size;
+    for (int v = 0; v < w; ++v) {          // AddTransitions of the workers before us, in order
+      const int n = e.done[v];
+      if (n > 0) { ring_add_plan(ring.cap, n, head, size); size += n; }
+    }
+    ring_add_plan(ring.cap, len, head, size);
+    s_start = (int)(((long long)head + size) % ring.cap);
+    // LabelTransitions (src/dqn.cpp:783-797): reverse scan, gamma double, float store
+    const float* r = e.ep_r + (size_t)w * e.T;
+    sm[len - 1] = r[len - 1];
+    for (int i = len - 2; i >= 0; --i) sm[i] = (float)((double)r[i] + gamma * (double)sm[i + 1]);
+    e.n_episodes[w] += 1;
+  }
+  __syncthreads();
+  const int start = s_start;
+  const int SP = e.SP;
+  for (int i = threadIdx.x; i < len * SP; i += 256) {
+    const int t = i / SP, c = i % SP;
+    const long long slot = ((long long)start + t) % ring.cap;
+    ring.state[slot * SP + c] = e.ep_s[((size_t)w * e.T + t) * SP + c];
+    ring.next[slot * SP + c] = (t + 1 < len) ? e.ep_s[((size_t)w * e.T + t + 1) * SP + c] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < len * kAP; i += 256) {
+    const int t = i / kAP, c = i % kAP;
+    const long long slot = ((long long)start + t) % ring.cap;
+    ring.act[slot * kAP + c] = e.ep_a[((size_t)w * e.T + t) * kAP + c];
+  }
+  for (int t = threadIdx.x; t < len; t += 256) {
+    const long long slot = ((long long)start + t) % ring.cap;
+    ring.reward[slot] = e.ep_r[(size_t)w * e.T + t];
+    ring.mc[slot] = sm[t];
+    ring.term[slot] = (t + 1 == len) ? 1 : 0;       // terminal <=> next_state == none
+  }
+  __syncthreads();
+  // new episode for this worker (same steps as env_reset_worker, 256 threads wide)
+  {
+    float* s_state = sm + e.T;
+    const unsigned long long g = e.g[w];
+    for (int f = threadIdx.x; f < e.SP; f += 256) {
+      const float v = f < e.S ? env_feature(e, g, w, f) : 0.0f;
+      s_state[f] = v; e.cur[(size_t)w * e.SP + f] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      GameState gs; game_reset(gs);
+      game_update(gs, s_state, 0, 0);
+      e.game[w] = gs; e.len[w] = 0; e.g[w] = g + 1;
+    }
+  }
+}
+
+// publish the ring bookkeeping after all flushes of this step
+__global__ void k_env_commit(EnvDev e, Ring ring, DevState* st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int head = st->ring_head, size = st->ring_size;
+  for (int v = 0; v < e.N; ++v) {
+    const int n = e.done[v];
+    if (n > 0) { ring_add_plan(ring.cap, n, head, size); size += n; e.done[v] = 0; }
+  }
+  st->ring_head = head; st->ring_size = size;
+}
+
+}  // namespace dqnhip

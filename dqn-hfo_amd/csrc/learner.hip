@@ -17,6 +17,8 @@
 #include <vector>
 
 #include "../../include/dqnhip.h"
+#include "../../include/dqnhip_env.h"
+#include "env.hip.h"
 #include "gemm_direct.hip.h"
 #include "gemm_mfma.hip.h"
 #include "small_kernels.hip.h"
@@ -108,6 +110,7 @@ struct dqnhip_learner {
   DevState* st = nullptr;
   int* done_counter = nullptr;
   long long h_head = 0, h_size = 0;     // host mirror of (head,size)
+  bool ring_stale = false;              // the device changed (head,size) on its own (env front-end)
   int h_actor_iter = 0, h_critic_iter = 0;
   // minibatch panels / activations: pass 0 AT, 1 A, 2 CT, 3 C1, 4 C2
   float* Xa_s = nullptr; float* Xa_n = nullptr; float* Xc_tr = nullptr; float* Xc_pl = nullptr; float* Xc_nx = nullptr;
@@ -502,8 +505,19 @@ int run_phase(H* h, int phase, const int* idx_dev) {
   return fail("phase must be 0, 1 or 2 (got %d)", phase);
 }
 
+// re-read (head,size) after the env front-end appended episodes on the device
+int refresh_ring(H* h) {
+  if (!h->ring_stale) return 0;
+  int hs[2];
+  HIPCHK(hipMemcpyAsync(hs, h->st, sizeof hs, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->h_head = hs[0]; h->h_size = hs[1]; h->ring_stale = false;
+  return 0;
+}
+
 int stage_indices(H* h, const int32_t* idx_host, const int** idx_dev) {
   *idx_dev = nullptr;
+  if (idx_host || h->h_size < 1) RC(refresh_ring(h));
   if (h->h_size < 1) return fail("replay memory is empty");
   if (idx_host) {
     for (int i = 0; i < h->B; ++i)
@@ -729,6 +743,7 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
   HIPCHK(hipSetDevice(h->cfg.device));
   if (h->cfg.dp_world > 1) return fail("dqnhip_update_async: dp_world > 1 requires dqnhip_update_phase + all-reduce");
   if (h->cfg.use_graph && !h->timing && !h->graph_failed) {
+    if (idx_host || h->h_size < 1) RC(refresh_ring(h));
     if (h->h_size < 1) return fail("replay memory is empty");
     const int which = idx_host ? 1 : 0;
     if (idx_host) {
@@ -891,6 +906,7 @@ int dqnhip_critic_forward(dqnhip_handle h, int32_t net, const float* states_host
 static int add_dev(H* h, const float* s, const float* a, const float* r, const float* mc, const float* nx,
                    const uint8_t* term, int n, int single) {
   if (n < 1) return fail("n must be >= 1");
+  RC(refresh_ring(h));
   const long long cap = h->ring.cap;
   if (!single && n >= cap) return fail("AddTransitions: batch of %d does not fit capacity %lld (the reference would pop an empty deque)", n, cap);
   hipLaunchKernelGGL(k_add_transitions, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->ring, h->st, s, a, r, mc, nx,
@@ -958,6 +974,8 @@ int dqnhip_label_transitions(double gamma, const float* rewards, int32_t n, floa
 
 int dqnhip_memory_size(dqnhip_handle h, int32_t* size) {
   if (!h || !size) return fail("null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RC(refresh_ring(h));
   *size = (int32_t)h->h_size;
   return 0;
 }
@@ -966,13 +984,15 @@ int dqnhip_clear_memory(dqnhip_handle h) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipMemsetAsync(h->st, 0, 2 * sizeof(int), h->stream));   // ring_head, ring_size
-  h->h_head = 0; h->h_size = 0;
+  h->h_head = 0; h->h_size = 0; h->ring_stale = false;
   return 0;
 }
 
 int dqnhip_read_memory(dqnhip_handle h, int32_t first, int32_t n, float* states, float* actor_out, float* rewards,
                        float* on_policy_targets, float* next_states, uint8_t* terminal) {
   if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RC(refresh_ring(h));
   if (n < 1 || first < 0 || (long long)first + n > h->h_size) return fail("read_memory range [%d,%d) outside [0,%lld)", first, first + n, h->h_size);
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t sb = round_up_z((size_t)n * h->S * 4, 256), ab = round_up_z((size_t)n * kNO * 4, 256), vb = round_up_z((size_t)n * 4, 256);
@@ -1124,4 +1144,150 @@ int dqnhip_get_kernel_timing(dqnhip_handle h, const char* family, float* avg_ms,
   return 0;
 }
 
+
+// ---- batched env front-end (include/dqnhip_env.h) -----------------------------------------
+}  // extern "C"
+
+struct dqnhip_env {
+  dqnhip_learner* h = nullptr;
+  dqnhip_env_config cfg{};
+  EnvDev d{};
+  int Npad = 0;
+  float* acts[kMaxL + 1] = {nullptr};
+  std::vector<void*> allocs;
+};
+
+namespace {
+template <typename T>
+int env_alloc(dqnhip_env* e, T** p, size_t n) {
+  HIPCHK(hipMalloc(p, n * sizeof(T)));
+  HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(T), e->h->stream));
+  e->allocs.push_back((void*)*p);
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int dqnhip_env_create(dqnhip_handle h, const dqnhip_env_config* cfg, dqnhip_env_handle* out) {
+  if (!h || !cfg || !out) return fail("null argument");
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(dqnhip_env_config)) return fail("dqnhip_env_config.struct_size mismatch");
+  if (cfg->workers < 1 || cfg->workers > (1 << 20)) return fail("workers out of range");
+  if (cfg->max_steps < 1 || cfg->max_steps > 4096) return fail("max_steps out of range");
+  if (h->S < 56) return fail("HFOGameState reads state indices up to 55: state_size must be >= 56 (src/hfo_game.cpp:130-152)");
+  if ((long long)cfg->workers * cfg->max_steps >= h->ring.cap)
+    return fail("replay capacity %d must exceed workers*max_steps = %lld", h->ring.cap, (long long)cfg->workers * cfg->max_steps);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  dqnhip_env* e = new dqnhip_env();
+  e->h = h; e->cfg = *cfg;
+  EnvDev& d = e->d;
+  d.N = cfg->workers; d.S = h->S; d.SP = h->la.kp[0]; d.T = cfg->max_steps; d.unum = cfg->unum;
+  d.p_end = cfg->p_end; d.p_goal = cfg->p_goal; d.seed = cfg->seed;
+  e->Npad = round_up(d.N, 32);
+  const size_t N = d.N, Np = e->Npad;
+  RC(env_alloc(e, &d.cur, Np * d.SP)); RC(env_alloc(e, &d.out16, Np * kAP));
+  RC(env_alloc(e, &d.ep_s, N * d.T * d.SP)); RC(env_alloc(e, &d.ep_a, N * d.T * kAP)); RC(env_alloc(e, &d.ep_r, N * d.T));
+  RC(env_alloc(e, &d.game, N)); RC(env_alloc(e, &d.len, N)); RC(env_alloc(e, &d.done, N)); RC(env_alloc(e, &d.g, N));
+  RC(env_alloc(e, &d.act, N)); RC(env_alloc(e, &d.arg1, N)); RC(env_alloc(e, &d.arg2, N)); RC(env_alloc(e, &d.rew, N));
+  RC(env_alloc(e, &d.n_steps, N)); RC(env_alloc(e, &d.n_episodes, N)); RC(env_alloc(e, &d.n_goals, N)); RC(env_alloc(e, &d.reward_sum, N));
+  e->acts[0] = d.cur;
+  for (int i = 1; i <= h->L; ++i) RC(env_alloc(e, &e->acts[i], Np * h->la.kp[i]));
+  hipLaunchKernelGGL(k_env_init, dim3(d.N), dim3(64), d.SP * sizeof(float), h->stream, d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *out = e;
+  return 0;
+}
+
+int dqnhip_env_destroy(dqnhip_env_handle e) {
+  if (!e) return 0;
+  hipSetDevice(e->h->cfg.device);
+  hipStreamSynchronize(e->h->stream);
+  for (void* p : e->allocs) hipFree(p);
+  delete e;
+  return 0;
+}
+
+int dqnhip_env_step(dqnhip_env_handle e, float epsilon, int32_t n_steps) {
+  if (!e) return fail("null env");
+  if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return fail("Check failed: epsilon >= 0.0 && epsilon <= 1.0");   // src/dqn.cpp:698
+  if (n_steps < 1) return fail("n_steps must be >= 1");
+  dqnhip_learner* h = e->h;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const EnvDev& d = e->d;
+  hipStream_t st = h->stream;
+  const NetLayout& la = h->la;
+  for (int s = 0; s < n_steps; ++s) {
+    // SelectActionGreedily(*actor_net_, states) for all workers in one batched forward
+    FwdPass fp{h->w[DQNHIP_ACTOR], &la, e->acts};
+    RC(tower_forward(h, st, &fp, 1, e->Npad));
+    HeadArgs a{}; a.X = e->acts[la.L]; a.ldx = la.dims[la.L]; a.H = la.dims[la.L]; a.rows = e->Npad;
+    a.W = h->w[DQNHIP_ACTOR] + la.hw_off; a.b = h->w[DQNHIP_ACTOR] + la.hb_off; a.out16 = d.out16;
+    RC((head_forward<kNO, HEAD_ACTOR>(h, st, a)));
+    hipLaunchKernelGGL(k_env_step, dim3(d.N), dim3(64), d.SP * sizeof(float), st, d, epsilon);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), (d.T + d.SP) * sizeof(float), st, d, h->ring,
+                       (const DevState*)h->st, h->cfg.gamma);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_env_commit, dim3(1), dim3(64), 0, st, d, h->ring, h->st);
+    HIPCHK(hipGetLastError());
+  }
+  h->ring_stale = true;
+  return 0;
+}
+
+int dqnhip_env_stats(dqnhip_env_handle e, int64_t* env_steps, int64_t* episodes, double* reward_sum, int64_t* goals) {
+  if (!e) return fail("null env");
+  dqnhip_learner* h = e->h;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t N = e->d.N;
+  std::vector<unsigned long long> a(N), b(N), c(N); std::vector<double> r(N);
+  HIPCHK(hipMemcpyAsync(a.data(), e->d.n_steps, N * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(b.data(), e->d.n_episodes, N * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(c.data(), e->d.n_goals, N * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(r.data(), e->d.reward_sum, N * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  long long s0 = 0, s1 = 0, s2 = 0; double s3 = 0;
+  for (size_t i = 0; i < N; ++i) { s0 += a[i]; s1 += b[i]; s2 += c[i]; s3 += r[i]; }
+  if (env_steps) *env_steps = s0; if (episodes) *episodes = s1; if (goals) *goals = s2; if (reward_sum) *reward_sum = s3;
+  return refresh_ring(h);
+}
+
+int dqnhip_env_debug_read(dqnhip_env_handle e, const char* name, float* host, size_t count) {
+  if (!e || !name || !host) return fail("null argument");
+  dqnhip_learner* h = e->h;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t N = e->d.N;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!strcmp(name, "action") || !strcmp(name, "episode_len")) {
+    if (count < N) return fail("buffer too small");
+    std::vector<int> t(N);
+    HIPCHK(hipMemcpy(t.data(), !strcmp(name, "action") ? e->d.act : e->d.len, N * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; ++i) host[i] = (float)t[i];
+    return 0;
+  }
+  const float* src = nullptr; size_t n = N;
+  if (!strcmp(name, "arg1")) src = e->d.arg1;
+  else if (!strcmp(name, "arg2")) src = e->d.arg2;
+  else if (!strcmp(name, "reward")) src = e->d.rew;
+  else if (!strcmp(name, "state")) {
+    if (count < N * h->S) return fail("buffer too small");
+    std::vector<float> t(N * e->d.SP);
+    HIPCHK(hipMemcpy(t.data(), e->d.cur, t.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; ++i) memcpy(host + i * h->S, &t[i * e->d.SP], h->S * 4);
+    return 0;
+  } else if (!strcmp(name, "actor_out")) {
+    // the ActorOutput chosen at the last step = last written row of the open episode, or (if the
+    // episode just ended) not available any more: report the greedy output instead
+    if (count < N * kNO) return fail("buffer too small");
+    std::vector<float> t(N * kAP);
+    HIPCHK(hipMemcpy(t.data(), e->d.out16, t.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; ++i) memcpy(host + i * kNO, &t[i * kAP], kNO * 4);
+    return 0;
+  } else return fail("unknown env debug buffer '%s'", name);
+  if (count < n) return fail("buffer too small");
+  HIPCHK(hipMemcpy(host, src, n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
 }  // extern "C"

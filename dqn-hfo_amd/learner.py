@@ -377,3 +377,44 @@ class DQN:
         ms, n = C.c_float(), C.c_int64()
         self._ck(self.lib.dqnhip_get_kernel_timing(self.h, family.encode(), C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
+
+
+class EnvFrontEnd:
+    """N concurrent (synthetic) HFO workers feeding one learner's device-resident replay:
+    the learner side of PlayOneEpisode (src/dqn_main.cpp:97-153), batched.  See
+    include/dqnhip_env.h."""
+
+    def __init__(self, dqn, workers, max_steps=500, unum=7, p_end=0.01, p_goal=0.3, seed=1):
+        self.dqn, self.N = dqn, workers
+        self.lib = dqn.lib
+        cfg = capi.EnvConfig()
+        cfg.struct_size = C.sizeof(capi.EnvConfig)
+        cfg.workers, cfg.max_steps, cfg.unum = workers, max_steps, unum
+        cfg.p_end, cfg.p_goal, cfg.seed = p_end, p_goal, seed
+        self.h = C.c_void_p()
+        dqn._ck(self.lib.dqnhip_env_create(dqn.h, C.byref(cfg), C.byref(self.h)))
+
+    def step(self, epsilon, n_steps=1):
+        self.dqn._ck(self.lib.dqnhip_env_step(self.h, float(epsilon), int(n_steps)))
+
+    def stats(self):
+        a, b, g = C.c_int64(), C.c_int64(), C.c_int64()
+        r = C.c_double()
+        self.dqn._ck(self.lib.dqnhip_env_stats(self.h, C.byref(a), C.byref(b), C.byref(r), C.byref(g)))
+        return a.value, b.value, r.value, g.value
+
+    def debug_read(self, name):
+        N, S = self.N, self.dqn.state_size_
+        n = N * (S if name == "state" else 10 if name == "actor_out" else 1)
+        out = np.empty(n, np.float32)
+        self.dqn._ck(self.lib.dqnhip_env_debug_read(self.h, name.encode(), _p(out), n))
+        if name == "state":
+            return out.reshape(N, S)
+        if name == "actor_out":
+            return out.reshape(N, 10)
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.dqnhip_env_destroy(self.h)
+            self.h = None

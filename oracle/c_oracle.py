@@ -93,6 +93,14 @@ def lib():
         L.orc_last_stats.argtypes = [C.c_void_p, fp, fp]
         L.orc_debug_read.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_size_t]
         L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_philox_index.restype = C.c_int32
+        L.orc_philox_index.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32]
+        L.orc_env_create.restype = C.c_void_p
+        L.orc_env_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64]
+        L.orc_env_destroy.argtypes = [C.c_void_p]
+        L.orc_env_step.argtypes = [C.c_void_p, C.c_float, C.c_int]
+        L.orc_env_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.orc_env_read.argtypes = [C.c_void_p, ip, fp, fp, fp, fp, ip]
         L.orc_game_update.argtypes = [C.POINTER(OrcGame), fp, C.c_int, C.c_int]
         L.orc_game_reward.restype = C.c_float
         L.orc_game_reward.argtypes = [C.POINTER(OrcGame)]
@@ -300,3 +308,41 @@ class GameState:
 
     def reward(self):
         return lib().orc_game_reward(C.byref(self.g))
+
+
+def philox_indices(seed, update_counter, B, size):
+    """What the learner's on-device sampler draws for update `update_counter`."""
+    L = lib()
+    return np.array([L.orc_philox_index(seed, update_counter, r, size) for r in range(B)], np.int32)
+
+
+class OracleEnv:
+    """N-worker env front-end on the CPU oracle (same synthetic state stream as the device)."""
+
+    def __init__(self, orc, workers, max_steps=500, unum=7, p_end=0.01, p_goal=0.3, seed=1):
+        self.orc, self.N = orc, workers
+        self.L = lib()
+        self.h = self.L.orc_env_create(orc.h, workers, max_steps, unum, p_end, p_goal, seed)
+
+    def step(self, epsilon, n_steps=1):
+        self.L.orc_env_step(self.h, float(epsilon), int(n_steps))
+
+    def stats(self):
+        a, b, g = C.c_int64(), C.c_int64(), C.c_int64()
+        r = C.c_double()
+        self.L.orc_env_stats(self.h, C.byref(a), C.byref(b), C.byref(r), C.byref(g))
+        return a.value, b.value, r.value, g.value
+
+    def read(self):
+        N, S = self.N, self.orc.S
+        act = np.empty(N, np.int32); ln = np.empty(N, np.int32)
+        a1 = np.empty(N, np.float32); a2 = np.empty(N, np.float32); rw = np.empty(N, np.float32)
+        st = np.empty((N, S), np.float32)
+        ip = C.POINTER(C.c_int32)
+        self.L.orc_env_read(self.h, act.ctypes.data_as(ip), _fp(a1), _fp(a2), _fp(rw), _fp(st), ln.ctypes.data_as(ip))
+        return dict(action=act, arg1=a1, arg2=a2, reward=rw, state=st, episode_len=ln)
+
+    def close(self):
+        if self.h:
+            self.L.orc_env_destroy(self.h)
+            self.h = None

@@ -727,3 +727,146 @@ float orc_game_reward(orc_game *g) {
   g->extrinsic_reward += eot; g->total_reward += reward;
   return reward;
 }
+
+/* ------------------------------------------------- batched env front-end (oracle side) */
+/* CPU restatement of PlayOneEpisode's learner side (src/dqn_main.cpp:97-153) for N workers on
+ * the SAME synthetic state stream as dqn-hfo_amd/csrc/env.hip.h (counter-based Philox-4x32-10
+ * keyed by (seed, per-worker draw counter, worker*256 + draw index)).  The synthetic stream
+ * stands in for rcssserver; everything after it is the reference's logic. */
+
+static void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+static uint32_t philox_u32(uint64_t seed, uint64_t ctr, uint32_t lane) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), lane, 0x9E3779B9u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  return c[0];
+}
+/* the learner's on-device sampler (SampleTransitionsFromMemory stand-in), for tests */
+int32_t orc_philox_index(uint64_t seed, uint64_t update_counter, uint32_t row, int32_t size) {
+  return (int32_t)(((uint64_t)philox_u32(seed, update_counter, row) * (uint64_t)size) >> 32);
+}
+
+typedef struct {
+  orc *o;
+  int N, T, unum;
+  float p_end, p_goal;
+  uint64_t seed;
+  float *cur;            /* [N][S] */
+  float *ep_s, *ep_a, *ep_r;
+  orc_game *game;
+  int *len;
+  uint64_t *g;
+  int32_t *act; float *arg1, *arg2, *rew;
+  int64_t n_steps, n_episodes, n_goals; double reward_sum;
+} orc_env;
+
+static float env_u01(const orc_env *e, uint64_t g, int w, int k) {
+  return (float)(philox_u32(e->seed, g, (uint32_t)(w * 256 + k)) >> 8) * (1.0f / 16777216.0f);
+}
+static float env_feature(const orc_env *e, uint64_t g, int w, int f) {
+  const float kPi = 3.14159265358979323846f;
+  if (f == 13 || f == 14) { const float th = fmaf(2.0f, env_u01(e, g, w, 16 + 13), -1.0f) * kPi; return f == 13 ? sinf(th) : cosf(th); }
+  if (f == 51 || f == 52) { const float th = fmaf(2.0f, env_u01(e, g, w, 16 + 51), -1.0f) * kPi; return f == 51 ? sinf(th) : cosf(th); }
+  const float u = env_u01(e, g, w, 16 + f);
+  if (f == 12 || f == 54) return u < 0.5f ? -1.0f : 1.0f;
+  return fmaf(2.0f, u, -1.0f);
+}
+static void env_reset_worker(orc_env *e, int w) {
+  const int S = e->o->cfg.S;
+  for (int f = 0; f < S; ++f) e->cur[(size_t)w * S + f] = env_feature(e, e->g[w], w, f);
+  memset(&e->game[w], 0, sizeof(orc_game));
+  e->game[w].our_unum = e->unum;
+  orc_game_update(&e->game[w], e->cur + (size_t)w * S, 0, 0);   /* after the forced DASH(0,0), src/dqn_main.cpp:103-105 */
+  e->len[w] = 0; e->g[w] += 1;
+}
+
+orc_env *orc_env_create(orc *o, int workers, int max_steps, int unum, float p_end, float p_goal, uint64_t seed) {
+  orc_env *e = (orc_env *)calloc(1, sizeof(orc_env));
+  const size_t N = workers, S = o->cfg.S, T = max_steps;
+  e->o = o; e->N = workers; e->T = max_steps; e->unum = unum; e->p_end = p_end; e->p_goal = p_goal; e->seed = seed;
+  e->cur = zalloc(N * S); e->ep_s = zalloc(N * T * S); e->ep_a = zalloc(N * T * ORC_NO); e->ep_r = zalloc(N * T);
+  e->game = (orc_game *)calloc(N, sizeof(orc_game)); e->len = (int *)calloc(N, sizeof(int));
+  e->g = (uint64_t *)calloc(N, sizeof(uint64_t));
+  e->act = (int32_t *)calloc(N, sizeof(int32_t)); e->arg1 = zalloc(N); e->arg2 = zalloc(N); e->rew = zalloc(N);
+  for (int w = 0; w < workers; ++w) env_reset_worker(e, w);
+  return e;
+}
+void orc_env_destroy(orc_env *e) {
+  if (!e) return;
+  free(e->cur); free(e->ep_s); free(e->ep_a); free(e->ep_r); free(e->game); free(e->len); free(e->g);
+  free(e->act); free(e->arg1); free(e->arg2); free(e->rew); free(e);
+}
+
+void orc_env_step(orc_env *e, float epsilon, int n_steps) {
+  orc *o = e->o;
+  const int S = o->cfg.S, N = e->N, T = e->T;
+  float *greedy = zalloc((size_t)N * ORC_NO);
+  float *next = zalloc(S);
+  for (int s = 0; s < n_steps; ++s) {
+    orc_actor_forward(o, 0, e->cur, N, greedy);            /* SelectActionGreedily, batched */
+    int *done = (int *)calloc(N, sizeof(int));
+    for (int w = 0; w < N; ++w) {
+      const uint64_t g = e->g[w];
+      const int len = e->len[w];
+      float ao[ORC_NO];
+      if (env_u01(e, g, w, 0) < epsilon) {                /* one epsilon draw per SelectAction call */
+        for (int j = 0; j < ORC_NO; ++j) {                /* GetRandomActorOutput ranges */
+          const float u = env_u01(e, g, w, 1 + j);
+          if (j < ORC_NA) ao[j] = fmaf(2.0f, u, -1.0f);
+          else if (j == ORC_NA + 0) ao[j] = fmaf(200.0f, u, -100.0f);
+          else if (j == ORC_NA + 4) ao[j] = 100.0f * u;
+          else ao[j] = fmaf(360.0f, u, -180.0f);
+        }
+      } else memcpy(ao, greedy + (size_t)w * ORC_NO, sizeof ao);
+      orc_get_action(ao, 1, &e->act[w], &e->arg1[w], &e->arg2[w]);
+      memcpy(e->ep_s + ((size_t)w * T + len) * S, e->cur + (size_t)w * S, S * sizeof(float));
+      memcpy(e->ep_a + ((size_t)w * T + len) * ORC_NO, ao, sizeof ao);
+      for (int f = 0; f < S; ++f) next[f] = env_feature(e, g, w, f);
+      int status = 0;
+      if (env_u01(e, g, w, 11) < e->p_end) status = env_u01(e, g, w, 12) < e->p_goal ? 1 : 2;
+      if (status == 0 && len + 1 >= T) status = 4;
+      const int pob = env_u01(e, g, w, 13) < 0.5f ? e->unum : -1;
+      orc_game_update(&e->game[w], next, status, pob);
+      const float r = orc_game_reward(&e->game[w]);
+      e->ep_r[(size_t)w * T + len] = r; e->rew[w] = r;
+      memcpy(e->cur + (size_t)w * S, next, S * sizeof(float));
+      e->len[w] = len + 1; e->g[w] = g + 1;
+      e->n_steps += 1; e->reward_sum += (double)r;
+      if (status == 1) e->n_goals += 1;
+      done[w] = status != 0;
+    }
+    for (int w = 0; w < N; ++w) {                         /* LabelTransitions + AddTransitions, worker order */
+      if (!done[w]) continue;
+      const int len = e->len[w];
+      float *mc = zalloc(len), *nx = zalloc((size_t)len * S);
+      uint8_t *term = (uint8_t *)calloc(len, 1);
+      orc_label_transitions(o->cfg.gamma, e->ep_r + (size_t)w * T, len, mc);
+      for (int t = 0; t + 1 < len; ++t) memcpy(nx + (size_t)t * S, e->ep_s + ((size_t)w * T + t + 1) * S, S * sizeof(float));
+      term[len - 1] = 1;
+      orc_add_transitions(o, e->ep_s + (size_t)w * T * S, e->ep_a + (size_t)w * T * ORC_NO, e->ep_r + (size_t)w * T, mc, nx, term, len);
+      free(mc); free(nx); free(term);
+      e->n_episodes += 1;
+      env_reset_worker(e, w);
+    }
+    free(done);
+  }
+  free(greedy); free(next);
+}
+void orc_env_stats(const orc_env *e, int64_t *steps, int64_t *episodes, double *reward_sum, int64_t *goals) {
+  *steps = e->n_steps; *episodes = e->n_episodes; *reward_sum = e->reward_sum; *goals = e->n_goals;
+}
+void orc_env_read(const orc_env *e, int32_t *act, float *arg1, float *arg2, float *rew, float *state, int32_t *len) {
+  const size_t N = e->N, S = e->o->cfg.S;
+  if (act) memcpy(act, e->act, N * 4);
+  if (arg1) memcpy(arg1, e->arg1, N * 4);
+  if (arg2) memcpy(arg2, e->arg2, N * 4);
+  if (rew) memcpy(rew, e->rew, N * 4);
+  if (state) memcpy(state, e->cur, N * S * 4);
+  if (len) for (size_t i = 0; i < N; ++i) len[i] = e->len[i];
+}

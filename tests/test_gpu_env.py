@@ -1,0 +1,59 @@
+"""Batched env front-end (include/dqnhip_env.h) vs its CPU restatement on the same synthetic
+state stream: per-step actions/rewards, and the replay contents after episodes were labelled
+and appended (LabelTransitions + AddTransitions in worker order)."""
+import numpy as np
+import pytest
+
+from helpers import make_pair
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("workers,eps", [(5, 0.0), (64, 0.3), (100, 1.0)])
+def test_env_front_end_matches_oracle(pkg, gpu, workers, eps):
+    dqn, orc, data, rng = make_pair(pkg, B=32, S=59, hidden=(128, 64, 64, 64), n_replay=100, capacity=20000)
+    kw = dict(max_steps=40, unum=7, p_end=0.05, p_goal=0.4, seed=11)
+    env = pkg.EnvFrontEnd(dqn, workers, **kw)
+    oenv = c_oracle.OracleEnv(orc, workers, **kw)
+    np.testing.assert_allclose(env.debug_read("state"), oenv.read()["state"], atol=1e-6)
+    for step in range(60):
+        env.step(eps); oenv.step(eps)
+        o = oenv.read()
+        np.testing.assert_array_equal(env.debug_read("action").astype(np.int32), o["action"])       # indices exact
+        np.testing.assert_allclose(env.debug_read("arg1"), o["arg1"], atol=1e-4)
+        np.testing.assert_allclose(env.debug_read("reward"), o["reward"], atol=2e-5)
+        np.testing.assert_array_equal(env.debug_read("episode_len").astype(np.int32), o["episode_len"])
+        np.testing.assert_allclose(env.debug_read("state"), o["state"], atol=1e-6)
+    s1, s2 = env.stats(), oenv.stats()
+    assert s1[0] == s2[0] == 60 * workers and s1[1] == s2[1] and s1[3] == s2[3] and s1[1] > 0
+    assert abs(s1[2] - s2[2]) < 1e-2
+    assert dqn.memory_size() == orc.memory_size()
+    a, b = dqn.read_memory(0, dqn.memory_size()), orc.read_memory(0, orc.memory_size())
+    np.testing.assert_allclose(a[0], b[0], atol=1e-6)          # states
+    np.testing.assert_allclose(a[1], b[1], atol=1e-4)          # actor outputs
+    np.testing.assert_allclose(a[2], b[2], atol=2e-5)          # rewards
+    np.testing.assert_allclose(a[3], b[3], atol=2e-4)          # Monte-Carlo labels
+    np.testing.assert_allclose(a[4], b[4], atol=1e-6)          # next states
+    np.testing.assert_array_equal(a[5], b[5])                  # terminal flags
+    # and the learner keeps working on what the workers produced
+    loss, q = dqn.UpdateActorCritic()
+    assert np.isfinite(loss) and np.isfinite(q)
+    env.close(); oenv.close(); dqn.close(); orc.close()
+
+
+def test_env_wraps_ring_and_rejects_bad_config(pkg, gpu):
+    dqn = pkg.DQN(59, minibatch=32, hidden=(64,), memory=3000)
+    with pytest.raises(pkg.DQNFatal):
+        pkg.EnvFrontEnd(dqn, 64, max_steps=100)                # workers*max_steps >= capacity
+    env = pkg.EnvFrontEnd(dqn, 16, max_steps=50, p_end=0.1)
+    env.step(0.5, 400)                                         # 6400 transitions through a 3000-slot ring
+    steps, episodes, _, _ = env.stats()
+    assert steps == 6400 and episodes > 50
+    assert 2900 - 16 * 50 <= dqn.memory_size() <= 2999          # AddTransitions keeps <= cap-1
+    with pytest.raises(pkg.DQNFatal):
+        env.step(1.5)
+    dqn2 = pkg.DQN(50, minibatch=32, hidden=(64,), memory=3000)
+    with pytest.raises(pkg.DQNFatal, match="56"):
+        pkg.EnvFrontEnd(dqn2, 4)                               # HFOGameState needs state indices up to 55
+    env.close(); dqn.close(); dqn2.close()
