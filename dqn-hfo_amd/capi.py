@@ -54,6 +54,8 @@ SIGNATURES = {
     "dqnhip_memory_size": (C.c_int, [H, ip]),
     "dqnhip_clear_memory": (C.c_int, [H]),
     "dqnhip_read_memory": (C.c_int, [H, C.c_int32, C.c_int32, fp, fp, fp, fp, fp, up]),
+    "dqnhip_snapshot_replay_memory": (C.c_int, [H, C.c_char_p]),
+    "dqnhip_load_replay_memory": (C.c_int, [H, C.c_char_p]),
     "dqnhip_param_count": (C.c_int, [H, C.c_int32, C.POINTER(C.c_size_t)]),
     "dqnhip_get_params": (C.c_int, [H, C.c_int32, C.c_int32, fp, C.c_size_t]),
     "dqnhip_set_params": (C.c_int, [H, C.c_int32, C.c_int32, fp, C.c_size_t]),

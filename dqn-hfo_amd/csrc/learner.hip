@@ -5,6 +5,7 @@
 // nothing crosses PCIe per update except (optionally) B sampled indices in and
 // two floats out.  See DESIGN.md for the data layout and the kernel list.
 #include <hip/hip_runtime.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cmath>
@@ -908,12 +909,14 @@ static int add_dev(H* h, const float* s, const float* a, const float* r, const f
   if (n < 1) return fail("n must be >= 1");
   RC(refresh_ring(h));
   const long long cap = h->ring.cap;
-  if (!single && n >= cap) return fail("AddTransitions: batch of %d does not fit capacity %lld (the reference would pop an empty deque)", n, cap);
+  if (single == 0 && n >= cap) return fail("AddTransitions: batch of %d does not fit capacity %lld (the reference would pop an empty deque)", n, cap);
+  if (single == 2 && h->h_size + n > cap) return fail("LoadReplayMemory: %lld transitions exceed the capacity %lld", h->h_size + n, cap);
   hipLaunchKernelGGL(k_add_transitions, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->ring, h->st, s, a, r, mc, nx,
                      term, n, single, h->done_counter);
   HIPCHK(hipGetLastError());
   // host mirror of the same deque arithmetic (src/dqn.cpp:768-781)
-  if (single) { if (h->h_size == cap) { h->h_head = (h->h_head + 1) % cap; h->h_size -= 1; } }
+  if (single == 2) { }
+  else if (single) { if (h->h_size == cap) { h->h_head = (h->h_head + 1) % cap; h->h_size -= 1; } }
   else {
     long long pops = h->h_size + n - cap + 1;
     pops = std::max(0LL, std::min(pops, h->h_size));
@@ -1012,6 +1015,87 @@ int dqnhip_read_memory(dqnhip_handle h, int32_t first, int32_t n, float* states,
   if (on_policy_targets) HIPCHK(hipMemcpyAsync(on_policy_targets, dm, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
   if (terminal) HIPCHK(hipMemcpyAsync(terminal, dt, (size_t)n, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+
+// ---- .replaymemory files (src/dqn.cpp:1146-1226) --------------------------------------------
+int dqnhip_snapshot_replay_memory(dqnhip_handle h, const char* filename) {
+  if (!h || !filename) return fail("null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RC(refresh_ring(h));
+  gzFile f = gzopen(filename, "wb");
+  if (!f) return fail("cannot open %s for writing", filename);
+  const int32_t n = (int32_t)h->h_size;
+  const size_t S = h->S;
+  bool ok = gzwrite(f, &n, sizeof n) == (int)sizeof n;
+  const int chunk = 65536;
+  std::vector<float> s((size_t)chunk * S), a((size_t)chunk * kNO), r(chunk), mc(chunk);
+  std::vector<uint8_t> term(chunk), rec;
+  for (int first = 0; first < n && ok; first += chunk) {
+    const int m = std::min(chunk, n - first);
+    if (dqnhip_read_memory(h, first, m, s.data(), a.data(), r.data(), mc.data(), nullptr, term.data())) { gzclose(f); return 1; }
+    const size_t rb = S * 4 + kNO * 4 + 4 + 4 + 1;
+    rec.resize((size_t)m * rb);
+    for (int i = 0; i < m; ++i) {
+      uint8_t* p = &rec[(size_t)i * rb];
+      memcpy(p, &s[(size_t)i * S], S * 4); p += S * 4;
+      memcpy(p, &a[(size_t)i * kNO], kNO * 4); p += kNO * 4;     // sizeof(ActorOutput)
+      memcpy(p, &r[i], 4); p += 4;
+      memcpy(p, &mc[i], 4); p += 4;
+      *p = term[i] ? 1 : 0;                                       // sizeof(bool) == 1
+    }
+    ok = gzwrite(f, rec.data(), (unsigned)rec.size()) == (int)rec.size();
+  }
+  if (gzclose(f) != Z_OK || !ok) return fail("short write to %s", filename);
+  return 0;
+}
+
+int dqnhip_load_replay_memory(dqnhip_handle h, const char* filename) {
+  if (!h || !filename) return fail("null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  gzFile f = gzopen(filename, "rb");
+  if (!f) return fail("Invalid file: %s", filename);              // CHECK(is_regular_file), src/dqn.cpp:1181
+  int32_t n = 0;
+  if (gzread(f, &n, sizeof n) != (int)sizeof n || n < 0) { gzclose(f); return fail("%s: bad header", filename); }
+  if (n > h->ring.cap) { gzclose(f); return fail("%s holds %d transitions, capacity is %d", filename, n, h->ring.cap); }
+  RC(dqnhip_clear_memory(h));
+  const size_t S = h->S, rb = S * 4 + kNO * 4 + 4 + 4 + 1;
+  const int chunk = 65536;
+  // one record of look-ahead: next state of the last row of a chunk is the first state of the next
+  std::vector<uint8_t> rec((size_t)(chunk + 1) * rb);
+  std::vector<float> s((size_t)chunk * S), nx((size_t)chunk * S), a((size_t)chunk * kNO), r(chunk), mc(chunk);
+  std::vector<uint8_t> term(chunk);
+  int have = 0;                       // records buffered in rec
+  int done = 0;
+  while (done < n) {
+    const int want = std::min(chunk + 1, n - done) - have;
+    if (want > 0) {
+      const int got = gzread(f, &rec[(size_t)have * rb], (unsigned)((size_t)want * rb));
+      if (got != (int)((size_t)want * rb)) { gzclose(f); return fail("%s: truncated", filename); }
+      have += want;
+    }
+    const int m = std::min(chunk, n - done);
+    for (int i = 0; i < m; ++i) {
+      const uint8_t* p = &rec[(size_t)i * rb];
+      memcpy(&s[(size_t)i * S], p, S * 4); p += S * 4;
+      memcpy(&a[(size_t)i * kNO], p, kNO * 4); p += kNO * 4;
+      memcpy(&r[i], p, 4); p += 4;
+      memcpy(&mc[i], p, 4); p += 4;
+      bool t = *p != 0;
+      const bool has_next = done + i + 1 < n;
+      if (!t && !has_next) t = true;                              // trailing non-terminal: next stays none
+      term[i] = t ? 1 : 0;
+      if (!t) memcpy(&nx[(size_t)i * S], &rec[(size_t)(i + 1) * rb], S * 4);
+      else memset(&nx[(size_t)i * S], 0, S * 4);
+    }
+    if (add_host(h, s.data(), a.data(), r.data(), mc.data(), nx.data(), term.data(), m, 2)) { gzclose(f); return 1; }
+    // keep the look-ahead record as the first record of the next chunk
+    if (have > m) memmove(&rec[0], &rec[(size_t)m * rb], rb);
+    have -= m;
+    done += m;
+  }
+  gzclose(f);
   return 0;
 }
 

@@ -68,7 +68,8 @@ __global__ void k_add_transitions(Ring ring, DevState* st, const float* __restri
                                   int* done_counter) {
   // every block derives the same post-eviction (head,size)
   int head = st->ring_head, size = st->ring_size;
-  if (single_mode) {           // AddTransition: pop iff size == capacity
+  if (single_mode == 2) {      // LoadReplayMemory: plain append, no eviction (caller checked the capacity)
+  } else if (single_mode) {    // AddTransition: pop iff size == capacity
     if (size == ring.cap) { head = (head + 1) % ring.cap; size -= 1; }
   } else {                     // AddTransitions: while (size + n >= capacity) pop_front
     int pops = size + n - ring.cap + 1;

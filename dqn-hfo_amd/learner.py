@@ -7,6 +7,7 @@ PyTorch is not used here at all — device memory and streams live inside the na
 library; torch only appears in parallel.py (torch.distributed over RCCL).
 """
 import ctypes as C
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -234,6 +235,14 @@ class DQN:
         self._ck(self.lib.dqnhip_read_memory(self.h, first, n, _p(s), _p(a), _p(r), _p(mc), _p(nx),
                                              t.ctypes.data_as(capi.up)))
         return s, a, r, mc, nx, t
+
+    def SnapshotReplayMemory(self, filename):
+        """src/dqn.cpp:1146-1178: gzip `.replaymemory` file in the reference's byte layout."""
+        self._ck(self.lib.dqnhip_snapshot_replay_memory(self.h, os.fsencode(filename)))
+
+    def LoadReplayMemory(self, filename):
+        """src/dqn.cpp:1180-1226."""
+        self._ck(self.lib.dqnhip_load_replay_memory(self.h, os.fsencode(filename)))
 
     # -- acting (src/dqn.cpp:664-711) -------------------------------------------------------
     def GetRandomActorOutput(self):

@@ -210,6 +210,17 @@ int dqnhip_read_memory(dqnhip_handle h, int32_t first, int32_t n, float* states,
                        float* actor_out, float* rewards, float* on_policy_targets,
                        float* next_states, uint8_t* terminal);
 
+/* Replaces DQN::SnapshotReplayMemory / LoadReplayMemory (src/dqn.cpp:1146-1226): the
+ * reference's `.replaymemory` file — a gzip stream holding int32 num_transitions, then per
+ * transition: state[S] floats, ActorOutput[10] floats, float reward, float on_policy_target,
+ * 1-byte bool terminal (= next_state is none).  Next states are not stored: transition i's
+ * next state is transition i+1's state when i is not terminal; a trailing non-terminal
+ * transition loads as terminal (boost::none), exactly as in the reference.  Load clears the
+ * memory first and does not evict (the reference resizes the deque to num_transitions);
+ * it fails if num_transitions exceeds the capacity. */
+int dqnhip_snapshot_replay_memory(dqnhip_handle h, const char* filename);
+int dqnhip_load_replay_memory(dqnhip_handle h, const char* filename);
+
 /* ---- parameters, iterations, targets ----------------------------------- */
 
 /* number of learnable parameters of a net in the dense order above */
