@@ -241,7 +241,9 @@ def main():
     env_res = None
     if rank == 0 and not args.no_env:
         env_res = {}
-        for workers in (64, 1024):            # workers * frames_per_trial must stay below the replay capacity
+        for workers in (64, 1024):
+            if workers * args.frames_per_trial >= args.replay:      # episode buffers must fit the replay ring
+                continue
             env = pkg.EnvFrontEnd(dqn, workers, max_steps=args.frames_per_trial, p_end=0.01, seed=5)
             env.step(0.1, 20)
             env.stats()

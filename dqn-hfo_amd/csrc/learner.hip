@@ -126,6 +126,7 @@ struct dqnhip_learner {
   float* loss_partial = nullptr; double* q_partial = nullptr; int n_head_blocks = 0;
   float* part[2] = {nullptr, nullptr};  // GEMM-epilogue sumsq partials per net
   float* part_dp = nullptr; int n_part_dp = 0;
+  float* head_slab = nullptr; int* head_ticket = nullptr;   // k_head_bwd cross-block reduction
   // host-staging for add_transitions / acting
   void* stage_dev = nullptr; size_t stage_bytes = 0;
   float* act_buf = nullptr; size_t act_floats = 0;
@@ -318,17 +319,19 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, const float* w, flo
 template <int NH, int MODE>
 int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nullptr) {
   HeadArgs2 a2{}; a2.p[0] = a; if (b) a2.p[1] = *b;
-  const int blocks = (a.rows + 3) / 4;
-  hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(blocks, b ? 2 : 1), dim3(256), 0, st, a2);
+  hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(a.rows, b ? 2 : 1), dim3(256), 0, st, a2);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 template <int NH>
-int head_backward(H* h, hipStream_t st, const HeadBwdArgs& a) {
-  const size_t lds = ((size_t)a.rows * NH + 16 * NH * 64 + 16) * sizeof(float);
-  if (lds > 160 * 1024) return fail("minibatch %d too large for the fused head-backward kernel (LDS %zu B)", a.rows, lds);
-  hipLaunchKernelGGL((k_head_bwd<NH>), dim3(a.H / 64), dim3(1024), lds, st, a);
+int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
+  // row chunks: enough blocks to cover the chip a few times over, <= 64 rows per chunk
+  const int RC = std::max(1, std::min(16, a.rows / 64));
+  const int rows_c = (a.rows + RC - 1) / RC;
+  const size_t lds = ((size_t)rows_c * NH + 16 * NH * 64 + 16) * sizeof(float);
+  a.slab = h->head_slab; a.ticket = h->head_ticket;
+  hipLaunchKernelGGL((k_head_bwd<NH>), dim3(a.H / 64, RC), dim3(1024), lds, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -487,7 +490,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     RC(stream_wait(h, st, ax));            // all actor wgrads done
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)nullptr, 0,
-                         (const double*)h->q_partial, h->n_head_blocks, inv_batch, (float*)nullptr, actor_tail);
+                         (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail);
       HIPCHK(hipGetLastError());
     }
     return 0;
@@ -497,7 +500,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     else RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena));
     hipLaunchKernelGGL(k_tick, dim3(1), dim3(64), 0, st, h->st, critic_tail, actor_tail,
                        (const float*)h->loss_partial, h->n_head_blocks,
-                       dp ? (const double*)nullptr : (const double*)h->q_partial, h->n_head_blocks,
+                       dp ? (const double*)nullptr : (const double*)h->q_partial, B,
                        (float)(B * h->cfg.dp_world));
     HIPCHK(hipGetLastError());
     h->h_actor_iter += 1; h->h_critic_iter += 1;
@@ -644,10 +647,16 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   RC(dalloc(&h->q_t, B)); RC(dalloc(&h->q1, B)); RC(dalloc(&h->q2, B)); RC(dalloc(&h->y, B)); RC(dalloc(&h->dq, B));
   h->n_head_blocks = (B + 3) / 4;
   RC(dalloc(&h->loss_partial, h->n_head_blocks));
-  HIPCHK(hipMalloc(&h->q_partial, h->n_head_blocks * sizeof(double)));
-  HIPCHK(hipMemsetAsync(h->q_partial, 0, h->n_head_blocks * sizeof(double), h->stream));
+  HIPCHK(hipMalloc(&h->q_partial, B * sizeof(double)));
+  HIPCHK(hipMemsetAsync(h->q_partial, 0, B * sizeof(double), h->stream));
   RC(dalloc(&h->part[0], h->la.n_part)); RC(dalloc(&h->part[1], h->lc.n_part));
   h->n_part_dp = 1024; RC(dalloc(&h->part_dp, h->n_part_dp));
+  {
+    const int Hmax = std::max(h->la.dims[L], h->lc.dims[L]);
+    RC(dalloc(&h->head_slab, (size_t)16 * (Hmax / 64) * kNO * 64 + 16 * 16));
+    HIPCHK(hipMalloc(&h->head_ticket, (Hmax / 64) * sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->head_ticket, 0, (Hmax / 64) * sizeof(int), h->stream));
+  }
   // weights: gaussian(std 0.01), zero bias (src/dqn.cpp:350-352); targets = hard copy (:660-661)
   {
     std::mt19937_64 rng(cfg->seed * 0x9E3779B97F4A7C15ull + 12345);
@@ -678,8 +687,6 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   HIPCHK(direct_prepare(gemm_wgrad_direct<1, 1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_bwd_pair_direct<1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4));
-  HIPCHK(direct_prepare(k_head_bwd<1>, 160 * 1024));
-  HIPCHK(direct_prepare(k_head_bwd<kNO>, 160 * 1024));
   HIPCHK(hipStreamSynchronize(h->stream));
   *out = h;
   return 0;
@@ -703,7 +710,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   hipHostFree(h->idx_pinned); hipHostFree(h->pinned_stats);
   hipFree(h->aout_t16); hipFree(h->aout16); hipFree(h->dA16);
   hipFree(h->q_t); hipFree(h->q1); hipFree(h->q2); hipFree(h->y); hipFree(h->dq);
-  hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp);
+  hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp); hipFree(h->head_slab); hipFree(h->head_ticket);
   if (h->stage_dev) hipFree(h->stage_dev);
   if (h->act_buf) hipFree(h->act_buf);
   if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }

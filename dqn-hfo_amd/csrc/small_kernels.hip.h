@@ -189,46 +189,44 @@ struct HeadArgs2 { HeadArgs p[2]; };
 
 template <int NH, int MODE>
 __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
+  // one block per row: the 4 waves split K (each lane one float4 strip per 1024 columns),
+  // butterfly within the wave, then the 4 wave sums are added in fixed order
   const HeadArgs& a = a2.p[blockIdx.y];
+  const int row = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave;
-  __shared__ double s_q[4];
+  __shared__ float s_acc[4][NH];
   float acc[NH];
 #pragma unroll
   for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
-  if (row < a.rows) {
-    const float* x = a.X + (size_t)row * a.ldx;
-    for (int k = lane * 4; k < a.H; k += 256) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
+  const float* x = a.X + (size_t)row * a.ldx;
+  for (int k = threadIdx.x * 4; k < a.H; k += 1024) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
 #pragma unroll
-      for (int j = 0; j < NH; ++j) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k);
-        acc[j] = fmaf(xv.x, wv.x, acc[j]); acc[j] = fmaf(xv.y, wv.y, acc[j]);
-        acc[j] = fmaf(xv.z, wv.z, acc[j]); acc[j] = fmaf(xv.w, wv.w, acc[j]);
-      }
+    for (int j = 0; j < NH; ++j) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k);
+      acc[j] = fmaf(xv.x, wv.x, acc[j]); acc[j] = fmaf(xv.y, wv.y, acc[j]);
+      acc[j] = fmaf(xv.z, wv.z, acc[j]); acc[j] = fmaf(xv.w, wv.w, acc[j]);
     }
   }
 #pragma unroll
   for (int j = 0; j < NH; ++j) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
-    acc[j] += a.b[j];
+    if (lane == 0) s_acc[wave][j] = acc[j];
   }
-  if constexpr (MODE == HEAD_ACTOR) {
-    if (row < a.rows && lane < kAP) {
-      float v = 0.0f;
-#pragma unroll
-      for (int j = 0; j < NH; ++j) if (lane == j) v = acc[j];
-      a.out16[(size_t)row * kAP + lane] = v;
-      if (a.xc != nullptr && lane < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + lane] = v;
-    }
-  } else {
-    const float q = acc[0];
-    if (row < a.rows && lane == 0) a.q[row] = q;
-    if constexpr (MODE == HEAD_Q_POLICY) {
-      if (lane == 0) s_q[wave] = row < a.rows ? (double)q : 0.0;
-      __syncthreads();
-      if (threadIdx.x == 0) a.qsum_partial[blockIdx.x] = ((s_q[0] + s_q[1]) + s_q[2]) + s_q[3];
+  __syncthreads();
+  if (threadIdx.x < kAP) {
+    const int j = threadIdx.x;
+    float v = 0.0f;
+    if (j < NH) v = ((s_acc[0][j] + s_acc[1][j]) + (s_acc[2][j] + s_acc[3][j])) + a.b[j];
+    if constexpr (MODE == HEAD_ACTOR) {
+      a.out16[(size_t)row * kAP + j] = v;
+      if (a.xc != nullptr && j < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + j] = v;
+    } else {
+      if (j == 0) {
+        a.q[row] = v;
+        if constexpr (MODE == HEAD_Q_POLICY) a.qsum_partial[row] = (double)v;   // summed in row order by k_tick / k_tails
+      }
     }
   }
 }
@@ -294,18 +292,27 @@ struct HeadBwdArgs {
   float* dA16;                         // actor: post-invert head diffs (debug / parity)
   const float* W; const float* X4; int H; int rows;
   float* dZ; float* dW; float* db; float* partial;
+  float* slab;                         // [gridDim.y][H/64][NH][64] per-row-chunk partial dW
+  int* ticket;                         // [H/64] arrival counters, zero before and after every launch
 };
+// Grid = (H/64 column blocks) x (RC row chunks); block = 64 columns x 16 row groups.  Each block
+// writes its dZ rows directly and a partial dW slab; the LAST block to arrive for a column block
+// (agent-scope release -> ticket -> acquire, guide G16) adds the RC slabs in fixed order, so the
+// result does not depend on which block that is.
 template <int NH>
 __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* s_dy = sm;                              // [rows][NH]
-  float* s_acc = sm + a.rows * NH;               // [16][NH][64]
-  float* s_red = s_acc + 16 * NH * 64;           // [16]
+  const int RC = gridDim.y, rc = blockIdx.y, nkb = gridDim.x;
+  const int rows_c = (a.rows + RC - 1) / RC;           // rows of this chunk
+  const int r0 = rc * rows_c, r1 = min(a.rows, r0 + rows_c);
+  float* s_dy = sm;                                    // [rows_c][NH]
+  float* s_acc = sm + rows_c * NH;                     // [16][NH][64]
+  __shared__ int s_last;
   const int tid = threadIdx.x;
   const bool want_w = a.dW != nullptr;
-  // ---- head diffs for every row into LDS
-  for (int i = tid; i < a.rows * NH; i += 1024) {
-    const int m = i / NH, j = i % NH;
+  // ---- head diffs of this chunk's rows into LDS
+  for (int i = tid; i < (r1 - r0) * NH; i += 1024) {
+    const int m = r0 + i / NH, j = i % NH;
     float d;
     if constexpr (NH == kNO) {
       d = a.dXc[(size_t)m * a.ldx + a.S + j];
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
     s_dy[i] = d;
   }
   __syncthreads();
-  const int kc = tid & 63, rg = tid >> 6;          // 16 row groups
+  const int kc = tid & 63, rg = tid >> 6;              // 16 row groups
   const int k = blockIdx.x * 64 + kc;
   float w[NH];
 #pragma unroll
@@ -330,14 +337,14 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   float acc[NH];
 #pragma unroll
   for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
-  const int per = (a.rows + 15) / 16;
-  const int m0 = rg * per, m1 = min(a.rows, m0 + per);
+  const int per = (r1 - r0 + 15) / 16;
+  const int m0 = r0 + rg * per, m1 = min(r1, m0 + per);
   for (int m = m0; m < m1; ++m) {
     const float xv = a.X4[(size_t)m * a.H + k];
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
-      const float d = s_dy[m * NH + j];
+      const float d = s_dy[(m - r0) * NH + j];
       // Split layer: action_layer's and actionpara_layer's bottom diffs are
       // formed separately and added
       if (NH == kNO && j >= kNA) s1 = fmaf(d, w[j], s1); else s0 = fmaf(d, w[j], s0);
@@ -350,27 +357,56 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
 #pragma unroll
   for (int j = 0; j < NH; ++j) s_acc[(rg * NH + j) * 64 + kc] = acc[j];
   __syncthreads();
-  float ssq = 0.0f;
+  // this chunk's partial: row groups added in fixed order
+  float* my_slab = a.slab + ((size_t)rc * nkb + blockIdx.x) * NH * 64;
   if (rg == 0) {
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
       float v = 0.0f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) v += s_acc[(g * NH + j) * 64 + kc];
+      my_slab[j * 64 + kc] = v;
+    }
+    if (blockIdx.x == 0 && kc < NH) {                 // partial bias gradient of this chunk
+      float v = 0.0f;
+      for (int m = 0; m < r1 - r0; ++m) v += s_dy[m * NH + kc];
+      a.slab[(size_t)RC * nkb * NH * 64 + rc * 16 + kc] = v;
+    }
+  }
+  // publish the slab, take a ticket; the last arriver reduces (placement independent)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(a.ticket + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == RC - 1);
+    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float ssq = 0.0f;
+  if (rg == 0) {
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      float v = 0.0f;
+      for (int c = 0; c < RC; ++c) v += a.slab[((size_t)c * nkb + blockIdx.x) * NH * 64 + j * 64 + kc];
       a.dW[(size_t)j * a.H + k] = v;
       ssq = fmaf(v, v, ssq);
     }
     if (blockIdx.x == 0 && kc < NH) {
       float v = 0.0f;
-      for (int m = 0; m < a.rows; ++m) v += s_dy[m * NH + kc];
+      for (int c = 0; c < RC; ++c) v += a.slab[(size_t)RC * nkb * NH * 64 + c * 16 + kc];
       a.db[kc] = v;
       ssq = fmaf(v, v, ssq);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
-    if (kc == 0 && a.partial != nullptr) a.partial[blockIdx.x] = ssq;
+    if (kc == 0) {
+      if (a.partial != nullptr) a.partial[blockIdx.x] = ssq;
+      a.ticket[blockIdx.x] = 0;                        // re-arm for the next launch
+    }
   }
-  (void)s_red;
 }
 
 // ---- optimiser -----------------------------------------------------------------
@@ -490,16 +526,19 @@ __global__ void k_tails(const float* loss_partial, int n_loss, const double* q_p
 // from the all-reduced float tail under data parallelism.
 __global__ void k_tick(DevState* st, float* critic_tail, float* actor_tail, const float* loss_partial,
                        int n_loss, const double* q_partial, int n_q, float batch) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: strided partial sums, fixed butterfly -> deterministic
+  const int lane = threadIdx.x;
   double qs = 0.0;
   if (q_partial != nullptr) {          // single GPU: reduce the per-block partials here
     float dot = 0.0f;
-    for (int i = 0; i < n_loss; ++i) dot += loss_partial[i];
-    critic_tail[0] = dot / batch / 2.0f;              // EuclideanLoss: dot / num / 2
-    for (int i = 0; i < n_q; ++i) qs += q_partial[i];
-    actor_tail[1] = (float)qs;
+    for (int i = lane; i < n_loss; i += 64) dot += loss_partial[i];
+    for (int i = lane; i < n_q; i += 64) qs += q_partial[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { dot += __shfl_xor(dot, off, 64); qs += __shfl_xor(qs, off, 64); }
+    if (lane == 0) { critic_tail[0] = dot / batch / 2.0f; actor_tail[1] = (float)qs; }   // EuclideanLoss: dot / num / 2
   } else qs = (double)actor_tail[1];   // data parallel: tails were all-reduced
-  st->critic_loss = critic_tail[0];
+  if (lane != 0) return;
+  st->critic_loss = q_partial != nullptr ? critic_tail[0] : critic_tail[0];
   st->avg_q = (float)(qs / (double)batch);
   st->actor_iter += 1; st->critic_iter += 1; st->update_counter += 1;
 }
