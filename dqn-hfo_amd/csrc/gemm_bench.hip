@@ -107,6 +107,8 @@ hipError_t launch_variant(int mode, int variant, GemmBatch& b, hipStream_t s) {
       case 2: return dgrad_direct_launch<1, 2>(b, s);  // 64x32
       case 3: return dgrad_direct_launch<2, 1>(b, s);  // 128x16
       case 4: return dgrad_direct_launch<1, 4>(b, s);  // 64x64
+      case 5: return dgrad_lds_launch<1, 1>(b, s);     // 64x16, dY through the LDS transpose
+      case 6: return dgrad_lds_launch<1, 2>(b, s);     // 64x32
     }
   } else {
     switch (variant) {

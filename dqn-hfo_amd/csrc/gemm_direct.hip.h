@@ -478,6 +478,122 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
   }
 }
 
+// ================================ DGRAD, coalesced ===================================
+// dgrad_direct_body with the k-contiguous operand (dY, 16-row blocks) fetched as whole 128-B
+// lines through the wave-private LDS transpose of fwd_lds_body; the weight operand (k-strided)
+// stays a direct full-line load.  Requires Kred % 256 == 0 and Kred >= 512.
+template <int TPB, int TQ>
+__device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
+  constexpr int NACC = TPB * 4 * TQ;
+  constexpr int SLOT = TQ * 512;
+  constexpr int WAVE_FLOATS = (2 * SLOT > NACC * 256) ? 2 * SLOT : NACC * 256;   // staging, later the parked tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int lr = lane >> 3, lc = lane & 7;
+  const int p0 = tile_p * 64 * TPB, q0 = tile_q * 16 * TQ;
+  const int Kw = pr.Kred >> 2;
+  const int T = Kw >> 5;
+  float* wsm = smem + wave * WAVE_FLOATS;
+  const float* pp = pr.P + (size_t)(wave * Kw + lg * 4) * pr.ldp + p0 + li * 4;
+  const size_t ldp = pr.ldp;
+  const float* gq[TQ];
+#pragma unroll
+  for (int a = 0; a < TQ; ++a) gq[a] = pr.Q + (size_t)(q0 + a * 16 + lr) * pr.ldq + wave * Kw + lc * 4;
+  const size_t ldq8 = (size_t)8 * pr.ldq;
+  const int woff = lr * 32 + ((lc ^ lr) << 2);
+  int roff[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) roff[kb] = li * 32 + ((((kb << 2) + lg) ^ (li & 7)) << 2);
+
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 G0[TQ][2], G1[TQ][2], F[TQ][2], Fn[TQ][2];
+  f32x4 P0[2][4][TPB], P1[2][4][TPB];
+
+#define D_GLOADQ(G, t)                                                                  \
+  { _Pragma("unroll") for (int a = 0; a < TQ; ++a) {                                    \
+      G[a][0] = *reinterpret_cast<const f32x4*>(gq[a] + ((t) << 5));                   \
+      G[a][1] = *reinterpret_cast<const f32x4*>(gq[a] + ldq8 + ((t) << 5)); } }
+#define D_GLOADP(PP, t)                                                                 \
+  { _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                    \
+    _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                    \
+    _Pragma("unroll") for (int b = 0; b < TPB; ++b)                                     \
+        PP[kb][s2][b] = *reinterpret_cast<const f32x4*>(pp + (size_t)(((t) << 5) + (kb << 4) + s2) * ldp + b * 64); }
+#define D_SWRITE(slot, G)                                                               \
+  { _Pragma("unroll") for (int a = 0; a < TQ; ++a) {                                    \
+      *reinterpret_cast<f32x4*>(wsm + (slot) * SLOT + a * 512 + woff) = G[a][0];        \
+      *reinterpret_cast<f32x4*>(wsm + (slot) * SLOT + a * 512 + 256 + woff) = G[a][1]; } }
+#define D_SREAD(FF, slot)                                                               \
+  { _Pragma("unroll") for (int a = 0; a < TQ; ++a) {                                    \
+      FF[a][0] = *reinterpret_cast<const f32x4*>(wsm + (slot) * SLOT + a * 512 + roff[0]); \
+      FF[a][1] = *reinterpret_cast<const f32x4*>(wsm + (slot) * SLOT + a * 512 + roff[1]); } }
+#define D_MFMA(FF, PP)                                                                  \
+  { _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                    \
+    _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                    \
+    _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
+    _Pragma("unroll") for (int b = 0; b < TPB; ++b)                                     \
+    _Pragma("unroll") for (int pc = 0; pc < 4; ++pc)                                    \
+        acc[(a * TPB + b) * 4 + pc] = DQN_MFMA(PP[kb][s2][b][pc], FF[a][kb][s2], acc[(a * TPB + b) * 4 + pc]); }
+
+  D_GLOADQ(G0, 0) D_GLOADQ(G1, 1) D_GLOADP(P0, 0)
+  D_SWRITE(0, G0) D_GLOADQ(G0, 2) D_SREAD(F, 0) D_GLOADP(P1, 1)
+  int t = 0;
+  for (; t + 4 < T; t += 2) {
+    D_SWRITE(1, G1) D_GLOADQ(G1, t + 3) D_SREAD(Fn, 1)
+    D_MFMA(F, P0) D_GLOADP(P0, t + 2)
+    D_SWRITE(0, G0) D_GLOADQ(G0, t + 4) D_SREAD(F, 0)
+    D_MFMA(Fn, P1) D_GLOADP(P1, t + 3)
+  }
+  // t == T-4
+  D_SWRITE(1, G1) D_GLOADQ(G1, T - 1) D_SREAD(Fn, 1)
+  D_MFMA(F, P0) D_GLOADP(P0, T - 2)
+  D_SWRITE(0, G0) D_SREAD(F, 0)
+  D_MFMA(Fn, P1) D_GLOADP(P1, T - 1)
+  D_SWRITE(1, G1) D_SREAD(Fn, 1)
+  D_MFMA(F, P0)
+  D_MFMA(Fn, P1)
+#undef D_GLOADQ
+#undef D_GLOADP
+#undef D_SWRITE
+#undef D_SREAD
+#undef D_MFMA
+
+  f32x4* park = reinterpret_cast<f32x4*>(wsm);
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) park[e * 64 + lane] = acc[e];
+  __syncthreads();
+  auto red = [&](int e) {
+    const f32x4 a0 = reinterpret_cast<const f32x4*>(smem + 0 * WAVE_FLOATS)[e * 64 + lane];
+    const f32x4 a1 = reinterpret_cast<const f32x4*>(smem + 1 * WAVE_FLOATS)[e * 64 + lane];
+    const f32x4 a2 = reinterpret_cast<const f32x4*>(smem + 2 * WAVE_FLOATS)[e * 64 + lane];
+    const f32x4 a3 = reinterpret_cast<const f32x4*>(smem + 3 * WAVE_FLOATS)[e * 64 + lane];
+    f32x4 v;
+    v.x = (a0.x + a1.x) + (a2.x + a3.x); v.y = (a0.y + a1.y) + (a2.y + a3.y);
+    v.z = (a0.z + a1.z) + (a2.z + a3.z); v.w = (a0.w + a1.w) + (a2.w + a3.w);
+    return v;
+  };
+#pragma unroll
+  for (int ab = 0; ab < TQ * TPB; ++ab) {
+    // with TQ*TPB < 4 the four pc-accumulator groups of one (a,b) are shared out over the waves by r
+    const int a = ab / TPB, b = ab % TPB;
+    const f32x4 r0 = red(ab * 4 + 0), r1 = red(ab * 4 + 1), r2 = red(ab * 4 + 2), r3 = red(ab * 4 + 3);
+    const int q = q0 + a * 16 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (((ab + r) & 3) == wave) {
+        const int p = p0 + b * 64 + (lg << 4) + (r << 2);
+        f32x4 v = f32x4{r0[r], r1[r], r2[r], r3[r]};
+        if (pr.mask != nullptr) {
+          const f32x4 mv = *reinterpret_cast<const f32x4*>(pr.mask + (size_t)q * pr.ldm + p);
+          v.x *= lrelu_mask(mv.x); v.y *= lrelu_mask(mv.y); v.z *= lrelu_mask(mv.z); v.w *= lrelu_mask(mv.w);
+        }
+        *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
+      }
+    }
+  }
+}
+
 // ---- kernels: thin wrappers over the bodies --------------------------------------------
 template <int TP, int TQ, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_fwd_direct(const GemmBatch batch) {
@@ -500,6 +616,13 @@ __global__ __launch_bounds__(256) void gemm_dgrad_direct(const GemmBatch batch) 
   tile_of_block(batch, pi, tile_p, tile_q);
   dgrad_direct_body<TPB, TQ>(batch.prob[pi], tile_p, tile_q, smem);
 }
+template <int TPB, int TQ>
+__global__ __launch_bounds__(256) void gemm_dgrad_lds(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  dgrad_lds_body<TPB, TQ>(batch.prob[pi], tile_p, tile_q, smem);
+}
 template <int TPB, int TQB>
 __global__ __launch_bounds__(256) void gemm_wgrad_direct(const GemmBatch batch) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -510,13 +633,14 @@ __global__ __launch_bounds__(256) void gemm_wgrad_direct(const GemmBatch batch) 
 // One layer's backward in ONE launch: problems with mode GEMM_DGRAD (64x16 tiles) and
 // GEMM_WGRAD (64x64 tiles) side by side.  dX_{l-1} = dZ_l W_l and dW_l = dZ_l^T X_{l-1} only
 // share their input dZ_l, so a 256x1024x1024 layer offers 256 + 256 workgroups = 2 per CU.
-template <int TQD = 1>
+template <int TQD = 1, bool DLDS = false>
 __global__ __launch_bounds__(256) void gemm_bwd_pair_direct(const GemmBatch batch) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int pi, tile_p, tile_q;
   tile_of_block(batch, pi, tile_p, tile_q);
   const GemmProblem& pr = batch.prob[pi];
   if (pr.mode == GEMM_WGRAD) wgrad_direct_body<1, 1>(pr, tile_p, tile_q, smem);
+  else if constexpr (DLDS) dgrad_lds_body<1, TQD>(pr, tile_p, tile_q, smem);
   else dgrad_direct_body<1, TQD>(pr, tile_p, tile_q, smem);
 }
 
@@ -567,13 +691,19 @@ template <int TPB, int TQ>
 inline hipError_t dgrad_direct_launch(GemmBatch& b, hipStream_t s) {
   return direct_launch(gemm_dgrad_direct<TPB, TQ>, b, 64 * TPB, 16 * TQ, 4 * TPB * 4 * TQ * 64 * 16, s);
 }
+template <int TPB, int TQ>
+constexpr int dgrad_lds_bytes() { return 4 * ((2 * TQ * 512 > TPB * 4 * TQ * 256) ? 2 * TQ * 512 : TPB * 4 * TQ * 256) * 4; }
+template <int TPB, int TQ>
+inline hipError_t dgrad_lds_launch(GemmBatch& b, hipStream_t s) {
+  return direct_launch(gemm_dgrad_lds<TPB, TQ>, b, 64 * TPB, 16 * TQ, dgrad_lds_bytes<TPB, TQ>(), s);
+}
 template <int TPB, int TQB>
 inline hipError_t wgrad_direct_launch(GemmBatch& b, hipStream_t s) {
   return direct_launch(gemm_wgrad_direct<TPB, TQB>, b, 64 * TPB, 64 * TQB,
                        4 * TPB * 4 * TQB * 4 * 64 * 16 + 4 * TQB * 16 * 16, s);
 }
 // mixed dgrad(64x16)/wgrad(64x64) launch; every problem carries its own mode
-template <int TQD>
+template <int TQD, bool DLDS = false>
 inline hipError_t bwd_pair_direct_launch(GemmBatch& batch, hipStream_t stream) {
   int base = 0;
   for (int i = 0; i < batch.n; ++i) {
@@ -585,8 +715,8 @@ inline hipError_t bwd_pair_direct_launch(GemmBatch& batch, hipStream_t stream) {
   }
   batch.total_tiles = base;
   LaunchTimer& lt = launch_timer();
-  if (lt.start) { hipExtLaunchKernelGGL(gemm_bwd_pair_direct<TQD>, dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, lt.start, lt.stop, 0, batch); lt.start = lt.stop = nullptr; }
-  else hipLaunchKernelGGL(gemm_bwd_pair_direct<TQD>, dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, batch);
+  if (lt.start) { hipExtLaunchKernelGGL((gemm_bwd_pair_direct<TQD, DLDS>), dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, lt.start, lt.stop, 0, batch); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL((gemm_bwd_pair_direct<TQD, DLDS>), dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, batch);
   return hipGetLastError();
 }
 template <typename K>

@@ -304,7 +304,10 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, const float* w, flo
     } else if (need_dx && want_w) {
       GemmBatch b{}; b.n = 2; b.prob[0] = bd.prob[0]; b.prob[1] = bw.prob[0];
       ScopedTiming t(h, 4, st);
-      HIPCHK(bwd_pair_direct_launch<1>(b, st));
+      // dY through the LDS transpose when the layer is wide enough (measured: pair 16.6 -> see DESIGN)
+      static const bool kPairLds = !getenv("DQNHIP_PAIR_DIRECT");
+      if (kPairLds && l.dims[i + 1] >= 512 && l.dims[i + 1] % 256 == 0) HIPCHK((bwd_pair_direct_launch<1, true>(b, st)));
+      else HIPCHK(bwd_pair_direct_launch<1>(b, st));
     } else if (need_dx) {
       ScopedTiming t(h, 1, st);
       HIPCHK((dgrad_direct_launch<1, 1>(bd, st)));
@@ -686,6 +689,7 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   }
   HIPCHK(direct_prepare(gemm_wgrad_direct<1, 1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_bwd_pair_direct<1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
+  HIPCHK(direct_prepare(gemm_bwd_pair_direct<1, true>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4));
   HIPCHK(hipStreamSynchronize(h->stream));
   *out = h;

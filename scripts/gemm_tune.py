@@ -12,7 +12,7 @@ fn.restype = C.c_int
 fn.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 3
 rows, n_out, k_in = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (256, 1024, 1024)
 names = {0: "FWD", 1: "DGRAD", 2: "WGRAD"}
-variants = {0: [1, 10, 11, 2, 12, 13, 4, 14], 1: [], 2: []}
+variants = {0: [], 1: [1, 5, 2, 6], 2: [1]}
 flops = 2.0 * rows * n_out * k_in
 for rep in range(1):
     for mode in (0, 1, 2):
