@@ -56,6 +56,15 @@ SIGNATURES = {
     "dqnhip_read_memory": (C.c_int, [H, C.c_int32, C.c_int32, fp, fp, fp, fp, fp, up]),
     "dqnhip_snapshot_replay_memory": (C.c_int, [H, C.c_char_p]),
     "dqnhip_load_replay_memory": (C.c_int, [H, C.c_char_p]),
+    "dqnhip_get_config": (C.c_int, [H, C.POINTER(Config)]),
+    "dqnhip_save_caffemodel": (C.c_int, [H, C.c_int32, C.c_char_p]),
+    "dqnhip_load_caffemodel": (C.c_int, [H, C.c_int32, C.c_char_p]),
+    "dqnhip_solver_snapshot": (C.c_int, [H, C.c_int32, C.c_char_p, ip]),
+    "dqnhip_solver_restore": (C.c_int, [H, C.c_int32, C.c_char_p]),
+    "dqnhip_snapshot": (C.c_int, [H, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]),
+    "dqnhip_find_latest_snapshot": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "dqnhip_find_hiscore": (C.c_int, [C.c_char_p, ip]),
+    "dqnhip_remove_files_matching_regexp": (C.c_int, [C.c_char_p]),
     "dqnhip_param_count": (C.c_int, [H, C.c_int32, C.POINTER(C.c_size_t)]),
     "dqnhip_get_params": (C.c_int, [H, C.c_int32, C.c_int32, fp, C.c_size_t]),
     "dqnhip_set_params": (C.c_int, [H, C.c_int32, C.c_int32, fp, C.c_size_t]),

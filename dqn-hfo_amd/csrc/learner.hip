@@ -583,6 +583,15 @@ void dqnhip_default_config(dqnhip_config* c, int32_t state_size) {
 }
 
 const char* dqnhip_last_error(void) { return g_err.c_str(); }
+// used by snapshot.cpp (same library, different translation unit) to report through the same channel
+int dqnhip_internal_set_error(const char* msg) { g_err = msg ? msg : ""; return 1; }
+
+int dqnhip_get_config(dqnhip_handle h, dqnhip_config* out) {
+  if (!h || !out) return fail("null argument");
+  *out = h->cfg;
+  out->stream = nullptr; out->grad_arena = nullptr; out->grad_arena_bytes = 0;
+  return 0;
+}
 
 size_t dqnhip_grad_arena_bytes(const dqnhip_config* cfg) {
   if (validate(cfg)) return 0;

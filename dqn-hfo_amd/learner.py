@@ -114,6 +114,8 @@ class DQN:
         self.random_engine = np.random.default_rng(seed)   # stands in for std::mt19937
         self.smoothed_critic_loss_ = 0.0
         self.smoothed_actor_loss_ = 0.0
+        self.last_snapshot_iter_ = 0
+        self.snapshot_freq = 10000                      # FLAGS_snapshot_freq, src/dqn.cpp:28
 
     # -- plumbing -----------------------------------------------------------------
     @staticmethod
@@ -236,6 +238,32 @@ class DQN:
                                              t.ctypes.data_as(capi.up)))
         return s, a, r, mc, nx, t
 
+    # -- snapshot / restore (src/dqn.cpp:525-620) ---------------------------------------------------
+    def Snapshot(self, snapshot_prefix=None, remove_old=None, snapshot_memory=None):
+        """DQN::Snapshot(): `<prefix>_{actor,critic}_iter_N.{caffemodel,solverstate}` (+
+        `<prefix>_iter_N.replaymemory`) in Caffe's binary protobuf layout.  With no arguments:
+        Snapshot(save_path_, FLAGS_remove_old_snapshots=True, FLAGS_snapshot_memory=True)."""
+        prefix = self.save_path_ if snapshot_prefix is None else snapshot_prefix
+        remove_old = True if remove_old is None and snapshot_prefix is None else bool(remove_old)
+        snapshot_memory = True if snapshot_memory is None else bool(snapshot_memory)
+        self._ck(self.lib.dqnhip_snapshot(self.h, os.fsencode(self.save_path_), os.fsencode(prefix),
+                                          int(remove_old), int(snapshot_memory)))
+        self.last_snapshot_iter_ = self.max_iter()
+
+    def RestoreActorSolver(self, actor_solver):
+        self._ck(self.lib.dqnhip_solver_restore(self.h, ACTOR, os.fsencode(actor_solver)))
+        self.last_snapshot_iter_ = self.max_iter()
+
+    def RestoreCriticSolver(self, critic_solver):
+        self._ck(self.lib.dqnhip_solver_restore(self.h, CRITIC, os.fsencode(critic_solver)))
+        self.last_snapshot_iter_ = self.max_iter()
+
+    def LoadActorWeights(self, actor_weights):
+        self._ck(self.lib.dqnhip_load_caffemodel(self.h, ACTOR, os.fsencode(actor_weights)))
+
+    def LoadCriticWeights(self, critic_weights):
+        self._ck(self.lib.dqnhip_load_caffemodel(self.h, CRITIC, os.fsencode(critic_weights)))
+
     def SnapshotReplayMemory(self, filename):
         """src/dqn.cpp:1146-1178: gzip `.replaymemory` file in the reference's byte layout."""
         self._ck(self.lib.dqnhip_snapshot_replay_memory(self.h, os.fsencode(filename)))
@@ -335,6 +363,10 @@ class DQN:
         self.smoothed_actor_loss_ += avg_q / float(loss_display_iter)
         for line in logs:
             print(line)
+        # periodic snapshot (src/dqn.cpp:818-825)
+        if (self.critic_iter() >= self.last_snapshot_iter_ + self.snapshot_freq or
+                self.actor_iter() >= self.last_snapshot_iter_ + self.snapshot_freq):
+            self.Snapshot()
         return critic_loss, avg_q
 
     def Benchmark(self, iterations=1000, warmup=0):
@@ -386,6 +418,31 @@ class DQN:
         ms, n = C.c_float(), C.c_int64()
         self._ck(self.lib.dqnhip_get_kernel_timing(self.h, family.encode(), C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
+
+
+def FindLatestSnapshot(snapshot_prefix):
+    """src/dqn.cpp:122-144 -> (actor_solverstate, critic_solverstate, replaymemory), '' if none."""
+    lib = capi.load()
+    bufs = [C.create_string_buffer(4096) for _ in range(3)]
+    if lib.dqnhip_find_latest_snapshot(os.fsencode(snapshot_prefix), bufs[0], bufs[1], bufs[2], 4096) != 0:
+        raise DQNFatal(lib.dqnhip_last_error().decode())
+    return tuple(os.fsdecode(b.value) for b in bufs)
+
+
+def FindHiScore(snapshot_prefix):
+    """src/dqn.cpp:146-158."""
+    lib = capi.load()
+    v = C.c_int32()
+    if lib.dqnhip_find_hiscore(os.fsencode(snapshot_prefix), C.byref(v)) != 0:
+        raise DQNFatal(lib.dqnhip_last_error().decode())
+    return v.value
+
+
+def RemoveFilesMatchingRegexp(regexp):
+    """src/dqn.cpp:92-98."""
+    lib = capi.load()
+    if lib.dqnhip_remove_files_matching_regexp(os.fsencode(regexp)) != 0:
+        raise DQNFatal(lib.dqnhip_last_error().decode())
 
 
 class EnvFrontEnd:

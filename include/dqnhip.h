@@ -237,6 +237,42 @@ int dqnhip_clone_to_target(dqnhip_handle h, int32_t net);
 int dqnhip_get_iters(dqnhip_handle h, int32_t* actor_iter, int32_t* critic_iter);
 int dqnhip_set_iters(dqnhip_handle h, int32_t actor_iter, int32_t critic_iter);
 
+/* The configuration the learner was created with (for clients that need the shapes). */
+int dqnhip_get_config(dqnhip_handle h, dqnhip_config* out);
+
+/* ---- Caffe snapshot layout (src/dqn.cpp:525-620; Caffe Solver::Snapshot/Restore) -------
+ * `.caffemodel` = binary caffe.NetParameter{name=1, layer=100{name=1, type=2, blobs=7}},
+ * `.solverstate` = binary caffe.SolverState{iter=1, learned_net=2, history=3, current_step=4},
+ * blobs = caffe.BlobProto{shape=7{dim=1 packed}, data=5 packed float}.  Layer names are the
+ * reference's: ip<i>_layer (src/dqn.cpp:406), action_layer, actionpara_layer (:426-427),
+ * q_values_layer (src/dqn.hpp:43); weight blob [num_output, K] then bias [num_output]; Adam
+ * history = [m of every param in order, then v of every param].
+ * net = DQNHIP_ACTOR or DQNHIP_CRITIC. */
+/* Net::ToProto + WriteProtoToBinaryFile */
+int dqnhip_save_caffemodel(dqnhip_handle h, int32_t net, const char* filename);
+/* Net::CopyTrainedLayersFrom (layers matched by NAME, others ignored) followed by CloneNet to
+ * the target net — DQN::LoadActorWeights / LoadCriticWeights (src/dqn.cpp:525-539) */
+int dqnhip_load_caffemodel(dqnhip_handle h, int32_t net, const char* filename);
+/* Solver::Snapshot: writes <prefix>_iter_<iter>.caffemodel and .solverstate (learned_net =
+ * the caffemodel's path), returns the iteration */
+int dqnhip_solver_snapshot(dqnhip_handle h, int32_t net, const char* prefix, int32_t* iter_out);
+/* Solver::Restore + CloneNet — DQN::RestoreActorSolver / RestoreCriticSolver (:541-557):
+ * iteration, learned_net weights, Adam history; the target net becomes a hard copy */
+int dqnhip_solver_restore(dqnhip_handle h, int32_t net, const char* solverstate);
+/* DQN::Snapshot (src/dqn.cpp:586-620): both solvers under save_path, renamed to
+ * snapshot_prefix, optional `<prefix>_iter_<max_iter>.replaymemory`, optional removal of
+ * older snapshots of the same prefix */
+int dqnhip_snapshot(dqnhip_handle h, const char* save_path, const char* snapshot_prefix,
+                    int32_t remove_old, int32_t snapshot_memory);
+/* FindLatestSnapshot (src/dqn.cpp:122-144): newest <prefix>_{actor,critic}_iter_N.solverstate
+ * and <prefix>_iter_N.replaymemory; each buffer receives "" when none is found */
+int dqnhip_find_latest_snapshot(const char* snapshot_prefix, char* actor, char* critic, char* memory,
+                                size_t buf_len);
+/* FindHiScore (src/dqn.cpp:146-158) */
+int dqnhip_find_hiscore(const char* snapshot_prefix, int32_t* score);
+/* RemoveFilesMatchingRegexp (src/dqn.cpp:92-98) */
+int dqnhip_remove_files_matching_regexp(const char* regexp);
+
 /* ---- introspection for parity tests ------------------------------------ */
 
 /* Copy a named [B, *] intermediate of the last update to the host:
