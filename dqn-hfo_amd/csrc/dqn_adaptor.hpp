@@ -80,6 +80,23 @@ inline Action GetAction(const ActorOutput& actor_output) {                  // s
   return action;
 }
 
+// free functions of src/dqn.hpp:204-242 -------------------------------------------------------
+inline void RemoveFilesMatchingRegexp(const std::string& regexp) { DQN_CK(dqnhip_remove_files_matching_regexp(regexp.c_str())); }
+inline void FindLatestSnapshot(const std::string& snapshot_prefix, std::string& actor_snapshot,
+                               std::string& critic_snapshot, std::string& memory_snapshot) {
+  char a[4096], c[4096], m[4096];
+  DQN_CK(dqnhip_find_latest_snapshot(snapshot_prefix.c_str(), a, c, m, sizeof a));
+  if (a[0]) actor_snapshot = a;
+  if (c[0]) critic_snapshot = c;
+  if (m[0]) memory_snapshot = m;
+}
+inline int FindHiScore(const std::string& snapshot_prefix) { int32_t s; DQN_CK(dqnhip_find_hiscore(snapshot_prefix.c_str(), &s)); return s; }
+inline std::string PrintActorOutput(const ActorOutput& o) {        // src/dqn.cpp:210-216
+  return "Dash(" + std::to_string(o[4]) + ", " + std::to_string(o[5]) + ")=" + std::to_string(o[0]) + ", Turn(" +
+         std::to_string(o[6]) + ")=" + std::to_string(o[1]) + ", Tackle(" + std::to_string(o[7]) + ")=" + std::to_string(o[2]) +
+         ", Kick(" + std::to_string(o[8]) + ", " + std::to_string(o[9]) + ")=" + std::to_string(o[3]);
+}
+
 class DQN {
  public:
   DQN(const SolverParams& actor_solver_param, const SolverParams& critic_solver_param, std::string save_path,
@@ -189,6 +206,39 @@ class DQN {
       smoothed_actor_loss_ = 0;
     }
     smoothed_actor_loss_ += res.second / float(flags_.loss_display_iter);
+    const bool critic_needs_snapshot = critic_iter() >= last_snapshot_iter_ + flags_.snapshot_freq;   // :818-825
+    const bool actor_needs_snapshot = actor_iter() >= last_snapshot_iter_ + flags_.snapshot_freq;
+    if (critic_needs_snapshot || actor_needs_snapshot) { Snapshot(); last_snapshot_iter_ = max_iter(); }
+  }
+
+  // Loading methods (src/dqn.hpp:66-71, src/dqn.cpp:525-557, 1180-1226)
+  void RestoreActorSolver(const std::string& f) { DQN_CK(dqnhip_solver_restore(h_, DQNHIP_ACTOR, f.c_str())); last_snapshot_iter_ = max_iter(); }
+  void RestoreCriticSolver(const std::string& f) { DQN_CK(dqnhip_solver_restore(h_, DQNHIP_CRITIC, f.c_str())); last_snapshot_iter_ = max_iter(); }
+  void LoadActorWeights(const std::string& f) { DQN_CK(dqnhip_load_caffemodel(h_, DQNHIP_ACTOR, f.c_str())); }
+  void LoadCriticWeights(const std::string& f) { DQN_CK(dqnhip_load_caffemodel(h_, DQNHIP_CRITIC, f.c_str())); }
+  void LoadReplayMemory(const std::string& f) { DQN_CK(dqnhip_load_replay_memory(h_, f.c_str())); }
+  void SnapshotReplayMemory(const std::string& f) { DQN_CK(dqnhip_snapshot_replay_memory(h_, f.c_str())); }
+
+  // Snapshot the model/solver/replay memory (src/dqn.cpp:582-620)
+  void Snapshot() { Snapshot(save_path_, flags_.remove_old_snapshots, flags_.snapshot_memory); }
+  void Snapshot(const std::string& snapshot_prefix, bool remove_old = false, bool snapshot_memory = true) {
+    DQN_CK(dqnhip_snapshot(h_, save_path_.c_str(), snapshot_prefix.c_str(), remove_old, snapshot_memory));
+  }
+
+  // Converts an ActorOutput into an action by sampling over discrete actions (src/dqn.cpp:180-194)
+  Action SampleAction(const ActorOutput& actor_output) {
+    float dash_prob = std::max(0., actor_output[DASH] + 1.0);
+    float turn_prob = std::max(0., actor_output[TURN] + 1.0);
+    float tackle_prob = 0;                                  // Remove tackle action
+    float kick_prob = std::max(0., actor_output[KICK] + 1.0);
+    std::discrete_distribution<int> dist{dash_prob, turn_prob, tackle_prob, kick_prob};
+    action_t max_act = (action_t)dist(random_engine);
+    Action action;
+    action.action = max_act;
+    action.arg1 = actor_output[kActionSize + GetParamOffset(max_act, 0)];
+    const int arg2_offset = GetParamOffset(max_act, 1);
+    action.arg2 = arg2_offset < 0 ? 0 : actor_output[kActionSize + arg2_offset];
+    return action;
   }
 
   void ClearReplayMemory() { DQN_CK(dqnhip_clear_memory(h_)); }
@@ -219,6 +269,7 @@ class DQN {
   const double gamma_;
   std::mt19937 random_engine;
   float smoothed_critic_loss_ = 0, smoothed_actor_loss_ = 0;
+  int last_snapshot_iter_ = 0;
   std::string save_path_;
   const int state_size_;
   int tid_;

@@ -12,7 +12,7 @@ int main() {
   dqn::SolverParams actor_sp, critic_sp;
   actor_sp.base_lr = 1e-5f;
   const int num_features = 59;                      // NumStateFeatures(1), src/hfo_game.hpp:13-16
-  dqn::DQN dqn(actor_sp, critic_sp, "state/test_agent0", num_features, 0, flags);
+  dqn::DQN dqn(actor_sp, critic_sp, "/tmp/dqnhip_adaptor_smoke_run_agent0", num_features, 0, flags);
   std::mt19937 env(1);
   std::uniform_real_distribution<float> U(-1.f, 1.f);
   int total_steps = 0;
@@ -41,6 +41,22 @@ int main() {
   }
   if (dqn.memory_size() != total_steps) { std::fprintf(stderr, "memory_size %d != %d\n", dqn.memory_size(), total_steps); return 2; }
   if (dqn.actor_iter() < 10 || dqn.actor_iter() != dqn.critic_iter()) { std::fprintf(stderr, "iters %d %d\n", dqn.actor_iter(), dqn.critic_iter()); return 3; }
+  // snapshot + resume through the adaptor, the way dqn_main.cpp does at start-up (:213-220, 268-286)
+  const std::string prefix = "/tmp/dqnhip_adaptor_smoke_agent0";
+  dqn::RemoveFilesMatchingRegexp(prefix + "_.*");
+  dqn.Snapshot(prefix, false, true);
+  std::string a_snap, c_snap, m_snap;
+  dqn::FindLatestSnapshot(prefix, a_snap, c_snap, m_snap);
+  if (a_snap.empty() || c_snap.empty() || m_snap.empty()) { std::fprintf(stderr, "FindLatestSnapshot found nothing\n"); return 5; }
+  {
+    dqn::DQN resumed(actor_sp, critic_sp, prefix, num_features, 0, flags);
+    resumed.RestoreActorSolver(a_snap); resumed.RestoreCriticSolver(c_snap); resumed.LoadReplayMemory(m_snap);
+    if (resumed.actor_iter() != dqn.actor_iter() || resumed.memory_size() != dqn.memory_size()) return 6;
+    resumed.Update();
+  }
+  dqn::RemoveFilesMatchingRegexp(prefix + "_.*");
+  Action sampled = dqn.SampleAction(dqn.GetRandomActorOutput());
+  if (sampled.action == TACKLE) return 7;
   auto res = dqn.UpdateActorCritic();
   if (!std::isfinite(res.first) || !std::isfinite(res.second)) return 4;
   std::printf("adaptor smoke OK: %d transitions, %d updates, loss %g avg_q %g\n", dqn.memory_size(), dqn.actor_iter(), res.first, res.second);
