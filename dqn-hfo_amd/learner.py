@@ -301,6 +301,15 @@ class DQN:
     def SelectAction(self, input_states, epsilon):
         return self.SelectActions(np.asarray(input_states, np.float32).reshape(1, -1), epsilon)[0]
 
+    def SampleAction(self, actor_output):
+        """src/dqn.cpp:180-194: sample the discrete action with probabilities max(0, logit+1),
+        TACKLE removed; not used on the reference's default path."""
+        ao = np.asarray(actor_output, dtype=np.float32)
+        p = np.array([max(0.0, ao[DASH] + 1.0), max(0.0, ao[TURN] + 1.0), 0.0, max(0.0, ao[KICK] + 1.0)])
+        act = int(self.random_engine.choice(4, p=p / p.sum()))
+        o1, o2 = GetParamOffset(act, 0), GetParamOffset(act, 1)
+        return Action(act, float(ao[kActionSize + o1]), 0.0 if o2 < 0 else float(ao[kActionSize + o2]))
+
     def CriticForward(self, states_batch, action_batch, net=CRITIC):
         s = _f32(states_batch).reshape(-1, self.state_size_)
         a = _f32(action_batch).reshape(-1, 10)
