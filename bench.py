@@ -145,6 +145,7 @@ def cpu_baseline(budget_s=12.0):
 
 
 def main():
+    global B
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -152,12 +153,14 @@ def main():
     ap.add_argument("--replay", type=int, default=REPLAY)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--minibatch", type=int, default=B, help="rows per GPU (BASELINE metric: 256)")
     ap.add_argument("--no-env", action="store_true", help="skip the env-steps/sec leg")
     ap.add_argument("--frames-per-trial", type=int, default=500)
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel path even with one rank (testing)")
     ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],
                     help="N>1: dp = gradient all-reduce (weak scaling), replicas = independent learners")
     args = ap.parse_args()
+    B = args.minibatch
 
     import torch
     pkg = load_package()
