@@ -69,6 +69,8 @@ SIGNATURES = {
     "dqnhip_get_params": (C.c_int, [H, C.c_int32, C.c_int32, fp, C.c_size_t]),
     "dqnhip_set_params": (C.c_int, [H, C.c_int32, C.c_int32, fp, C.c_size_t]),
     "dqnhip_clone_to_target": (C.c_int, [H, C.c_int32]),
+    "dqnhip_share_parameters": (C.c_int, [H, H, C.c_int32, C.c_int32]),
+    "dqnhip_share_replay_memory": (C.c_int, [H, H]),
     "dqnhip_get_iters": (C.c_int, [H, ip, ip]),
     "dqnhip_set_iters": (C.c_int, [H, C.c_int32, C.c_int32]),
     "dqnhip_debug_read": (C.c_int, [H, C.c_char_p, fp, C.c_size_t]),

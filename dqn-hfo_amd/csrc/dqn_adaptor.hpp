@@ -219,6 +219,13 @@ class DQN {
   void LoadReplayMemory(const std::string& f) { DQN_CK(dqnhip_load_replay_memory(h_, f.c_str())); }
   void SnapshotReplayMemory(const std::string& f) { DQN_CK(dqnhip_snapshot_replay_memory(h_, f.c_str())); }
 
+  // Share the parameters of the first layers / the replay memory with a teammate
+  // (src/dqn.hpp:121-124, src/dqn.cpp:1047-1083); this learner stays the owner
+  void ShareParameters(DQN& other, int num_actor_layers_to_share, int num_critic_layers_to_share) {
+    DQN_CK(dqnhip_share_parameters(h_, other.h_, num_actor_layers_to_share, num_critic_layers_to_share));
+  }
+  void ShareReplayMemory(DQN& other) { DQN_CK(dqnhip_share_replay_memory(h_, other.h_)); }
+
   // Snapshot the model/solver/replay memory (src/dqn.cpp:582-620)
   void Snapshot() { Snapshot(save_path_, flags_.remove_old_snapshots, flags_.snapshot_memory); }
   void Snapshot(const std::string& snapshot_prefix, bool remove_old = false, bool snapshot_memory = true) {

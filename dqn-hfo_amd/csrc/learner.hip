@@ -16,6 +16,7 @@
 #include <random>
 #include <string>
 #include <vector>
+#include <mutex>
 
 #include "../../include/dqnhip.h"
 #include "../../include/dqnhip_env.h"
@@ -112,6 +113,15 @@ struct dqnhip_learner {
   int* done_counter = nullptr;
   long long h_head = 0, h_size = 0;     // host mirror of (head,size)
   bool ring_stale = false;              // the device changed (head,size) on its own (env front-end)
+  // sharing (DQN::ShareParameters / ShareReplayMemory, src/dqn.cpp:1036-1083): a sharer keeps
+  // its own allocations and reads the owner's through these
+  dqnhip_learner* ring_owner = nullptr; // whose ring / (head,size) this learner uses (nullptr: own)
+  dqnhip_learner* w_owner = nullptr;    // owner of the shared first layers
+  size_t shared_fl[2] = {0, 0};         // arena floats [0, shared_fl) of actor / critic (+targets) live in w_owner
+  int sharers = 0;                      // learners that reference this one
+  bool ring_shared = false;             // more than one learner uses this ring: order users across streams
+  hipEvent_t ring_ev = nullptr; hipStream_t ring_last = nullptr; bool ring_ev_valid = false;
+  std::mutex ring_mu;
   int h_actor_iter = 0, h_critic_iter = 0;
   // minibatch panels / activations: pass 0 AT, 1 A, 2 CT, 3 C1, 4 C2
   float* Xa_s = nullptr; float* Xa_n = nullptr; float* Xc_tr = nullptr; float* Xc_pl = nullptr; float* Xc_nx = nullptr;
@@ -142,6 +152,29 @@ struct dqnhip_learner {
 namespace {
 
 using H = dqnhip_learner;
+
+// ring owner / weight views under sharing
+inline H* RO(H* h) { return h->ring_owner ? h->ring_owner : h; }
+inline const H* RO(const H* h) { return h->ring_owner ? h->ring_owner : h; }
+inline float* wat(const H* h, int net, size_t off) {
+  return ((off < h->shared_fl[net & 1]) ? h->w_owner->w[net] : h->w[net]) + off;
+}
+
+// Orders the users of a SHARED ring across their streams in host-call order: each user waits
+// for the previous user's completion event.  No-op (no lock, no event) for a private ring.
+struct RingUse {
+  H* o; hipStream_t st; bool on;
+  RingUse(H* h) : o(RO(h)), st(h->stream), on(RO(h)->ring_shared) {
+    if (!on) return;
+    o->ring_mu.lock();
+    if (o->ring_ev_valid && o->ring_last != st) hipStreamWaitEvent(st, o->ring_ev, 0);
+  }
+  ~RingUse() {
+    if (!on) return;
+    hipEventRecord(o->ring_ev, st); o->ring_last = st; o->ring_ev_valid = true;
+    o->ring_mu.unlock();
+  }
+};
 
 const char* kFamily[] = {"gemm_fwd_lds_4x2", "gemm_dgrad", "gemm_wgrad", "adam", "gemm_bwd_pair", "gemm_fwd_lds_2x2", "gemm_fwd_direct"};
 constexpr int kNumFamily = 7;
@@ -238,7 +271,7 @@ int stream_wait(H* h, hipStream_t waiter, hipStream_t signaler) {
 
 // ---- forward / backward building blocks ----------------------------------------
 
-struct FwdPass { const float* w; const NetLayout* l; float** act; };
+struct FwdPass { int net; const NetLayout* l; float** act; };
 
 // One tower layer forward for up to kMaxGroup passes of identical shape.
 int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, int i) {
@@ -246,11 +279,11 @@ int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, 
   GemmBatch b{}; b.n = n;
   for (int j = 0; j < n; ++j) {
     GemmProblem& p = b.prob[j];
-    p.P = passes[j].w + l.w_off[i]; p.ldp = l.kp[i];
+    p.P = wat(h, passes[j].net, l.w_off[i]); p.ldp = l.kp[i];
     p.Q = passes[j].act[i]; p.ldq = l.kp[i];
     p.C = passes[j].act[i + 1]; p.ldc = l.kp[i + 1];
     p.Pdim = l.dims[i + 1]; p.Qdim = rows; p.Kred = l.kp[i];
-    p.bias = passes[j].w + l.b_off[i]; p.relu = 1;
+    p.bias = wat(h, passes[j].net, l.b_off[i]); p.relu = 1;
   }
   // K >= 512 and K % 256 == 0: full-line loads + wave-private LDS transpose; else (first
   // layer, narrow towers) the plain direct kernel.  One problem: 32x32 tiles (256 workgroups
@@ -271,7 +304,7 @@ int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows) 
 // stream when there is one, else shares a mixed-mode launch with the dgrad.
 // want_w: produce dW/db (+sumsq partials) into garena; input_grad: also dZ[0].
 // On return the aux stream may still be running wgrads: the caller joins before using them.
-int tower_backward(H* h, hipStream_t st, const NetLayout& l, const float* w, float* garena, float* partial,
+int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* garena, float* partial,
                    float** act, float** dZ, int rows, bool want_w, bool input_grad) {
   hipStream_t ax = aux_of(h);
   const bool split = want_w && ax != st;
@@ -281,7 +314,7 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, const float* w, flo
     if (need_dx) {                         // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
       GemmProblem& p = bd.prob[bd.n++];
       p.mode = GEMM_DGRAD;
-      p.P = w + l.w_off[i]; p.ldp = l.kp[i];
+      p.P = wat(h, net, l.w_off[i]); p.ldp = l.kp[i];
       p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
       p.C = dZ[i]; p.ldc = l.kp[i];
       p.Pdim = l.kp[i]; p.Qdim = rows; p.Kred = l.dims[i + 1];
@@ -339,23 +372,16 @@ int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
   return 0;
 }
 
-AdamArgs adam_args(H* h, int net, const float* partial, int n_partial, size_t begin, size_t end) {
-  AdamArgs a{};
-  a.w = h->w[net] + begin; a.g = h->g[net] + begin; a.m = h->m[net] + begin; a.v = h->v[net] + begin;
-  a.wt = h->w[net + 2] + begin;
-  a.n4 = (end - begin) / 4; a.partial = partial; a.n_partial = n_partial;
-  a.lr = net == DQNHIP_ACTOR ? h->cfg.actor_lr : h->cfg.critic_lr;
-  a.beta1 = h->cfg.momentum; a.beta2 = h->cfg.momentum2; a.eps = h->cfg.delta;
-  a.clip = h->cfg.clip_gradients; a.tau = (float)h->cfg.tau;
-  a.soft_update_freq = h->cfg.soft_update_freq; a.which = net; a.st = h->st;
-  return a;
-}
-
 // clip + Adam + Net::Update + soft target update over arena floats [begin, end)
 int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end) {
   AdamArgs a{};
   a.w = h->w[net] + begin; a.g = h->g[net] + begin; a.m = h->m[net] + begin; a.v = h->v[net] + begin;
   a.wt = h->w[net + 2] + begin;
+  const size_t sh = h->shared_fl[net];                 // shared prefix of this net's arena (floats)
+  if (sh > begin) {
+    a.w_sh = h->w_owner->w[net] + begin; a.wt_sh = h->w_owner->w[net + 2] + begin;
+    a.n4_sh = (std::min(sh, end) - begin) / 4;
+  }
   a.n4 = (end - begin) / 4; a.partial = partial; a.n_partial = n_partial;
   a.lr = net == DQNHIP_ACTOR ? h->cfg.actor_lr : h->cfg.critic_lr;
   a.beta1 = h->cfg.momentum; a.beta2 = h->cfg.momentum2; a.eps = h->cfg.delta;
@@ -391,16 +417,17 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // 1-2: sample + gather (src/dqn.cpp:846-887)
     GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
                  h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
-    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, h->ring, h->st, idx_dev,
+    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
+                       (const DevState*)h->st, idx_dev,
                        (uint64_t)h->cfg.seed, go, B);
     HIPCHK(hipGetLastError());
-    FwdPass pAT{h->w[DQNHIP_ACTOR_TARGET], &la, h->act[0]}, pA{h->w[DQNHIP_ACTOR], &la, h->act[1]};
-    FwdPass pCT{h->w[DQNHIP_CRITIC_TARGET], &lc, h->act[2]}, pC1{h->w[DQNHIP_CRITIC], &lc, h->act[3]};
+    FwdPass pAT{DQNHIP_ACTOR_TARGET, &la, h->act[0]}, pA{DQNHIP_ACTOR, &la, h->act[1]};
+    FwdPass pCT{DQNHIP_CRITIC_TARGET, &lc, h->act[2]}, pC1{DQNHIP_CRITIC, &lc, h->act[3]};
     HeadArgs hAT{}; hAT.X = h->act[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
-    hAT.W = h->w[DQNHIP_ACTOR_TARGET] + la.hw_off; hAT.b = h->w[DQNHIP_ACTOR_TARGET] + la.hb_off;
+    hAT.W = wat(h, DQNHIP_ACTOR_TARGET, la.hw_off); hAT.b = wat(h, DQNHIP_ACTOR_TARGET, la.hb_off);
     hAT.out16 = h->aout_t16; hAT.xc = h->Xc_nx; hAT.ldxc = lc.kp[0]; hAT.xc_col = h->S;
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
-    hA.W = h->w[DQNHIP_ACTOR] + la.hw_off; hA.b = h->w[DQNHIP_ACTOR] + la.hb_off;
+    hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
     hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
     if (ax != st) {
       // branch 1 (st):  actor_target(s') -> critic_target(s', mu'(s'))   [src/dqn.cpp:889-891]
@@ -422,8 +449,8 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     }
     {
       HeadTrainArgs t{};
-      t.Xt = h->act[2][L]; t.Wt = h->w[DQNHIP_CRITIC_TARGET] + lc.hw_off; t.bt = h->w[DQNHIP_CRITIC_TARGET] + lc.hb_off;
-      t.X = h->act[3][L]; t.W = h->w[DQNHIP_CRITIC] + lc.hw_off; t.b = h->w[DQNHIP_CRITIC] + lc.hb_off;
+      t.Xt = h->act[2][L]; t.Wt = wat(h, DQNHIP_CRITIC_TARGET, lc.hw_off); t.bt = wat(h, DQNHIP_CRITIC_TARGET, lc.hb_off);
+      t.X = h->act[3][L]; t.W = wat(h, DQNHIP_CRITIC, lc.hw_off); t.b = wat(h, DQNHIP_CRITIC, lc.hb_off);
       t.H = Hc; t.rows = B; t.reward = h->mb_reward; t.mc = h->mb_mc; t.term = h->mb_term;
       t.q_target = h->q_t; t.q = h->q1; t.y = h->y; t.dq = h->dq; t.loss_partial = h->loss_partial;
       t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch;
@@ -433,12 +460,12 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // critic backward (rest of Step(1)): head (dgrad + ReLU' + wgrad fused), then tower; wgrad
     // writes (beta=0) so ClearParamDiffs/ZeroGradParameters (src/dqn.cpp:63-78, 908-909) vanish
     {
-      HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = h->w[DQNHIP_CRITIC] + lc.hw_off; a.X4 = h->act[3][L];
+      HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[3][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L]; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
       RC(head_backward<1>(h, st, a));
     }
-    RC(tower_backward(h, st, lc, h->w[DQNHIP_CRITIC], h->g[1], h->part[1], h->act[3], h->dZc, B, true, false));
+    RC(tower_backward(h, st, lc, DQNHIP_CRITIC, h->g[1], h->part[1], h->act[3], h->dZc, B, true, false));
     RC(stream_wait(h, st, ax));            // all critic wgrads done
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)h->loss_partial,
@@ -453,7 +480,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // the Adam of layer i (every launch re-derives the same global clip scale from the partials).
     const float* part = h->part[1]; int n_part = lc.n_part;
     if (dp) { RC(sumsq_launch(h, 1)); part = h->part_dp; n_part = h->n_part_dp; }
-    FwdPass pC2{h->w[DQNHIP_CRITIC], &lc, h->act[4]};
+    FwdPass pC2{DQNHIP_CRITIC, &lc, h->act[4]};
     h->act[4][0] = h->Xc_pl;
     if (ax != st) {
       RC(stream_wait(h, ax, st));
@@ -470,26 +497,26 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     }
     {
       HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
-      a.W = h->w[DQNHIP_CRITIC] + lc.hw_off; a.b = h->w[DQNHIP_CRITIC] + lc.hb_off; a.q = h->q2;
+      a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.b = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q = h->q2;
       a.qsum_partial = h->q_partial;
       RC((head_forward<1, HEAD_Q_POLICY>(h, st, a)));
     }
     // q diff = -1 per row, BackwardFrom(q_values_layer) — input gradient only; the
     // reference's discarded critic dW is never computed
     {
-      HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = h->w[DQNHIP_CRITIC] + lc.hw_off; a.X4 = h->act[4][L];
+      HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
       RC(head_backward<1>(h, st, a));
     }
-    RC(tower_backward(h, st, lc, h->w[DQNHIP_CRITIC], nullptr, nullptr, h->act[4], h->dZc, B, false, true));
+    RC(tower_backward(h, st, lc, DQNHIP_CRITIC, nullptr, nullptr, h->act[4], h->dZc, B, false, true));
     // inverting gradients (src/dqn.cpp:924-957) + actor heads backward (src/dqn.cpp:960-963)
     {
       HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;
-      a.W = h->w[DQNHIP_ACTOR] + la.hw_off; a.X4 = h->act[1][L]; a.H = Hh; a.rows = B; a.dZ = h->dZa[L];
+      a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.X4 = h->act[1][L]; a.H = Hh; a.rows = B; a.dZ = h->dZa[L];
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
       RC(head_backward<kNO>(h, st, a));
     }
-    RC(tower_backward(h, st, la, h->w[DQNHIP_ACTOR], h->g[0], h->part[0], h->act[1], h->dZa, B, true, false));
+    RC(tower_backward(h, st, la, DQNHIP_ACTOR, h->g[0], h->part[0], h->act[1], h->dZa, B, true, false));
     RC(stream_wait(h, st, ax));            // all actor wgrads done
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)nullptr, 0,
@@ -514,22 +541,22 @@ int run_phase(H* h, int phase, const int* idx_dev) {
 
 // re-read (head,size) after the env front-end appended episodes on the device
 int refresh_ring(H* h) {
-  if (!h->ring_stale) return 0;
+  if (!RO(h)->ring_stale) return 0;
   int hs[2];
-  HIPCHK(hipMemcpyAsync(hs, h->st, sizeof hs, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(hs, RO(h)->st, sizeof hs, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  h->h_head = hs[0]; h->h_size = hs[1]; h->ring_stale = false;
+  RO(h)->h_head = hs[0]; RO(h)->h_size = hs[1]; RO(h)->ring_stale = false;
   return 0;
 }
 
 int stage_indices(H* h, const int32_t* idx_host, const int** idx_dev) {
   *idx_dev = nullptr;
-  if (idx_host || h->h_size < 1) RC(refresh_ring(h));
-  if (h->h_size < 1) return fail("replay memory is empty");
+  if (idx_host || RO(h)->h_size < 1) RC(refresh_ring(h));
+  if (RO(h)->h_size < 1) return fail("replay memory is empty");
   if (idx_host) {
     for (int i = 0; i < h->B; ++i)
-      if (idx_host[i] < 0 || idx_host[i] >= h->h_size)
-        return fail("sampled index %d = %d out of range [0,%lld)", i, idx_host[i], h->h_size);
+      if (idx_host[i] < 0 || idx_host[i] >= RO(h)->h_size)
+        return fail("sampled index %d = %d out of range [0,%lld)", i, idx_host[i], RO(h)->h_size);
     // the pinned staging buffer may still be in flight from the previous update
     HIPCHK(hipStreamSynchronize(h->stream));
     memcpy(h->idx_pinned, idx_host, h->B * sizeof(int));
@@ -707,6 +734,10 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
 
 int dqnhip_destroy(dqnhip_handle h) {
   if (!h) return 0;
+  if (h->sharers > 0) return fail("dqnhip_destroy: %d learner(s) still share this learner's layers / replay memory; destroy them first", h->sharers);
+  if (h->w_owner) h->w_owner->sharers -= 1;
+  if (h->ring_owner) h->ring_owner->sharers -= 1;
+  if (h->ring_ev) hipEventDestroy(h->ring_ev);
   hipSetDevice(h->cfg.device);
   hipStreamSynchronize(h->stream);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -763,13 +794,14 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   if (h->cfg.dp_world > 1) return fail("dqnhip_update_async: dp_world > 1 requires dqnhip_update_phase + all-reduce");
+  RingUse ring_use(h);
   if (h->cfg.use_graph && !h->timing && !h->graph_failed) {
-    if (idx_host || h->h_size < 1) RC(refresh_ring(h));
-    if (h->h_size < 1) return fail("replay memory is empty");
+    if (idx_host || RO(h)->h_size < 1) RC(refresh_ring(h));
+    if (RO(h)->h_size < 1) return fail("replay memory is empty");
     const int which = idx_host ? 1 : 0;
     if (idx_host) {
       for (int i = 0; i < h->B; ++i)
-        if (idx_host[i] < 0 || idx_host[i] >= h->h_size) return fail("sampled index out of range");
+        if (idx_host[i] < 0 || idx_host[i] >= RO(h)->h_size) return fail("sampled index out of range");
       HIPCHK(hipStreamSynchronize(h->stream));
       memcpy(h->idx_pinned, idx_host, h->B * sizeof(int));
     }
@@ -792,7 +824,9 @@ int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host)
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   const int* idx_dev = nullptr;
-  if (phase == 0) RC(stage_indices(h, idx_host, &idx_dev));
+  if (phase != 0) return run_phase(h, phase, idx_dev);
+  RingUse ring_use(h);
+  RC(stage_indices(h, idx_host, &idx_dev));
   return run_phase(h, phase, idx_dev);
 }
 
@@ -855,10 +889,10 @@ static int actor_forward_dev(H* h, int net, const float* states_dev, int n, floa
   hipLaunchKernelGGL(k_pack_rows, dim3((rows * l.kp[0] + 255) / 256), dim3(256), 0, h->stream, states_dev, n,
                      h->S, acts[0], rows, l.kp[0]);
   HIPCHK(hipGetLastError());
-  FwdPass fp[1] = {{h->w[net], &l, acts}};
+  FwdPass fp[1] = {{net, &l, acts}};
   RC(tower_forward(h, h->stream, fp, 1, rows));
   HeadArgs a{}; a.X = acts[l.L]; a.ldx = l.dims[l.L]; a.H = l.dims[l.L]; a.rows = rows;
-  a.W = h->w[net] + l.hw_off; a.b = h->w[net] + l.hb_off; a.out16 = out16;
+  a.W = wat(h, net, l.hw_off); a.b = wat(h, net, l.hb_off); a.out16 = out16;
   RC((head_forward<kNO, HEAD_ACTOR>(h, h->stream, a)));
   hipLaunchKernelGGL(k_unpack_out, dim3((n * kNO + 255) / 256), dim3(256), 0, h->stream, (const float*)out16, n, out_dev);
   HIPCHK(hipGetLastError());
@@ -912,10 +946,10 @@ int dqnhip_critic_forward(dqnhip_handle h, int32_t net, const float* states_host
   hipLaunchKernelGGL(k_pack_critic, dim3((rows * l.kp[0] + 255) / 256), dim3(256), 0, h->stream, (const float*)sdev,
                      (const float*)adev, n, h->S, acts[0], rows, l.kp[0]);
   HIPCHK(hipGetLastError());
-  FwdPass fp[1] = {{h->w[net], &l, acts}};
+  FwdPass fp[1] = {{net, &l, acts}};
   RC(tower_forward(h, h->stream, fp, 1, rows));
   HeadArgs a{}; a.X = acts[l.L]; a.ldx = l.dims[l.L]; a.H = l.dims[l.L]; a.rows = rows;
-  a.W = h->w[net] + l.hw_off; a.b = h->w[net] + l.hb_off; a.q = qdev;
+  a.W = wat(h, net, l.hw_off); a.b = wat(h, net, l.hb_off); a.q = qdev;
   RC((head_forward<1, HEAD_Q>(h, h->stream, a)));
   HIPCHK(hipMemcpyAsync(q_host, qdev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -927,22 +961,23 @@ int dqnhip_critic_forward(dqnhip_handle h, int32_t net, const float* states_host
 static int add_dev(H* h, const float* s, const float* a, const float* r, const float* mc, const float* nx,
                    const uint8_t* term, int n, int single) {
   if (n < 1) return fail("n must be >= 1");
+  RingUse ring_use(h);
   RC(refresh_ring(h));
-  const long long cap = h->ring.cap;
+  const long long cap = RO(h)->ring.cap;
   if (single == 0 && n >= cap) return fail("AddTransitions: batch of %d does not fit capacity %lld (the reference would pop an empty deque)", n, cap);
-  if (single == 2 && h->h_size + n > cap) return fail("LoadReplayMemory: %lld transitions exceed the capacity %lld", h->h_size + n, cap);
-  hipLaunchKernelGGL(k_add_transitions, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->ring, h->st, s, a, r, mc, nx,
-                     term, n, single, h->done_counter);
+  if (single == 2 && RO(h)->h_size + n > cap) return fail("LoadReplayMemory: %lld transitions exceed the capacity %lld", RO(h)->h_size + n, cap);
+  hipLaunchKernelGGL(k_add_transitions, dim3((n + 3) / 4), dim3(256), 0, h->stream, RO(h)->ring, RO(h)->st, s, a, r, mc, nx,
+                     term, n, single, RO(h)->done_counter);
   HIPCHK(hipGetLastError());
   // host mirror of the same deque arithmetic (src/dqn.cpp:768-781)
   if (single == 2) { }
-  else if (single) { if (h->h_size == cap) { h->h_head = (h->h_head + 1) % cap; h->h_size -= 1; } }
+  else if (single) { if (RO(h)->h_size == cap) { RO(h)->h_head = (RO(h)->h_head + 1) % cap; RO(h)->h_size -= 1; } }
   else {
-    long long pops = h->h_size + n - cap + 1;
-    pops = std::max(0LL, std::min(pops, h->h_size));
-    h->h_head = (h->h_head + pops) % cap; h->h_size -= pops;
+    long long pops = RO(h)->h_size + n - cap + 1;
+    pops = std::max(0LL, std::min(pops, RO(h)->h_size));
+    RO(h)->h_head = (RO(h)->h_head + pops) % cap; RO(h)->h_size -= pops;
   }
-  h->h_size += n;
+  RO(h)->h_size += n;
   return 0;
 }
 
@@ -998,16 +1033,18 @@ int dqnhip_label_transitions(double gamma, const float* rewards, int32_t n, floa
 int dqnhip_memory_size(dqnhip_handle h, int32_t* size) {
   if (!h || !size) return fail("null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
+  RingUse ring_use(h);
   RC(refresh_ring(h));
-  *size = (int32_t)h->h_size;
+  *size = (int32_t)RO(h)->h_size;
   return 0;
 }
 
 int dqnhip_clear_memory(dqnhip_handle h) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipMemsetAsync(h->st, 0, 2 * sizeof(int), h->stream));   // ring_head, ring_size
-  h->h_head = 0; h->h_size = 0; h->ring_stale = false;
+  RingUse ring_use(h);
+  HIPCHK(hipMemsetAsync(RO(h)->st, 0, 2 * sizeof(int), h->stream));   // ring_head, ring_size
+  RO(h)->h_head = 0; RO(h)->h_size = 0; RO(h)->ring_stale = false;
   return 0;
 }
 
@@ -1015,8 +1052,9 @@ int dqnhip_read_memory(dqnhip_handle h, int32_t first, int32_t n, float* states,
                        float* on_policy_targets, float* next_states, uint8_t* terminal) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
+  RingUse ring_use(h);
   RC(refresh_ring(h));
-  if (n < 1 || first < 0 || (long long)first + n > h->h_size) return fail("read_memory range [%d,%d) outside [0,%lld)", first, first + n, h->h_size);
+  if (n < 1 || first < 0 || (long long)first + n > RO(h)->h_size) return fail("read_memory range [%d,%d) outside [0,%lld)", first, first + n, RO(h)->h_size);
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t sb = round_up_z((size_t)n * h->S * 4, 256), ab = round_up_z((size_t)n * kNO * 4, 256), vb = round_up_z((size_t)n * 4, 256);
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1025,7 +1063,7 @@ int dqnhip_read_memory(dqnhip_handle h, int32_t first, int32_t n, float* states,
   float* ds = (float*)base; float* dn = (float*)(base + sb); float* da = (float*)(base + 2 * sb);
   float* dr = (float*)(base + 2 * sb + ab); float* dm = (float*)(base + 2 * sb + ab + vb);
   uint8_t* dt = (uint8_t*)(base + 2 * sb + ab + 2 * vb);
-  hipLaunchKernelGGL(k_read_memory, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->ring, (const DevState*)h->st, first, n,
+  hipLaunchKernelGGL(k_read_memory, dim3((n + 3) / 4), dim3(256), 0, h->stream, RO(h)->ring, (const DevState*)RO(h)->st, first, n,
                      ds, da, dr, dm, dn, dt);
   HIPCHK(hipGetLastError());
   if (states) HIPCHK(hipMemcpyAsync(states, ds, (size_t)n * h->S * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1046,7 +1084,7 @@ int dqnhip_snapshot_replay_memory(dqnhip_handle h, const char* filename) {
   RC(refresh_ring(h));
   gzFile f = gzopen(filename, "wb");
   if (!f) return fail("cannot open %s for writing", filename);
-  const int32_t n = (int32_t)h->h_size;
+  const int32_t n = (int32_t)RO(h)->h_size;
   const size_t S = h->S;
   bool ok = gzwrite(f, &n, sizeof n) == (int)sizeof n;
   const int chunk = 65536;
@@ -1078,7 +1116,7 @@ int dqnhip_load_replay_memory(dqnhip_handle h, const char* filename) {
   if (!f) return fail("Invalid file: %s", filename);              // CHECK(is_regular_file), src/dqn.cpp:1181
   int32_t n = 0;
   if (gzread(f, &n, sizeof n) != (int)sizeof n || n < 0) { gzclose(f); return fail("%s: bad header", filename); }
-  if (n > h->ring.cap) { gzclose(f); return fail("%s holds %d transitions, capacity is %d", filename, n, h->ring.cap); }
+  if (n > RO(h)->ring.cap) { gzclose(f); return fail("%s holds %d transitions, capacity is %d", filename, n, RO(h)->ring.cap); }
   RC(dqnhip_clear_memory(h));
   const size_t S = h->S, rb = S * 4 + kNO * 4 + 4 + 4 + 1;
   const int chunk = 65536;
@@ -1142,7 +1180,9 @@ int dqnhip_get_params(dqnhip_handle h, int32_t net, int32_t kind, float* host, s
   if (count != l.dense) return fail("count %zu != parameter count %zu", count, l.dense);
   HIPCHK(hipSetDevice(h->cfg.device));
   std::vector<float> arena(l.arena);
-  HIPCHK(hipMemcpyAsync(arena.data(), p, l.arena * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  const size_t sh = kind == DQNHIP_KIND_W ? h->shared_fl[net & 1] : 0;   // shared first layers: the owner's storage
+  if (sh) HIPCHK(hipMemcpyAsync(arena.data(), h->w_owner->w[net], sh * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (sh < l.arena) HIPCHK(hipMemcpyAsync(arena.data() + sh, p + sh, (l.arena - sh) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   arena_to_dense(l, arena, host);
   return 0;
@@ -1157,7 +1197,9 @@ int dqnhip_set_params(dqnhip_handle h, int32_t net, int32_t kind, const float* h
   HIPCHK(hipSetDevice(h->cfg.device));
   std::vector<float> arena;
   dense_to_arena(l, host, arena);
-  HIPCHK(hipMemcpyAsync(p, arena.data(), l.arena * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  const size_t sh = kind == DQNHIP_KIND_W ? h->shared_fl[net & 1] : 0;
+  if (sh) HIPCHK(hipMemcpyAsync(h->w_owner->w[net], arena.data(), sh * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if (sh < l.arena) HIPCHK(hipMemcpyAsync(p + sh, arena.data() + sh, (l.arena - sh) * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1166,7 +1208,72 @@ int dqnhip_clone_to_target(dqnhip_handle h, int32_t net) {
   if (!h) return fail("null handle");
   if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return fail("net must be ACTOR or CRITIC");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipMemcpyAsync(h->w[net + 2], h->w[net], layout_of(h, net).arena * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  const size_t sh = h->shared_fl[net], n = layout_of(h, net).arena;
+  if (sh) HIPCHK(hipMemcpyAsync(h->w_owner->w[net + 2], h->w_owner->w[net], sh * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  if (sh < n) HIPCHK(hipMemcpyAsync(h->w[net + 2] + sh, h->w[net] + sh, (n - sh) * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  return 0;
+}
+
+// ---- multi-agent sharing (src/dqn.cpp:1036-1083, src/dqn_main.cpp:305-323) ------------------
+
+static void drop_graphs(H* h) {
+  for (int i = 0; i < 2; ++i) if (h->graph_exec[i]) { hipGraphExecDestroy(h->graph_exec[i]); h->graph_exec[i] = nullptr; }
+}
+
+static bool same_nets(const H* a, const H* b) {
+  if (a->S != b->S || a->L != b->L) return false;
+  for (int i = 0; i < a->L; ++i) if (a->cfg.hidden[i] != b->cfg.hidden[i]) return false;
+  return true;
+}
+
+// floats of the arena covered by the first `n` layers-with-blobs of a net (Caffe layer order:
+// ip1..ipL, then action_layer, actionpara_layer / q_values_layer)
+static int shared_prefix(const NetLayout& l, int n, size_t* fl) {
+  const int heads = l.NH == kNO ? 2 : 1;
+  if (n < 0 || n > l.L + heads) return fail("cannot share %d layers of a net with %d", n, l.L + heads);   // CHECK_LT, src/dqn.cpp:1060
+  if (n < l.L) *fl = l.w_off[n];
+  else if (n == l.L) *fl = l.hw_off;
+  else if (n == l.L + heads) *fl = l.arena;
+  else return fail("sharing action_layer without actionpara_layer is not supported (the two heads are one [10][H] matrix here)");
+  return 0;
+}
+
+int dqnhip_share_parameters(dqnhip_handle owner, dqnhip_handle other, int32_t num_actor_layers, int32_t num_critic_layers) {
+  if (!owner || !other || owner == other) return fail("ShareParameters needs two distinct learners");
+  if (owner->cfg.device != other->cfg.device) return fail("ShareParameters: both learners must live on the same device");
+  if (!same_nets(owner, other)) return fail("ShareParameters: net shapes differ");
+  if (owner->w_owner) return fail("ShareParameters: the owner itself shares another learner's layers; share from the root");
+  if (other->w_owner && other->w_owner != owner) return fail("ShareParameters: already sharing with a different owner");
+  size_t fa = 0, fc = 0;
+  RC(shared_prefix(owner->la, num_actor_layers, &fa));
+  RC(shared_prefix(owner->lc, num_critic_layers, &fc));
+  HIPCHK(hipSetDevice(owner->cfg.device));
+  HIPCHK(hipStreamSynchronize(owner->stream));
+  HIPCHK(hipStreamSynchronize(other->stream));
+  if (!other->w_owner && (fa || fc)) owner->sharers += 1;
+  if (other->w_owner && !(fa || fc)) owner->sharers -= 1;
+  other->w_owner = (fa || fc) ? owner : nullptr;
+  other->shared_fl[0] = fa; other->shared_fl[1] = fc;
+  drop_graphs(other);                      // captured launches hold the old weight pointers
+  return 0;
+}
+
+int dqnhip_share_replay_memory(dqnhip_handle owner, dqnhip_handle other) {
+  if (!owner || !other || owner == other) return fail("ShareReplayMemory needs two distinct learners");
+  if (owner->cfg.device != other->cfg.device) return fail("ShareReplayMemory: both learners must live on the same device");
+  if (owner->S != other->S) return fail("ShareReplayMemory: state sizes differ");
+  H* root = RO(owner);
+  if (RO(other) == root) return 0;
+  if (other->sharers && other->ring_shared) return fail("ShareReplayMemory: other learners already use this learner's memory");
+  HIPCHK(hipSetDevice(owner->cfg.device));
+  HIPCHK(hipStreamSynchronize(owner->stream));
+  HIPCHK(hipStreamSynchronize(other->stream));
+  if (other->ring_owner) other->ring_owner->sharers -= 1;
+  if (!root->ring_ev) HIPCHK(hipEventCreateWithFlags(&root->ring_ev, hipEventDisableTiming));
+  root->ring_shared = true;
+  root->sharers += 1;
+  other->ring_owner = root;                // other's deque is dropped: shared_ptr assignment, src/dqn.cpp:1081
+  drop_graphs(other);
   return 0;
 }
 
@@ -1280,8 +1387,8 @@ int dqnhip_env_create(dqnhip_handle h, const dqnhip_env_config* cfg, dqnhip_env_
   if (cfg->workers < 1 || cfg->workers > (1 << 20)) return fail("workers out of range");
   if (cfg->max_steps < 1 || cfg->max_steps > 4096) return fail("max_steps out of range");
   if (h->S < 56) return fail("HFOGameState reads state indices up to 55: state_size must be >= 56 (src/hfo_game.cpp:130-152)");
-  if ((long long)cfg->workers * cfg->max_steps >= h->ring.cap)
-    return fail("replay capacity %d must exceed workers*max_steps = %lld", h->ring.cap, (long long)cfg->workers * cfg->max_steps);
+  if ((long long)cfg->workers * cfg->max_steps >= RO(h)->ring.cap)
+    return fail("replay capacity %d must exceed workers*max_steps = %lld", RO(h)->ring.cap, (long long)cfg->workers * cfg->max_steps);
   HIPCHK(hipSetDevice(h->cfg.device));
   dqnhip_env* e = new dqnhip_env();
   e->h = h; e->cfg = *cfg;
@@ -1322,22 +1429,23 @@ int dqnhip_env_step(dqnhip_env_handle e, float epsilon, int32_t n_steps) {
   const EnvDev& d = e->d;
   hipStream_t st = h->stream;
   const NetLayout& la = h->la;
+  RingUse ring_use(h);
   for (int s = 0; s < n_steps; ++s) {
     // SelectActionGreedily(*actor_net_, states) for all workers in one batched forward
-    FwdPass fp{h->w[DQNHIP_ACTOR], &la, e->acts};
+    FwdPass fp{DQNHIP_ACTOR, &la, e->acts};
     RC(tower_forward(h, st, &fp, 1, e->Npad));
     HeadArgs a{}; a.X = e->acts[la.L]; a.ldx = la.dims[la.L]; a.H = la.dims[la.L]; a.rows = e->Npad;
-    a.W = h->w[DQNHIP_ACTOR] + la.hw_off; a.b = h->w[DQNHIP_ACTOR] + la.hb_off; a.out16 = d.out16;
+    a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.b = wat(h, DQNHIP_ACTOR, la.hb_off); a.out16 = d.out16;
     RC((head_forward<kNO, HEAD_ACTOR>(h, st, a)));
     hipLaunchKernelGGL(k_env_step, dim3(d.N), dim3(64), d.SP * sizeof(float), st, d, epsilon);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), (d.T + d.SP) * sizeof(float), st, d, h->ring,
-                       (const DevState*)h->st, h->cfg.gamma);
+    hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), (d.T + d.SP) * sizeof(float), st, d, RO(h)->ring,
+                       (const DevState*)RO(h)->st, h->cfg.gamma);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_env_commit, dim3(1), dim3(64), 0, st, d, h->ring, h->st);
+    hipLaunchKernelGGL(k_env_commit, dim3(1), dim3(64), 0, st, d, RO(h)->ring, RO(h)->st);
     HIPCHK(hipGetLastError());
   }
-  h->ring_stale = true;
+  RO(h)->ring_stale = true;
   return 0;
 }
 
@@ -1355,6 +1463,7 @@ int dqnhip_env_stats(dqnhip_env_handle e, int64_t* env_steps, int64_t* episodes,
   long long s0 = 0, s1 = 0, s2 = 0; double s3 = 0;
   for (size_t i = 0; i < N; ++i) { s0 += a[i]; s1 += b[i]; s2 += c[i]; s3 += r[i]; }
   if (env_steps) *env_steps = s0; if (episodes) *episodes = s1; if (goals) *goals = s2; if (reward_sum) *reward_sum = s3;
+  RingUse ring_use(h);
   return refresh_ring(h);
 }
 

@@ -128,12 +128,14 @@ struct GatherOut {
   float* Xc_tr; float* Xc_pl; float* Xc_nx; int KcP;
   float* reward; float* mc; float* term; int* idx;
 };
-__global__ void k_gather(Ring ring, const DevState* st, const int* __restrict__ idx_in,
+// rs: the DevState that holds the ring's (head,size) — another learner's under
+// ShareReplayMemory; st: this learner's (sampling counter)
+__global__ void k_gather(Ring ring, const DevState* rs, const DevState* st, const int* __restrict__ idx_in,
                          uint64_t seed, GatherOut o, int B) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= B) return;
-  const int size = st->ring_size;
+  const int size = rs->ring_size;
   int li;
   if (idx_in != nullptr) li = idx_in[row];
   else {
@@ -143,7 +145,7 @@ __global__ void k_gather(Ring ring, const DevState* st, const int* __restrict__ 
     li = (int)(((uint64_t)u * (uint64_t)size) >> 32);
   }
   li = li < 0 ? 0 : (li >= size ? size - 1 : li);
-  const long long slot = ((long long)st->ring_head + li) % ring.cap;
+  const long long slot = ((long long)rs->ring_head + li) % ring.cap;
   const float* sp = ring.state + slot * ring.SP;
   const float* np = ring.next + slot * ring.SP;
   const float* ap = ring.act + slot * kAP;
@@ -435,6 +437,7 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, size
 // ~7 separate param-sized passes plus the separate soft-update pass.
 struct AdamArgs {
   float* w; float* g; float* m; float* v; float* wt;
+  float* w_sh; float* wt_sh; size_t n4_sh;   // float4 [0, n4_sh) of w / wt live in another learner's arena (ShareParameters)
   size_t n4;                      // arena length / 4
   const float* partial; int n_partial;
   float lr, beta1, beta2, eps, clip, tau;
@@ -475,8 +478,10 @@ __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int n
     f32x4 g = reinterpret_cast<f32x4*>(a.g)[i];
     f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
     f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
-    f32x4 w = reinterpret_cast<f32x4*>(a.w)[i];
-    f32x4 wt = reinterpret_cast<f32x4*>(a.wt)[i];
+    f32x4* wq = reinterpret_cast<f32x4*>(i < a.n4_sh ? a.w_sh : a.w) + i;
+    f32x4* tq = reinterpret_cast<f32x4*>(i < a.n4_sh ? a.wt_sh : a.wt) + i;
+    f32x4 w = *wq;
+    f32x4 wt = *tq;
     float* gp = reinterpret_cast<float*>(&g); float* mp = reinterpret_cast<float*>(&m);
     float* vp = reinterpret_cast<float*>(&v); float* wp = reinterpret_cast<float*>(&w);
     float* tp = reinterpret_cast<float*>(&wt);
@@ -492,8 +497,8 @@ __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int n
     }
     reinterpret_cast<f32x4*>(a.m)[i] = m;
     reinterpret_cast<f32x4*>(a.v)[i] = v;
-    reinterpret_cast<f32x4*>(a.w)[i] = w;
-    if (soft) reinterpret_cast<f32x4*>(a.wt)[i] = wt;
+    *wq = w;
+    if (soft) *tq = wt;
   }
 }
 __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {

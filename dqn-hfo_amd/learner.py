@@ -135,7 +135,7 @@ class DQN:
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
-            self.lib.dqnhip_destroy(self.h)
+            self._ck(self.lib.dqnhip_destroy(self.h))      # refuses while sharers exist
             self.h = None
 
     def __del__(self):
@@ -402,6 +402,17 @@ class DQN:
     def CloneNet(self, net):
         """src/dqn.cpp:1022-1035: hard copy online -> target."""
         self._ck(self.lib.dqnhip_clone_to_target(self.h, net))
+
+    def ShareParameters(self, other, num_actor_layers_to_share, num_critic_layers_to_share):
+        """src/dqn.cpp:1047-1078: `other`'s first layers (and its targets') use this learner's weights."""
+        self._ck(self.lib.dqnhip_share_parameters(self.h, other.h, int(num_actor_layers_to_share),
+                                                  int(num_critic_layers_to_share)))
+        other._share_keepalive = getattr(other, "_share_keepalive", []) + [self]
+
+    def ShareReplayMemory(self, other):
+        """src/dqn.cpp:1080-1082: `other` uses this learner's replay memory."""
+        self._ck(self.lib.dqnhip_share_replay_memory(self.h, other.h))
+        other._share_keepalive = getattr(other, "_share_keepalive", []) + [self]
 
     def debug_read(self, name):
         B = self.kMinibatchSize

@@ -237,6 +237,23 @@ int dqnhip_clone_to_target(dqnhip_handle h, int32_t net);
 int dqnhip_get_iters(dqnhip_handle h, int32_t* actor_iter, int32_t* critic_iter);
 int dqnhip_set_iters(dqnhip_handle h, int32_t actor_iter, int32_t critic_iter);
 
+/* ---- multi-agent sharing (src/dqn.cpp:1036-1083; src/dqn_main.cpp:305-323) ------------
+ * DQN::ShareParameters(other, n_actor, n_critic): the first n layers-with-blobs (Caffe layer
+ * order: ip1..ipL, then the head layers) of `other`'s actor / critic AND of its two target nets
+ * read and write `owner`'s storage from now on (Blob::ShareData — data only: gradients and
+ * Adam history stay per learner, exactly the reference's Hogwild arrangement; both learners'
+ * solvers and soft updates write the shared weights).  n may be 0..L (tower layers) or all
+ * layers; splitting the actor's two heads is refused.  Both learners must be on one device
+ * and of the same shape.  Calling again changes the layer counts; (0, 0) un-shares.
+ * `owner` must outlive `other` (dqnhip_destroy(owner) fails while sharers exist). */
+int dqnhip_share_parameters(dqnhip_handle owner, dqnhip_handle other, int32_t num_actor_layers,
+                            int32_t num_critic_layers);
+/* DQN::ShareReplayMemory(other) (src/dqn.cpp:1080-1082): `other` drops its own deque and uses
+ * `owner`'s ring (capacity included) for AddTransition(s), sampling, memory_size, snapshot
+ * and load.  Users of a shared ring on different streams are ordered in host-call order by
+ * events; a private ring pays nothing. */
+int dqnhip_share_replay_memory(dqnhip_handle owner, dqnhip_handle other);
+
 /* The configuration the learner was created with (for clients that need the shapes). */
 int dqnhip_get_config(dqnhip_handle h, dqnhip_config* out);
 
