@@ -65,7 +65,22 @@ def family_flops(B, S, hidden):
     }
 
 
-KERNEL_NAMES = {"gemm_fwd_lds_4x2": "gemm_fwd_lds<4,2,false>", "gemm_fwd_lds_2x2": "gemm_fwd_lds<2,2,false>",
+def family_flops16(B, S, hidden):
+    """Same algorithmic FLOPs, grouped by the fp16 learner's timing families (hgemm_nt launches)."""
+    wa = tower_weights(S, hidden)
+    wc = tower_weights(S + 10, hidden)
+    h1 = hidden[0]
+    return {
+        "hgemm_fwd": 2 * B * (2 * sum(wa) + 3 * sum(wc)),
+        "hgemm_dgrad": 2 * B * (sum(wc[1:]) + sum(wa[1:]) + sum(wc[1:]) + 10 * h1),
+        "hgemm_wgrad": 2 * B * (sum(wc) + sum(wa)),
+    }
+
+
+MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: fp16/bf16 dense MFMA peak
+
+KERNEL_NAMES = {"hgemm_fwd": "hgemm_nt<2,2>/<1,1> (forward epilogue)", "hgemm_dgrad": "hgemm_nt (dgrad epilogue)",
+                "hgemm_wgrad": "hgemm_nt (wgrad epilogue)","gemm_fwd_lds_4x2": "gemm_fwd_lds<4,2,false>", "gemm_fwd_lds_2x2": "gemm_fwd_lds<2,2,false>",
                 "gemm_fwd_direct": "gemm_fwd_direct<*>", "gemm_bwd_pair": "gemm_bwd_pair_direct<1>",
                 "gemm_dgrad": "gemm_dgrad_direct<1,1>", "gemm_wgrad": "gemm_wgrad_direct<1,1>"}
 
@@ -154,6 +169,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--minibatch", type=int, default=B, help="rows per GPU (BASELINE metric: 256)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
+                    help="fp16: tower GEMMs on fp16 MFMA with fp32 accumulate (BASELINE config #5); not the headline metric")
     ap.add_argument("--no-env", action="store_true", help="skip the env-steps/sec leg")
     ap.add_argument("--frames-per-trial", type=int, default=500)
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel path even with one rank (testing)")
@@ -183,11 +200,11 @@ def main():
         from importlib import import_module
         par = import_module("dqn_hfo_amd.parallel")
         dqn, dp = par.make_hip_data_parallel(pkg, S, rank, world, local_rank, minibatch=B, hidden=HIDDEN,
-                                             memory=args.replay, seed=1 + rank)
+                                             memory=args.replay, seed=1 + rank, precision=args.precision)
         step = lambda: dp.update(None)
     else:
         dqn = pkg.DQN(S, minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1 + rank, device=local_rank,
-                      use_graph=not args.no_graph)
+                      use_graph=not args.no_graph, precision=args.precision)
         step = lambda: dqn.update_async(None)
     prefill(dqn, args.replay - 1, seed=100 + rank)     # AddTransitions keeps <= capacity-1 (src/dqn.cpp:776)
 
@@ -216,7 +233,9 @@ def main():
     # roofline of the dominant kernel family, timed live with HIP events on the learner's stream
     roof = None
     if rank == 0:
-        fam_flops = family_flops(B, S, HIDDEN)
+        fp16 = args.precision == "fp16"
+        fam_flops = family_flops16(B, S, HIDDEN) if fp16 else family_flops(B, S, HIDDEN)
+        peak = MFMA_F16_PEAK_TF if fp16 else MFMA_F32_PEAK_TF
         dqn.set_kernel_timing(True)
         n_t = 20
         for _ in range(n_t):
@@ -232,8 +251,8 @@ def main():
         per_update_launches = cnt / n_t
         flops_per_launch = fam_flops[dom] / per_update_launches
         ach = flops_per_launch / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
-                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": pmc_traffic(KERNEL_NAMES[dom]),
+        roof = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": round(ach, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(KERNEL_NAMES[dom]),
                 "avg_launch_us": round(ms * 1e3, 2), "launches_per_update": per_update_launches,
                 "flops_per_launch": flops_per_launch,
                 "families_us": {f: [round(stats[f][0] * 1e3, 2), stats[f][1] / n_t] for f in stats}}
@@ -276,10 +295,11 @@ def main():
         value = ups * (world if world > 1 else 1)
         fl = sum(family_flops(B, S, HIDDEN).values())
         out = {
-            "metric": "DQN updates/sec, 1v0 HFO, 4x1024 MLP, minibatch 256",
+            "metric": "DQN updates/sec, 1v0 HFO, 4x1024 MLP, minibatch %d" % B,
             "value": round(value, 2), "unit": "updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f16 operands, f32 accumulate (master weights / Adam / heads f32)",
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 1v0 HFO, 1 MI355X, 4x1024 actor-critic MLP, "
                                    "minibatch 256, device-resident replay %d transitions, 58-dim synthetic states"
@@ -291,7 +311,7 @@ def main():
                        "hip_graph": (not args.no_graph) and not use_dp,
                        "sampling": "on-device Philox, uniform with replacement"},
             "update_gflop": round(fl / 1e9, 3),
-            "update_mfma_frac": round(fl * ups / 1e12 / MFMA_F32_PEAK_TF, 4),
+            "update_mfma_frac": round(fl * ups / 1e12 / (MFMA_F16_PEAK_TF if args.precision == "fp16" else MFMA_F32_PEAK_TF), 4),
             "last_critic_loss": loss, "last_avg_q": avgq,
             "roofline": roof,
             "env_steps": env_res,

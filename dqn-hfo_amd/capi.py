@@ -20,7 +20,7 @@ class Config(C.Structure):
         ("momentum2", C.c_float), ("delta", C.c_float), ("clip_gradients", C.c_float),
         ("device", C.c_int32), ("dp_world", C.c_int32), ("dp_rank", C.c_int32), ("use_graph", C.c_int32),
         ("seed", C.c_uint64), ("stream", C.c_void_p), ("grad_arena", C.c_void_p),
-        ("grad_arena_bytes", C.c_size_t),
+        ("grad_arena_bytes", C.c_size_t), ("precision", C.c_int32), ("loss_scale", C.c_float),
     ]
 
 

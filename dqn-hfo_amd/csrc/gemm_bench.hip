@@ -236,3 +236,139 @@ extern "C" int dqnhip_test_gemm(int32_t mode, int32_t variant, int32_t rows, int
   hipFree(dres); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
   return 0;
 }
+
+// ======================= fp16-input family (hgemm.hip.h) ========================================
+#include "hgemm.hip.h"
+
+namespace {
+
+__global__ void k_fill_h(h16* p, size_t n, uint32_t seed, float lo, float hi) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = (h16)(lo + (hi - lo) * (float)(x >> 8) * (1.0f / 16777216.0f));
+  }
+}
+// naive reference of the whole epilogue, fp32 accumulation of the fp16 inputs in k order
+__global__ void k_ref_h(const h16* A, int lda, const h16* B, int ldb, int M, int N, int K, const float* bias, int relu,
+                        const h16* mask, int ldm, float* ref) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * N) return;
+  const int m = (int)(i / N), n = (int)(i % N);
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf((float)A[(size_t)m * lda + k], (float)B[(size_t)n * ldb + k], acc);
+  if (bias) acc += bias[n];
+  if (relu) acc = acc > 0.f ? acc : 0.01f * acc;
+  if (mask) acc *= ((float)mask[(size_t)m * ldm + n] > 0.f ? 1.0f : 0.01f);
+  ref[i] = acc;
+}
+// compare fp32 ref [M][N] with: fp16 m-major, fp16 transposed, fp32 (scaled, first n_valid columns)
+__global__ void k_cmp_h(const float* ref, int M, int N, const h16* C16, int ldc16, const h16* CT16, int ldct, const float* C32,
+                        int ldc32, int n_valid, float scale, float* out /*[2]: max err, max |ref|*/) {
+  __shared__ float sd[256], sr[256];
+  float d = 0.f, r = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)M * N; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / N), n = (int)(i % N);
+    const float v = ref[i];
+    r = fmaxf(r, fabsf(v));
+    const float tol16 = fabsf(v) * (1.0f / 1024.0f);          // one fp16 rounding of the result is allowed
+    if (C16) d = fmaxf(d, fmaxf(0.f, fabsf((float)C16[(size_t)m * ldc16 + n] - v) - tol16));
+    if (CT16) d = fmaxf(d, fmaxf(0.f, fabsf((float)CT16[(size_t)n * ldct + m] - v) - tol16));
+    if (C32 && n < n_valid) d = fmaxf(d, fabsf(C32[(size_t)m * ldc32 + n] - v * scale) / fmaxf(scale, 1e-30f));
+  }
+  sd[threadIdx.x] = d; sr[threadIdx.x] = r;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sd[threadIdx.x] = fmaxf(sd[threadIdx.x], sd[threadIdx.x + s]); sr[threadIdx.x] = fmaxf(sr[threadIdx.x], sr[threadIdx.x + s]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { atomicMax((int*)&out[0], __float_as_int(sd[0])); atomicMax((int*)&out[1], __float_as_int(sr[0])); }
+}
+
+}  // namespace
+
+// fp16 GEMM harness.  mode 0: FWD-like (bias + leaky ReLU; fp16, transposed fp16 and fp32 outputs)
+//                     mode 1: DGRAD-like (ReLU' mask; fp16 + transposed fp16 + scaled fp32 outputs)
+//                     mode 2: WGRAD-like (scaled fp32 output only, the upper half of the columns not written)
+//                     mode 3: k_cvt16 + k_db16 glue check (M x N panel)
+// tile: 0 auto, 1 force 128x128, 2 force 64x64 split-K.  max_abs_err excludes one fp16 rounding of the result.
+extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t N, int32_t K, int32_t iters,
+                                 float* avg_us, float* max_abs_err, float* max_ref) {
+  if (iters < 1 || M % 64 || N % 64 || K % 64) return 1;
+  static bool prepared = false;
+  if (!prepared) { CK((hgemm_prepare<2, 2>())); CK((hgemm_prepare<1, 1>())); prepared = true; }
+  hipStream_t s; CK(hipStreamCreate(&s));
+  float* dres; CK(hipMalloc(&dres, 8)); CK(hipMemsetAsync(dres, 0, 8, s));
+  float hres[2] = {0, 0};
+  if (mode == 3) {
+    float* src; h16 *d16, *dT; float *db; 
+    const int ld16 = (N + 127) / 128 * 128;
+    CK(hipMalloc(&src, (size_t)M * N * 4)); CK(hipMalloc(&d16, (size_t)M * ld16 * 2)); CK(hipMalloc(&dT, (size_t)ld16 * M * 2)); CK(hipMalloc(&db, ld16 * 4));
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, src, (size_t)M * N, 5u, -1.f, 1.f);
+    CK(hipMemsetAsync(d16, 0xff, (size_t)M * ld16 * 2, s)); CK(hipMemsetAsync(dT, 0xff, (size_t)ld16 * M * 2, s));
+    Cvt16Batch b{}; cvt16_add(b, src, N, M, N - 3, d16, ld16, dT, M, 2.0f);
+    CK(cvt16_launch(b, s));
+    Db16Batch q{}; q.n = 1; q.scale = 0.5f; q.d[0] = Db16{dT, M, ld16, M, db, 0};
+    hipLaunchKernelGGL(k_db16<0>, dim3(ld16), dim3(256), 0, s, q);
+    std::vector<float> hs((size_t)M * N), hdb(ld16); std::vector<h16> h16v((size_t)M * ld16), hT((size_t)ld16 * M);
+    CK(hipMemcpyAsync(hs.data(), src, hs.size() * 4, hipMemcpyDeviceToHost, s));
+    CK(hipMemcpyAsync(h16v.data(), d16, h16v.size() * 2, hipMemcpyDeviceToHost, s));
+    CK(hipMemcpyAsync(hT.data(), dT, hT.size() * 2, hipMemcpyDeviceToHost, s));
+    CK(hipMemcpyAsync(hdb.data(), db, hdb.size() * 4, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    float err = 0.f, mx = 0.f;
+    for (int c = 0; c < ld16; ++c) {
+      double colsum = 0;
+      for (int r = 0; r < M; ++r) {
+        const float want = c < N - 3 ? (float)(h16)(hs[(size_t)r * N + c] * 2.0f) : 0.f;
+        err = fmaxf(err, fabsf((float)h16v[(size_t)r * ld16 + c] - want));
+        err = fmaxf(err, fabsf((float)hT[(size_t)c * M + r] - want));
+        mx = fmaxf(mx, fabsf(want)); colsum += want;
+      }
+      err = fmaxf(err, fabsf(hdb[c] - (float)(colsum * 0.5)) / 64.0f);
+    }
+    if (max_abs_err) *max_abs_err = err; if (max_ref) *max_ref = mx; if (avg_us) *avg_us = 0;
+    hipFree(src); hipFree(d16); hipFree(dT); hipFree(db); hipFree(dres); hipStreamDestroy(s);
+    return 0;
+  }
+  h16 *A, *B, *mask, *C16, *CT16; float *bias, *C32, *ref;
+  CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&mask, (size_t)M * N * 2));
+  CK(hipMalloc(&C16, (size_t)M * N * 2)); CK(hipMalloc(&CT16, (size_t)M * N * 2)); CK(hipMalloc(&bias, N * 4));
+  CK(hipMalloc(&C32, (size_t)M * N * 4)); CK(hipMalloc(&ref, (size_t)M * N * 4));
+  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, A, (size_t)M * K, 11u, -1.f, 1.f);
+  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, B, (size_t)N * K, 23u, -1.f, 1.f);
+  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, mask, (size_t)M * N, 31u, -1.f, 1.f);
+  hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, s, bias, (size_t)N, 41u, -1.f, 1.f);
+  CK(hipMemsetAsync(C16, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(CT16, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(C32, 0xff, (size_t)M * N * 4, s));
+  HGemm g{};
+  g.A = A; g.lda = K; g.B = B; g.ldb = K; g.M = M; g.N = N; g.K = K; g.scale32 = 1.0f; g.n_valid32 = N;
+  if (mode == 0) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; g.C32 = C32; g.ldc32 = N; }
+  else if (mode == 4) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; }
+  else if (mode == 5) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; }
+  else if (mode == 1) { g.mask = mask; g.ldm = N; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 64.0f; }
+  else { g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 1024.0f; g.n_valid32 = N / 2; }
+  for (int i = 0; i < 3; ++i) CK(hgemm_launch(g, s, tile));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipStreamSynchronize(s));
+  CK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) CK(hgemm_launch(g, s, tile));
+  CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+  if (avg_us) *avg_us = ms * 1000.0f / iters;
+  hipLaunchKernelGGL(k_ref_h, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, (const h16*)A, K, (const h16*)B, K, M, N, K,
+                     (const float*)g.bias, g.relu, g.mask, g.ldm, ref);
+  hipLaunchKernelGGL(k_cmp_h, dim3(256), dim3(256), 0, s, (const float*)ref, M, N, (const h16*)g.C16, N, (const h16*)g.CT16, M, (const float*)g.C32, N,
+                     g.n_valid32, g.scale32, dres);
+  CK(hipMemcpyAsync(hres, dres, 8, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  if (mode == 2) {   // untouched upper columns must still hold the 0xff fill
+    std::vector<uint32_t> row(N);
+    CK(hipMemcpy(row.data(), C32, N * 4, hipMemcpyDeviceToHost));
+    for (int n = N / 2; n < N; ++n) if (row[n] != 0xffffffffu) hres[0] = 1e30f;
+  }
+  if (max_abs_err) *max_abs_err = hres[0];
+  if (max_ref) *max_ref = hres[1];
+  hipFree(A); hipFree(B); hipFree(mask); hipFree(C16); hipFree(CT16); hipFree(bias); hipFree(C32); hipFree(ref); hipFree(dres);
+  hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+  return 0;
+}

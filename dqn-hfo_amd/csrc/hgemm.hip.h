@@ -1,0 +1,384 @@
+// hgemm.hip.h — fp16-input / fp32-accumulate MFMA GEMM family for the mixed-precision learner
+// (BASELINE.json config #5: "minibatch 4096, fp16 MFMA with fp32 accumulate").
+//
+// One kernel shape serves the three uses of a tower layer (reference: Caffe InnerProduct
+// forward / backward, called from src/dqn.cpp:904, 923, 963):
+//
+//     C[m][n] = sum_k A[m][k] * B[n][k]          A: [M][lda], B: [N][ldb], both k-contiguous
+//
+//   FWD    m = batch row, n = out unit, k = in unit   A = X16,   B = W16  [N_out][K_in]
+//   DGRAD  m = batch row, n = in unit,  k = out unit  A = dY16,  B = WT16 [K_in][N_out]
+//   WGRAD  m = out unit,  n = in unit,  k = batch row A = dYT16, B = XT16
+//
+// i.e. every operand is kept in HBM in BOTH orientations (fp16, written by the producing
+// epilogue) so that the reduction index is always the contiguous one: a v_mfma_f32_32x32x16_f16
+// lane consumes 8 consecutive k of one row = one 16-B piece.
+//
+// Data path: global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no
+// VGPR staging), 3-4 stage ring, one s_barrier per 64-deep K tile, counted vmcnt so the next
+// tiles stay in flight across the barrier.  The LDS image is [rows][64 halves] = 128-B rows
+// whose 16-B chunks are XOR-swizzled with (row>>1)&7: the DMA writes lane-linearly, so the
+// swizzle is applied to the per-lane SOURCE address; the ds_read_b128 lane groups of a 32-row
+// fragment ({0-3,12-15,20-27}, ...) then hit 16 distinct 16-B slots of the 256-B bank row.
+// Wave tile 64x64 (2x2 MFMA 32x32x16): 4 ds_read_b128 per 4 MFMA = 50 % of the LDS read rate.
+//   <2,2>: 128x128 workgroup tile, waves 2x2.
+//   <1,1>:  64x64  workgroup tile, the 4 waves split each K tile (k16 slice w) and the four
+//           partial tiles are added in the fixed order (w0+w1)+(w2+w3) — for problems with
+//           fewer than ~200 128x128 tiles (wgrad: N_out x K_in is only 8x8 tiles).
+// Epilogue through LDS (fp32 tile): bias + leaky-ReLU / ReLU' mask / scale, then coalesced
+// stores of the m-major fp16 panel, the fp32 panel and the transposed fp16 panel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace dqnhip {
+
+typedef _Float16 h16;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+typedef __attribute__((ext_vector_type(16))) float hg_f32x16;
+typedef __attribute__((ext_vector_type(4))) float hg_f32x4;
+
+struct HGemm {
+  const h16* A; int lda;
+  const h16* B; int ldb;
+  int M, N, K;                 // M % BM == 0, N % BN == 0, K % 64 == 0
+  h16* C16; int ldc16;         // [M][ldc16]  m-major fp16 (may be null)
+  h16* CT16; int ldct16;       // [N][ldct16] transposed fp16 (may be null)
+  float* C32; int ldc32;       // [M][ldc32]  fp32 (may be null); columns >= n_valid32 are not written
+  int n_valid32;
+  const float* bias;           // [N] added before the activation (may be null)
+  int relu;                    // leaky ReLU(0.01) on the result
+  const h16* mask; int ldm;    // [M][ldm]: multiply by lrelu'(mask) = mask > 0 ? 1 : 0.01 (may be null)
+  float scale32;               // the fp32 output is multiplied by this (loss-scale removal)
+};
+
+__device__ __forceinline__ int hg_tile_of_block(int bid, int total) {
+  // XCD x (= bid % 8) gets a contiguous run of row-major tiles: they share A row panels and
+  // sweep all of B, so each XCD's L2 holds its A panels + B once (bijective for any total)
+  const int xcd = bid & 7, j = bid >> 3;
+  const int q = total >> 3, r = total & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+template <int WM, int WN>
+struct HGCfg {
+  static constexpr int WK = 4 / (WM * WN);
+  static constexpr int BM = WM * 64, BN = WN * 64;
+  // A stage is 256 row slots of 128 B (32 KiB).  <2,2>: slots 0-127 = A rows, 128-255 = B rows of one
+  // 64-deep K tile.  <1,1>: two 64-deep sub-tiles, each 64 A rows + 64 B rows (K step 128).
+  static constexpr int KSTEP = (WK == 1) ? 64 : 128;
+  static constexpr int STAGE = 32768, STAGES = 4;
+  static constexpr int LOADS = 8;                                           // 1-KiB pieces per wave per stage
+  static constexpr int NSUB = (WK == 1) ? 4 : 2;                            // k16 steps per wave per stage
+  static constexpr int TLD = BN + 4;                                        // fp32 epilogue tile row stride
+  static constexpr int T_BYTES = WK * BM * TLD * 4;
+  static constexpr int PIPE_BYTES = STAGES * STAGE;
+  static constexpr int LDS_BYTES = PIPE_BYTES > T_BYTES ? PIPE_BYTES : T_BYTES;
+};
+
+// counted wait: at most N of this wave's vector-memory operations (the LDS-DMA pieces) outstanding
+template <int N> __device__ __forceinline__ void hg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define HG_PIN() __builtin_amdgcn_sched_barrier(0)
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 1) void hgemm_nt(HGemm g) {
+  using Cfg = HGCfg<WM, WN>;
+  constexpr int WK = Cfg::WK, BM = Cfg::BM, BN = Cfg::BN, STAGES = Cfg::STAGES, TLD = Cfg::TLD;
+  constexpr int NSUB = Cfg::NSUB, LOADS = Cfg::LOADS, KSTEP = Cfg::KSTEP;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char hg_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = (WK == 1) ? (w >> 1) : 0, wn = (WK == 1) ? (w & 1) : 0;
+  const int tiles_n = g.N / BN, tiles_m = g.M / BM;
+  const int T = hg_tile_of_block(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (T / tiles_n) * BM, n0 = (T % tiles_n) * BN;
+  const int nk = g.K / KSTEP;
+
+  // ---- LDS-DMA source addresses.  Wave w owns pieces w*8 .. w*8+7 of every stage; piece p = row
+  // slots p*8 .. p*8+7; lane -> (slot R, physical chunk pc) fetches logical chunk pc ^ ((R>>1)&7).
+  // A wave's 64 slots belong to ONE matrix (waves {0,1}/{2,3} = A/B for <2,2>; even/odd for <1,1>),
+  // so the source is a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset.
+  const int r8 = lane >> 3, pc = lane & 7;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const bool from_a = (WK == 1) ? (wu < 2) : ((wu & 1) == 0);
+  const int row_w = (WK == 1) ? (wu & 1) * 64 : 0;              // first matrix row (inside the tile) of this wave's slots
+  const int ld = from_a ? g.lda : g.ldb;
+  const h16* wbase = (from_a ? g.A + (size_t)m0 * g.lda : g.B + (size_t)n0 * g.ldb) + (size_t)row_w * ld +
+                     ((WK == 1) ? 0 : (wu >> 1) * 64);
+  uint32_t voff[LOADS];
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) {
+    const int R = (wu * LOADS + i) * 8 + r8;                    // stage slot
+    const int c = pc ^ ((R >> 1) & 7);
+    voff[i] = (uint32_t)(((i * 8 + r8) * ld + c * 8) * 2);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)hg_smem;
+  // one piece of stage kt.  Inline asm: the compiler's waitcnt pass models a global_load_lds as a FLAT
+  // operation that may touch LDS and then turns every later lgkmcnt wait into lgkmcnt(0), which
+  // serialises the fragment prefetch; all ordering of the DMA is done by hand (counted vmcnt + barrier).
+  auto issue1 = [&](int kt, int i) {
+    const h16* base = wbase + (size_t)kt * KSTEP;
+    const uint32_t dst = lds0 + (uint32_t)((kt % STAGES) * Cfg::STAGE + (wu * LOADS + i) * 1024);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff[i]), "s"(base), "s"(dst) : "memory");
+  };
+
+  // ---- fragment read offsets (bytes inside a stage) for sub-step s
+  const int l31 = lane & 31, hi = lane >> 5, sw = (l31 >> 1) & 7;
+  int offa[NSUB], offb[NSUB];
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) {
+    if constexpr (WK == 1) {
+      const int o = (((2 * s + hi) ^ sw) << 4) + l31 * 128;
+      offa[s] = wm * 64 * 128 + o; offb[s] = (128 + wn * 64) * 128 + o;
+    } else {
+      const int o = (((2 * w + hi) ^ sw) << 4) + l31 * 128;     // this wave's k16 slice of each sub-tile
+      offa[s] = s * 16384 + o; offb[s] = s * 16384 + 8192 + o;
+    }
+  }
+
+  hg_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  h16x8 fa[2][2], fb[2][2];                 // [register buffer][32-row half]
+  auto load_frags = [&](int buf, int kt, int s) {
+    const unsigned char* st = hg_smem + (kt % STAGES) * Cfg::STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[buf][i] = *reinterpret_cast<const h16x8*>(st + offa[s] + i * 32 * 128);
+      fb[buf][i] = *reinterpret_cast<const h16x8*>(st + offb[s] + i * 32 * 128);
+    }
+  };
+
+  // ---- main loop.  Stages kt+1..kt+3 are in flight / landed while stage kt is multiplied; the barrier
+  // at the top of iteration kt publishes stage kt+1 (so its first fragments can be fetched at the end
+  // of iteration kt) and retires every wave's reads of stage kt-1, whose buffer stage kt+3 then reuses.
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) {
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i) issue1(s, i);
+    }
+  if (nk >= 3) hg_wait_vm<2 * LOADS>(); else if (nk == 2) hg_wait_vm<LOADS>(); else hg_wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  load_frags(0, 0, 0);
+  auto stage_body = [&](int kt, auto more_c) {
+    constexpr bool more = decltype(more_c)::value;      // stage kt+3 exists: issue its pieces between the MFMAs
+    if (more || kt + 1 < nk) {
+      if (more || kt + 2 < nk) hg_wait_vm<LOADS>(); else hg_wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      const int cur = s & 1;                // NSUB is even: register buffer 0 again at s = 0 of the next stage
+      constexpr int PPS = LOADS / NSUB;     // pieces per sub-step
+      HG_PIN();
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
+      HG_PIN();
+      if (s + 1 < NSUB) load_frags(cur ^ 1, kt, s + 1);
+      else if (more || kt + 1 < nk) load_frags(cur ^ 1, kt + 1, 0);
+      HG_PIN();
+      if constexpr (more) {
+#pragma unroll
+        for (int i = 0; i < PPS / 2; ++i) issue1(kt + STAGES - 1, s * PPS + i);
+      }
+      HG_PIN();
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
+      HG_PIN();
+      if constexpr (more) {
+#pragma unroll
+        for (int i = PPS / 2; i < PPS; ++i) issue1(kt + STAGES - 1, s * PPS + i);
+      }
+      HG_PIN();
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+    }
+  };
+  int kt = 0;
+  for (; kt + STAGES - 1 < nk; ++kt) stage_body(kt, std::true_type{});
+  for (; kt < nk; ++kt) stage_body(kt, std::false_type{});
+  __syncthreads();                          // pipeline buffers are dead: reuse them as the fp32 tile
+
+  // ---- epilogue 1: accumulators -> fp32 tile  Tt[wk][m][n]   (C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
+  float* Tt = reinterpret_cast<float*>(hg_smem);
+  {
+    float* Tw = Tt + (WK == 1 ? 0 : w * BM * TLD);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+          const int n = wn * 64 + j * 32 + l31;
+          Tw[m * TLD + n] = acc[i][j][e];
+        }
+  }
+  __syncthreads();
+
+  // ---- epilogue 2: m-major outputs, 8 consecutive n per thread
+  constexpr int CPR = BN / 8;               // chunks per row
+  for (int q = tid; q < BM * CPR; q += 256) {
+    const int row = q / CPR, c8 = q % CPR;
+    float v[8];
+    {
+      const hg_f32x4* p = reinterpret_cast<const hg_f32x4*>(Tt + row * TLD + c8 * 8);
+      hg_f32x4 x0 = p[0], x1 = p[1];
+      if constexpr (WK > 1) {
+        const hg_f32x4* p1 = reinterpret_cast<const hg_f32x4*>(Tt + (BM + row) * TLD + c8 * 8);
+        const hg_f32x4* p2 = reinterpret_cast<const hg_f32x4*>(Tt + (2 * BM + row) * TLD + c8 * 8);
+        const hg_f32x4* p3 = reinterpret_cast<const hg_f32x4*>(Tt + (3 * BM + row) * TLD + c8 * 8);
+        x0 = (x0 + p1[0]) + (p2[0] + p3[0]);
+        x1 = (x1 + p1[1]) + (p2[1] + p3[1]);
+      }
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    }
+    const int gm = m0 + row, gn = n0 + c8 * 8;
+    if (g.bias) {
+      const hg_f32x4 b0 = *reinterpret_cast<const hg_f32x4*>(g.bias + gn), b1 = *reinterpret_cast<const hg_f32x4*>(g.bias + gn + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (g.relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+    }
+    if (g.mask) {
+      const h16x8 mk = *reinterpret_cast<const h16x8*>(g.mask + (size_t)gm * g.ldm + gn);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= ((float)mk[e] > 0.f ? 1.0f : 0.01f);
+    }
+    if (g.C16) {
+      h16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (h16)v[e];
+      *reinterpret_cast<h16x8*>(g.C16 + (size_t)gm * g.ldc16 + gn) = o;
+    }
+    if (g.C32 && gn < g.n_valid32) {
+      const float s = g.scale32;
+      float* d = g.C32 + (size_t)gm * g.ldc32 + gn;
+      *reinterpret_cast<hg_f32x4*>(d) = hg_f32x4{v[0] * s, v[1] * s, v[2] * s, v[3] * s};
+      *reinterpret_cast<hg_f32x4*>(d + 4) = hg_f32x4{v[4] * s, v[5] * s, v[6] * s, v[7] * s};
+    }
+    if (g.CT16) {                            // keep the finished values for the transposed pass
+      hg_f32x4* p = reinterpret_cast<hg_f32x4*>(Tt + row * TLD + c8 * 8);
+      p[0] = hg_f32x4{v[0], v[1], v[2], v[3]}; p[1] = hg_f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+  if (!g.CT16) return;
+  __syncthreads();
+  // ---- epilogue 3: transposed output  CT16[n][m]: 4 lanes cover 32 consecutive m of one n (64 B)
+  constexpr int CPC = BM / 8;               // 8-m chunks per column
+  for (int q = tid; q < BN * CPC; q += 256) {
+    const int clo = q & 3, n = (q >> 2) % BN, chi = (q >> 2) / BN;
+    const int c8 = chi * 4 + clo;
+    h16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (h16)Tt[(c8 * 8 + e) * TLD + n];
+    *reinterpret_cast<h16x8*>(g.CT16 + (size_t)(n0 + n) * g.ldct16 + m0 + c8 * 8) = o;
+  }
+}
+
+template <int WM, int WN>
+inline hipError_t hgemm_prepare() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_nt<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             HGCfg<WM, WN>::LDS_BYTES);
+}
+
+// picks the tile: 128x128 when that fills the chip, else 64x64 with in-workgroup split-K
+inline hipError_t hgemm_launch(const HGemm& g, hipStream_t st, int force = 0, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+  const bool big_ok = (g.M % 128 == 0) && (g.N % 128 == 0);
+  const long tiles_big = big_ok ? (long)(g.M / 128) * (g.N / 128) : 0;
+  const bool big = force == 1 || (force == 0 && tiles_big >= 192);
+  if (g.K % 64 || g.K < 64) return hipErrorInvalidValue;
+  if (big) {
+    if (!big_ok) return hipErrorInvalidValue;
+    if (t0) hipExtLaunchKernelGGL((hgemm_nt<2, 2>), dim3((unsigned)tiles_big), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, g);
+    else hipLaunchKernelGGL((hgemm_nt<2, 2>), dim3((unsigned)tiles_big), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, g);
+  } else {
+    if (g.M % 64 || g.N % 64 || g.K % 128) return hipErrorInvalidValue;
+    const unsigned nb = (unsigned)((g.M / 64) * (g.N / 64));
+    if (t0) hipExtLaunchKernelGGL((hgemm_nt<1, 1>), dim3(nb), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, g);
+    else hipLaunchKernelGGL((hgemm_nt<1, 1>), dim3(nb), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, g);
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 [rows][ld_src] -> fp16 [rows][ld16] (+ transposed fp16 [ld16][ldT]) glue: minibatch panels,
+// head gradients (with the loss scale) and the per-update fp16 weight copies.
+struct Cvt16 {
+  const float* src; int ld_src; int rows; int cols;   // cols = valid source columns (<= ld_src)
+  h16* dst; int ld16;                                 // [rows][ld16], columns >= cols written as 0 (may be null)
+  h16* dstT; int ldT;                                 // [ld16][ldT] transposed (may be null)
+  float scale;
+  int tiles_r, tiles_c, tile_base;
+};
+struct Cvt16Batch { Cvt16 d[8]; int n; };
+
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_cvt16(Cvt16Batch b) {
+  __shared__ float t[64][65];
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.d[j + 1].tile_base) ++j;
+  const Cvt16& d = b.d[j];
+  const int tl = blockIdx.x - d.tile_base;
+  const int r0 = (tl / d.tiles_c) * 64, c0 = (tl % d.tiles_c) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int row = r0 + r, col = c0 + tx;
+    float v = 0.f;
+    if (row < d.rows && col < d.cols) v = d.src[(size_t)row * d.ld_src + col] * d.scale;
+    t[r][tx] = v;
+    if (d.dst && row < d.rows) d.dst[(size_t)row * d.ld16 + col] = (h16)v;
+  }
+  if (!d.dstT) return;
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int row = r0 + tx;
+    if (row < d.ldT) d.dstT[(size_t)(c0 + c) * d.ldT + row] = (h16)(row < d.rows ? t[tx][c] : 0.f);
+  }
+}
+
+inline void cvt16_add(Cvt16Batch& b, const float* src, int ld_src, int rows, int cols, h16* dst, int ld16, h16* dstT, int ldT, float scale) {
+  Cvt16& d = b.d[b.n];
+  d.src = src; d.ld_src = ld_src; d.rows = rows; d.cols = cols; d.dst = dst; d.ld16 = ld16; d.dstT = dstT; d.ldT = ldT; d.scale = scale;
+  d.tiles_r = (rows + 63) / 64; d.tiles_c = ld16 / 64;
+  d.tile_base = b.n ? b.d[b.n - 1].tile_base + b.d[b.n - 1].tiles_r * b.d[b.n - 1].tiles_c : 0;
+  b.n += 1;
+}
+inline hipError_t cvt16_launch(const Cvt16Batch& b, hipStream_t st) {
+  if (!b.n) return hipSuccess;
+  const Cvt16& l = b.d[b.n - 1];
+  hipLaunchKernelGGL(k_cvt16<0>, dim3(l.tile_base + l.tiles_r * l.tiles_c), dim3(256), 0, st, b);
+  return hipGetLastError();
+}
+
+// bias gradients of all tower layers of one net: db_l[n] = scale * sum_b dYT_l[n][b]
+struct Db16 { const h16* dyt; int ld; int n_out; int rows; float* db; int row_base; };
+struct Db16Batch { Db16 d[8]; int n; float scale; };
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_db16(Db16Batch b) {
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.d[j + 1].row_base) ++j;
+  const Db16& d = b.d[j];
+  const int n = blockIdx.x - d.row_base;
+  const h16* p = d.dyt + (size_t)n * d.ld;
+  float acc = 0.f;
+  for (int i = threadIdx.x * 8; i < d.rows; i += 256 * 8) {
+    const h16x8 v = *reinterpret_cast<const h16x8*>(p + i);
+    acc += (((float)v[0] + (float)v[1]) + ((float)v[2] + (float)v[3])) + (((float)v[4] + (float)v[5]) + ((float)v[6] + (float)v[7]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  __shared__ float s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) d.db[n] = ((s[0] + s[1]) + (s[2] + s[3])) * b.scale;
+}
+
+}  // namespace dqnhip

@@ -23,6 +23,7 @@
 #include "env.hip.h"
 #include "gemm_direct.hip.h"
 #include "gemm_mfma.hip.h"
+#include "hgemm.hip.h"
 #include "small_kernels.hip.h"
 
 using namespace dqnhip;
@@ -137,6 +138,19 @@ struct dqnhip_learner {
   float* part[2] = {nullptr, nullptr};  // GEMM-epilogue sumsq partials per net
   float* part_dp = nullptr; int n_part_dp = 0;
   float* head_slab = nullptr; int* head_ticket = nullptr;   // k_head_bwd cross-block reduction
+  // mixed precision (cfg.precision == DQNHIP_FP16): fp16 copies of the tower weights in both
+  // orientations, fp16 activations / gradients in both orientations (hgemm.hip.h)
+  bool fp16 = false;
+  float ls_c = 1.f, ls_q = 1.f, ls_a = 1.f;  // static loss scales: critic step, dQ/da pass, actor step
+  int k16[2][kMaxL + 1] = {{0}};             // fp16 panel widths per net kind (k16[.][0] = in_dim rounded to 128)
+  h16* w16[4][kMaxL] = {{nullptr}};          // [N_out][k16]
+  h16* wt16[2][kMaxL] = {{nullptr}};         // [k16][N_out], online nets only (dgrad operand)
+  h16* act16[5][kMaxL + 1] = {{nullptr}};    // [B][k16]
+  h16* actT16[5][kMaxL + 1] = {{nullptr}};   // [k16][B], passes 1 (actor) and 3 (critic train): wgrad operand
+  h16* dZ16[2][kMaxL + 1] = {{nullptr}};     // [B][k16]   per net kind
+  h16* dZT16[2][kMaxL + 1] = {{nullptr}};    // [k16][B]
+  bool w16_dirty[4] = {true, true, true, true};
+  std::vector<void*> allocs16;
   // host-staging for add_transitions / acting
   void* stage_dev = nullptr; size_t stage_bytes = 0;
   float* act_buf = nullptr; size_t act_floats = 0;
@@ -176,8 +190,9 @@ struct RingUse {
   }
 };
 
-const char* kFamily[] = {"gemm_fwd_lds_4x2", "gemm_dgrad", "gemm_wgrad", "adam", "gemm_bwd_pair", "gemm_fwd_lds_2x2", "gemm_fwd_direct"};
-constexpr int kNumFamily = 7;
+const char* kFamily[] = {"gemm_fwd_lds_4x2", "gemm_dgrad", "gemm_wgrad", "adam", "gemm_bwd_pair", "gemm_fwd_lds_2x2", "gemm_fwd_direct",
+                         "hgemm_fwd", "hgemm_dgrad", "hgemm_wgrad"};
+constexpr int kNumFamily = 10;
 
 // Timing mode: the NEXT kernel launch (through direct_launch / adam_launch) is bracketed by the
 // dispatch packet's own timestamps (hipExtLaunchKernelGGL start/stop events).
@@ -246,6 +261,12 @@ int validate(const dqnhip_config* c) {
   if (c->replay_capacity < 2) return fail("replay_capacity must be >= 2");
   if (c->soft_update_freq < 1) return fail("soft_update_freq must be >= 1");
   if (c->dp_world < 1 || c->dp_rank < 0 || c->dp_rank >= c->dp_world) return fail("bad dp_world/dp_rank");
+  if (c->precision != DQNHIP_FP32 && c->precision != DQNHIP_FP16) return fail("precision must be DQNHIP_FP32 or DQNHIP_FP16");
+  if (c->precision == DQNHIP_FP16) {
+    if (c->minibatch % 128) return fail("fp16 mode: minibatch must be a multiple of 128 (got %d)", c->minibatch);
+    for (int i = 0; i < c->num_hidden; ++i)
+      if (c->hidden[i] % 128) return fail("fp16 mode: hidden[%d]=%d must be a multiple of 128", i, c->hidden[i]);
+  }
   return 0;
 }
 
@@ -403,8 +424,223 @@ int sumsq_launch(H* h, int net) {
   return 0;
 }
 
+int sumsq_launch(H* h, int net);
+
+// ---- mixed-precision building blocks (hgemm.hip.h) --------------------------------------------
+
+int hgemm_timed(H* h, hipStream_t st, const HGemm& g, int fam) {
+  ScopedTiming t(h, fam, st);
+  LaunchTimer& lt = launch_timer();
+  hipEvent_t a = lt.start, b = lt.stop;
+  lt.start = lt.stop = nullptr;
+  HIPCHK(hgemm_launch(g, st, 0, a, b));
+  return 0;
+}
+
+// fp32 master weights of `net` -> fp16 [N][k16] (+ transposed for the online nets)
+int sync_w16(H* h, hipStream_t st, int net) {
+  const NetLayout& l = layout_of(h, net);
+  const int kind = net & 1;
+  Cvt16Batch b{};
+  for (int i = 0; i < l.L; ++i) {
+    cvt16_add(b, h->w[net] + l.w_off[i], l.kp[i], l.dims[i + 1], l.kp[i], h->w16[net][i], h->k16[kind][i],
+              net < 2 ? h->wt16[net][i] : nullptr, l.dims[i + 1], 1.0f);
+    if (b.n == 8) { HIPCHK(cvt16_launch(b, st)); b = Cvt16Batch{}; }
+  }
+  HIPCHK(cvt16_launch(b, st));
+  h->w16_dirty[net] = false;
+  return 0;
+}
+
+int tower_forward16(H* h, hipStream_t st, int p, int net, int rows) {
+  const NetLayout& l = layout_of(h, net);
+  const int kind = net & 1;
+  const bool needT = (p == 1 || p == 3);
+  for (int i = 0; i < l.L; ++i) {
+    HGemm g{};
+    g.A = h->act16[p][i]; g.lda = h->k16[kind][i];
+    g.B = h->w16[net][i]; g.ldb = h->k16[kind][i];
+    g.M = rows; g.N = l.dims[i + 1]; g.K = h->k16[kind][i];
+    g.C16 = h->act16[p][i + 1]; g.ldc16 = l.dims[i + 1];
+    if (needT) { g.CT16 = h->actT16[p][i + 1]; g.ldct16 = rows; }
+    if (i == l.L - 1) { g.C32 = h->act[p][l.L]; g.ldc32 = l.kp[l.L]; g.n_valid32 = l.dims[l.L]; }
+    g.bias = h->w[net] + l.b_off[i]; g.relu = 1; g.scale32 = 1.0f;
+    RC(hgemm_timed(h, st, g, 7));
+  }
+  return 0;
+}
+
+// Tower backward in fp16 from dZ16[kind][L] (already scaled by `ls`).  want_w: dW (fp32, unscaled)
+// into garena + bias gradients; input_grad: fp32 dZ32_0[rows][kp0] (unscaled).
+int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float* dZ32_0, int rows,
+                     bool want_w, bool input_grad, float ls) {
+  const NetLayout& l = layout_of(h, net);
+  const int kind = net & 1;
+  h16** dZ = h->dZ16[kind]; h16** dZT = h->dZT16[kind];
+  for (int i = l.L - 1; i >= 0; --i) {
+    if (i > 0 || input_grad) {             // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
+      HGemm g{};
+      g.A = dZ[i + 1]; g.lda = l.dims[i + 1];
+      g.B = h->wt16[net][i]; g.ldb = l.dims[i + 1];
+      g.M = rows; g.N = h->k16[kind][i]; g.K = l.dims[i + 1];
+      if (i > 0) {
+        g.mask = h->act16[p][i]; g.ldm = h->k16[kind][i];
+        g.C16 = dZ[i]; g.ldc16 = h->k16[kind][i];
+        if (want_w) { g.CT16 = dZT[i]; g.ldct16 = rows; }
+      } else {
+        g.C32 = dZ32_0; g.ldc32 = l.kp[0]; g.n_valid32 = l.kp[0]; g.scale32 = 1.0f / ls;
+      }
+      RC(hgemm_timed(h, st, g, 8));
+    }
+    if (want_w) {                          // dW_i = dZ[i+1]^T . act[i]
+      HGemm g{};
+      g.A = dZT[i + 1]; g.lda = rows;
+      g.B = h->actT16[p][i]; g.ldb = rows;
+      g.M = l.dims[i + 1]; g.N = h->k16[kind][i]; g.K = rows;
+      g.C32 = garena + l.w_off[i]; g.ldc32 = l.kp[i]; g.n_valid32 = l.kp[i]; g.scale32 = 1.0f / ls;
+      RC(hgemm_timed(h, st, g, 9));
+    }
+  }
+  if (want_w) {                            // db_i = colsum(dZ[i+1]) for all layers in one launch
+    Db16Batch b{}; b.scale = 1.0f / ls;
+    int base = 0;
+    for (int i = 0; i < l.L; ++i) { b.d[b.n++] = Db16{dZT[i + 1], rows, l.dims[i + 1], rows, garena + l.b_off[i], base}; base += l.dims[i + 1]; }
+    hipLaunchKernelGGL(k_db16<0>, dim3(base), dim3(256), 0, st, b);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+// fp32 [rows][ld] gradient wrt the last tower activation -> scaled fp16 (+ transposed)
+int head_grad16(H* h, hipStream_t st, int kind, const float* dZL, int rows, float ls, bool withT) {
+  const NetLayout& l = kind ? h->lc : h->la;
+  Cvt16Batch b{};
+  cvt16_add(b, dZL, l.kp[l.L], rows, l.dims[l.L], h->dZ16[kind][l.L], l.dims[l.L], withT ? h->dZT16[kind][l.L] : nullptr, rows, ls);
+  HIPCHK(cvt16_launch(b, st));
+  return 0;
+}
+
+int run_phase16(H* h, int phase, const int* idx_dev) {
+  const int B = h->B, L = h->L;
+  const NetLayout &la = h->la, &lc = h->lc;
+  const bool dp = h->cfg.dp_world > 1;
+  const float inv_batch = 1.0f / (float)(B * h->cfg.dp_world);
+  float* actor_tail = h->g[0] + la.arena;
+  float* critic_tail = h->g[1] + lc.arena;
+  const int Hh = la.dims[L], Hc = lc.dims[L];
+  hipStream_t st = h->stream;
+  if (phase == 0) {
+    GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
+                 h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
+    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
+                       (const DevState*)h->st, idx_dev, (uint64_t)h->cfg.seed, go, B);
+    HIPCHK(hipGetLastError());
+    {
+      Cvt16Batch b{};
+      cvt16_add(b, h->Xa_n, la.kp[0], B, la.kp[0], h->act16[0][0], h->k16[0][0], nullptr, B, 1.0f);
+      cvt16_add(b, h->Xa_s, la.kp[0], B, la.kp[0], h->act16[1][0], h->k16[0][0], h->actT16[1][0], B, 1.0f);
+      cvt16_add(b, h->Xc_tr, lc.kp[0], B, lc.kp[0], h->act16[3][0], h->k16[1][0], h->actT16[3][0], B, 1.0f);
+      HIPCHK(cvt16_launch(b, st));
+    }
+    RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B));
+    RC(tower_forward16(h, st, 1, DQNHIP_ACTOR, B));
+    HeadArgs hAT{}; hAT.X = h->act[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
+    hAT.W = wat(h, DQNHIP_ACTOR_TARGET, la.hw_off); hAT.b = wat(h, DQNHIP_ACTOR_TARGET, la.hb_off);
+    hAT.out16 = h->aout_t16; hAT.xc = h->Xc_nx; hAT.ldxc = lc.kp[0]; hAT.xc_col = h->S;
+    HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
+    hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
+    hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
+    RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));
+    {
+      Cvt16Batch b{};
+      cvt16_add(b, h->Xc_nx, lc.kp[0], B, lc.kp[0], h->act16[2][0], h->k16[1][0], nullptr, B, 1.0f);
+      cvt16_add(b, h->Xc_pl, lc.kp[0], B, lc.kp[0], h->act16[4][0], h->k16[1][0], nullptr, B, 1.0f);
+      HIPCHK(cvt16_launch(b, st));
+    }
+    RC(tower_forward16(h, st, 2, DQNHIP_CRITIC_TARGET, B));
+    RC(tower_forward16(h, st, 3, DQNHIP_CRITIC, B));
+    {
+      HeadTrainArgs t{};
+      t.Xt = h->act[2][L]; t.Wt = wat(h, DQNHIP_CRITIC_TARGET, lc.hw_off); t.bt = wat(h, DQNHIP_CRITIC_TARGET, lc.hb_off);
+      t.X = h->act[3][L]; t.W = wat(h, DQNHIP_CRITIC, lc.hw_off); t.b = wat(h, DQNHIP_CRITIC, lc.hb_off);
+      t.H = Hc; t.rows = B; t.reward = h->mb_reward; t.mc = h->mb_mc; t.term = h->mb_term;
+      t.q_target = h->q_t; t.q = h->q1; t.y = h->y; t.dq = h->dq; t.loss_partial = h->loss_partial;
+      t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch;
+      hipLaunchKernelGGL(k_head_q_train, dim3((B + 3) / 4), dim3(256), 0, st, t);
+      HIPCHK(hipGetLastError());
+    }
+    {
+      HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[3][L];
+      a.H = Hc; a.rows = B; a.dZ = h->dZc[L]; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
+      a.partial = h->part[1] + lc.part_off[L];
+      RC(head_backward<1>(h, st, a));
+    }
+    RC(head_grad16(h, st, 1, h->dZc[L], B, h->ls_c, true));
+    RC(tower_backward16(h, st, DQNHIP_CRITIC, 3, h->g[1], nullptr, B, true, false, h->ls_c));
+    if (dp) {
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)h->loss_partial,
+                         h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }
+  if (phase == 1) {
+    RC(sumsq_launch(h, 1));
+    RC(adam_launch(h, st, 1, h->part_dp, h->n_part_dp, 0, lc.arena));
+    RC(sync_w16(h, st, DQNHIP_CRITIC)); RC(sync_w16(h, st, DQNHIP_CRITIC_TARGET));
+    RC(tower_forward16(h, st, 4, DQNHIP_CRITIC, B));
+    {
+      HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
+      a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.b = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q = h->q2;
+      a.qsum_partial = h->q_partial;
+      RC((head_forward<1, HEAD_Q_POLICY>(h, st, a)));
+    }
+    {
+      HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
+      a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
+      RC(head_backward<1>(h, st, a));
+    }
+    RC(head_grad16(h, st, 1, h->dZc[L], B, h->ls_q, false));
+    RC(tower_backward16(h, st, DQNHIP_CRITIC, 4, nullptr, h->dZc[0], B, false, true, h->ls_q));
+    {
+      HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;
+      a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.X4 = h->act[1][L]; a.H = Hh; a.rows = B; a.dZ = h->dZa[L];
+      a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
+      RC(head_backward<kNO>(h, st, a));
+    }
+    RC(head_grad16(h, st, 0, h->dZa[L], B, h->ls_a, true));
+    RC(tower_backward16(h, st, DQNHIP_ACTOR, 1, h->g[0], nullptr, B, true, false, h->ls_a));
+    if (dp) {
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)nullptr, 0,
+                         (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }
+  if (phase == 2) {
+    RC(sumsq_launch(h, 0));
+    RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena));
+    RC(sync_w16(h, st, DQNHIP_ACTOR)); RC(sync_w16(h, st, DQNHIP_ACTOR_TARGET));
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(64), 0, st, h->st, critic_tail, actor_tail,
+                       (const float*)h->loss_partial, h->n_head_blocks,
+                       dp ? (const double*)nullptr : (const double*)h->q_partial, B,
+                       (float)(B * h->cfg.dp_world));
+    HIPCHK(hipGetLastError());
+    h->h_actor_iter += 1; h->h_critic_iter += 1;
+    return 0;
+  }
+  return fail("phase must be 0, 1 or 2 (got %d)", phase);
+}
+
+int sync_dirty16(H* h) {
+  if (!h->fp16) return 0;
+  for (int net = 0; net < 4; ++net) if (h->w16_dirty[net]) RC(sync_w16(h, h->stream, net));
+  return 0;
+}
+
 // ---- the update, in three phases (see dqnhip.h) ---------------------------------
 int run_phase(H* h, int phase, const int* idx_dev) {
+  if (h->fp16) return run_phase16(h, phase, idx_dev);
   const int B = h->B, L = h->L;
   const NetLayout &la = h->la, &lc = h->lc;
   const bool dp = h->cfg.dp_world > 1;
@@ -696,6 +932,44 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
     HIPCHK(hipMalloc(&h->head_ticket, (Hmax / 64) * sizeof(int)));
     HIPCHK(hipMemsetAsync(h->head_ticket, 0, (Hmax / 64) * sizeof(int), h->stream));
   }
+  if (cfg->precision == DQNHIP_FP16) {
+    h->fp16 = true;
+    const float user = cfg->loss_scale > 0.f ? cfg->loss_scale : 1.0f;
+    h->ls_c = 16.0f * (float)(B * cfg->dp_world) * user;   // dq = (q-y)/B_global: back to O(q-y)
+    h->ls_q = 4096.0f * user;
+    h->ls_a = 16384.0f * user;
+    auto halloc = [&](h16** p, size_t n) -> int {
+      HIPCHK(hipMalloc(p, n * sizeof(h16)));
+      HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(h16), h->stream));
+      h->allocs16.push_back((void*)*p);
+      return 0;
+    };
+    for (int kind = 0; kind < 2; ++kind) {
+      const NetLayout& l = kind ? h->lc : h->la;
+      h->k16[kind][0] = round_up(l.in_dim, 128);
+      for (int i = 1; i <= L; ++i) h->k16[kind][i] = l.dims[i];
+    }
+    for (int net = 0; net < 4; ++net) {
+      const NetLayout& l = layout_of(h, net);
+      for (int i = 0; i < L; ++i) {
+        RC(halloc(&h->w16[net][i], (size_t)l.dims[i + 1] * h->k16[net & 1][i]));
+        if (net < 2) RC(halloc(&h->wt16[net][i], (size_t)h->k16[net & 1][i] * l.dims[i + 1]));
+      }
+    }
+    for (int p = 0; p < 5; ++p) {
+      const int kind = p >= 2;
+      for (int i = 0; i <= L; ++i) {
+        RC(halloc(&h->act16[p][i], (size_t)B * h->k16[kind][i]));
+        if (p == 1 || p == 3) RC(halloc(&h->actT16[p][i], (size_t)h->k16[kind][i] * B));
+      }
+    }
+    for (int kind = 0; kind < 2; ++kind)
+      for (int i = 0; i <= L; ++i) {
+        RC(halloc(&h->dZ16[kind][i], (size_t)B * h->k16[kind][i]));
+        RC(halloc(&h->dZT16[kind][i], (size_t)h->k16[kind][i] * B));
+      }
+    HIPCHK((hgemm_prepare<2, 2>())); HIPCHK((hgemm_prepare<1, 1>()));
+  }
   // weights: gaussian(std 0.01), zero bias (src/dqn.cpp:350-352); targets = hard copy (:660-661)
   {
     std::mt19937_64 rng(cfg->seed * 0x9E3779B97F4A7C15ull + 12345);
@@ -727,6 +1001,7 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   HIPCHK(direct_prepare(gemm_bwd_pair_direct<1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_bwd_pair_direct<1, true>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4));
+  RC(sync_dirty16(h));
   HIPCHK(hipStreamSynchronize(h->stream));
   *out = h;
   return 0;
@@ -755,6 +1030,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   hipFree(h->aout_t16); hipFree(h->aout16); hipFree(h->dA16);
   hipFree(h->q_t); hipFree(h->q1); hipFree(h->q2); hipFree(h->y); hipFree(h->dq);
   hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp); hipFree(h->head_slab); hipFree(h->head_ticket);
+  for (void* p : h->allocs16) hipFree(p);
   if (h->stage_dev) hipFree(h->stage_dev);
   if (h->act_buf) hipFree(h->act_buf);
   if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
@@ -795,6 +1071,7 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
   HIPCHK(hipSetDevice(h->cfg.device));
   if (h->cfg.dp_world > 1) return fail("dqnhip_update_async: dp_world > 1 requires dqnhip_update_phase + all-reduce");
   RingUse ring_use(h);
+  RC(sync_dirty16(h));
   if (h->cfg.use_graph && !h->timing && !h->graph_failed) {
     if (idx_host || RO(h)->h_size < 1) RC(refresh_ring(h));
     if (RO(h)->h_size < 1) return fail("replay memory is empty");
@@ -826,6 +1103,7 @@ int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host)
   const int* idx_dev = nullptr;
   if (phase != 0) return run_phase(h, phase, idx_dev);
   RingUse ring_use(h);
+  RC(sync_dirty16(h));
   RC(stage_indices(h, idx_host, &idx_dev));
   return run_phase(h, phase, idx_dev);
 }
@@ -1201,6 +1479,7 @@ int dqnhip_set_params(dqnhip_handle h, int32_t net, int32_t kind, const float* h
   if (sh) HIPCHK(hipMemcpyAsync(h->w_owner->w[net], arena.data(), sh * sizeof(float), hipMemcpyHostToDevice, h->stream));
   if (sh < l.arena) HIPCHK(hipMemcpyAsync(p + sh, arena.data() + sh, (l.arena - sh) * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (kind == DQNHIP_KIND_W) h->w16_dirty[net] = true;
   return 0;
 }
 
@@ -1211,6 +1490,7 @@ int dqnhip_clone_to_target(dqnhip_handle h, int32_t net) {
   const size_t sh = h->shared_fl[net], n = layout_of(h, net).arena;
   if (sh) HIPCHK(hipMemcpyAsync(h->w_owner->w[net + 2], h->w_owner->w[net], sh * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   if (sh < n) HIPCHK(hipMemcpyAsync(h->w[net + 2] + sh, h->w[net] + sh, (n - sh) * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  h->w16_dirty[net + 2] = true;
   return 0;
 }
 
@@ -1242,6 +1522,7 @@ int dqnhip_share_parameters(dqnhip_handle owner, dqnhip_handle other, int32_t nu
   if (!owner || !other || owner == other) return fail("ShareParameters needs two distinct learners");
   if (owner->cfg.device != other->cfg.device) return fail("ShareParameters: both learners must live on the same device");
   if (!same_nets(owner, other)) return fail("ShareParameters: net shapes differ");
+  if (owner->fp16 || other->fp16) return fail("ShareParameters is not supported in fp16 mode (each learner keeps private fp16 weight copies)");
   if (owner->w_owner) return fail("ShareParameters: the owner itself shares another learner's layers; share from the root");
   if (other->w_owner && other->w_owner != owner) return fail("ShareParameters: already sharing with a different owner");
   size_t fa = 0, fc = 0;
@@ -1337,7 +1618,7 @@ int dqnhip_get_kernel_timing(dqnhip_handle h, const char* family, float* avg_ms,
   HIPCHK(hipSetDevice(h->cfg.device));
   int fam = -1;
   for (int i = 0; i < kNumFamily; ++i) if (!strcmp(family, kFamily[i])) fam = i;
-  if (fam < 0) return fail("unknown kernel family '%s' (gemm_fwd_lds_4x2|gemm_fwd_lds_2x2|gemm_fwd_direct|gemm_dgrad|gemm_wgrad|gemm_bwd_pair|adam)", family);
+  if (fam < 0) return fail("unknown kernel family '%s' (gemm_fwd_lds_4x2|gemm_fwd_lds_2x2|gemm_fwd_direct|gemm_dgrad|gemm_wgrad|gemm_bwd_pair|adam|hgemm_fwd|hgemm_dgrad|hgemm_wgrad)", family);
   HIPCHK(hipStreamSynchronize(h->stream));
   double total = 0; int64_t cnt = 0;
   for (auto& r : h->recs) {

@@ -83,7 +83,7 @@ class DQN:
                  gamma=0.99, beta=0.5, tau=0.001, soft_update_freq=1, actor_lr=1e-5, critic_lr=1e-3,
                  momentum=0.95, momentum2=0.999, clip_grad=10.0, memory_threshold=1000, seed=1,
                  device=0, dp_world=1, dp_rank=0, use_graph=False, stream=None, grad_arena=None,
-                 grad_arena_bytes=0, tid=0, save_path="state/dqn"):
+                 grad_arena_bytes=0, tid=0, save_path="state/dqn", precision="fp32", loss_scale=0.0):
         self.lib = capi.load()
         cfg = capi.Config()
         self.lib.dqnhip_default_config(C.byref(cfg), state_size)
@@ -101,6 +101,8 @@ class DQN:
         cfg.stream = stream
         cfg.grad_arena = grad_arena
         cfg.grad_arena_bytes = grad_arena_bytes
+        cfg.precision = {"fp32": 0, "fp16": 1}[precision]
+        cfg.loss_scale = loss_scale
         self.cfg = cfg
         self.h = capi.H()
         self._ck(self.lib.dqnhip_create(C.byref(cfg), C.byref(self.h)))

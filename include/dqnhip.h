@@ -66,6 +66,9 @@ enum dqnhip_param_kind {
  * Replaces: the compile-time constants of src/dqn.hpp:18-21, the Tower()
  * size list of src/dqn.cpp:425,449, the 11 learner gflags of
  * src/dqn.cpp:21-31 and the solver fields set in src/dqn_main.cpp:249-262. */
+#define DQNHIP_FP32 0
+#define DQNHIP_FP16 1
+
 typedef struct dqnhip_config {
   int32_t struct_size;       /* = sizeof(dqnhip_config); ABI check            */
   int32_t minibatch;         /* kMinibatchSize (32); multiple of 32           */
@@ -94,6 +97,13 @@ typedef struct dqnhip_config {
                                 can all-reduce it in place); NULL: library
                                 allocates.  Size: dqnhip_grad_arena_bytes().  */
   size_t grad_arena_bytes;
+  int32_t precision;         /* DQNHIP_FP32 (default): exact-fp32 MFMA, the parity path.
+                                DQNHIP_FP16: tower GEMMs take fp16 operands with fp32
+                                accumulation (BASELINE.json config #5); master weights,
+                                Adam, heads, TD target and losses stay fp32.  Needs
+                                minibatch % 128 == 0 and hidden[i] % 128 == 0.       */
+  float loss_scale;          /* FP16 only: multiplies the built-in static scales of the
+                                back-propagated gradients (0 or 1: defaults)           */
 } dqnhip_config;
 
 typedef struct dqnhip_learner* dqnhip_handle;

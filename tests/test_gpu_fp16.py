@@ -1,0 +1,216 @@
+"""Mixed-precision learner (BASELINE.json config #5: "fp16 MFMA with fp32 accumulate").
+
+Three layers of evidence:
+  1. the fp16 GEMM family itself (csrc/hgemm.hip.h) against a naive device reference on the same
+     fp16 inputs — all epilogues, both tile configurations, ragged K, first-layer shapes;
+  2. the learner's fp16 pipeline against a numpy emulation that rounds to fp16 at exactly the points
+     the kernels do (weights, panels, every stored activation / gradient) and accumulates in
+     fp32 — tight (the only differences are fp32 summation order);
+  3. the learner against the full-precision C oracle — loose: an fp16 forward moves pre-activations
+     by ~1e-3 relative, which flips ReLU' for the units nearest zero; per row that is a several-%
+     change of dQ/da (measured 7-12 % Frobenius per column at width 128-256), averaging out over
+     the minibatch to ~1-2 % in the parameter gradients.  north_star's 1e-4 applies to the fp32 path.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import make_pair
+from oracle import torch_ref
+
+pytestmark = pytest.mark.gpu
+
+SLOPE = np.float32(0.01)
+
+
+def r16(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def lrelu(x):
+    return np.where(x > 0, x, SLOPE * x).astype(np.float32)
+
+
+def unpack(vec, in_dim, hidden, heads):
+    out, off = [], 0
+    for (n, k) in torch_ref.layout(in_dim, hidden, heads):
+        W = vec[off:off + n * k].reshape(n, k); off += n * k
+        b = vec[off:off + n]; off += n
+        out.append((W.astype(np.float32), b.astype(np.float32)))
+    assert off == vec.size
+    return out
+
+
+def tower16(x, params, L):
+    """fp16 tower as the kernels run it: returns (list of stored fp16 activations, fp32 last layer)."""
+    acts = [r16(x)]
+    y = None
+    for i in range(L):
+        W, b = params[i]
+        y = lrelu(acts[-1] @ r16(W).T + b)
+        acts.append(r16(y))
+    return acts, y
+
+
+def heads32(y, params, L):
+    return np.concatenate([y @ W.T + b for (W, b) in params[L:]], axis=1).astype(np.float32)
+
+
+def close16(got, want, name=""):
+    """Same rounding points, different fp32 summation order: almost every element agrees to fp32
+    round-off; a value that lands next to an fp16 rounding boundary may round the other way
+    (1 fp16 ulp = 1e-3 relative) and carry that into the rows it feeds."""
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    scale = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got - want)
+    # (wide layers: each output sums ~1000 units, a few of which rounded the other way: ~1e-3/sqrt(1000))
+    assert np.quantile(err, 0.9) <= 1e-4 * scale, (name, np.quantile(err, 0.9), scale)
+    assert err.max() <= 5e-3 * scale, (name, err.max(), scale)
+
+
+def test_hgemm_kernels(pkg, gpu):
+    lib = pkg.capi.load()
+    lib.dqnhip_test_hgemm.restype = C.c_int
+
+    def run(mode, tile, M, N, K):
+        us, err, ref = C.c_float(), C.c_float(), C.c_float()
+        rc = lib.dqnhip_test_hgemm(mode, tile, M, N, K, 2, C.byref(us), C.byref(err), C.byref(ref))
+        return rc, err.value, ref.value
+
+    cases = [(0, 1, 128, 128, 64), (0, 1, 256, 384, 192), (0, 2, 64, 64, 128), (0, 2, 128, 192, 256),
+             (1, 1, 256, 128, 128), (1, 2, 128, 128, 128), (2, 2, 128, 128, 512), (2, 1, 128, 256, 512),
+             (4, 1, 512, 256, 1024), (5, 2, 256, 256, 384), (0, 0, 1024, 1024, 128), (2, 0, 1024, 128, 512),
+             (0, 1, 4096, 1024, 1024), (2, 2, 1024, 1024, 4096), (3, 0, 256, 192, 64)]
+    for c in cases:
+        rc, err, ref = run(*c)
+        assert rc == 0, c
+        # fp32 accumulation of K products in a different order: ~sqrt(K) * 2^-24 relative to the row norm
+        assert err <= 2e-5 * max(ref, 1.0), (c, err, ref)
+    assert run(0, 2, 64, 64, 64)[0] != 0           # the split-K tile needs K % 128 == 0: refused, not wrong
+    assert run(0, 1, 192, 128, 64)[0] != 0          # 128x128 tile on M = 192: refused
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=128, S=59, hidden=(256, 128, 128, 128), wscale=5.0),
+    dict(B=256, S=58, hidden=(1024, 1024, 1024, 1024), wscale=2.0),
+    dict(B=128, S=77, hidden=(128, 256), wscale=5.0),
+])
+def test_fp16_pipeline_matches_emulation(pkg, gpu, shape):
+    shape = dict(shape)
+    B, S, hid = shape["B"], shape["S"], shape["hidden"]
+    L = len(hid)
+    dqn, orc, data, rng = make_pair(pkg, n_replay=2048, precision="fp16", **shape)
+    s, a, r, mc, nx, term = data
+    for it in range(2):
+        idx = rng.integers(0, 2048, size=B)
+        pa = unpack(dqn.get_params(0), S, hid, (4, 6)); pat = unpack(dqn.get_params(2), S, hid, (4, 6))
+        pc = unpack(dqn.get_params(1), S + 10, hid, (1,)); pct = unpack(dqn.get_params(3), S + 10, hid, (1,))
+        dqn.update_phase(0, idx)
+        # forward passes of phase 0
+        _, yat = tower16(nx[idx], pat, L); mu_t = heads32(yat, pat, L)
+        _, ya = tower16(s[idx], pa, L); mu = heads32(ya, pa, L)
+        _, yct = tower16(np.concatenate([nx[idx], mu_t], 1), pct, L); q_t = heads32(yct, pct, L)[:, 0]
+        _, yc = tower16(np.concatenate([s[idx], a[idx]], 1), pc, L); q1 = heads32(yc, pc, L)[:, 0]
+        close16(dqn.debug_read("actor_out"), mu, "actor_out")
+        close16(dqn.debug_read("q_target"), q_t, "q_target")
+        close16(dqn.debug_read("q_train"), q1, "q_train")
+        dqn.update_phase(1)
+        # critic(s, mu(s)) with the UPDATED critic, then dQ/da through the fp16 tower
+        pc2 = unpack(dqn.get_params(1), S + 10, hid, (1,))
+        acts, y4 = tower16(np.concatenate([s[idx], mu], 1), pc2, L)
+        q2 = heads32(y4, pc2, L)[:, 0]
+        close16(dqn.debug_read("q_policy"), q2, "q_policy")
+        ls = np.float32(4096.0)
+        wq = pc2[L][0][0]
+        dz = r16((-wq[None, :] * np.where(y4 > 0, np.float32(1), SLOPE)) * ls)
+        for i in range(L - 1, 0, -1):
+            dz = r16((dz @ r16(pc2[i][0])) * np.where(acts[i] > 0, np.float32(1), SLOPE))
+        dx = (dz @ r16(pc2[0][0])) / ls
+        d = dx[:, S:S + 10].astype(np.float32)
+        mn = np.array([-1] * 4 + [0, -180, -180, -180, 0, -180], np.float32)
+        mx = np.array([1] * 4 + [100, 180, 180, 180, 100, 180], np.float32)
+        inv = np.where(d < 0, d * (mx - mu) / (mx - mn), np.where(d > 0, d * (mu - mn) / (mx - mn), d))
+        got = dqn.debug_read("dq_da")
+        scale = np.abs(inv).max()
+        # rows whose emulated pre-activation sits within fp32 summation noise of 0 may still flip: bound the
+        # bulk tightly and the tail loosely
+        err = np.abs(got - inv)
+        assert np.quantile(err, 0.99) <= 2e-3 * scale, (np.quantile(err, 0.99), scale)
+        assert np.linalg.norm(got - inv) <= 1e-2 * np.linalg.norm(inv)
+        dqn.update_phase(2)
+    dqn.close(); orc.close()
+
+
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_fp16_update_tracks_fp32_oracle(pkg, gpu, use_graph):
+    B, S, hid = 128, 59, (256, 128, 128, 128)
+    dqn, orc, data, rng = make_pair(pkg, B=B, S=S, hidden=hid, n_replay=2048, wscale=5.0, precision="fp16",
+                                    use_graph=use_graph)
+
+    def fro(x, y):
+        return np.linalg.norm(np.asarray(x, np.float64) - y) / max(np.linalg.norm(y), 1e-300)
+
+    n_it = 3
+    for it in range(n_it):
+        idx = rng.integers(0, 2048, size=B)
+        if use_graph:
+            l1, q1 = dqn.UpdateActorCritic(idx); l2, q2 = orc.update(idx)
+        else:
+            dqn.update_phase(0, idx); orc.update_phase(0, idx)
+            assert fro(dqn.get_params(1, 3), orc.grad_view(1)) <= 0.1
+            dqn.update_phase(1); orc.update_phase(1, idx)
+            assert fro(dqn.get_params(0, 3), orc.grad_view(0)) <= 0.1
+            dqn.update_phase(2); orc.update_phase(2, idx)
+            l1, q1 = dqn.read_stats(); l2, q2 = orc.last_stats()
+        assert abs(l1 - l2) <= 5e-3 * max(1.0, abs(l2)), (l1, l2)
+        assert abs(q1 - q2) <= 5e-3 * max(1.0, abs(q2)), (q1, q2)
+        for name in ("q_target", "q_train", "q_policy", "y"):
+            ref = orc.debug_read(name)
+            assert np.abs(dqn.debug_read(name) - ref).max() <= 2e-2 * max(1.0, np.abs(ref).max()), name
+        np.testing.assert_array_equal(dqn.debug_read("terminal"), orc.debug_read("terminal"))
+    # Adam's normalised step: parameters stay within a few steps of the oracle's, on average within 10 % of one
+    lr = {0: 1e-5, 1: 1e-3}
+    for net in range(4):
+        d = np.abs(dqn.get_params(net) - orc.get_params(net))
+        step = 2 * n_it * lr[net & 1]                       # an element may take opposite-sign steps every update
+        bound = step if net < 2 else 1e-3 * n_it * step     # targets: tau times the accumulated online difference
+        assert d.max() <= bound + 1e-6, (net, d.max())
+        assert d.mean() <= 0.1 * (lr[net & 1] if net < 2 else 1e-3 * n_it * lr[net & 1]) + 1e-8, (net, d.mean())
+    assert dqn.actor_iter() == n_it and dqn.critic_iter() == n_it
+    # acting uses the fp32 master weights with the exact-fp32 kernels
+    st = data[0][:50]
+    np.testing.assert_allclose(dqn.SelectActionGreedily(st), _actor32(dqn, st, S, hid), rtol=1e-4, atol=1e-5)
+    dqn.close(); orc.close()
+
+
+def _actor32(dqn, st, S, hid):
+    p = unpack(dqn.get_params(0), S, hid, (4, 6))
+    x = st.astype(np.float32)
+    for i in range(len(hid)):
+        x = lrelu(x @ p[i][0].T + p[i][1])
+    return heads32(x, p, len(hid))
+
+
+def test_fp16_config_rejects(pkg, gpu):
+    with pytest.raises(pkg.DQNFatal):
+        pkg.DQN(59, minibatch=96, hidden=(256, 128), memory=1000, precision="fp16")      # minibatch % 128
+    with pytest.raises(pkg.DQNFatal):
+        pkg.DQN(59, minibatch=128, hidden=(256, 192), memory=1000, precision="fp16")     # hidden % 128
+    a = pkg.DQN(59, minibatch=128, hidden=(256, 128), memory=1000, precision="fp16")
+    b = pkg.DQN(59, minibatch=128, hidden=(256, 128), memory=1000, precision="fp16")
+    with pytest.raises(pkg.DQNFatal):
+        a.ShareParameters(b, 1, 1)
+    b.close(); a.close()
+
+
+def test_fp16_deterministic(pkg, gpu):
+    res = []
+    for rep in range(2):
+        dqn, orc, data, rng = make_pair(pkg, B=128, S=59, hidden=(256, 128, 128, 128), seed=5, precision="fp16")
+        for it in range(3):
+            dqn.UpdateActorCritic(rng.integers(0, 2048, size=128))
+        res.append([dqn.get_params(n).copy() for n in range(4)])
+        dqn.close(); orc.close()
+    for x, y in zip(*res):
+        np.testing.assert_array_equal(x, y)
