@@ -35,6 +35,7 @@ struct EnvDev {
   int* act; float* arg1; float* arg2; float* rew;
   // totals
   unsigned long long* n_steps; unsigned long long* n_episodes; unsigned long long* n_goals; double* reward_sum;
+  const float* eps;                // device scalar: this call's epsilon (not a kernel argument, so a captured step replays)
 };
 
 __device__ __forceinline__ float env_u01(unsigned long long seed, unsigned long long g, int w, int k) {
@@ -122,7 +123,8 @@ __global__ void k_env_init(EnvDev e) {
 }
 
 // one environment step of every worker (block = one wave = one worker)
-__global__ void k_env_step(EnvDev e, float epsilon) {
+__global__ void k_env_step(EnvDev e) {
+  const float epsilon = e.eps[0];
   extern __shared__ float s_next[];
   __shared__ float s_ao[16];
   const int w = blockIdx.x, lane = threadIdx.x;
@@ -249,6 +251,9 @@ __global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const De
 }
 
 // publish the ring bookkeeping after all flushes of this step
+template <int UNUSED = 0>
+__global__ void k_set_float(float* p, float v) { *p = v; }
+
 __global__ void k_env_commit(EnvDev e, Ring ring, DevState* st) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int head = st->ring_head, size = st->ring_size;

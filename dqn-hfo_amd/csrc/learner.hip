@@ -621,7 +621,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     RC(sumsq_launch(h, 0));
     RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena));
     RC(sync_w16(h, st, DQNHIP_ACTOR)); RC(sync_w16(h, st, DQNHIP_ACTOR_TARGET));
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(64), 0, st, h->st, critic_tail, actor_tail,
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(256), 0, st, h->st, critic_tail, actor_tail,
                        (const float*)h->loss_partial, h->n_head_blocks,
                        dp ? (const double*)nullptr : (const double*)h->q_partial, B,
                        (float)(B * h->cfg.dp_world));
@@ -764,7 +764,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
   if (phase == 2) {
     if (dp) { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena)); }
     else RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena));
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(64), 0, st, h->st, critic_tail, actor_tail,
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(256), 0, st, h->st, critic_tail, actor_tail,
                        (const float*)h->loss_partial, h->n_head_blocks,
                        dp ? (const double*)nullptr : (const double*)h->q_partial, B,
                        (float)(B * h->cfg.dp_world));
@@ -1647,7 +1647,11 @@ struct dqnhip_env {
   int Npad = 0;
   float* acts[kMaxL + 1] = {nullptr};
   std::vector<void*> allocs;
+  float* eps_dev = nullptr;
+  hipGraphExec_t graph[2] = {nullptr, nullptr};   // one batched step / kEnvUnroll steps, captured on first use
+  bool graph_failed = false;
 };
+constexpr int kEnvUnroll = 16;
 
 namespace {
 template <typename T>
@@ -1685,6 +1689,7 @@ int dqnhip_env_create(dqnhip_handle h, const dqnhip_env_config* cfg, dqnhip_env_
   RC(env_alloc(e, &d.n_steps, N)); RC(env_alloc(e, &d.n_episodes, N)); RC(env_alloc(e, &d.n_goals, N)); RC(env_alloc(e, &d.reward_sum, N));
   e->acts[0] = d.cur;
   for (int i = 1; i <= h->L; ++i) RC(env_alloc(e, &e->acts[i], Np * h->la.kp[i]));
+  RC(env_alloc(e, &e->eps_dev, 16)); d.eps = e->eps_dev;
   hipLaunchKernelGGL(k_env_init, dim3(d.N), dim3(64), d.SP * sizeof(float), h->stream, d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1697,7 +1702,46 @@ int dqnhip_env_destroy(dqnhip_env_handle e) {
   hipSetDevice(e->h->cfg.device);
   hipStreamSynchronize(e->h->stream);
   for (void* p : e->allocs) hipFree(p);
+  for (int i = 0; i < 2; ++i) if (e->graph[i]) hipGraphExecDestroy(e->graph[i]);
   delete e;
+  return 0;
+}
+
+// one batched env step on the learner's stream: SelectActionGreedily for all workers, then the
+// per-worker epsilon draw / GetAction / reward / episode bookkeeping / AddTransitions
+static int env_one_step(dqnhip_env* e) {
+  dqnhip_learner* h = e->h;
+  const EnvDev& d = e->d;
+  hipStream_t st = h->stream;
+  const NetLayout& la = h->la;
+  FwdPass fp{DQNHIP_ACTOR, &la, e->acts};
+  RC(tower_forward(h, st, &fp, 1, e->Npad));
+  HeadArgs a{}; a.X = e->acts[la.L]; a.ldx = la.dims[la.L]; a.H = la.dims[la.L]; a.rows = e->Npad;
+  a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.b = wat(h, DQNHIP_ACTOR, la.hb_off); a.out16 = d.out16;
+  RC((head_forward<kNO, HEAD_ACTOR>(h, st, a)));
+  hipLaunchKernelGGL(k_env_step, dim3(d.N), dim3(64), d.SP * sizeof(float), st, d);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), (d.T + d.SP) * sizeof(float), st, d, RO(h)->ring,
+                     (const DevState*)RO(h)->st, h->cfg.gamma);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(k_env_commit, dim3(1), dim3(64), 0, st, d, RO(h)->ring, RO(h)->st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int env_capture(dqnhip_env* e, int which) {
+  dqnhip_learner* h = e->h;
+  hipGraph_t graph = nullptr;
+  HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  const int n = which ? kEnvUnroll : 1;
+  for (int s = 0; s < n && !rc; ++s) rc = env_one_step(e);
+  hipError_t err = hipStreamEndCapture(h->stream, &graph);
+  if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+  if (err != hipSuccess) return fail("hipStreamEndCapture (env): %s", hipGetErrorString(err));
+  err = hipGraphInstantiate(&e->graph[which], graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (err != hipSuccess) return fail("hipGraphInstantiate (env): %s", hipGetErrorString(err));
   return 0;
 }
 
@@ -1707,25 +1751,26 @@ int dqnhip_env_step(dqnhip_env_handle e, float epsilon, int32_t n_steps) {
   if (n_steps < 1) return fail("n_steps must be >= 1");
   dqnhip_learner* h = e->h;
   HIPCHK(hipSetDevice(h->cfg.device));
-  const EnvDev& d = e->d;
   hipStream_t st = h->stream;
-  const NetLayout& la = h->la;
   RingUse ring_use(h);
-  for (int s = 0; s < n_steps; ++s) {
-    // SelectActionGreedily(*actor_net_, states) for all workers in one batched forward
-    FwdPass fp{DQNHIP_ACTOR, &la, e->acts};
-    RC(tower_forward(h, st, &fp, 1, e->Npad));
-    HeadArgs a{}; a.X = e->acts[la.L]; a.ldx = la.dims[la.L]; a.H = la.dims[la.L]; a.rows = e->Npad;
-    a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.b = wat(h, DQNHIP_ACTOR, la.hb_off); a.out16 = d.out16;
-    RC((head_forward<kNO, HEAD_ACTOR>(h, st, a)));
-    hipLaunchKernelGGL(k_env_step, dim3(d.N), dim3(64), d.SP * sizeof(float), st, d, epsilon);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), (d.T + d.SP) * sizeof(float), st, d, RO(h)->ring,
-                       (const DevState*)RO(h)->st, h->cfg.gamma);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_env_commit, dim3(1), dim3(64), 0, st, d, RO(h)->ring, RO(h)->st);
-    HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(k_set_float<0>, dim3(1), dim3(1), 0, st, e->eps_dev, epsilon);
+  HIPCHK(hipGetLastError());
+  // the step is a fixed launch sequence (9 launches at L = 4, ~6 us each when launch-bound): replay it
+  // as a hipGraph unless the learner's layers may be re-pointed (sharing) or graphs are off
+  const bool use_graph = h->cfg.use_graph && !e->graph_failed && !h->timing && !h->w_owner && !h->ring_owner;
+  int s = 0;
+  if (use_graph) {
+    for (int which = 1; which >= 0; --which) {
+      const int n = which ? kEnvUnroll : 1;
+      while (n_steps - s >= n) {
+        if (!e->graph[which] && env_capture(e, which)) { e->graph_failed = true; break; }
+        HIPCHK(hipGraphLaunch(e->graph[which], st));
+        s += n;
+      }
+      if (e->graph_failed) break;
+    }
   }
+  for (; s < n_steps; ++s) RC(env_one_step(e));
   RO(h)->ring_stale = true;
   return 0;
 }

@@ -529,21 +529,29 @@ __global__ void k_tails(const float* loss_partial, int n_loss, const double* q_p
 // avg_q = std::accumulate(q, 0.0) / float(B) (src/dqn.cpp:915-916): the double sum
 // is taken from the per-block double partials when they are local (single GPU),
 // from the all-reduced float tail under data parallelism.
-__global__ void k_tick(DevState* st, float* critic_tail, float* actor_tail, const float* loss_partial,
-                       int n_loss, const double* q_partial, int n_q, float batch) {
-  // one wave: strided partial sums, fixed butterfly -> deterministic
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_tick(DevState* st, float* critic_tail, float* actor_tail, const float* loss_partial,
+                                              int n_loss, const double* q_partial, int n_q, float batch) {
+  // one block: strided partial sums, fixed butterfly + fixed cross-wave order -> deterministic
+  __shared__ float sdot[4];
+  __shared__ double sq[4];
+  const int t = threadIdx.x;
   double qs = 0.0;
   if (q_partial != nullptr) {          // single GPU: reduce the per-block partials here
     float dot = 0.0f;
-    for (int i = lane; i < n_loss; i += 64) dot += loss_partial[i];
-    for (int i = lane; i < n_q; i += 64) qs += q_partial[i];
+    for (int i = t; i < n_loss; i += 256) dot += loss_partial[i];
+    for (int i = t; i < n_q; i += 256) qs += q_partial[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { dot += __shfl_xor(dot, off, 64); qs += __shfl_xor(qs, off, 64); }
-    if (lane == 0) { critic_tail[0] = dot / batch / 2.0f; actor_tail[1] = (float)qs; }   // EuclideanLoss: dot / num / 2
+    if ((t & 63) == 0) { sdot[t >> 6] = dot; sq[t >> 6] = qs; }
+    __syncthreads();
+    if (t == 0) {
+      dot = (sdot[0] + sdot[1]) + (sdot[2] + sdot[3]);
+      qs = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+      critic_tail[0] = dot / batch / 2.0f; actor_tail[1] = (float)qs;     // EuclideanLoss: dot / num / 2
+    }
   } else qs = (double)actor_tail[1];   // data parallel: tails were all-reduced
-  if (lane != 0) return;
-  st->critic_loss = q_partial != nullptr ? critic_tail[0] : critic_tail[0];
+  if (t != 0) return;
+  st->critic_loss = critic_tail[0];
   st->avg_q = (float)(qs / (double)batch);
   st->actor_iter += 1; st->critic_iter += 1; st->update_counter += 1;
 }

@@ -42,6 +42,34 @@ def test_env_front_end_matches_oracle(pkg, gpu, workers, eps):
     env.close(); oenv.close(); dqn.close(); orc.close()
 
 
+def test_env_graph_replay_matches_oracle(pkg, gpu):
+    """use_graph: the batched step is replayed as captured hipGraphs (16-step and 1-step), epsilon is
+    a device scalar; 37 = 2 x 16 + 5 exercises both graphs, a changed epsilon the scalar."""
+    workers = 64
+    dqn, orc, data, rng = make_pair(pkg, B=32, S=59, hidden=(128, 64, 64, 64), n_replay=100, capacity=20000,
+                                    use_graph=True)
+    kw = dict(max_steps=40, unum=7, p_end=0.05, p_goal=0.4, seed=11)
+    env = pkg.EnvFrontEnd(dqn, workers, **kw)
+    oenv = c_oracle.OracleEnv(orc, workers, **kw)
+    total = 0
+    for eps, n in ((0.3, 37), (0.05, 16), (1.0, 3)):
+        env.step(eps, n); oenv.step(eps, n); total += n
+        o = oenv.read()
+        np.testing.assert_array_equal(env.debug_read("action").astype(np.int32), o["action"])
+        np.testing.assert_array_equal(env.debug_read("episode_len").astype(np.int32), o["episode_len"])
+        np.testing.assert_allclose(env.debug_read("state"), o["state"], atol=1e-6)
+    s1, s2 = env.stats(), oenv.stats()
+    assert s1[0] == s2[0] == total * workers and s1[1] == s2[1] and s1[3] == s2[3] and s1[1] > 0
+    assert dqn.memory_size() == orc.memory_size()
+    a, b = dqn.read_memory(0, dqn.memory_size()), orc.read_memory(0, orc.memory_size())
+    np.testing.assert_allclose(a[0], b[0], atol=1e-6); np.testing.assert_allclose(a[3], b[3], atol=2e-4)
+    np.testing.assert_array_equal(a[5], b[5])
+    loss, q = dqn.UpdateActorCritic()                       # the captured update and the captured steps coexist
+    env.step(0.1, 20); oenv.step(0.1, 20)
+    assert dqn.memory_size() == orc.memory_size() and np.isfinite(loss)
+    env.close(); oenv.close(); dqn.close(); orc.close()
+
+
 def test_env_wraps_ring_and_rejects_bad_config(pkg, gpu):
     dqn = pkg.DQN(59, minibatch=32, hidden=(64,), memory=3000)
     with pytest.raises(pkg.DQNFatal):
