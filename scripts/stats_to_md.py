@@ -1,0 +1,19 @@
+"""rocprofv3 kernel_stats.csv -> markdown table for profiles/ (usage: stats_to_md.py csv n_updates title cmd)."""
+import csv, sys
+f, n_upd, title, cmd = sys.argv[1], float(sys.argv[2]), sys.argv[3], sys.argv[4]
+rows = list(csv.DictReader(open(f)))
+print("# %s\n" % title)
+print("Command: `%s` (MI355X, via gpurun).  %d updates in the trace (warm-up + timed + the 20-update event-timing pass).\n" % (cmd, n_upd))
+print("| kernel | calls | calls/update | avg (us) | us/update | % |")
+print("|---|---|---|---|---|---|")
+tot = 0.0
+for r in rows:
+    name = r["Name"].replace("dqnhip::", "").replace("void ", "")
+    if "(" in name: name = name[:name.index("(")]
+    calls = int(r["Calls"]); avg = float(r["AverageNs"]) / 1e3
+    per = calls / n_upd
+    if name.startswith("__amd_rocclr") or name.startswith("k_add_transitions") or per < 0.5:
+        continue
+    tot += avg * per
+    print("| `%s` | %d | %.1f | %.2f | %.1f | %s |" % (name, calls, per, avg, avg * per, r["Percentage"]))
+print("\nSum of kernel time per update: **%.0f us** (prefill / copies excluded)." % tot)
