@@ -361,19 +361,17 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   __syncthreads();
   // this chunk's partial: row groups added in fixed order
   float* my_slab = a.slab + ((size_t)rc * nkb + blockIdx.x) * NH * 64;
-  if (rg == 0) {
+  if (rg < NH) {                                      // wave j folds head j (NH <= 16 waves)
+    const int j = rg;
+    float v = 0.0f;
 #pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      float v = 0.0f;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) v += s_acc[(g * NH + j) * 64 + kc];
-      my_slab[j * 64 + kc] = v;
-    }
-    if (blockIdx.x == 0 && kc < NH) {                 // partial bias gradient of this chunk
-      float v = 0.0f;
-      for (int m = 0; m < r1 - r0; ++m) v += s_dy[m * NH + kc];
-      a.slab[(size_t)RC * nkb * NH * 64 + rc * 16 + kc] = v;
-    }
+    for (int g = 0; g < 16; ++g) v += s_acc[(g * NH + j) * 64 + kc];
+    my_slab[j * 64 + kc] = v;
+  }
+  if (rg == NH && blockIdx.x == 0 && kc < NH) {       // partial bias gradient of this chunk (a spare wave)
+    float v = 0.0f;
+    for (int m = 0; m < r1 - r0; ++m) v += s_dy[m * NH + kc];
+    a.slab[(size_t)RC * nkb * NH * 64 + rc * 16 + kc] = v;
   }
   // publish the slab, take a ticket; the last arriver reduces (placement independent)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -388,26 +386,28 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   __syncthreads();
   if (!s_last) return;
   float ssq = 0.0f;
-  if (rg == 0) {
+  if (rg < NH) {
+    const int j = rg;
+    float v = 0.0f;
+    for (int c = 0; c < RC; ++c) v += a.slab[((size_t)c * nkb + blockIdx.x) * NH * 64 + j * 64 + kc];
+    a.dW[(size_t)j * a.H + k] = v;
+    ssq = v * v;
+  } else if (rg == NH && blockIdx.x == 0 && kc < NH) {
+    float v = 0.0f;
+    for (int c = 0; c < RC; ++c) v += a.slab[(size_t)RC * nkb * NH * 64 + c * 16 + kc];
+    a.db[kc] = v;
+    ssq = v * v;
+  }
 #pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      float v = 0.0f;
-      for (int c = 0; c < RC; ++c) v += a.slab[((size_t)c * nkb + blockIdx.x) * NH * 64 + j * 64 + kc];
-      a.dW[(size_t)j * a.H + k] = v;
-      ssq = fmaf(v, v, ssq);
-    }
-    if (blockIdx.x == 0 && kc < NH) {
-      float v = 0.0f;
-      for (int c = 0; c < RC; ++c) v += a.slab[(size_t)RC * nkb * NH * 64 + c * 16 + kc];
-      a.db[kc] = v;
-      ssq = fmaf(v, v, ssq);
-    }
+  for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
+  if (kc == 0) s_acc[rg] = ssq;                        // s_acc is free again
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.0f;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
-    if (kc == 0) {
-      if (a.partial != nullptr) a.partial[blockIdx.x] = ssq;
-      a.ticket[blockIdx.x] = 0;                        // re-arm for the next launch
-    }
+    for (int g = 0; g <= NH; ++g) t += s_acc[g];        // heads in order, then the bias wave
+    if (a.partial != nullptr) a.partial[blockIdx.x] = t;
+    a.ticket[blockIdx.x] = 0;                          // re-arm for the next launch
   }
 }
 
