@@ -49,6 +49,20 @@ for u in range(3):                       # on-device sampling through the DP pat
     dp.update(None)
 l, q = dqn_dp.read_stats()
 assert np.isfinite(l) and np.isfinite(q)
+# the mixed-precision learner through the same three phases (bit-identical: same kernels, same order)
+B16, hid16 = 128, (256, 128)
+w16 = [torch_ref.init_params_np(rng, S, hid16, a) * 5 for a in (True, False)]
+idx16 = rng.integers(0, 1024, size=(3, B16))
+d16, dp16 = par.make_hip_data_parallel(pkg, S, 0, 1, 0, minibatch=B16, hidden=hid16, memory=4096, seed=2, precision="fp16")
+r16 = pkg.DQN(S, minibatch=B16, hidden=hid16, memory=4096, seed=2, precision="fp16")
+for d in (d16, r16):
+    for net in (0, 1):
+        d.set_params(net, w16[net]); d.CloneNet(net)
+    d.add_transitions_arrays(*data)
+for u in range(3):
+    dp16.update(idx16[u]); r16.UpdateActorCritic(idx16[u])
+for net in range(4):
+    np.testing.assert_array_equal(d16.get_params(net), r16.get_params(net))
 dist.barrier(); dist.destroy_process_group()
 print("DP-1 OK")
 '''
