@@ -70,7 +70,8 @@ struct NetLayout {
 
 void layout_init(NetLayout& l, int in_dim, const dqnhip_config& c, bool actor) {
   l.L = c.num_hidden; l.in_dim = in_dim; l.NH = actor ? kNO : 1;
-  l.dims[0] = in_dim; l.kp[0] = round_up(in_dim, 64);
+  // fp16 mode: 128-wide first panel so that the fp16 weight arena mirrors this one offset for offset
+  l.dims[0] = in_dim; l.kp[0] = round_up(in_dim, c.precision == DQNHIP_FP16 ? 128 : 64);
   for (int i = 0; i < l.L; ++i) { l.dims[i + 1] = c.hidden[i]; l.kp[i + 1] = c.hidden[i]; }
   size_t off = 0, dense = 0;
   int part = 0;
@@ -143,7 +144,8 @@ struct dqnhip_learner {
   bool fp16 = false;
   float ls_c = 1.f, ls_q = 1.f, ls_a = 1.f;  // static loss scales: critic step, dQ/da pass, actor step
   int k16[2][kMaxL + 1] = {{0}};             // fp16 panel widths per net kind (k16[.][0] = in_dim rounded to 128)
-  h16* w16[4][kMaxL] = {{nullptr}};          // [N_out][k16]
+  h16* w16a[4] = {nullptr, nullptr, nullptr, nullptr};   // fp16 mirror of each weight arena (written by the Adam pass)
+  h16* w16[4][kMaxL] = {{nullptr}};          // = w16a[net] + w_off[i]: [N_out][kp]
   h16* wt16[2][kMaxL] = {{nullptr}};         // [k16][N_out], online nets only (dgrad operand)
   h16* act16[5][kMaxL + 1] = {{nullptr}};    // [B][k16]
   h16* actT16[5][kMaxL + 1] = {{nullptr}};   // [k16][B], passes 1 (actor) and 3 (critic train): wgrad operand
@@ -376,7 +378,7 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
 template <int NH, int MODE>
 int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nullptr) {
   HeadArgs2 a2{}; a2.p[0] = a; if (b) a2.p[1] = *b;
-  hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(a.rows, b ? 2 : 1), dim3(256), 0, st, a2);
+  hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(std::min(a.rows, 1024), b ? 2 : 1), dim3(256), 0, st, a2);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -384,7 +386,7 @@ int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nu
 template <int NH>
 int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
   // row chunks: enough blocks to cover the chip a few times over, <= 64 rows per chunk
-  const int RC = std::max(1, std::min(16, a.rows / 64));
+  const int RC = std::max(1, std::min(64, a.rows / 64));
   const int rows_c = (a.rows + RC - 1) / RC;
   const size_t lds = ((size_t)rows_c * NH + 16 * NH * 64 + 16) * sizeof(float);
   a.slab = h->head_slab; a.ticket = h->head_ticket;
@@ -398,6 +400,7 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   AdamArgs a{};
   a.w = h->w[net] + begin; a.g = h->g[net] + begin; a.m = h->m[net] + begin; a.v = h->v[net] + begin;
   a.wt = h->w[net + 2] + begin;
+  if (h->fp16) { a.w16 = h->w16a[net] + begin; a.wt16 = h->w16a[net + 2] + begin; }
   const size_t sh = h->shared_fl[net];                 // shared prefix of this net's arena (floats)
   if (sh > begin) {
     a.w_sh = h->w_owner->w[net] + begin; a.wt_sh = h->w_owner->w[net + 2] + begin;
@@ -437,18 +440,21 @@ int hgemm_timed(H* h, hipStream_t st, const HGemm& g, int fam) {
   return 0;
 }
 
-// fp32 master weights of `net` -> fp16 [N][k16] (+ transposed for the online nets)
-int sync_w16(H* h, hipStream_t st, int net) {
+// fp32 master weights of `net` -> fp16 mirror [N][kp] (unless only_t) + transposed copies for the
+// online nets.  The Adam pass keeps the mirrors current by itself; after it only the transposes
+// are rebuilt (only_t).  The full form runs after host-side weight changes (w16_dirty).
+int sync_w16(H* h, hipStream_t st, int net, bool only_t = false) {
   const NetLayout& l = layout_of(h, net);
   const int kind = net & 1;
+  if (only_t && net >= 2) return 0;
   Cvt16Batch b{};
   for (int i = 0; i < l.L; ++i) {
-    cvt16_add(b, h->w[net] + l.w_off[i], l.kp[i], l.dims[i + 1], l.kp[i], h->w16[net][i], h->k16[kind][i],
+    cvt16_add(b, h->w[net] + l.w_off[i], l.kp[i], l.dims[i + 1], l.kp[i], only_t ? nullptr : h->w16[net][i], h->k16[kind][i],
               net < 2 ? h->wt16[net][i] : nullptr, l.dims[i + 1], 1.0f);
     if (b.n == 8) { HIPCHK(cvt16_launch(b, st)); b = Cvt16Batch{}; }
   }
   HIPCHK(cvt16_launch(b, st));
-  h->w16_dirty[net] = false;
+  if (!only_t) h->w16_dirty[net] = false;
   return 0;
 }
 
@@ -587,7 +593,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
   if (phase == 1) {
     RC(sumsq_launch(h, 1));
     RC(adam_launch(h, st, 1, h->part_dp, h->n_part_dp, 0, lc.arena));
-    RC(sync_w16(h, st, DQNHIP_CRITIC)); RC(sync_w16(h, st, DQNHIP_CRITIC_TARGET));
+    RC(sync_w16(h, st, DQNHIP_CRITIC, true));          // the Adam pass wrote the fp16 mirrors of critic and target
     RC(tower_forward16(h, st, 4, DQNHIP_CRITIC, B));
     {
       HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
@@ -620,7 +626,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
   if (phase == 2) {
     RC(sumsq_launch(h, 0));
     RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena));
-    RC(sync_w16(h, st, DQNHIP_ACTOR)); RC(sync_w16(h, st, DQNHIP_ACTOR_TARGET));
+    RC(sync_w16(h, st, DQNHIP_ACTOR, true));
     hipLaunchKernelGGL(k_tick, dim3(1), dim3(256), 0, st, h->st, critic_tail, actor_tail,
                        (const float*)h->loss_partial, h->n_head_blocks,
                        dp ? (const double*)nullptr : (const double*)h->q_partial, B,
@@ -928,7 +934,7 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   h->n_part_dp = 1024; RC(dalloc(&h->part_dp, h->n_part_dp));
   {
     const int Hmax = std::max(h->la.dims[L], h->lc.dims[L]);
-    RC(dalloc(&h->head_slab, (size_t)16 * (Hmax / 64) * kNO * 64 + 16 * 16));
+    RC(dalloc(&h->head_slab, (size_t)64 * (Hmax / 64) * kNO * 64 + 64 * 16));
     HIPCHK(hipMalloc(&h->head_ticket, (Hmax / 64) * sizeof(int)));
     HIPCHK(hipMemsetAsync(h->head_ticket, 0, (Hmax / 64) * sizeof(int), h->stream));
   }
@@ -946,13 +952,13 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
     };
     for (int kind = 0; kind < 2; ++kind) {
       const NetLayout& l = kind ? h->lc : h->la;
-      h->k16[kind][0] = round_up(l.in_dim, 128);
-      for (int i = 1; i <= L; ++i) h->k16[kind][i] = l.dims[i];
+      for (int i = 0; i <= L; ++i) h->k16[kind][i] = l.kp[i];
     }
     for (int net = 0; net < 4; ++net) {
       const NetLayout& l = layout_of(h, net);
+      RC(halloc(&h->w16a[net], l.arena));
       for (int i = 0; i < L; ++i) {
-        RC(halloc(&h->w16[net][i], (size_t)l.dims[i + 1] * h->k16[net & 1][i]));
+        h->w16[net][i] = h->w16a[net] + l.w_off[i];
         if (net < 2) RC(halloc(&h->wt16[net][i], (size_t)h->k16[net & 1][i] * l.dims[i + 1]));
       }
     }

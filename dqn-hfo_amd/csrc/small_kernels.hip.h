@@ -191,45 +191,55 @@ struct HeadArgs2 { HeadArgs p[2]; };
 
 template <int NH, int MODE>
 __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
-  // one block per row: the 4 waves split K (each lane one float4 strip per 1024 columns),
-  // butterfly within the wave, then the 4 wave sums are added in fixed order
+  // one block per row (grid-strided when there are more rows than blocks): the 4 waves split K
+  // (each lane one float4 strip per 1024 columns), butterfly within the wave, then the 4 wave
+  // sums are added in fixed order.  For H <= 1024 the head weights stay in registers across rows.
   const HeadArgs& a = a2.p[blockIdx.y];
-  const int row = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ float s_acc[4][NH];
-  float acc[NH];
+  const bool hoist = a.H <= 1024;
+  f32x4 wreg[NH];
+  if (hoist) {
 #pragma unroll
-  for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
-  const float* x = a.X + (size_t)row * a.ldx;
-  for (int k = threadIdx.x * 4; k < a.H; k += 1024) {
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
-#pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k);
-      acc[j] = fmaf(xv.x, wv.x, acc[j]); acc[j] = fmaf(xv.y, wv.y, acc[j]);
-      acc[j] = fmaf(xv.z, wv.z, acc[j]); acc[j] = fmaf(xv.w, wv.w, acc[j]);
-    }
+    for (int j = 0; j < NH; ++j)
+      wreg[j] = (threadIdx.x * 4 < a.H) ? *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + threadIdx.x * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
+    float acc[NH];
 #pragma unroll
-  for (int j = 0; j < NH; ++j) {
+    for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
+    const float* x = a.X + (size_t)row * a.ldx;
+    for (int k = threadIdx.x * 4; k < a.H; k += 1024) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
-    if (lane == 0) s_acc[wave][j] = acc[j];
-  }
-  __syncthreads();
-  if (threadIdx.x < kAP) {
-    const int j = threadIdx.x;
-    float v = 0.0f;
-    if (j < NH) v = ((s_acc[0][j] + s_acc[1][j]) + (s_acc[2][j] + s_acc[3][j])) + a.b[j];
-    if constexpr (MODE == HEAD_ACTOR) {
-      a.out16[(size_t)row * kAP + j] = v;
-      if (a.xc != nullptr && j < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + j] = v;
-    } else {
-      if (j == 0) {
-        a.q[row] = v;
-        if constexpr (MODE == HEAD_Q_POLICY) a.qsum_partial[row] = (double)v;   // summed in row order by k_tick / k_tails
+      for (int j = 0; j < NH; ++j) {
+        const f32x4 wv = hoist ? wreg[j] : *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k);
+        acc[j] = fmaf(xv.x, wv.x, acc[j]); acc[j] = fmaf(xv.y, wv.y, acc[j]);
+        acc[j] = fmaf(xv.z, wv.z, acc[j]); acc[j] = fmaf(xv.w, wv.w, acc[j]);
       }
     }
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
+      if (lane == 0) s_acc[wave][j] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < kAP) {
+      const int j = threadIdx.x;
+      float v = 0.0f;
+      if (j < NH) v = ((s_acc[0][j] + s_acc[1][j]) + (s_acc[2][j] + s_acc[3][j])) + a.b[j];
+      if constexpr (MODE == HEAD_ACTOR) {
+        a.out16[(size_t)row * kAP + j] = v;
+        if (a.xc != nullptr && j < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + j] = v;
+      } else {
+        if (j == 0) {
+          a.q[row] = v;
+          if constexpr (MODE == HEAD_Q_POLICY) a.qsum_partial[row] = (double)v;   // summed in row order by k_tick / k_tails
+        }
+      }
+    }
+    __syncthreads();                       // s_acc is rewritten by the next row
   }
 }
 
@@ -437,6 +447,7 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, size
 // ~7 separate param-sized passes plus the separate soft-update pass.
 struct AdamArgs {
   float* w; float* g; float* m; float* v; float* wt;
+  _Float16* w16; _Float16* wt16;             // fp16 mode: fp16 mirrors of w / wt, same offsets (null otherwise)
   float* w_sh; float* wt_sh; size_t n4_sh;   // float4 [0, n4_sh) of w / wt live in another learner's arena (ShareParameters)
   size_t n4;                      // arena length / 4
   const float* partial; int n_partial;
@@ -499,6 +510,11 @@ __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int n
     reinterpret_cast<f32x4*>(a.v)[i] = v;
     *wq = w;
     if (soft) *tq = wt;
+    if (a.w16 != nullptr) {
+      typedef __attribute__((ext_vector_type(4))) _Float16 h16x4_t;
+      reinterpret_cast<h16x4_t*>(a.w16)[i] = h16x4_t{(_Float16)wp[0], (_Float16)wp[1], (_Float16)wp[2], (_Float16)wp[3]};
+      if (soft) reinterpret_cast<h16x4_t*>(a.wt16)[i] = h16x4_t{(_Float16)tp[0], (_Float16)tp[1], (_Float16)tp[2], (_Float16)tp[3]};
+    }
   }
 }
 __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {

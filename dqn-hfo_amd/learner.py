@@ -121,11 +121,12 @@ class DQN:
 
     # -- plumbing -----------------------------------------------------------------
     @staticmethod
-    def grad_arena_bytes(state_size, minibatch, hidden):
+    def grad_arena_bytes(state_size, minibatch, hidden, precision="fp32"):
         lib = capi.load()
         cfg = capi.Config()
         lib.dqnhip_default_config(C.byref(cfg), state_size)
         cfg.minibatch = minibatch
+        cfg.precision = {"fp32": 0, "fp16": 1}[precision]
         cfg.num_hidden = len(hidden)
         for i, hsz in enumerate(hidden):
             cfg.hidden[i] = hsz

@@ -41,7 +41,7 @@ def make_hip_data_parallel(pkg, state_size, rank, world, device, group=None, **d
     torch.cuda.set_device(device)
     hidden = dqn_kwargs.get("hidden", (1024, 512, 256, 128))
     B = dqn_kwargs.get("minibatch", 32)
-    nbytes = pkg.DQN.grad_arena_bytes(state_size, B, hidden)
+    nbytes = pkg.DQN.grad_arena_bytes(state_size, B, hidden, dqn_kwargs.get("precision", "fp32"))
     arena = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda:%d" % device)
     stream = torch.cuda.current_stream().cuda_stream
     dqn = pkg.DQN(state_size, device=device, dp_world=world, dp_rank=rank, stream=stream,
