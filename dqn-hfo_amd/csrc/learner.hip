@@ -386,7 +386,7 @@ int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nu
 template <int NH>
 int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
   // row chunks: enough blocks to cover the chip a few times over, <= 64 rows per chunk
-  const int RC = std::max(1, std::min(64, a.rows / 64));
+  const int RC = std::max(1, std::min(16, a.rows / 64));   // (64 chunks measured slower at B=4096: the last arriver's slab walk)
   const int rows_c = (a.rows + RC - 1) / RC;
   const size_t lds = ((size_t)rows_c * NH + 16 * NH * 64 + 16) * sizeof(float);
   a.slab = h->head_slab; a.ticket = h->head_ticket;
