@@ -68,7 +68,10 @@ struct HGCfg {
   // A stage is 256 row slots of 128 B (32 KiB).  <2,2>: slots 0-127 = A rows, 128-255 = B rows of one
   // 64-deep K tile.  <1,1>: two 64-deep sub-tiles, each 64 A rows + 64 B rows (K step 128).
   static constexpr int KSTEP = (WK == 1) ? 64 : 128;
-  static constexpr int STAGE = 32768, STAGES = 4;
+#ifndef HG_STAGES
+#define HG_STAGES 4
+#endif
+  static constexpr int STAGE = 32768, STAGES = HG_STAGES;
   static constexpr int LOADS = 8;                                           // 1-KiB pieces per wave per stage
   static constexpr int NSUB = (WK == 1) ? 4 : 2;                            // k16 steps per wave per stage
   static constexpr int TLD = BN + 4;                                        // fp32 epilogue tile row stride
@@ -164,13 +167,21 @@ __global__ __launch_bounds__(256, 1) void hgemm_nt(HGemm g) {
 #pragma unroll
       for (int i = 0; i < LOADS; ++i) issue1(s, i);
     }
-  if (nk >= 3) hg_wait_vm<2 * LOADS>(); else if (nk == 2) hg_wait_vm<LOADS>(); else hg_wait_vm<0>();
+  {                                        // stage 0 landed: the other prologue stages may stay in flight
+    const int newer = (nk < STAGES - 1 ? nk : STAGES - 1) - 1;
+    if (newer >= 3) hg_wait_vm<3 * LOADS>(); else if (newer == 2) hg_wait_vm<2 * LOADS>(); else if (newer == 1) hg_wait_vm<LOADS>(); else hg_wait_vm<0>();
+  }
   __builtin_amdgcn_s_barrier();
   load_frags(0, 0, 0);
   auto stage_body = [&](int kt, auto more_c) {
     constexpr bool more = decltype(more_c)::value;      // stage kt+3 exists: issue its pieces between the MFMAs
     if (more || kt + 1 < nk) {
-      if (more || kt + 2 < nk) hg_wait_vm<LOADS>(); else hg_wait_vm<0>();
+      // stage kt+1 landed: stages kt+2 .. kt+STAGES-2 may stay in flight
+      if constexpr (more) hg_wait_vm<(STAGES - 3) * LOADS>();
+      else {
+        const int newer = (nk - 2 - kt) < (STAGES - 3) ? (nk - 2 - kt) : (STAGES - 3);
+        if (newer >= 2) hg_wait_vm<2 * LOADS>(); else if (newer == 1) hg_wait_vm<LOADS>(); else hg_wait_vm<0>();
+      }
       __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
