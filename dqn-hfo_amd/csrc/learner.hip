@@ -85,7 +85,7 @@ void layout_init(NetLayout& l, int in_dim, const dqnhip_config& c, bool actor) {
   l.hw_off = off; off += round_up_z((size_t)l.NH * H, 64);
   l.hb_off = off; off += 64;
   dense += (size_t)l.NH * H + l.NH;
-  l.part_off[l.L] = part; part += H / 64;
+  l.part_off[l.L] = part; part += (H / 64) * l.NH;    // k_head_bwd uses the first H/64, k_head_wred one per (head, 64 columns)
   l.arena = round_up_z(off, 64);
   l.dense = dense;
   l.n_part = part;
@@ -139,6 +139,7 @@ struct dqnhip_learner {
   float* part[2] = {nullptr, nullptr};  // GEMM-epilogue sumsq partials per net
   float* part_dp = nullptr; int n_part_dp = 0;
   float* head_slab = nullptr; int* head_ticket = nullptr;   // k_head_bwd cross-block reduction
+  float* head_slab2 = nullptr;                               // k_head_bwd_big row-chunk slabs (minibatch >= 1024)
   // mixed precision (cfg.precision == DQNHIP_FP16): fp16 copies of the tower weights in both
   // orientations, fp16 activations / gradients in both orientations (hgemm.hip.h)
   bool fp16 = false;
@@ -383,8 +384,27 @@ int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nu
   return 0;
 }
 
+// rows >= 1024: the bandwidth-tiled kernel pair; optionally emits the scaled fp16 panels itself
+template <int NH>
+int head_backward_big(H* h, hipStream_t st, HeadBwdArgs a, h16* dZ16, h16* dZT16, float scale16) {
+  HeadBwdBigArgs b{}; b.a = a; b.dZ16 = dZ16; b.dZT16 = dZT16; b.ldT = a.rows; b.scale16 = scale16; b.slab2 = h->head_slab2;
+  const int chunks = a.rows / 64;
+  const size_t lds = (size_t)(64 * NH + 4 * NH * 256) * sizeof(float) + 256 * 72 * sizeof(h16);
+  static bool prepared = false;
+  if (!prepared) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_bwd_big<NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); prepared = true; }
+  hipLaunchKernelGGL((k_head_bwd_big<NH>), dim3(chunks, a.H / 256), dim3(256), lds, st, b);
+  HIPCHK(hipGetLastError());
+  if (a.dW != nullptr) {
+    hipLaunchKernelGGL((k_head_wred<NH>), dim3(a.H / 64, NH), dim3(256), 0, st, b, chunks);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+inline bool head_big_ok(const H* h, int rows, int Hd) { return h->head_slab2 != nullptr && rows >= 1024 && rows % 64 == 0 && Hd % 256 == 0; }
+
 template <int NH>
 int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
+  if (head_big_ok(h, a.rows, a.H)) return head_backward_big<NH>(h, st, a, nullptr, nullptr, 1.0f);
   // row chunks: enough blocks to cover the chip a few times over, <= 64 rows per chunk
   const int RC = std::max(1, std::min(16, a.rows / 64));   // (64 chunks measured slower at B=4096: the last arriver's slab walk)
   const int rows_c = (a.rows + RC - 1) / RC;
@@ -579,9 +599,9 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[3][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L]; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
-      RC(head_backward<1>(h, st, a));
+      if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->dZT16[1][L], h->ls_c)); }
+      else { RC(head_backward<1>(h, st, a)); RC(head_grad16(h, st, 1, h->dZc[L], B, h->ls_c, true)); }
     }
-    RC(head_grad16(h, st, 1, h->dZc[L], B, h->ls_c, true));
     RC(tower_backward16(h, st, DQNHIP_CRITIC, 3, h->g[1], nullptr, B, true, false, h->ls_c));
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)h->loss_partial,
@@ -604,17 +624,17 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     {
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
-      RC(head_backward<1>(h, st, a));
+      if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], nullptr, h->ls_q)); }
+      else { RC(head_backward<1>(h, st, a)); RC(head_grad16(h, st, 1, h->dZc[L], B, h->ls_q, false)); }
     }
-    RC(head_grad16(h, st, 1, h->dZc[L], B, h->ls_q, false));
     RC(tower_backward16(h, st, DQNHIP_CRITIC, 4, nullptr, h->dZc[0], B, false, true, h->ls_q));
     {
       HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;
       a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.X4 = h->act[1][L]; a.H = Hh; a.rows = B; a.dZ = h->dZa[L];
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
-      RC(head_backward<kNO>(h, st, a));
+      if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->dZT16[0][L], h->ls_a)); }
+      else { RC(head_backward<kNO>(h, st, a)); RC(head_grad16(h, st, 0, h->dZa[L], B, h->ls_a, true)); }
     }
-    RC(head_grad16(h, st, 0, h->dZa[L], B, h->ls_a, true));
     RC(tower_backward16(h, st, DQNHIP_ACTOR, 1, h->g[0], nullptr, B, true, false, h->ls_a));
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)nullptr, 0,
@@ -935,6 +955,7 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   {
     const int Hmax = std::max(h->la.dims[L], h->lc.dims[L]);
     RC(dalloc(&h->head_slab, (size_t)64 * (Hmax / 64) * kNO * 64 + 64 * 16));
+    if (B >= 1024 && B % 64 == 0) RC(dalloc(&h->head_slab2, (size_t)(B / 64) * kNO * Hmax + (size_t)(B / 64) * 16));
     HIPCHK(hipMalloc(&h->head_ticket, (Hmax / 64) * sizeof(int)));
     HIPCHK(hipMemsetAsync(h->head_ticket, 0, (Hmax / 64) * sizeof(int), h->stream));
   }
@@ -1035,7 +1056,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   hipHostFree(h->idx_pinned); hipHostFree(h->pinned_stats);
   hipFree(h->aout_t16); hipFree(h->aout16); hipFree(h->dA16);
   hipFree(h->q_t); hipFree(h->q1); hipFree(h->q2); hipFree(h->y); hipFree(h->dq);
-  hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp); hipFree(h->head_slab); hipFree(h->head_ticket);
+  hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp); hipFree(h->head_slab); hipFree(h->head_ticket); if (h->head_slab2) hipFree(h->head_slab2);
   for (void* p : h->allocs16) hipFree(p);
   if (h->stage_dev) hipFree(h->stage_dev);
   if (h->act_buf) hipFree(h->act_buf);

@@ -421,6 +421,132 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   }
 }
 
+// ---- head backward for large minibatches (rows >= 1024) -------------------------------------
+// Same arithmetic as k_head_bwd, re-tiled for bandwidth: block = 64 rows x 256 columns, wave = 16
+// rows, lane = 4 consecutive columns (16-B loads / stores of X4 and dZ).  Per-chunk partial head
+// gradients go to a slab [rows/64][NH][H]; k_head_wred adds the chunks in index order.  In fp16
+// mode the tower-top gradient is written directly as the scaled fp16 panel in both orientations
+// (the transposed one through an LDS tile), replacing the fp32 panel + conversion pass.
+struct HeadBwdBigArgs {
+  HeadBwdArgs a;
+  _Float16* dZ16; _Float16* dZT16; int ldT; float scale16;   // fp16 outputs (null: fp32 a.dZ only)
+  float* slab2;                                              // [rows/64][NH][H] then [rows/64][16]
+};
+template <int NH>
+__global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
+  typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+  typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+  const HeadBwdArgs& a = b.a;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_dy = sm;                                    // [64][NH]
+  float* s_red = sm + 64 * NH;                         // [4][NH][256]
+  _Float16* s_t = reinterpret_cast<_Float16*>(s_red + 4 * NH * 256);   // [256][72] halves
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int m0 = blockIdx.x * 64, kb = blockIdx.y * 256, k0 = kb + lane * 4;
+  const bool want_w = a.dW != nullptr;
+  for (int i = tid; i < 64 * NH; i += 256) {
+    const int m = m0 + i / NH, j = i % NH;
+    float d;
+    if constexpr (NH == kNO) {
+      d = a.dXc[(size_t)m * a.ldx + a.S + j];
+      const float out = a.aout16[(size_t)m * kAP + j];
+      float mn, mx;
+      if (j < kNA) { mn = -1.0f; mx = 1.0f; }
+      else { const int p = j - kNA; if (p == 0 || p == 4) { mn = 0.0f; mx = 100.0f; } else { mn = -180.0f; mx = 180.0f; } }
+      if (d < 0) d *= (mx - out) / (mx - mn);
+      else if (d > 0) d *= (out - mn) / (mx - mn);
+      if (blockIdx.y == 0) a.dA16[(size_t)m * kAP + j] = d;
+    } else {
+      d = a.dyh ? a.dyh[(size_t)m * a.lddy + j] : -1.0f;
+    }
+    s_dy[i] = d;
+  }
+  __syncthreads();
+  f32x4 wv[NH], acc[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) { wv[j] = *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k0); acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int ml = w * 16 + r, m = m0 + ml;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(a.X4 + (size_t)m * a.H + k0);
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const float d = s_dy[ml * NH + j];
+      if (NH == kNO && j >= kNA) { s1.x = fmaf(d, wv[j].x, s1.x); s1.y = fmaf(d, wv[j].y, s1.y); s1.z = fmaf(d, wv[j].z, s1.z); s1.w = fmaf(d, wv[j].w, s1.w); }
+      else { s0.x = fmaf(d, wv[j].x, s0.x); s0.y = fmaf(d, wv[j].y, s0.y); s0.z = fmaf(d, wv[j].z, s0.z); s0.w = fmaf(d, wv[j].w, s0.w); }
+      acc[j].x = fmaf(d, x.x, acc[j].x); acc[j].y = fmaf(d, x.y, acc[j].y); acc[j].z = fmaf(d, x.z, acc[j].z); acc[j].w = fmaf(d, x.w, acc[j].w);
+    }
+    if (NH == kNO) { s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w; }
+    const f32x4 dz = f32x4{s0.x * lrelu_mask(x.x), s0.y * lrelu_mask(x.y), s0.z * lrelu_mask(x.z), s0.w * lrelu_mask(x.w)};
+    if (a.dZ != nullptr) *reinterpret_cast<f32x4*>(a.dZ + (size_t)m * a.H + k0) = dz;
+    if (b.dZ16 != nullptr) {
+      const h4 hz = h4{(_Float16)(dz.x * b.scale16), (_Float16)(dz.y * b.scale16), (_Float16)(dz.z * b.scale16), (_Float16)(dz.w * b.scale16)};
+      *reinterpret_cast<h4*>(b.dZ16 + (size_t)m * a.H + k0) = hz;
+      if (b.dZT16 != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_t[(lane * 4 + c) * 72 + ml] = hz[c];
+      }
+    }
+  }
+  if (want_w) {
+#pragma unroll
+    for (int j = 0; j < NH; ++j) *reinterpret_cast<f32x4*>(s_red + ((w * NH + j) * 256 + lane * 4)) = acc[j];
+  }
+  __syncthreads();
+  if (b.dZT16 != nullptr) {                              // [256 columns][64 rows] -> 128-B row pieces
+    for (int q = tid; q < 256 * 8; q += 256) {
+      const int col = q >> 3, c8 = q & 7;
+      *reinterpret_cast<h8*>(b.dZT16 + (size_t)(kb + col) * b.ldT + m0 + c8 * 8) = *reinterpret_cast<const h8*>(s_t + col * 72 + c8 * 8);
+    }
+  }
+  if (!want_w) return;
+  float* slab = b.slab2 + (size_t)blockIdx.x * NH * a.H;
+  for (int i = tid; i < NH * 256; i += 256) {
+    const int j = i >> 8, c = i & 255;
+    slab[(size_t)j * a.H + kb + c] = (s_red[(0 * NH + j) * 256 + c] + s_red[(1 * NH + j) * 256 + c]) +
+                                     (s_red[(2 * NH + j) * 256 + c] + s_red[(3 * NH + j) * 256 + c]);
+  }
+  if (blockIdx.y == 0 && tid < NH) {
+    float v = 0.0f;
+    for (int m = 0; m < 64; ++m) v += s_dy[m * NH + tid];
+    b.slab2[(size_t)gridDim.x * NH * a.H + blockIdx.x * 16 + tid] = v;
+  }
+}
+// adds the row-chunk slabs of k_head_bwd_big: block = (64 columns, head j); the 4 waves take every
+// 4th chunk and are combined in fixed order.  Writes dW, db and one sum-of-squares partial per
+// (head, 64 columns) into partial[j * H/64 + column block].
+template <int NH>
+__global__ __launch_bounds__(256) void k_head_wred(HeadBwdBigArgs b, int chunks) {
+  const HeadBwdArgs& a = b.a;
+  __shared__ float s[4][64];
+  __shared__ float s_bias;
+  const int j = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 64 + lane;
+  float v = 0.0f;
+#pragma unroll 4
+  for (int c = w; c < chunks; c += 4) v += b.slab2[((size_t)c * NH + j) * a.H + k];
+  s[w][lane] = v;
+  if (w == 1) {
+    float t = 0.0f;
+    if (blockIdx.x == 0) {
+      for (int c = lane; c < chunks; c += 64) t += b.slab2[(size_t)chunks * NH * a.H + c * 16 + j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+      if (lane == 0) a.db[j] = t;
+    }
+    if (lane == 0) s_bias = t * t;
+  }
+  __syncthreads();
+  if (w != 0) return;
+  v = (s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]);
+  a.dW[(size_t)j * a.H + k] = v;
+  float ssq = v * v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
+  if (lane == 0 && a.partial != nullptr) a.partial[j * gridDim.x + blockIdx.x] = ssq + s_bias;
+}
+
 // ---- optimiser -----------------------------------------------------------------
 // Sum of squares of a gradient arena -> per-block partials (used after an
 // all-reduce, where the GEMM-epilogue partials no longer describe the reduced

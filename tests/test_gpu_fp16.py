@@ -95,6 +95,7 @@ def test_hgemm_kernels(pkg, gpu):
     dict(B=128, S=59, hidden=(256, 128, 128, 128), wscale=5.0),
     dict(B=256, S=58, hidden=(1024, 1024, 1024, 1024), wscale=2.0),
     dict(B=128, S=77, hidden=(128, 256), wscale=5.0),
+    dict(B=1024, S=58, hidden=(256, 256), wscale=4.0),      # large minibatch: head kernels emit the fp16 panels
 ])
 def test_fp16_pipeline_matches_emulation(pkg, gpu, shape):
     shape = dict(shape)

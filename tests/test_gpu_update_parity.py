@@ -69,6 +69,7 @@ def _check_update(dqn, orc, idx, t64=None, data=None):
     dict(B=32, S=59, hidden=(1024, 512, 256, 128)),        # reference defaults (src/dqn.hpp:19, dqn.cpp:425)
     dict(B=32, S=68, hidden=(128, 64, 64, 64)),            # 1v1 state size, small tower
     dict(B=64, S=77, hidden=(256, 128), ),                 # 2v1 state size, 2-layer tower
+    dict(B=1024, S=58, hidden=(256, 256), wscale=3.0),     # large minibatch: the bandwidth-tiled head kernels
     # BASELINE.json config #2.  wscale 2 (weights N(0, 0.02^2)): at 5x the 4x1024 critic's loss
     # explodes to 5e4 after one lr=1e-3 Adam step and HIP, the C oracle and a float64 reference
     # then differ from each other by ReLU-mask flips in different rows (all three measured).
