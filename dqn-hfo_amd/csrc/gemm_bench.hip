@@ -96,6 +96,8 @@ hipError_t launch_variant(int mode, int variant, GemmBatch& b, hipStream_t s) {
       case 12: return fwd_lds_launch<4, 2, false>(b, s);  // 64x32
       case 13: return fwd_lds_launch<4, 2, true>(b, s);
       case 14: return fwd_lds_launch<4, 4, false>(b, s);  // 64x64
+      case 15: return fwd_lds_launch<1, 1, false>(b, s);  // 16x16 (acting-time batches)
+      case 16: return fwd_lds_launch<2, 1, false>(b, s);  // 32 outputs x 16 rows
       case 9: return direct_launch(gemm_fwd_direct<2, 2, 3>, b, 32, 32, 4 * 4 * 64 * 16, s);  // ablation: coalesced loads only
       case 7: return direct_launch(gemm_fwd_direct<4, 4, 1>, b, 64, 64, 4 * 16 * 64 * 16, s);
       case 8: return direct_launch(gemm_fwd_direct<4, 4, 2>, b, 64, 64, 4 * 16 * 64 * 16, s);

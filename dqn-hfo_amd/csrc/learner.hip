@@ -314,7 +314,11 @@ int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, 
   // for a 256x1024 layer); grouped: 64x32.
   const bool lds_ok = (l.kp[i] >= 512) && (l.kp[i] % 256 == 0);
   ScopedTiming t(h, !lds_ok ? 6 : (n == 1 ? 5 : 0), st);
-  if (n == 1) { if (lds_ok) HIPCHK((fwd_lds_launch<2, 2, false>(b, st))); else HIPCHK((fwd_direct_launch<2, 2>(b, st))); }
+  // acting-time batches (<= 128 rows, e.g. 64 env workers): 16x16 tiles so that one layer still spreads
+  // over 256 workgroups (64 rows x 1024 outputs = 256 tiles) instead of 64
+  static const bool kSmallTiles = !getenv("DQNHIP_NO_SMALL_TILES");
+  if (n == 1 && rows <= 128 && lds_ok && kSmallTiles) HIPCHK((fwd_lds_launch<1, 1, false>(b, st)));
+  else if (n == 1) { if (lds_ok) HIPCHK((fwd_lds_launch<2, 2, false>(b, st))); else HIPCHK((fwd_direct_launch<2, 2>(b, st))); }
   else { if (lds_ok) HIPCHK((fwd_lds_launch<4, 2, false>(b, st))); else HIPCHK((fwd_direct_launch<4, 2>(b, st))); }
   return 0;
 }
@@ -431,7 +435,8 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   a.beta1 = h->cfg.momentum; a.beta2 = h->cfg.momentum2; a.eps = h->cfg.delta;
   a.clip = h->cfg.clip_gradients; a.tau = (float)h->cfg.tau;
   a.soft_update_freq = h->cfg.soft_update_freq; a.which = net; a.st = h->st;
-  int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, 2048);
+  static const int kAdamCap = getenv("DQNHIP_ADAM_BLOCKS") ? atoi(getenv("DQNHIP_ADAM_BLOCKS")) : 2048;
+  int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)kAdamCap);
   ScopedTiming t(h, 3, st);
   LaunchTimer& lt = launch_timer();
   if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
