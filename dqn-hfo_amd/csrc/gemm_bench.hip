@@ -98,6 +98,9 @@ hipError_t launch_variant(int mode, int variant, GemmBatch& b, hipStream_t s) {
       case 14: return fwd_lds_launch<4, 4, false>(b, s);  // 64x64
       case 15: return fwd_lds_launch<1, 1, false>(b, s);  // 16x16 (acting-time batches)
       case 16: return fwd_lds_launch<2, 1, false>(b, s);  // 32 outputs x 16 rows
+      case 17: return fwd_lds_launch<4, 2, false, 1>(b, s);  // 64x32, one LDS image per wave (2 workgroups per CU)
+      case 18: return fwd_lds_launch<2, 2, false, 1>(b, s);
+      case 19: return fwd_lds_launch<4, 4, false, 1>(b, s);
       case 9: return direct_launch(gemm_fwd_direct<2, 2, 3>, b, 32, 32, 4 * 4 * 64 * 16, s);  // ablation: coalesced loads only
       case 7: return direct_launch(gemm_fwd_direct<4, 4, 1>, b, 64, 64, 4 * 16 * 64 * 16, s);
       case 8: return direct_launch(gemm_fwd_direct<4, 4, 2>, b, 64, 64, 4 * 16 * 64 * 16, s);
@@ -152,6 +155,7 @@ extern "C" int dqnhip_test_gemm(int32_t mode, int32_t variant, int32_t rows, int
     CK(direct_prepare(gemm_fwd_direct<4, 4>, 4 * 16 * 64 * 16));
     CK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4)); CK(direct_prepare(gemm_fwd_lds<4, 2, true>, 4 * 2 * 6 * 512 * 4));
     CK(direct_prepare(gemm_fwd_lds<4, 4, false>, 4 * 2 * 8 * 512 * 4));
+    CK(direct_prepare((gemm_fwd_lds<4, 4, false, 1>), (fwd_lds_bytes<4, 4, false, 1>())));
     CK(direct_prepare(gemm_fwd_direct<4, 4, 1>, 4 * 16 * 64 * 16)); CK(direct_prepare(gemm_fwd_direct<4, 4, 2>, 4 * 16 * 64 * 16));
     CK(direct_prepare(gemm_dgrad_direct<1, 4>, 4 * 16 * 64 * 16));
     prepared = true;

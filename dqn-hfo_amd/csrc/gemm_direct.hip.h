@@ -379,18 +379,22 @@ __device__ __forceinline__ void wgrad_direct_body(const GemmProblem& pr, int til
 // The LDS image is private to the wave (no barrier anywhere in the main loop); two images
 // ping-pong, global loads run two 32-k steps ahead in registers.
 // Requires Kred % 256 == 0 and Kred >= 512 (>= 4 steps of 32 k per wave, even count).
-template <int TP, int TQ, bool PIN>
+template <int TP, int TQ, bool PIN, int NSLOT = 2>
 __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
   constexpr int NB = TP + TQ;
   constexpr int NACC = TP * TQ;
   constexpr int SLOT = NB * 512;                 // floats per LDS image (NB blocks x 16 rows x 32 k)
+  // NSLOT = 1: one image per wave.  LDS operations of one wave execute in issue order, so the next
+  // step's ds_write cannot overtake this step's ds_read of the same image; half the LDS lets two
+  // workgroups share a CU.
+  constexpr int WSTR = (NSLOT * SLOT > NACC * 256) ? NSLOT * SLOT : NACC * 256;   // floats per wave region (images, later the parked tile)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int lr = lane >> 3, lc = lane & 7;
   const int p0 = tile_p * 16 * TP, q0 = tile_q * 16 * TQ;
   const int Kw = pr.Kred >> 2;
   const int T = Kw >> 5;                         // steps of 32 k
-  float* wsm = smem + wave * (2 * SLOT);
+  float* wsm = smem + wave * WSTR;
   const float* gp[NB];
   size_t ld8[NB];
 #pragma unroll
@@ -414,12 +418,12 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
       G[b][1] = *reinterpret_cast<const f32x4*>(gp[b] + ld8[b] + ((t) << 5)); } }
 #define L_SWRITE(slot, G)                                                               \
   { _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                    \
-      *reinterpret_cast<f32x4*>(wsm + (slot) * SLOT + b * 512 + woff) = G[b][0];        \
-      *reinterpret_cast<f32x4*>(wsm + (slot) * SLOT + b * 512 + 256 + woff) = G[b][1]; } }
+      *reinterpret_cast<f32x4*>(wsm + ((slot) % NSLOT) * SLOT + b * 512 + woff) = G[b][0];        \
+      *reinterpret_cast<f32x4*>(wsm + ((slot) % NSLOT) * SLOT + b * 512 + 256 + woff) = G[b][1]; } }
 #define L_SREAD(FF, slot)                                                               \
   { _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                    \
-      FF[b][0] = *reinterpret_cast<const f32x4*>(wsm + (slot) * SLOT + b * 512 + roff[0]); \
-      FF[b][1] = *reinterpret_cast<const f32x4*>(wsm + (slot) * SLOT + b * 512 + roff[1]); } }
+      FF[b][0] = *reinterpret_cast<const f32x4*>(wsm + ((slot) % NSLOT) * SLOT + b * 512 + roff[0]); \
+      FF[b][1] = *reinterpret_cast<const f32x4*>(wsm + ((slot) % NSLOT) * SLOT + b * 512 + roff[1]); } }
 #define L_MFMA(FF)                                                                      \
   { _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                    \
     _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
@@ -460,10 +464,10 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
   for (int e = 0; e < NACC; ++e) {
     if ((e & 3) == wave) {
       const int a = e / TP, c = e % TP;
-      const f32x4 a0 = reinterpret_cast<const f32x4*>(smem + 0 * (2 * SLOT))[e * 64 + lane];
-      const f32x4 a1 = reinterpret_cast<const f32x4*>(smem + 1 * (2 * SLOT))[e * 64 + lane];
-      const f32x4 a2 = reinterpret_cast<const f32x4*>(smem + 2 * (2 * SLOT))[e * 64 + lane];
-      const f32x4 a3 = reinterpret_cast<const f32x4*>(smem + 3 * (2 * SLOT))[e * 64 + lane];
+      const f32x4 a0 = reinterpret_cast<const f32x4*>(smem + 0 * WSTR)[e * 64 + lane];
+      const f32x4 a1 = reinterpret_cast<const f32x4*>(smem + 1 * WSTR)[e * 64 + lane];
+      const f32x4 a2 = reinterpret_cast<const f32x4*>(smem + 2 * WSTR)[e * 64 + lane];
+      const f32x4 a3 = reinterpret_cast<const f32x4*>(smem + 3 * WSTR)[e * 64 + lane];
       f32x4 v;
       v.x = (a0.x + a1.x) + (a2.x + a3.x); v.y = (a0.y + a1.y) + (a2.y + a3.y);
       v.z = (a0.z + a1.z) + (a2.z + a3.z); v.w = (a0.w + a1.w) + (a2.w + a3.w);
@@ -602,12 +606,12 @@ __global__ __launch_bounds__(256) void gemm_fwd_direct(const GemmBatch batch) {
   tile_of_block(batch, pi, tile_p, tile_q);
   fwd_direct_body<TP, TQ, ABL>(batch.prob[pi], tile_p, tile_q, smem);
 }
-template <int TP, int TQ, bool PIN>
+template <int TP, int TQ, bool PIN, int NSLOT = 2>
 __global__ __launch_bounds__(256) void gemm_fwd_lds(const GemmBatch batch) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int pi, tile_p, tile_q;
   tile_of_block(batch, pi, tile_p, tile_q);
-  fwd_lds_body<TP, TQ, PIN>(batch.prob[pi], tile_p, tile_q, smem);
+  fwd_lds_body<TP, TQ, PIN, NSLOT>(batch.prob[pi], tile_p, tile_q, smem);
 }
 template <int TPB, int TQ>
 __global__ __launch_bounds__(256) void gemm_dgrad_direct(const GemmBatch batch) {
@@ -683,9 +687,13 @@ template <int TP, int TQ>
 inline hipError_t fwd_direct_launch(GemmBatch& b, hipStream_t s) {
   return direct_launch(gemm_fwd_direct<TP, TQ>, b, 16 * TP, 16 * TQ, 4 * TP * TQ * 64 * 16, s);
 }
-template <int TP, int TQ, bool PIN>
+template <int TP, int TQ, bool PIN, int NSLOT = 2>
+constexpr int fwd_lds_bytes() {
+  return 4 * 4 * ((NSLOT * (TP + TQ) * 512 > TP * TQ * 256) ? NSLOT * (TP + TQ) * 512 : TP * TQ * 256);
+}
+template <int TP, int TQ, bool PIN, int NSLOT = 2>
 inline hipError_t fwd_lds_launch(GemmBatch& b, hipStream_t s) {
-  return direct_launch(gemm_fwd_lds<TP, TQ, PIN>, b, 16 * TP, 16 * TQ, 4 * 2 * (TP + TQ) * 512 * 4, s);
+  return direct_launch(gemm_fwd_lds<TP, TQ, PIN, NSLOT>, b, 16 * TP, 16 * TQ, (fwd_lds_bytes<TP, TQ, PIN, NSLOT>()), s);
 }
 template <int TPB, int TQ>
 inline hipError_t dgrad_direct_launch(GemmBatch& b, hipStream_t s) {
