@@ -198,14 +198,22 @@ __global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const De
   const int w = blockIdx.x;
   const int len = e.done[w];
   if (len == 0) return;
+  // AddTransitions of the workers before us, in worker order.  Every AddTransitions(n) (n <= cap-1)
+  // moves the deque's tail by exactly n and leaves size = min(size + n, cap - 1), so this worker's
+  // first slot is tail0 + (transitions flushed by lower-numbered workers): a parallel prefix sum
+  // instead of replaying the deque arithmetic serially.
+  __shared__ int s_pre[4];
+  {
+    int part = 0;
+    for (int v = threadIdx.x; v < w; v += 256) part += e.done[v];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((threadIdx.x & 63) == 0) s_pre[threadIdx.x >> 6] = part;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    int head = st->ring_head, size = st->ring_size;
-    for (int v = 0; v < w; ++v) {          // AddTransitions of the workers before us, in order
-      const int n = e.done[v];
-      if (n > 0) { ring_add_plan(ring.cap, n, head, size); size += n; }
-    }
-    ring_add_plan(ring.cap, len, head, size);
-    s_start = (int)(((long long)head + size) % ring.cap);
+    const long long tail0 = (long long)st->ring_head + st->ring_size;
+    s_start = (int)((tail0 + ((s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]))) % ring.cap);
     // LabelTransitions (src/dqn.cpp:783-797): reverse scan, gamma double, float store
     const float* r = e.ep_r + (size_t)w * e.T;
     sm[len - 1] = r[len - 1];
@@ -254,14 +262,24 @@ __global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const De
 template <int UNUSED = 0>
 __global__ void k_set_float(float* p, float v) { *p = v; }
 
-__global__ void k_env_commit(EnvDev e, Ring ring, DevState* st) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int head = st->ring_head, size = st->ring_size;
-  for (int v = 0; v < e.N; ++v) {
-    const int n = e.done[v];
-    if (n > 0) { ring_add_plan(ring.cap, n, head, size); size += n; e.done[v] = 0; }
-  }
-  st->ring_head = head; st->ring_size = size;
+__global__ __launch_bounds__(256) void k_env_commit(EnvDev e, Ring ring, DevState* st) {
+  // the closed form of the same sequence of AddTransitions (see k_env_flush): tail += total,
+  // size = min(size + total, cap - 1)
+  __shared__ int s_tot[4];
+  int part = 0;
+  for (int v = threadIdx.x; v < e.N; v += 256) { part += e.done[v]; e.done[v] = 0; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const long long total = (long long)(s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
+  if (total == 0) return;
+  const long long tail = (long long)st->ring_head + st->ring_size + total;
+  long long size = (long long)st->ring_size + total;
+  if (size > ring.cap - 1) size = ring.cap - 1;
+  st->ring_head = (int)((tail - size) % ring.cap);
+  st->ring_size = (int)size;
 }
 
 }  // namespace dqnhip

@@ -1756,7 +1756,7 @@ static int env_one_step(dqnhip_env* e) {
   hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), (d.T + d.SP) * sizeof(float), st, d, RO(h)->ring,
                      (const DevState*)RO(h)->st, h->cfg.gamma);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(k_env_commit, dim3(1), dim3(64), 0, st, d, RO(h)->ring, RO(h)->st);
+  hipLaunchKernelGGL(k_env_commit, dim3(1), dim3(256), 0, st, d, RO(h)->ring, RO(h)->st);
   HIPCHK(hipGetLastError());
   return 0;
 }
