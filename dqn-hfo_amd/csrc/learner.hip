@@ -609,7 +609,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     }
     RC(tower_backward16(h, st, DQNHIP_CRITIC, 3, h->g[1], nullptr, B, true, false, h->ls_c));
     if (dp) {
-      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)h->loss_partial,
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)h->loss_partial,
                          h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr);
       HIPCHK(hipGetLastError());
     }
@@ -642,7 +642,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     }
     RC(tower_backward16(h, st, DQNHIP_ACTOR, 1, h->g[0], nullptr, B, true, false, h->ls_a));
     if (dp) {
-      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)nullptr, 0,
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)nullptr, 0,
                          (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail);
       HIPCHK(hipGetLastError());
     }
@@ -735,7 +735,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     RC(tower_backward(h, st, lc, DQNHIP_CRITIC, h->g[1], h->part[1], h->act[3], h->dZc, B, true, false));
     RC(stream_wait(h, st, ax));            // all critic wgrads done
     if (dp) {
-      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)h->loss_partial,
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)h->loss_partial,
                          h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr);
       HIPCHK(hipGetLastError());
     }
@@ -786,7 +786,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     RC(tower_backward(h, st, la, DQNHIP_ACTOR, h->g[0], h->part[0], h->act[1], h->dZa, B, true, false));
     RC(stream_wait(h, st, ax));            // all actor wgrads done
     if (dp) {
-      hipLaunchKernelGGL(k_tails, dim3(1), dim3(64), 0, st, (const float*)nullptr, 0,
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)nullptr, 0,
                          (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail);
       HIPCHK(hipGetLastError());
     }

@@ -650,18 +650,27 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
 
 // Reduce the per-block loss / q partials into the gradient-arena tails
 // ([loss_sum, q_sum, 0, 0]) so they ride in the gradient all-reduce.
-__global__ void k_tails(const float* loss_partial, int n_loss, const double* q_partial, int n_q,
-                        float inv_batch, float* critic_tail, float* actor_tail) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void k_tails(const float* loss_partial, int n_loss, const double* q_partial, int n_q,
+                                               float inv_batch, float* critic_tail, float* actor_tail) {
+  // one block, same reduction tree as k_tick (strided partials, butterfly, fixed cross-wave order)
+  __shared__ float sdot[4];
+  __shared__ double sq[4];
+  const int t = threadIdx.x;
+  float dot = 0.0f; double qs = 0.0;
+  if (critic_tail != nullptr) for (int i = t; i < n_loss; i += 256) dot += loss_partial[i];
+  if (actor_tail != nullptr) for (int i = t; i < n_q; i += 256) qs += q_partial[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { dot += __shfl_xor(dot, off, 64); qs += __shfl_xor(qs, off, 64); }
+  if ((t & 63) == 0) { sdot[t >> 6] = dot; sq[t >> 6] = qs; }
+  __syncthreads();
+  if (t != 0) return;
   if (critic_tail != nullptr) {
-    float dot = 0.0f;
-    for (int i = 0; i < n_loss; ++i) dot += loss_partial[i];
+    dot = (sdot[0] + sdot[1]) + (sdot[2] + sdot[3]);
     critic_tail[0] = dot * inv_batch / 2.0f;   // EuclideanLoss: dot / num / 2
     critic_tail[1] = 0.f; critic_tail[2] = 0.f; critic_tail[3] = 0.f;
   }
   if (actor_tail != nullptr) {
-    double qs = 0.0;
-    for (int i = 0; i < n_q; ++i) qs += q_partial[i];
+    qs = (sq[0] + sq[1]) + (sq[2] + sq[3]);
     actor_tail[0] = 0.f; actor_tail[1] = (float)qs; actor_tail[2] = 0.f; actor_tail[3] = 0.f;
   }
 }
