@@ -54,6 +54,17 @@ int main() {
     if (resumed.actor_iter() != dqn.actor_iter() || resumed.memory_size() != dqn.memory_size()) return 6;
     resumed.Update();
   }
+  {
+    // a teammate sharing the first layers and the replay memory (src/dqn_main.cpp:305-323)
+    dqn::DQN mate(actor_sp, critic_sp, prefix + "_mate", num_features, 1, flags);
+    dqn.ShareParameters(mate, 2, 1);
+    dqn.ShareReplayMemory(mate);
+    if (mate.memory_size() != dqn.memory_size()) return 8;
+    const int it = dqn.actor_iter();
+    mate.Update();                                   // the teammate's solver writes the shared layers
+    if (dqn.actor_iter() != it || mate.actor_iter() != 1) return 9;
+    dqn.Update();
+  }
   dqn::RemoveFilesMatchingRegexp(prefix + "_.*");
   Action sampled = dqn.SampleAction(dqn.GetRandomActorOutput());
   if (sampled.action == TACKLE) return 7;
