@@ -1,0 +1,13 @@
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package
+pkg = load_package(); lib = pkg.capi.load()
+fn = lib.dqnhip_test_gemm; fn.restype = C.c_int
+fn.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 3
+def run(mode, variant, rows, n, k, groups):
+    us, err, ref = C.c_float(), C.c_float(), C.c_float()
+    rc = fn(mode, variant, rows, n, k, groups, 200, C.byref(us), C.byref(err), C.byref(ref))
+    print("mode %d var %2d rows %4d groups %d: rc %d %7.2f us  (%.2f us/layer) err %.2e" % (mode, variant, rows, groups, rc, us.value, us.value / groups, err.value), flush=True)
+for v in (12, 17, 10, 18):
+    for g in (1, 2, 3, 4):
+        run(0, v, 256, 1024, 1024, g)
