@@ -560,7 +560,19 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
   float* critic_tail = h->g[1] + lc.arena;
   const int Hh = la.dims[L], Hc = lc.dims[L];
   hipStream_t st = h->stream;
-  if (phase == 0) {
+  const bool split = phase == 10;
+  if (phase == 11) {
+    HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
+    hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
+    hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
+    RC(tower_forward16(h, st, 1, DQNHIP_ACTOR, B));
+    RC((head_forward<kNO, HEAD_ACTOR>(h, st, hA)));
+    Cvt16Batch b{};
+    cvt16_add(b, h->Xc_pl, lc.kp[0], B, lc.kp[0], h->act16[4][0], h->k16[1][0], nullptr, B, 1.0f);
+    HIPCHK(cvt16_launch(b, st));
+    return 0;
+  }
+  if (phase == 0 || phase == 10) {
     GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
                  h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
     hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
@@ -574,18 +586,19 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       HIPCHK(cvt16_launch(b, st));
     }
     RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B));
-    RC(tower_forward16(h, st, 1, DQNHIP_ACTOR, B));
+    if (!split) RC(tower_forward16(h, st, 1, DQNHIP_ACTOR, B));
     HeadArgs hAT{}; hAT.X = h->act[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
     hAT.W = wat(h, DQNHIP_ACTOR_TARGET, la.hw_off); hAT.b = wat(h, DQNHIP_ACTOR_TARGET, la.hb_off);
     hAT.out16 = h->aout_t16; hAT.xc = h->Xc_nx; hAT.ldxc = lc.kp[0]; hAT.xc_col = h->S;
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
     hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
-    RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));
+    if (split) RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT)));
+    else RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));
     {
       Cvt16Batch b{};
       cvt16_add(b, h->Xc_nx, lc.kp[0], B, lc.kp[0], h->act16[2][0], h->k16[1][0], nullptr, B, 1.0f);
-      cvt16_add(b, h->Xc_pl, lc.kp[0], B, lc.kp[0], h->act16[4][0], h->k16[1][0], nullptr, B, 1.0f);
+      if (!split) cvt16_add(b, h->Xc_pl, lc.kp[0], B, lc.kp[0], h->act16[4][0], h->k16[1][0], nullptr, B, 1.0f);
       HIPCHK(cvt16_launch(b, st));
     }
     RC(tower_forward16(h, st, 2, DQNHIP_CRITIC_TARGET, B));
@@ -680,7 +693,17 @@ int run_phase(H* h, int phase, const int* idx_dev) {
   float* critic_tail = h->g[1] + lc.arena;
   const int Hh = la.dims[L], Hc = lc.dims[L];
   hipStream_t st = h->stream, ax = aux_of(h);
-  if (phase == 0) {
+  const bool split = phase == 10;          // phase 10 = phase 0 without the online actor's forward, 11 = that forward
+  if (phase == 11) {
+    FwdPass pA{DQNHIP_ACTOR, &la, h->act[1]};
+    HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
+    hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
+    hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
+    RC(tower_forward(h, st, &pA, 1, B));
+    RC((head_forward<kNO, HEAD_ACTOR>(h, st, hA)));
+    return 0;
+  }
+  if (phase == 0 || phase == 10) {
     // 1-2: sample + gather (src/dqn.cpp:846-887)
     GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
                  h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
@@ -696,7 +719,14 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
     hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
-    if (ax != st) {
+    if (split) {
+      // data-parallel overlap form: the online actor's forward (phase 11) is left out so that it can
+      // run while the critic gradients are being all-reduced
+      RC(tower_forward(h, st, &pAT, 1, B));
+      RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT)));
+      FwdPass cp[2] = {pCT, pC1};
+      RC(tower_forward(h, st, cp, 2, B));
+    } else if (ax != st) {
       // branch 1 (st):  actor_target(s') -> critic_target(s', mu'(s'))   [src/dqn.cpp:889-891]
       // branch 2 (aux): actor(s) [:910-911, pre-update weights] -> critic(s, a) train fwd [:904]
       RC(stream_wait(h, ax, st));
@@ -803,7 +833,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     h->h_actor_iter += 1; h->h_critic_iter += 1;
     return 0;
   }
-  return fail("phase must be 0, 1 or 2 (got %d)", phase);
+  return fail("phase must be 0, 1, 2, 10 or 11 (got %d)", phase);
 }
 
 // re-read (head,size) after the env front-end appended episodes on the device
@@ -1133,7 +1163,7 @@ int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host)
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   const int* idx_dev = nullptr;
-  if (phase != 0) return run_phase(h, phase, idx_dev);
+  if (phase != 0 && phase != 10) return run_phase(h, phase, idx_dev);
   RingUse ring_use(h);
   RC(sync_dirty16(h));
   RC(stage_indices(h, idx_host, &idx_dev));

@@ -73,6 +73,7 @@ def PrintActorOutput(ao):
 
 
 class DQN:
+    supports_split_phase0 = True        # dqnhip_update_phase accepts 10 / 11 (parallel.DataParallelUpdate)
     """Device-resident learner with the reference's method surface.
 
     Constructor arguments replace the reference's SolverParameter pair + gflags

@@ -14,27 +14,47 @@ applies the identical Adam step and the replicas never diverge.
 `backend` is anything with update_phase(phase, idx) — the HIP learner on the GPU, a
 stand-in in the CPU/gloo tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
+_SYNC_PROBE = bool(os.environ.get("DQNHIP_DP_SYNC_PROBE"))   # measurement aid: split phases, blocking collective
+
 
 class DataParallelUpdate:
-    def __init__(self, backend, critic_grad, actor_grad, group=None):
+    def __init__(self, backend, critic_grad, actor_grad, group=None, overlap=False):
         self.backend = backend
         self.critic_grad = critic_grad      # flat view: critic gradient arena + [loss_sum, q_sum, 0, 0]
         self.actor_grad = actor_grad
         self.group = group
+        # The online actor's forward mu(s) (src/dqn.cpp:910-911) neither reads nor writes the critic
+        # gradients: a backend that can split it off (phase 10 / 11 of dqnhip_update_phase) runs it
+        # while the first all-reduce is in flight on RCCL's own stream.  OFF by default: measured on one
+        # rank the split costs +18 us (the two actors' layers no longer share launches) and the async
+        # collective +35 us more (cross-stream edges), against <= 36 us of forward it can hide.
+        self.overlap = bool(overlap) and getattr(backend, "supports_split_phase0", False)
 
     def update(self, idx=None):
         b = self.backend
-        b.update_phase(0, idx)
-        dist.all_reduce(self.critic_grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self.overlap:
+            b.update_phase(10, idx)
+            if _SYNC_PROBE:
+                dist.all_reduce(self.critic_grad, op=dist.ReduceOp.SUM, group=self.group)
+                b.update_phase(11, None)
+            else:
+                work = dist.all_reduce(self.critic_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b.update_phase(11, None)
+                work.wait()                 # stream dependency, not a host sync
+        else:
+            b.update_phase(0, idx)
+            dist.all_reduce(self.critic_grad, op=dist.ReduceOp.SUM, group=self.group)
         b.update_phase(1, None)
         dist.all_reduce(self.actor_grad, op=dist.ReduceOp.SUM, group=self.group)
         b.update_phase(2, None)
 
 
-def make_hip_data_parallel(pkg, state_size, rank, world, device, group=None, **dqn_kwargs):
+def make_hip_data_parallel(pkg, state_size, rank, world, device, group=None, overlap=False, **dqn_kwargs):
     """Build a HIP learner whose gradient arenas live in a torch tensor (so RCCL can reduce
     them in place) and which enqueues on torch's current stream (so collectives and kernels
     are ordered by the stream, no host sync)."""
@@ -51,6 +71,7 @@ def make_hip_data_parallel(pkg, state_size, rank, world, device, group=None, **d
         ptr, n = dqn.grad_buffer(net)
         off = (ptr - arena.data_ptr()) // 4
         views.append(arena[off:off + n])
-    dp = DataParallelUpdate(dqn, critic_grad=views[1], actor_grad=views[0], group=group)
+    dp = DataParallelUpdate(dqn, critic_grad=views[1], actor_grad=views[0], group=group,
+                            overlap=overlap)
     dp.arena = arena       # keep the storage alive
     return dqn, dp

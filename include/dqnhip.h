@@ -151,7 +151,11 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host);
  *   phase 2: actor clip+Adam(+soft update), iteration counters
  * Between phases the caller sum-all-reduces dqnhip_grad_buffer(net) across
  * the DP group (RCCL).  With dp_world == 1 running 0,1,2 back to back is
- * identical to dqnhip_update_async. */
+ * identical to dqnhip_update_async.
+ * Overlap form: phase 10 = phase 0 without the online actor's forward mu(s)
+ * (src/dqn.cpp:910-911), phase 11 = that forward; 11 touches neither gradient
+ * arena, so 10, [start all-reduce of the critic gradients], 11, [wait], 1, .. hides
+ * it behind the collective.  10 + 11 compute exactly what 0 computes. */
 int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host);
 
 /* Device pointer + length (floats) of one net's gradient arena, including a

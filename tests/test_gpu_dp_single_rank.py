@@ -45,6 +45,17 @@ for u in range(4):
 for net in range(4):
     a, b = dqn_dp.get_params(net), ref.get_params(net)
     assert np.abs(a - b).max() <= 1e-6, (net, np.abs(a - b).max())
+assert not dp.overlap
+# the overlap form (phase 10 / async all-reduce / phase 11) gives the same bits (10 + 11 == 0)
+dqn_b, dp_b = par.make_hip_data_parallel(pkg, S, 0, 1, 0, overlap=True, minibatch=B, hidden=hid, memory=4096, seed=2)
+assert dp_b.overlap
+for net in (0, 1):
+    dqn_b.set_params(net, w[net]); dqn_b.CloneNet(net)
+dqn_b.add_transitions_arrays(*data)
+for u in range(4):
+    dp_b.update(idx[u])
+for net in range(4):
+    np.testing.assert_array_equal(dqn_b.get_params(net), dqn_dp.get_params(net))
 for u in range(3):                       # on-device sampling through the DP path
     dp.update(None)
 l, q = dqn_dp.read_stats()
