@@ -925,6 +925,8 @@ size_t dqnhip_grad_arena_bytes(const dqnhip_config* cfg) {
   return grad_arena_floats(la, lc) * sizeof(float);
 }
 
+static int create_impl(H* h, const dqnhip_config* cfg);
+
 int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   if (!out) return fail("out is null");
   *out = nullptr;
@@ -934,6 +936,18 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail("device %d not available (%d visible)", cfg->device, ndev);
   HIPCHK(hipSetDevice(cfg->device));
   H* h = new H();
+  const int rc = create_impl(h, cfg);
+  if (rc) {                                  // free whatever was allocated; keep the first error message
+    const std::string msg = g_err;
+    dqnhip_destroy(h);
+    g_err = msg;
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+static int create_impl(H* h, const dqnhip_config* cfg) {
   h->cfg = *cfg; h->B = cfg->minibatch; h->S = cfg->state_size; h->L = cfg->num_hidden;
   layout_init(h->la, h->S, *cfg, true);
   layout_init(h->lc, h->S + kNO, *cfg, false);
@@ -1065,7 +1079,6 @@ int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4));
   RC(sync_dirty16(h));
   HIPCHK(hipStreamSynchronize(h->stream));
-  *out = h;
   return 0;
 }
 
@@ -1727,6 +1740,8 @@ int env_alloc(dqnhip_env* e, T** p, size_t n) {
 
 extern "C" {
 
+static int env_create_impl(dqnhip_env* e);
+
 int dqnhip_env_create(dqnhip_handle h, const dqnhip_env_config* cfg, dqnhip_env_handle* out) {
   if (!h || !cfg || !out) return fail("null argument");
   *out = nullptr;
@@ -1739,6 +1754,15 @@ int dqnhip_env_create(dqnhip_handle h, const dqnhip_env_config* cfg, dqnhip_env_
   HIPCHK(hipSetDevice(h->cfg.device));
   dqnhip_env* e = new dqnhip_env();
   e->h = h; e->cfg = *cfg;
+  const int rc = env_create_impl(e);
+  if (rc) { const std::string msg = g_err; dqnhip_env_destroy(e); g_err = msg; return rc; }
+  *out = e;
+  return 0;
+}
+
+static int env_create_impl(dqnhip_env* e) {
+  dqnhip_learner* h = e->h;
+  const dqnhip_env_config* cfg = &e->cfg;
   EnvDev& d = e->d;
   d.N = cfg->workers; d.S = h->S; d.SP = h->la.kp[0]; d.T = cfg->max_steps; d.unum = cfg->unum;
   d.p_end = cfg->p_end; d.p_goal = cfg->p_goal; d.seed = cfg->seed;
@@ -1755,7 +1779,6 @@ int dqnhip_env_create(dqnhip_handle h, const dqnhip_env_config* cfg, dqnhip_env_
   hipLaunchKernelGGL(k_env_init, dim3(d.N), dim3(64), d.SP * sizeof(float), h->stream, d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
-  *out = e;
   return 0;
 }
 
