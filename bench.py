@@ -174,6 +174,10 @@ def main():
     ap.add_argument("--no-env", action="store_true", help="skip the env-steps/sec leg")
     ap.add_argument("--frames-per-trial", type=int, default=500)
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel path even with one rank (testing)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL; gloo only for the 2-ranks-on-one-GPU flow test)")
+    ap.add_argument("--share-device0", action="store_true",
+                    help="testing: every rank uses GPU 0 (needs --backend gloo; RCCL refuses duplicate devices)")
     ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],
                     help="N>1: dp = gradient all-reduce (weak scaling), replicas = independent learners")
     args = ap.parse_args()
@@ -187,13 +191,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if args.share_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist_on = world > 1 or args.force_dp
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     use_dp = dist_on and args.mode == "dp"
     if use_dp:
@@ -232,14 +240,17 @@ def main():
 
     # roofline of the dominant kernel family, timed live with HIP events on the learner's stream
     roof = None
+    n_t = 20
+    # every rank runs the extra updates (under data parallelism they contain collectives); only rank 0
+    # brackets its launches with events
+    if rank == 0:
+        dqn.set_kernel_timing(True)
+    for _ in range(n_t):
+        step()
     if rank == 0:
         fp16 = args.precision == "fp16"
         fam_flops = family_flops16(B, S, HIDDEN) if fp16 else family_flops(B, S, HIDDEN)
         peak = MFMA_F16_PEAK_TF if fp16 else MFMA_F32_PEAK_TF
-        dqn.set_kernel_timing(True)
-        n_t = 20
-        for _ in range(n_t):
-            step()
         stats = {}
         for fam in list(fam_flops) + ["adam"]:
             ms, cnt = dqn.kernel_timing(fam)
@@ -256,7 +267,7 @@ def main():
                 "avg_launch_us": round(ms * 1e3, 2), "launches_per_update": per_update_launches,
                 "flops_per_launch": flops_per_launch,
                 "families_us": {f: [round(stats[f][0] * 1e3, 2), stats[f][1] / n_t] for f in stats}}
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
 
     # env-steps/sec (the other half of BASELINE.json's metric): N synthetic workers -> batched
     # SelectActions + GetAction + HFOGameState reward + LabelTransitions/AddTransitions, all on device

@@ -96,3 +96,21 @@ def test_bench_runs_under_torchrun_one_rank(pkg, gpu):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 100 and d["config"]["parallelism"].startswith("dp1")
+
+
+def test_bench_two_ranks_flow_on_one_gpu(pkg, gpu):
+    """The whole N = 2 bench flow (rendezvous, per-rank replay shards, the two all-reduces per update,
+    the all-rank timing pass, rank-0-only legs, final barrier) with both ranks on GPU 0 and gloo as
+    the transport — RCCL refuses two ranks on one device, but a collective that only some ranks
+    enter hangs the same way on either backend."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29643", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "20", "--warmup", "5", "--replay", "20000", "--no-cpu-baseline",
+           "--backend", "gloo", "--share-device0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 10 and d["config"]["parallelism"].startswith("dp2")
+    assert d["config"]["global_minibatch"] == 512 and d["roofline"] is not None
