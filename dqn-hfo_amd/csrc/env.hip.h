@@ -210,14 +210,25 @@ __global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const De
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
     if ((threadIdx.x & 63) == 0) s_pre[threadIdx.x >> 6] = part;
   }
+  // rewards of the episode into LDS (all threads), so that the serial label scan below has no
+  // global-memory latency inside its dependent chain
+  for (int i = threadIdx.x; i < len; i += 256) sm[i] = e.ep_r[(size_t)w * e.T + i];
   __syncthreads();
   if (threadIdx.x == 0) {
     const long long tail0 = (long long)st->ring_head + st->ring_size;
     s_start = (int)((tail0 + ((s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]))) % ring.cap);
-    // LabelTransitions (src/dqn.cpp:783-797): reverse scan, gamma double, float store
-    const float* r = e.ep_r + (size_t)w * e.T;
-    sm[len - 1] = r[len - 1];
-    for (int i = len - 2; i >= 0; --i) sm[i] = (float)((double)r[i] + gamma * (double)sm[i + 1]);
+    // LabelTransitions (src/dqn.cpp:783-797): reverse scan, gamma double, float store — the
+    // float rounding of every step makes the chain inherently serial; in place: sm[i] r -> mc
+    float target = sm[len - 1];
+    int i = len - 2;
+    for (; i >= 3; i -= 4) {
+      const float r0 = sm[i], r1 = sm[i - 1], r2 = sm[i - 2], r3 = sm[i - 3];
+      target = (float)((double)r0 + gamma * (double)target); sm[i] = target;
+      target = (float)((double)r1 + gamma * (double)target); sm[i - 1] = target;
+      target = (float)((double)r2 + gamma * (double)target); sm[i - 2] = target;
+      target = (float)((double)r3 + gamma * (double)target); sm[i - 3] = target;
+    }
+    for (; i >= 0; --i) { target = (float)((double)sm[i] + gamma * (double)target); sm[i] = target; }
     e.n_episodes[w] += 1;
   }
   __syncthreads();
