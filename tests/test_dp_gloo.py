@@ -107,3 +107,54 @@ def test_two_rank_dp_matches_single_learner(tmp_path):
     for n in range(4):
         np.testing.assert_allclose(r0["w%d" % n], one.get_params(n), rtol=1e-4, atol=2e-6)
     one.close()
+
+
+def _worker_groups(rank, world, port, out_dir):
+    """BASELINE config #4's process layout: 2 agents x a 2-rank data-parallel group each (src/dqn_main.cpp
+    runs the agents as independent DQNs; here each agent is a DP group on its own sub-communicator)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    groups = [dist.new_group([0, 1]), dist.new_group([2, 3])]      # every rank creates every group
+    agent, grank = rank // 2, rank % 2
+    c_oracle, w, shards, idx = _setup(world, rank)
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    load_package()
+    from importlib import import_module
+    par = import_module("dqn_hfo_amd.parallel")
+    orc = c_oracle.Oracle(B=B_LOCAL, S=S, hidden=HIDDEN, capacity=N_REP + 1, global_B=B_LOCAL * 2)
+    for net in (0, 1):
+        orc.set_params(net, w[net] * (1.0 + 0.25 * agent)); orc.clone_to_target(net)   # the agents start apart
+    orc.add_transitions(*shards[rank])
+    be = OracleBackend(orc)
+    dp = par.DataParallelUpdate(be, critic_grad=be.flat[1], actor_grad=be.flat[0], group=groups[agent])
+    for u in range(2):
+        dp.update(idx[rank][u])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **{"w%d" % n: orc.get_params(n) for n in range(4)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_agents_times_two_rank_groups(tmp_path):
+    world = 4
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_groups, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(world)]
+    for n in range(4):
+        np.testing.assert_array_equal(r[0]["w%d" % n], r[1]["w%d" % n])     # replicas inside an agent's group
+        np.testing.assert_array_equal(r[2]["w%d" % n], r[3]["w%d" % n])
+        assert np.abs(r[0]["w%d" % n] - r[2]["w%d" % n]).max() > 1e-4       # no exchange between the agents
+    # each agent equals ONE learner on its group's concatenated minibatch
+    c_oracle, w, shards, idx = _setup(world, 0)
+    for agent in range(2):
+        ranks = (2 * agent, 2 * agent + 1)
+        cat = [np.concatenate([shards[k][j] for k in ranks]) for j in range(6)]
+        one = c_oracle.Oracle(B=B_LOCAL * 2, S=S, hidden=HIDDEN, capacity=N_REP * 2 + 1)
+        for net in (0, 1):
+            one.set_params(net, w[net] * (1.0 + 0.25 * agent)); one.clone_to_target(net)
+        one.add_transitions(*cat)
+        for u in range(2):
+            one.update(np.concatenate([idx[k][u] + i * N_REP for i, k in enumerate(ranks)]))
+        for n in range(4):
+            np.testing.assert_allclose(r[ranks[0]]["w%d" % n], one.get_params(n), rtol=1e-4, atol=2e-6)
+        one.close()
