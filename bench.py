@@ -274,10 +274,12 @@ def main():
     env_res = None
     if rank == 0 and not args.no_env:
         env_res = {}
-        for workers in (64, 1024):
-            if workers * args.frames_per_trial >= args.replay:      # episode buffers must fit the replay ring
+        for workers in (64, 1024, 2048):          # BASELINE configs #3 (64 workers) and #5 (2048 workers)
+            # episode buffers must fit the replay ring: cap the episode length for the widest runs
+            T = min(args.frames_per_trial, (args.replay - 1) // workers)
+            if T < 100:
                 continue
-            env = pkg.EnvFrontEnd(dqn, workers, max_steps=args.frames_per_trial, p_end=0.01, seed=5)
+            env = pkg.EnvFrontEnd(dqn, workers, max_steps=T, p_end=0.01, seed=5)
             env.step(0.1, 20)
             env.stats()
             t1 = time.perf_counter()
@@ -287,7 +289,7 @@ def main():
             dt = time.perf_counter() - t1
             env_res["workers_%d" % workers] = {"env_steps_per_s": round(workers * n_env / dt, 1),
                                                "us_per_batched_step": round(dt / n_env * 1e6, 2),
-                                               "episodes": st[1]}
+                                               "episodes": st[1], "max_episode_steps": T}
             env.close()
         if not args.no_cpu_baseline and world == 1:
             from oracle import c_oracle, torch_ref
