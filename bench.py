@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--no-env", action="store_true", help="skip the env-steps/sec leg")
     ap.add_argument("--frames-per-trial", type=int, default=500)
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel path even with one rank (testing)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --minibatch is the GLOBAL minibatch, split over the ranks (value = global updates/s)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only for the 2-ranks-on-one-GPU flow test)")
     ap.add_argument("--share-device0", action="store_true",
@@ -182,6 +184,11 @@ def main():
                     help="N>1: dp = gradient all-reduce (weak scaling), replicas = independent learners")
     args = ap.parse_args()
     B = args.minibatch
+    if args.strong:
+        w_ = int(os.environ.get("WORLD_SIZE", "1"))
+        if B % (32 * w_):
+            raise SystemExit("--strong: global minibatch %d is not a multiple of 32 x %d ranks" % (B, w_))
+        B //= w_
 
     import torch
     pkg = load_package()
@@ -305,21 +312,22 @@ def main():
 
     if rank == 0:
         ups = args.steps / elapsed
-        value = ups * (world if world > 1 else 1)
+        value = ups if args.strong else ups * (world if world > 1 else 1)
         fl = sum(family_flops(B, S, HIDDEN).values())
         out = {
-            "metric": "DQN updates/sec, 1v0 HFO, 4x1024 MLP, minibatch %d" % B,
+            "metric": "DQN updates/sec, 1v0 HFO, 4x1024 MLP, minibatch %d" % (B * world if args.strong else B),
             "value": round(value, 2), "unit": "updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f16 operands, f32 accumulate (master weights / Adam / heads f32)",
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 1v0 HFO, 1 MI355X, 4x1024 actor-critic MLP, "
-                                   "minibatch 256, device-resident replay %d transitions, 58-dim synthetic states"
-                                   % args.replay,
+                                   "minibatch %d per GPU, device-resident replay %d transitions, 58-dim synthetic states"
+                                   % (B, args.replay),
                        "minibatch_per_gpu": B, "global_minibatch": B * (world if use_dp else 1),
-                       "parallelism": ("dp%d (RCCL all-reduce of critic then actor gradients); value counts "
-                                       "minibatch-256 updates" % world) if use_dp else
+                       "parallelism": ("dp%d (%s all-reduce of critic then actor gradients); value counts %s"
+                                       % (world, "RCCL" if args.backend == "nccl" else args.backend,
+                                          "global-minibatch updates" if args.strong else "minibatch-%d updates" % B)) if use_dp else
                                       ("replicas x%d" % world if world > 1 else "single"),
                        "hip_graph": (not args.no_graph) and not use_dp,
                        "sampling": "on-device Philox, uniform with replacement"},
