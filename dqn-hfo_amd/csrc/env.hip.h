@@ -233,12 +233,13 @@ __global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const De
   }
   __syncthreads();
   const int start = s_start;
-  const int SP = e.SP;
-  for (int i = threadIdx.x; i < len * SP; i += 256) {
-    const int t = i / SP, c = i % SP;
+  const int SP = e.SP;                   // episode-buffer row = the actor's input panel width
+  const int RSP = ring.SP;               // ring row (<= SP: the fp16 learner pads its panels to 128)
+  for (int i = threadIdx.x; i < len * RSP; i += 256) {
+    const int t = i / RSP, c = i % RSP;
     const long long slot = ((long long)start + t) % ring.cap;
-    ring.state[slot * SP + c] = e.ep_s[((size_t)w * e.T + t) * SP + c];
-    ring.next[slot * SP + c] = (t + 1 < len) ? e.ep_s[((size_t)w * e.T + t + 1) * SP + c] : 0.0f;
+    ring.state[slot * RSP + c] = e.ep_s[((size_t)w * e.T + t) * SP + c];
+    ring.next[slot * RSP + c] = (t + 1 < len) ? e.ep_s[((size_t)w * e.T + t + 1) * SP + c] : 0.0f;
   }
   for (int i = threadIdx.x; i < len * kAP; i += 256) {
     const int t = i / kAP, c = i % kAP;
