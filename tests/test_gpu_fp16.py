@@ -96,6 +96,7 @@ def test_hgemm_kernels(pkg, gpu):
     dict(B=256, S=58, hidden=(1024, 1024, 1024, 1024), wscale=2.0),
     dict(B=128, S=77, hidden=(128, 256), wscale=5.0),
     dict(B=1024, S=58, hidden=(256, 256), wscale=4.0),      # large minibatch: head kernels emit the fp16 panels
+    dict(B=128, S=58, hidden=(2048, 1536), wscale=2.0),     # wider than 1024
 ])
 def test_fp16_pipeline_matches_emulation(pkg, gpu, shape):
     shape = dict(shape)
@@ -215,3 +216,28 @@ def test_fp16_deterministic(pkg, gpu):
         dqn.close(); orc.close()
     for x, y in zip(*res):
         np.testing.assert_array_equal(x, y)
+
+
+def test_fp16_weight_mirrors_follow_host_changes(pkg, gpu):
+    """set_params / CloneNet / restore mark the fp16 mirrors dirty: a second learner given the first one's
+    state (weights, Adam history, iterations, replay) continues bit-identically."""
+    B, S, hid = 128, 59, (256, 128)
+    a, orc, data, rng = make_pair(pkg, B=B, S=S, hidden=hid, n_replay=1024, wscale=5.0, precision="fp16", use_graph=True)
+    for it in range(3):
+        a.UpdateActorCritic(rng.integers(0, 1024, size=B))
+    b = pkg.DQN(S, minibatch=B, hidden=hid, memory=4096, seed=99, precision="fp16", use_graph=True)
+    b.add_transitions_arrays(*data)
+    b.UpdateActorCritic(rng.integers(0, 1024, size=B))           # b has its own captured graph and mirrors already
+    for net in range(4):
+        b.set_params(net, a.get_params(net))
+    for kind in (1, 2):
+        for net in (0, 1):
+            b.set_params(net, a.get_params(net, kind), kind)
+    b.set_iters(a.actor_iter(), a.critic_iter())
+    for it in range(2):
+        idx = rng.integers(0, 1024, size=B)
+        ra = a.UpdateActorCritic(idx); rb = b.UpdateActorCritic(idx)
+        assert ra == rb
+    for net in range(4):
+        np.testing.assert_array_equal(a.get_params(net), b.get_params(net))
+    a.close(); b.close(); orc.close()

@@ -73,6 +73,7 @@ def _check_update(dqn, orc, idx, t64=None, data=None):
     dict(B=96, S=61, hidden=(192, 320, 64), wscale=5.0),   # ragged: no dimension a multiple of 128, 3 layers
     dict(B=32, S=120, hidden=(64,), wscale=5.0),           # one hidden layer, 130-wide critic input (3 K panels)
     dict(B=64, S=59, hidden=(128, 64, 64, 128, 64, 64), wscale=8.0),   # six layers
+    dict(B=32, S=58, hidden=(2048, 1536), wscale=2.0),     # wider than the 1024-column head strips
     # BASELINE.json config #2.  wscale 2 (weights N(0, 0.02^2)): at 5x the 4x1024 critic's loss
     # explodes to 5e4 after one lr=1e-3 Adam step and HIP, the C oracle and a float64 reference
     # then differ from each other by ReLU-mask flips in different rows (all three measured).
