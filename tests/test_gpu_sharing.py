@@ -137,3 +137,29 @@ def test_share_replay_memory(pkg, gpu):
     with pytest.raises(pkg.DQNFatal):
         A.close()
     Bl.close(); A.close(); oA.close(); oB.close()
+
+
+def test_two_agents_share_ring_and_layers_under_load(pkg, gpu):
+    """Both agents run their own batched workers into ONE replay memory and update alternately on their
+    own streams (the reference's two KeepPlayingGames threads, src/dqn_main.cpp:305-323): the event
+    ordering of the shared ring and the aliased layers hold up, nothing faults, everything stays finite."""
+    A = pkg.DQN(58, minibatch=64, hidden=(128, 64, 64), memory=5000, seed=1)
+    Bl = pkg.DQN(58, minibatch=64, hidden=(128, 64, 64), memory=700, seed=2)
+    A.ShareParameters(Bl, 2, 1)
+    A.ShareReplayMemory(Bl)
+    envA = pkg.EnvFrontEnd(A, 32, max_steps=50, p_end=0.04, seed=3)
+    envB = pkg.EnvFrontEnd(Bl, 32, max_steps=50, p_end=0.04, seed=4)
+    for it in range(30):
+        envA.step(0.5, 10); envB.step(0.5, 10)
+        if A.memory_size() >= 500:
+            la, qa = A.UpdateActorCritic(); lb, qb = Bl.UpdateActorCritic()
+            assert np.isfinite([la, qa, lb, qb]).all()
+    sa, sb = envA.stats(), envB.stats()
+    assert sa[0] == sb[0] == 30 * 10 * 32
+    assert A.memory_size() == Bl.memory_size() == 4999            # 19200 transitions through the owner's 5000 slots
+    ka = 58 * 128 + 128 + 128 * 64 + 64
+    np.testing.assert_array_equal(A.get_params(0)[:ka], Bl.get_params(0)[:ka])
+    assert np.abs(A.get_params(0)[ka:] - Bl.get_params(0)[ka:]).max() > 0
+    s = A.read_memory(0, 4999)[0]
+    assert np.isfinite(s).all() and (np.abs(s) <= 1 + 1e-6).all()
+    envB.close(); envA.close(); Bl.close(); A.close()

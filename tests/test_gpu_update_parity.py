@@ -74,6 +74,7 @@ def _check_update(dqn, orc, idx, t64=None, data=None):
     dict(B=32, S=120, hidden=(64,), wscale=5.0),           # one hidden layer, 130-wide critic input (3 K panels)
     dict(B=64, S=59, hidden=(128, 64, 64, 128, 64, 64), wscale=8.0),   # six layers
     dict(B=32, S=58, hidden=(2048, 1536), wscale=2.0),     # wider than the 1024-column head strips
+    dict(B=4096, S=58, hidden=(256, 256), wscale=3.0),     # config #5's minibatch on the fp32 path
     # BASELINE.json config #2.  wscale 2 (weights N(0, 0.02^2)): at 5x the 4x1024 critic's loss
     # explodes to 5e4 after one lr=1e-3 Adam step and HIP, the C oracle and a float64 reference
     # then differ from each other by ReLU-mask flips in different rows (all three measured).
