@@ -92,3 +92,28 @@ def test_load_errors(pkg, gpu, tmp_path):
     with pytest.raises(pkg.DQNFatal, match="capacity"):
         dqn.LoadReplayMemory(path)
     dqn.close()
+
+
+def test_snapshot_of_a_wrapped_ring(pkg, gpu, tmp_path):
+    """After eviction the deque's front is in the middle of the ring: the file holds the logical order."""
+    S, cap = 59, 300
+    rng = np.random.default_rng(4)
+    dqn = pkg.DQN(S, minibatch=32, hidden=(64,), memory=cap)
+    chunks = [synth_replay(rng, n, S, mean_len=9) for n in (200, 150, 120, 90)]
+    for c in chunks:
+        dqn.add_transitions_arrays(*c)
+    assert dqn.memory_size() == cap - 1
+    allrows = [np.concatenate([c[k] for c in chunks]) for k in range(6)]
+    want = [x[-(cap - 1):] for x in allrows]                     # the last cap-1 transitions survive
+    path = str(tmp_path / "wrapped.replaymemory")
+    dqn.SnapshotReplayMemory(path)
+    got = py_read(path, S)
+    for k in (0, 1, 2, 3):
+        np.testing.assert_array_equal(got[k], want[k])
+    dqn2 = pkg.DQN(S, minibatch=32, hidden=(64,), memory=cap)
+    dqn2.LoadReplayMemory(path)
+    assert dqn2.memory_size() == cap - 1
+    a, b = dqn2.read_memory(0, cap - 1), dqn.read_memory(0, cap - 1)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    dqn.close(); dqn2.close()
