@@ -431,29 +431,62 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
     _Pragma("unroll") for (int c = 0; c < TP; ++c)                                      \
         acc[a * TP + c] = DQN_MFMA(FF[c][kb][s], FF[TP + a][kb][s], acc[a * TP + c]); }
 #define L_PIN() { if (PIN) DQN_PIN(); }
+  // PIN: every half step {stage the next image: ds_write x2NB, global_load x2NB, ds_read x2NB | MFMA of the
+  // current fragments} is one scheduling region whose staging instructions are spread through the MFMAs
+  // in that order (hipcc on its own either sinks the loads to the end of the iteration — zero lookahead —
+  // or, with plain order pinning, issues the 3 x 2NB staging instructions as a block with the MFMA pipe idle)
+  constexpr int NOPS = 2 * NB, NMF = 8 * NACC;
+  constexpr int MW = (NMF >= 5 * NOPS) ? 2 : 1, ML = MW, MR = 1;
+  constexpr bool SGB = PIN && (NMF >= 3 * NOPS);
+#define L_SCHED_(HASLD)                                                                 \
+  { if constexpr (SGB) {                                                                \
+      _Pragma("unroll") for (int i_ = 0; i_ < NOPS; ++i_) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, MW, 0); } \
+      if (HASLD) { _Pragma("unroll") for (int i_ = 0; i_ < NOPS; ++i_) {                \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, ML, 0); } } \
+      _Pragma("unroll") for (int i_ = 0; i_ < NOPS; ++i_) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, MR, 0); } \
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF - (MW + (HASLD ? ML : 0) + MR) * NOPS, 0); } }
+#define L_SCHED() L_SCHED_(true)
 
-  L_GLOAD(G0, 0) L_GLOAD(G1, 1)
-  L_SWRITE(0, G0) L_GLOAD(G0, 2) L_SREAD(F, 0)
+  // (pinned prologue: the waitcnt pass merges the prologue's load order into the loop header, so an
+  // interleaved prologue makes every in-loop vmcnt wait conservative)
+  L_GLOAD(G0, 0) L_PIN() L_GLOAD(G1, 1) L_PIN()
+  L_SWRITE(0, G0) L_PIN() L_GLOAD(G0, 2) L_PIN() L_SREAD(F, 0) L_PIN()
   int t = 0;
   for (; t + 4 < T; t += 2) {
-    L_SWRITE(1, G1) L_GLOAD(G1, t + 3) L_SREAD(Fn, 1) L_PIN()
-    L_MFMA(F) L_PIN()
-    L_SWRITE(0, G0) L_GLOAD(G0, t + 4) L_SREAD(F, 0) L_PIN()
-    L_MFMA(Fn) L_PIN()
+    if constexpr (SGB) {
+      L_SWRITE(1, G1) L_GLOAD(G1, t + 3) L_SREAD(Fn, 1) L_MFMA(F) L_SCHED() L_PIN()
+      L_SWRITE(0, G0) L_GLOAD(G0, t + 4) L_SREAD(F, 0) L_MFMA(Fn) L_SCHED() L_PIN()
+    } else {
+      L_SWRITE(1, G1) L_PIN() L_GLOAD(G1, t + 3) L_PIN() L_SREAD(Fn, 1) L_PIN()
+      L_MFMA(F) L_PIN()
+      L_SWRITE(0, G0) L_PIN() L_GLOAD(G0, t + 4) L_PIN() L_SREAD(F, 0) L_PIN()
+      L_MFMA(Fn) L_PIN()
+    }
   }
   // t == T-4
-  L_SWRITE(1, G1) L_GLOAD(G1, T - 1) L_SREAD(Fn, 1) L_PIN()
-  L_MFMA(F) L_PIN()
-  L_SWRITE(0, G0) L_SREAD(F, 0) L_PIN()
-  L_MFMA(Fn) L_PIN()
-  L_SWRITE(1, G1) L_SREAD(Fn, 1) L_PIN()
-  L_MFMA(F) L_PIN()
-  L_MFMA(Fn)
+  if constexpr (SGB) {
+    L_SWRITE(1, G1) L_GLOAD(G1, T - 1) L_SREAD(Fn, 1) L_MFMA(F) L_SCHED() L_PIN()
+    L_SWRITE(0, G0) L_SREAD(F, 0) L_MFMA(Fn) L_SCHED_(false) L_PIN()
+    L_SWRITE(1, G1) L_SREAD(Fn, 1) L_MFMA(F) L_SCHED_(false) L_PIN()
+    L_MFMA(Fn)
+  } else {
+    L_SWRITE(1, G1) L_GLOAD(G1, T - 1) L_SREAD(Fn, 1) L_PIN()
+    L_MFMA(F) L_PIN()
+    L_SWRITE(0, G0) L_SREAD(F, 0) L_PIN()
+    L_MFMA(Fn) L_PIN()
+    L_SWRITE(1, G1) L_SREAD(Fn, 1) L_PIN()
+    L_MFMA(F) L_PIN()
+    L_MFMA(Fn)
+  }
 #undef L_GLOAD
 #undef L_SWRITE
 #undef L_SREAD
 #undef L_MFMA
 #undef L_PIN
+#undef L_SCHED
+#undef L_SCHED_
 
   // park into this wave's own (now idle) staging region, reduce across waves in fixed order
   f32x4* park = reinterpret_cast<f32x4*>(wsm);

@@ -318,9 +318,9 @@ int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, 
   // over 256 workgroups (64 rows x 1024 outputs = 256 tiles) instead of 64
   static const bool kSmallTiles = !getenv("DQNHIP_NO_SMALL_TILES");
   if (n == 1 && rows <= 128 && lds_ok && kSmallTiles) HIPCHK((fwd_lds_launch<1, 1, false>(b, st)));
-  else if (n == 1 && rows >= 512 && lds_ok && l.dims[i + 1] % 64 == 0) HIPCHK((fwd_lds_launch<4, 2, false>(b, st)));   // enough rows to fill the chip with 64x32 tiles (fewer bytes per FLOP)
-  else if (n == 1) { if (lds_ok) HIPCHK((fwd_lds_launch<2, 2, false>(b, st))); else HIPCHK((fwd_direct_launch<2, 2>(b, st))); }
-  else { if (lds_ok) HIPCHK((fwd_lds_launch<4, 2, false>(b, st))); else HIPCHK((fwd_direct_launch<4, 2>(b, st))); }
+  else if (n == 1 && rows >= 512 && lds_ok && l.dims[i + 1] % 64 == 0) HIPCHK((fwd_lds_launch<4, 2, true>(b, st)));   // enough rows to fill the chip with 64x32 tiles (fewer bytes per FLOP)
+  else if (n == 1) { if (lds_ok) HIPCHK((fwd_lds_launch<2, 2, true>(b, st))); else HIPCHK((fwd_direct_launch<2, 2>(b, st))); }
+  else { if (lds_ok) HIPCHK((fwd_lds_launch<4, 2, true>(b, st))); else HIPCHK((fwd_direct_launch<4, 2>(b, st))); }
   return 0;
 }
 int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows) {
@@ -1078,6 +1078,7 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
   HIPCHK(direct_prepare(gemm_bwd_pair_direct<1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_bwd_pair_direct<1, true>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4));
+  HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, true>, 4 * 2 * 6 * 512 * 4));
   RC(sync_dirty16(h));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;

@@ -8,6 +8,6 @@ def run(mode, variant, rows, n, k, groups):
     us, err, ref = C.c_float(), C.c_float(), C.c_float()
     rc = fn(mode, variant, rows, n, k, groups, 200, C.byref(us), C.byref(err), C.byref(ref))
     print("mode %d var %2d rows %4d groups %d: rc %d %7.2f us  (%.2f us/layer) err %.2e" % (mode, variant, rows, groups, rc, us.value, us.value / groups, err.value), flush=True)
-for v in (12, 17, 10, 18):
-    for g in (1, 2, 3, 4):
+for v in (12, 13, 10, 11):
+    for g in (1, 2):
         run(0, v, 256, 1024, 1024, g)
