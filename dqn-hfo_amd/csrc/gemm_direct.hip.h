@@ -519,7 +519,7 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
 // dgrad_direct_body with the k-contiguous operand (dY, 16-row blocks) fetched as whole 128-B
 // lines through the wave-private LDS transpose of fwd_lds_body; the weight operand (k-strided)
 // stays a direct full-line load.  Requires Kred % 256 == 0 and Kred >= 512.
-template <int TPB, int TQ>
+template <int TPB, int TQ, bool SCH = true>
 __device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
   constexpr int NACC = TPB * 4 * TQ;
   constexpr int SLOT = TQ * 512;
@@ -573,23 +573,39 @@ __device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p
     _Pragma("unroll") for (int pc = 0; pc < 4; ++pc)                                    \
         acc[(a * TPB + b) * 4 + pc] = DQN_MFMA(PP[kb][s2][b][pc], FF[a][kb][s2], acc[(a * TPB + b) * 4 + pc]); }
 
-  D_GLOADQ(G0, 0) D_GLOADQ(G1, 1) D_GLOADP(P0, 0)
-  D_SWRITE(0, G0) D_GLOADQ(G0, 2) D_SREAD(F, 0) D_GLOADP(P1, 1)
+  // One scheduling region per half step, staging instructions spread through the MFMAs in this order
+  // (see fwd_lds_body): dY image ds_writes, next dY loads, fragment ds_reads among the first MFMAs;
+  // the W loads that refill the P registers among the second half (their registers are free once the
+  // kb = 0 MFMAs have issued).  Pinned prologue so that the in-loop vmcnt waits are counted, not 0.
+  constexpr int NQ = 2 * TQ, NPL = 8 * TPB, NMF = 32 * TQ * TPB, HALF = NMF / 2;
+#define D_PIN() { if (SCH) DQN_PIN(); }
+#define D_SCHED_(HASQ, HASP)                                                            \
+  if constexpr (SCH) { _Pragma("unroll") for (int i_ = 0; i_ < NQ; ++i_) {                                 \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); } \
+    if (HASQ) { _Pragma("unroll") for (int i_ = 0; i_ < NQ; ++i_) {                     \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); } } \
+    _Pragma("unroll") for (int i_ = 0; i_ < NQ; ++i_) {                                 \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); } \
+    __builtin_amdgcn_sched_group_barrier(0x008, HALF - (HASQ ? 3 : 2) * NQ, 0);         \
+    if (HASP) { _Pragma("unroll") for (int i_ = 0; i_ < NPL; ++i_) {                    \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, HALF / NPL, 0); } } \
+    else __builtin_amdgcn_sched_group_barrier(0x008, HALF, 0);                          \
+    DQN_PIN(); }
+
+  D_GLOADQ(G0, 0) D_PIN() D_GLOADQ(G1, 1) D_PIN() D_GLOADP(P0, 0) D_PIN()
+  D_SWRITE(0, G0) D_PIN() D_GLOADQ(G0, 2) D_PIN() D_SREAD(F, 0) D_PIN() D_GLOADP(P1, 1) D_PIN()
   int t = 0;
   for (; t + 4 < T; t += 2) {
-    D_SWRITE(1, G1) D_GLOADQ(G1, t + 3) D_SREAD(Fn, 1)
-    D_MFMA(F, P0) D_GLOADP(P0, t + 2)
-    D_SWRITE(0, G0) D_GLOADQ(G0, t + 4) D_SREAD(F, 0)
-    D_MFMA(Fn, P1) D_GLOADP(P1, t + 3)
+    D_SWRITE(1, G1) D_GLOADQ(G1, t + 3) D_SREAD(Fn, 1) D_MFMA(F, P0) D_GLOADP(P0, t + 2) D_SCHED_(true, true)
+    D_SWRITE(0, G0) D_GLOADQ(G0, t + 4) D_SREAD(F, 0) D_MFMA(Fn, P1) D_GLOADP(P1, t + 3) D_SCHED_(true, true)
   }
   // t == T-4
-  D_SWRITE(1, G1) D_GLOADQ(G1, T - 1) D_SREAD(Fn, 1)
-  D_MFMA(F, P0) D_GLOADP(P0, T - 2)
-  D_SWRITE(0, G0) D_SREAD(F, 0)
-  D_MFMA(Fn, P1) D_GLOADP(P1, T - 1)
-  D_SWRITE(1, G1) D_SREAD(Fn, 1)
-  D_MFMA(F, P0)
+  D_SWRITE(1, G1) D_GLOADQ(G1, T - 1) D_SREAD(Fn, 1) D_MFMA(F, P0) D_GLOADP(P0, T - 2) D_SCHED_(true, true)
+  D_SWRITE(0, G0) D_SREAD(F, 0) D_MFMA(Fn, P1) D_GLOADP(P1, T - 1) D_SCHED_(false, true)
+  D_SWRITE(1, G1) D_SREAD(Fn, 1) D_MFMA(F, P0) D_SCHED_(false, false)
   D_MFMA(Fn, P1)
+#undef D_SCHED_
+#undef D_PIN
 #undef D_GLOADQ
 #undef D_GLOADP
 #undef D_SWRITE
@@ -677,7 +693,7 @@ __global__ __launch_bounds__(256) void gemm_bwd_pair_direct(const GemmBatch batc
   tile_of_block(batch, pi, tile_p, tile_q);
   const GemmProblem& pr = batch.prob[pi];
   if (pr.mode == GEMM_WGRAD) wgrad_direct_body<1, 1>(pr, tile_p, tile_q, smem);
-  else if constexpr (DLDS) dgrad_lds_body<1, TQD>(pr, tile_p, tile_q, smem);
+  else if constexpr (DLDS) dgrad_lds_body<1, TQD, false>(pr, tile_p, tile_q, smem);   // (scheduled form measured 0.5 us slower beside the co-resident wgrad wave)
   else dgrad_direct_body<1, TQD>(pr, tile_p, tile_q, smem);
 }
 

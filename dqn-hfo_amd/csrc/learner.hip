@@ -372,7 +372,9 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
       else HIPCHK(bwd_pair_direct_launch<1>(b, st));
     } else if (need_dx) {
       ScopedTiming t(h, 1, st);
-      HIPCHK((dgrad_direct_launch<1, 1>(bd, st)));
+      // reduction width (the layer's outputs) wide enough: dY through the LDS transpose, scheduled form
+      if (l.dims[i + 1] >= 512 && l.dims[i + 1] % 256 == 0) HIPCHK((dgrad_lds_launch<1, 1>(bd, st)));
+      else HIPCHK((dgrad_direct_launch<1, 1>(bd, st)));
     } else {
       ScopedTiming t(h, 2, st);
       HIPCHK((wgrad_direct_launch<1, 1>(bw, st)));
