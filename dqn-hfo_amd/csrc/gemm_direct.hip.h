@@ -37,14 +37,7 @@ namespace dqnhip {
 
 // ---- shared pieces ----------------------------------------------------------------
 
-__device__ __forceinline__ void tile_of_block(const GemmBatch& batch, int& pi, int& tile_p, int& tile_q) {
-  int b = blockIdx.x;
-  pi = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxGroup; ++i)
-    if (i < batch.n && b >= batch.prob[i].tile_base) pi = i;
-  const GemmProblem& pr = batch.prob[pi];
-  b -= pr.tile_base;
+__device__ __forceinline__ void tile_of_problem(const GemmProblem& pr, int b, int& tile_p, int& tile_q) {
   if ((pr.tiles_p & 7) == 0) {       // same P panel (weight slice) -> same XCD L2 (b % 8)
     const int xcd = b & 7, j = b >> 3;
     tile_q = j % pr.tiles_q;
@@ -53,6 +46,15 @@ __device__ __forceinline__ void tile_of_block(const GemmBatch& batch, int& pi, i
     tile_q = b % pr.tiles_q;
     tile_p = b / pr.tiles_q;
   }
+}
+__device__ __forceinline__ void tile_of_block(const GemmBatch& batch, int& pi, int& tile_p, int& tile_q) {
+  int b = blockIdx.x;
+  pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < batch.n && b >= batch.prob[i].tile_base) pi = i;
+  const GemmProblem& pr = batch.prob[pi];
+  tile_of_problem(pr, b - pr.tile_base, tile_p, tile_q);
 }
 
 // Each wave parks its NACC accumulators in LDS (lane-linear: conflict free), then wave w
@@ -254,6 +256,7 @@ __device__ __forceinline__ void dgrad_direct_body(const GemmProblem& pr, int til
 // ================================ WGRAD ==============================================
 // dW[n][j] = sum_m dY[m][n] X[m][j];  db[n] = sum_m dY[m][n].  P = X (KS, 64-wide blocks of
 // j), Q = dY (KS, 64-wide blocks of n).  Tile = (64*TPB) x (64*TQB).  Kred (= rows m) % 16 == 0.
+constexpr int kWgradRing = 4;   // register ring of wgrad_direct_body (8 measured slower inside the pair kernel: 16.4 vs 15.3 us)
 template <int TPB, int TQB>
 __device__ __forceinline__ void wgrad_direct_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
   constexpr int NACC = TPB * 4 * TQB * 4;
@@ -274,7 +277,7 @@ __device__ __forceinline__ void wgrad_direct_body(const GemmProblem& pr, int til
 #pragma unroll
   for (int d = 0; d < TQB; ++d) dbacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   // register ring of NS steps (4 rows of X and dY each): NS-1 steps of lookahead
-  constexpr int NS = 4;   // (8 measured slower inside the pair kernel: 16.4 vs 15.3 us)
+  constexpr int NS = kWgradRing;
   f32x4 rp[NS][TPB], rq[NS][TQB];
 
 #define WG_LOAD(slot, st)                                                               \
@@ -699,6 +702,31 @@ __global__ __launch_bounds__(256) void gemm_bwd_pair_direct(const GemmBatch batc
   else dgrad_direct_body<1, TQD>(pr, tile_p, tile_q, smem);
 }
 
+// The same layer backward with ONE workgroup type: workgroup b computes wgrad tile b and then dgrad
+// tile b in one instruction stream (prob[0] = dgrad, prob[1] = wgrad).  Two co-resident workgroups
+// per CU measured ~ the SUM of their stand-alone times (the pair kernel above: 15.5 us for 2 x 4.2 us
+// of MFMA); one workgroup doing both pays the per-launch fixed cost once and keeps one wave per SIMD.
+template <bool DLDS>
+__global__ __launch_bounds__(256) void gemm_bwd_seq(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  int tile_p, tile_q;
+  // wgrad first (measured 14.9 us; dgrad first 15.3, also with the wgrad ring pre-issued under the
+  // dgrad epilogue)
+  const GemmProblem& pw = batch.prob[1];
+  if (b < pw.tiles_p * pw.tiles_q) {
+    tile_of_problem(pw, b, tile_p, tile_q);
+    wgrad_direct_body<1, 1>(pw, tile_p, tile_q, smem);
+  }
+  __syncthreads();
+  const GemmProblem& pd = batch.prob[0];
+  if (b < pd.tiles_p * pd.tiles_q) {
+    tile_of_problem(pd, b, tile_p, tile_q);
+    if constexpr (DLDS) dgrad_lds_body<1, 1, true>(pd, tile_p, tile_q, smem);
+    else dgrad_direct_body<1, 1>(pd, tile_p, tile_q, smem);
+  }
+}
+
 // ---- launchers ------------------------------------------------------------------------
 
 // When set (by the learner's timing mode), the next launch is bracketed by these events through
@@ -776,6 +804,21 @@ inline hipError_t bwd_pair_direct_launch(GemmBatch& batch, hipStream_t stream) {
   LaunchTimer& lt = launch_timer();
   if (lt.start) { hipExtLaunchKernelGGL((gemm_bwd_pair_direct<TQD, DLDS>), dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, lt.start, lt.stop, 0, batch); lt.start = lt.stop = nullptr; }
   else hipLaunchKernelGGL((gemm_bwd_pair_direct<TQD, DLDS>), dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, batch);
+  return hipGetLastError();
+}
+template <bool DLDS>
+inline hipError_t bwd_seq_launch(GemmBatch& batch, hipStream_t stream) {
+  // prob[0] dgrad (64 x 16 tiles), prob[1] wgrad (64 x 64 tiles)
+  GemmProblem& d = batch.prob[0]; GemmProblem& w = batch.prob[1];
+  d.tiles_p = d.Pdim / 64; d.tiles_q = d.Qdim / 16; d.tile_base = 0;
+  w.tiles_p = w.Pdim / 64; w.tiles_q = w.Qdim / 64; w.tile_base = 0;
+  const int nd = d.tiles_p * d.tiles_q, nw = w.tiles_p * w.tiles_q;
+  const int grid = nd > nw ? nd : nw;
+  batch.total_tiles = grid;
+  constexpr int lds = 4 * 16 * 64 * 16 + 4 * 16 * 16;
+  LaunchTimer& lt = launch_timer();
+  if (lt.start) { hipExtLaunchKernelGGL((gemm_bwd_seq<DLDS>), dim3(grid), dim3(256), lds, stream, lt.start, lt.stop, 0, batch); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL((gemm_bwd_seq<DLDS>), dim3(grid), dim3(256), lds, stream, batch);
   return hipGetLastError();
 }
 template <typename K>

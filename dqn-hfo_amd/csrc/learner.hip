@@ -368,7 +368,10 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
       ScopedTiming t(h, 4, st);
       // dY through the LDS transpose when the layer is wide enough (measured: pair 16.6 -> see DESIGN)
       static const bool kPairLds = !getenv("DQNHIP_PAIR_DIRECT");
-      if (kPairLds && l.dims[i + 1] >= 512 && l.dims[i + 1] % 256 == 0) HIPCHK((bwd_pair_direct_launch<1, true>(b, st)));
+      static const bool kSeq = !getenv("DQNHIP_PAIR_COOP");
+      const bool lds_ok = kPairLds && l.dims[i + 1] >= 512 && l.dims[i + 1] % 256 == 0;
+      if (kSeq) { if (lds_ok) HIPCHK((bwd_seq_launch<true>(b, st))); else HIPCHK((bwd_seq_launch<false>(b, st))); }
+      else if (lds_ok) HIPCHK((bwd_pair_direct_launch<1, true>(b, st)));
       else HIPCHK(bwd_pair_direct_launch<1>(b, st));
     } else if (need_dx) {
       ScopedTiming t(h, 1, st);
@@ -1079,6 +1082,8 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
   HIPCHK(direct_prepare(gemm_wgrad_direct<1, 1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_bwd_pair_direct<1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_bwd_pair_direct<1, true>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
+  HIPCHK(direct_prepare(gemm_bwd_seq<true>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
+  HIPCHK(direct_prepare(gemm_bwd_seq<false>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4));
   HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, true>, 4 * 2 * 6 * 512 * 4));
   RC(sync_dirty16(h));
