@@ -80,9 +80,9 @@ def family_flops16(B, S, hidden):
 MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: fp16/bf16 dense MFMA peak
 
 KERNEL_NAMES = {"hgemm_fwd": "hgemm_nt<2,2>/<1,1> (forward epilogue)", "hgemm_dgrad": "hgemm_nt (dgrad epilogue)",
-                "hgemm_wgrad": "hgemm_nt (wgrad epilogue)","gemm_fwd_lds_4x2": "gemm_fwd_lds<4,2,true>", "gemm_fwd_lds_2x2": "gemm_fwd_lds<2,2,true>",
-                "gemm_fwd_direct": "gemm_fwd_direct<*>", "gemm_bwd_pair": "gemm_bwd_pair_direct<1>",
-                "gemm_dgrad": "gemm_dgrad_direct<1,1>", "gemm_wgrad": "gemm_wgrad_direct<1,1>"}
+                "hgemm_wgrad": "hgemm_nt (wgrad epilogue)","gemm_fwd_lds_4x2": "gemm_fwd_lds<4,2,true,2>", "gemm_fwd_lds_2x2": "gemm_fwd_lds<2,2,true,2>",
+                "gemm_fwd_direct": "gemm_fwd_direct<4,2,0>", "gemm_bwd_pair": "gemm_bwd_seq<true>",
+                "gemm_dgrad": "gemm_dgrad_lds<1,1>", "gemm_wgrad": "gemm_wgrad_direct<1,1>"}
 
 
 def pmc_traffic(kernel):
