@@ -119,6 +119,7 @@ hipError_t launch_variant(int mode, int variant, GemmBatch& b, hipStream_t s) {
     switch (variant) {
       case 0: return gemm_launch<GEMM_WGRAD, 64, 64, 2, 2>(b, s);
       case 1: return wgrad_direct_launch<1, 1>(b, s);  // 64x64
+      case 2: return wgrad_narrow_launch<1>(b, s);     // 64 x 16 outputs (first layer)
     }
   }
   return hipErrorInvalidValue;

@@ -370,6 +370,98 @@ __device__ __forceinline__ void wgrad_direct_body(const GemmProblem& pr, int til
   }
 }
 
+// ---- WGRAD, narrow: 16 columns of dY per workgroup ------------------------------------------
+// The first tower layer's dW_0[n][j] has only K_in = 64 / 128 columns j: with 64 x 64 tiles it is 16 / 32
+// workgroups whose waves each hold 4.2 us of MFMA (a latency-bound 8 us launch on a sliver of the chip).
+// Here a workgroup owns 16 outputs n (one dY column per lane, scalar loads) x 64 columns j: a quarter of
+// the MFMA chain per wave, four times the workgroups.  Same K split over the 4 waves, same fixed-order
+// reduction; db and the sum-of-squares partial (slot = tile_q * tiles_p + tile_p over 16-wide tiles).
+template <int TPB>
+__device__ __forceinline__ void wgrad_narrow_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
+  constexpr int NACC = TPB * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int p0 = tile_p * 64 * TPB, q0 = tile_q * 16;
+  const int Kw = pr.Kred >> 2;
+  const int nst = Kw >> 2;
+  const float* pp = pr.P + (size_t)(wave * Kw + lg) * pr.ldp + p0 + li * 4;
+  const float* qp = pr.Q + (size_t)(wave * Kw + lg) * pr.ldq + q0 + li;
+  const size_t ldp = pr.ldp, ldq = pr.ldq;
+  const bool want_db = (pr.db != nullptr) && (tile_p == 0);
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbacc = 0.0f;
+  constexpr int NS = kWgradRing;
+  f32x4 rp[NS][TPB]; float rq[NS];
+#define WN_LOAD(slot, st)                                                               \
+  {                                                                                     \
+    _Pragma("unroll") for (int b = 0; b < TPB; ++b)                                     \
+        rp[slot][b] = *reinterpret_cast<const f32x4*>(pp + (size_t)((st) << 2) * ldp + b * 64); \
+    rq[slot] = qp[(size_t)((st) << 2) * ldq];                                           \
+  }
+#define WN_COMPUTE(slot)                                                                \
+  {                                                                                     \
+    dbacc += rq[slot];                                                                  \
+    _Pragma("unroll") for (int b = 0; b < TPB; ++b)                                     \
+    _Pragma("unroll") for (int pc = 0; pc < 4; ++pc)                                    \
+        acc[b * 4 + pc] = DQN_MFMA(rp[slot][b][pc], rq[slot], acc[b * 4 + pc]);         \
+  }
+  const int nstN = nst - nst % NS;
+  if (nstN > 0) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { WN_LOAD(i, i) DQN_PIN(); }
+    int st = 0;
+    for (; st + NS < nstN; st += NS) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) { WN_COMPUTE(i) DQN_PIN(); WN_LOAD(i, st + NS + i) DQN_PIN(); }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { WN_COMPUTE(i) }
+  }
+  for (int st = nstN; st < nst; ++st) { WN_LOAD(0, st) WN_COMPUTE(0) }
+#undef WN_LOAD
+#undef WN_COMPUTE
+
+  park_accumulators<NACC>(smem, acc, wave, lane);
+  float* sdb = smem + 4 * NACC * 64 * 4;      // [4 waves][16 li]
+  if (want_db) {
+    float v = dbacc;                          // add the 4 lane groups (rows m+0..3)
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if (lg == 0) sdb[wave * 16 + li] = v;
+  }
+  __syncthreads();
+  float ssq = 0.0f;
+#pragma unroll
+  for (int b = 0; b < TPB; ++b) {
+    const f32x4 r0 = reduce_accumulator<NACC>(smem, b * 4 + 0, lane), r1 = reduce_accumulator<NACC>(smem, b * 4 + 1, lane);
+    const f32x4 r2 = reduce_accumulator<NACC>(smem, b * 4 + 2, lane), r3 = reduce_accumulator<NACC>(smem, b * 4 + 3, lane);
+    const int n = q0 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (((b + r) & 3) == wave) {           // the four row groups of an accumulator set are shared out over the waves
+        const int p = p0 + b * 64 + (lg << 4) + (r << 2);
+        const f32x4 v = f32x4{r0[r], r1[r], r2[r], r3[r]};
+        ssq = fmaf(v.x, v.x, ssq); ssq = fmaf(v.y, v.y, ssq); ssq = fmaf(v.z, v.z, ssq); ssq = fmaf(v.w, v.w, ssq);
+        *reinterpret_cast<f32x4*>(pr.C + (size_t)n * pr.ldc + p) = v;
+      }
+    }
+  }
+  if (want_db && wave == 0 && lane < 16) {
+    const float v = (sdb[0 * 16 + lane] + sdb[1 * 16 + lane]) + (sdb[2 * 16 + lane] + sdb[3 * 16 + lane]);
+    pr.db[q0 + lane] = v;
+    ssq = fmaf(v, v, ssq);
+  }
+  if (pr.partial != nullptr) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
+    __syncthreads();
+    if (lane == 0) smem[wave] = ssq;
+    __syncthreads();
+    if (threadIdx.x == 0) pr.partial[tile_q * pr.tiles_p + tile_p] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+  }
+}
+
 // ================================ FWD, coalesced =====================================
 // Same tile / split-K structure as fwd_direct_body, but the k-contiguous operands are
 // fetched as WHOLE 128-byte lines (8 rows x 128 B per wave instruction) and transposed into
@@ -688,6 +780,13 @@ __global__ __launch_bounds__(256) void gemm_wgrad_direct(const GemmBatch batch) 
   tile_of_block(batch, pi, tile_p, tile_q);
   wgrad_direct_body<TPB, TQB>(batch.prob[pi], tile_p, tile_q, smem);
 }
+template <int TPB>
+__global__ __launch_bounds__(256) void gemm_wgrad_narrow(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  wgrad_narrow_body<TPB>(batch.prob[pi], tile_p, tile_q, smem);
+}
 // One layer's backward in ONE launch: problems with mode GEMM_DGRAD (64x16 tiles) and
 // GEMM_WGRAD (64x64 tiles) side by side.  dX_{l-1} = dZ_l W_l and dW_l = dZ_l^T X_{l-1} only
 // share their input dZ_l, so a 256x1024x1024 layer offers 256 + 256 workgroups = 2 per CU.
@@ -805,6 +904,10 @@ inline hipError_t bwd_pair_direct_launch(GemmBatch& batch, hipStream_t stream) {
   if (lt.start) { hipExtLaunchKernelGGL((gemm_bwd_pair_direct<TQD, DLDS>), dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, lt.start, lt.stop, 0, batch); lt.start = lt.stop = nullptr; }
   else hipLaunchKernelGGL((gemm_bwd_pair_direct<TQD, DLDS>), dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, batch);
   return hipGetLastError();
+}
+template <int TPB>
+inline hipError_t wgrad_narrow_launch(GemmBatch& b, hipStream_t s) {
+  return direct_launch(gemm_wgrad_narrow<TPB>, b, 64 * TPB, 16, 4 * TPB * 4 * 64 * 16 + 4 * 16 * 4, s);
 }
 template <bool DLDS>
 inline hipError_t bwd_seq_launch(GemmBatch& batch, hipStream_t stream) {

@@ -79,7 +79,8 @@ void layout_init(NetLayout& l, int in_dim, const dqnhip_config& c, bool actor) {
     l.w_off[i] = off; off += (size_t)l.dims[i + 1] * l.kp[i];
     l.b_off[i] = off; off += round_up(l.dims[i + 1], 64);
     dense += (size_t)l.dims[i + 1] * l.dims[i] + l.dims[i + 1];
-    l.part_off[i] = part; part += (l.kp[i] / 64) * (l.dims[i + 1] / 64);
+    // one slot per wgrad tile; the first layer may run the 16-output tiles of wgrad_narrow_body
+    l.part_off[i] = part; part += (l.kp[i] / 64) * (l.dims[i + 1] / (i == 0 ? 16 : 64));
   }
   const int H = l.dims[l.L];
   l.hw_off = off; off += round_up_z((size_t)l.NH * H, 64);
@@ -380,7 +381,10 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
       else HIPCHK((dgrad_direct_launch<1, 1>(bd, st)));
     } else {
       ScopedTiming t(h, 2, st);
-      HIPCHK((wgrad_direct_launch<1, 1>(bw, st)));
+      // wgrad alone = the first layer (K_in = 64 / 128 columns): 16-output tiles, 4x the workgroups
+      static const bool kNarrow = !getenv("DQNHIP_NO_NARROW_WGRAD");
+      if (kNarrow) HIPCHK((wgrad_narrow_launch<1>(bw, st)));
+      else HIPCHK((wgrad_direct_launch<1, 1>(bw, st)));
     }
   }
   return 0;
