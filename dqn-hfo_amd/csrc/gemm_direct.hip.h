@@ -253,6 +253,62 @@ __device__ __forceinline__ void dgrad_direct_body(const GemmProblem& pr, int til
   }
 }
 
+// ---- DGRAD, narrow: 16 input columns per workgroup ------------------------------------------
+// The critic's first-layer input gradient is consumed only in the 10 action columns (inverting
+// gradients, src/dqn.cpp:924-957): instead of 64-wide tiles over the whole 128-column panel (32
+// workgroups, 4.2 us of MFMA per wave) only the 16-column tiles that contain those columns are
+// computed, a quarter of the MFMA chain per wave.  P = W (one column per lane, scalar loads),
+// Q = dY (16 rows).  Same K split over the 4 waves, same fixed-order reduction.
+__device__ __forceinline__ void dgrad_narrow_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
+  constexpr int NACC = 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int p0 = tile_p * 16, q0 = tile_q * 16;
+  const int Kw = pr.Kred >> 2;
+  const int nkb = Kw >> 4;
+  const float* pp = pr.P + (size_t)(wave * Kw + lg * 4) * pr.ldp + p0 + li;
+  const float* qp = pr.Q + (size_t)(q0 + li) * pr.ldq + wave * Kw + lg * 4;
+  const size_t ldp = pr.ldp;
+  f32x4 acc[NACC];
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NS = 4;
+  float rp[NS][4]; f32x4 rq[NS];
+#define DN_LOAD(slot, kb)                                                               \
+  {                                                                                     \
+    rq[slot] = *reinterpret_cast<const f32x4*>(qp + ((kb) << 4));                      \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) rp[slot][s] = pp[(size_t)(((kb) << 4) + s) * ldp]; \
+  }
+#define DN_COMPUTE(slot)                                                                \
+  { _Pragma("unroll") for (int s = 0; s < 4; ++s) acc[0] = DQN_MFMA(rp[slot][s], rq[slot][s], acc[0]); }
+  const int nkb4 = nkb & ~3;
+  if (nkb4 > 0) {
+    DN_LOAD(0, 0) DQN_PIN(); DN_LOAD(1, 1) DQN_PIN(); DN_LOAD(2, 2) DQN_PIN(); DN_LOAD(3, 3) DQN_PIN();
+    int kb = 0;
+    for (; kb + 4 < nkb4; kb += 4) {
+      DN_COMPUTE(0) DQN_PIN(); DN_LOAD(0, kb + 4) DQN_PIN();
+      DN_COMPUTE(1) DQN_PIN(); DN_LOAD(1, kb + 5) DQN_PIN();
+      DN_COMPUTE(2) DQN_PIN(); DN_LOAD(2, kb + 6) DQN_PIN();
+      DN_COMPUTE(3) DQN_PIN(); DN_LOAD(3, kb + 7) DQN_PIN();
+    }
+    DN_COMPUTE(0) DN_COMPUTE(1) DN_COMPUTE(2) DN_COMPUTE(3)
+  }
+  for (int kb = nkb4; kb < nkb; ++kb) { DN_LOAD(0, kb) DN_COMPUTE(0) }
+#undef DN_LOAD
+#undef DN_COMPUTE
+  park_accumulators<NACC>(smem, acc, wave, lane);
+  __syncthreads();
+  if (wave == 0) {
+    // C/D map: lane (li, lg) register r = C[i = 4 lg + r][j = li] = dX[row q0 + li][column p0 + 4 lg + r]
+    f32x4 v = reduce_accumulator<NACC>(smem, 0, lane);
+    const int q = q0 + li, p = p0 + (lg << 2);
+    if (pr.mask != nullptr) {
+      const f32x4 mv = *reinterpret_cast<const f32x4*>(pr.mask + (size_t)q * pr.ldm + p);
+      v.x *= lrelu_mask(mv.x); v.y *= lrelu_mask(mv.y); v.z *= lrelu_mask(mv.z); v.w *= lrelu_mask(mv.w);
+    }
+    *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
+  }
+}
+
 // ================================ WGRAD ==============================================
 // dW[n][j] = sum_m dY[m][n] X[m][j];  db[n] = sum_m dY[m][n].  P = X (KS, 64-wide blocks of
 // j), Q = dY (KS, 64-wide blocks of n).  Tile = (64*TPB) x (64*TQB).  Kred (= rows m) % 16 == 0.
@@ -780,6 +836,13 @@ __global__ __launch_bounds__(256) void gemm_wgrad_direct(const GemmBatch batch) 
   tile_of_block(batch, pi, tile_p, tile_q);
   wgrad_direct_body<TPB, TQB>(batch.prob[pi], tile_p, tile_q, smem);
 }
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void gemm_dgrad_narrow(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  dgrad_narrow_body(batch.prob[pi], tile_p, tile_q, smem);
+}
 template <int TPB>
 __global__ __launch_bounds__(256) void gemm_wgrad_narrow(const GemmBatch batch) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -904,6 +967,9 @@ inline hipError_t bwd_pair_direct_launch(GemmBatch& batch, hipStream_t stream) {
   if (lt.start) { hipExtLaunchKernelGGL((gemm_bwd_pair_direct<TQD, DLDS>), dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, lt.start, lt.stop, 0, batch); lt.start = lt.stop = nullptr; }
   else hipLaunchKernelGGL((gemm_bwd_pair_direct<TQD, DLDS>), dim3(base), dim3(256), 4 * 16 * 64 * 16 + 4 * 16 * 16, stream, batch);
   return hipGetLastError();
+}
+inline hipError_t dgrad_narrow_launch(GemmBatch& b, hipStream_t s) {
+  return direct_launch(gemm_dgrad_narrow<0>, b, 16, 16, 4 * 64 * 16, s);
 }
 template <int TPB>
 inline hipError_t wgrad_narrow_launch(GemmBatch& b, hipStream_t s) {

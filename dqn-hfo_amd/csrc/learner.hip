@@ -334,8 +334,10 @@ int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows) 
 // stream when there is one, else shares a mixed-mode launch with the dgrad.
 // want_w: produce dW/db (+sumsq partials) into garena; input_grad: also dZ[0].
 // On return the aux stream may still be running wgrads: the caller joins before using them.
+// in_lo / in_hi: when only these input columns of dZ[0] are consumed (the critic's action columns), the
+// first layer's dgrad computes just the 16-column tiles that cover them.
 int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* garena, float* partial,
-                   float** act, float** dZ, int rows, bool want_w, bool input_grad) {
+                   float** act, float** dZ, int rows, bool want_w, bool input_grad, int in_lo = 0, int in_hi = -1) {
   hipStream_t ax = aux_of(h);
   const bool split = want_w && ax != st;
   for (int i = l.L - 1; i >= 0; --i) {
@@ -374,6 +376,13 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
       if (kSeq) { if (lds_ok) HIPCHK((bwd_seq_launch<true>(b, st))); else HIPCHK((bwd_seq_launch<false>(b, st))); }
       else if (lds_ok) HIPCHK((bwd_pair_direct_launch<1, true>(b, st)));
       else HIPCHK(bwd_pair_direct_launch<1>(b, st));
+    } else if (need_dx && i == 0 && in_hi > in_lo && rows % 16 == 0 && !getenv("DQNHIP_NO_NARROW_DGRAD")) {
+      GemmProblem& p = bd.prob[0];
+      const int c0 = (in_lo / 16) * 16, c1 = std::min(l.kp[0], (in_hi + 15) / 16 * 16);
+      p.P += c0; p.C += c0; p.Pdim = c1 - c0;
+      if (p.mask) p.mask += c0;
+      ScopedTiming t(h, 1, st);
+      HIPCHK(dgrad_narrow_launch(bd, st));
     } else if (need_dx) {
       ScopedTiming t(h, 1, st);
       // reduction width (the layer's outputs) wide enough: dY through the LDS transpose, scheduled form
@@ -815,7 +824,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
       RC(head_backward<1>(h, st, a));
     }
-    RC(tower_backward(h, st, lc, DQNHIP_CRITIC, nullptr, nullptr, h->act[4], h->dZc, B, false, true));
+    RC(tower_backward(h, st, lc, DQNHIP_CRITIC, nullptr, nullptr, h->act[4], h->dZc, B, false, true, h->S, h->S + kNO));
     // inverting gradients (src/dqn.cpp:924-957) + actor heads backward (src/dqn.cpp:960-963)
     {
       HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;

@@ -28,7 +28,7 @@ SHAPES = [(256, 1024, 1024), (32, 512, 1024), (32, 128, 256), (64, 1024, 64), (2
 
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("mode,variant", [(FWD, 1), (FWD, 2), (FWD, 10), (FWD, 12), (FWD, 15), (FWD, 16), (FWD, 17), (DGRAD, 1), (DGRAD, 2),
-                                          (DGRAD, 5), (DGRAD, 6), (WGRAD, 1), (WGRAD, 2), (FWD, 0), (DGRAD, 0), (WGRAD, 0)])
+                                          (DGRAD, 5), (DGRAD, 6), (DGRAD, 7), (WGRAD, 1), (WGRAD, 2), (FWD, 0), (DGRAD, 0), (WGRAD, 0)])
 def test_gemm_variant_vs_naive(pkg, gpu, mode, variant, shape):
     rows, n_out, k_in = shape
     # tile divisibility of each variant (the learner only launches shapes that satisfy them)
