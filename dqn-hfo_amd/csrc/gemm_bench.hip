@@ -98,6 +98,7 @@ hipError_t launch_variant(int mode, int variant, GemmBatch& b, hipStream_t s) {
       case 14: return fwd_lds_launch<4, 4, false>(b, s);  // 64x64
       case 15: return fwd_lds_launch<1, 1, false>(b, s);  // 16x16 (acting-time batches)
       case 16: return fwd_lds_launch<2, 1, false>(b, s);  // 32 outputs x 16 rows
+      case 20: return fwd_lds_launch<1, 1, true>(b, s);   // 16x16, staged instructions interleaved
       case 17: return fwd_lds_launch<4, 2, false, 1>(b, s);  // 64x32, one LDS image per wave (2 workgroups per CU)
       case 18: return fwd_lds_launch<2, 2, false, 1>(b, s);
       case 19: return fwd_lds_launch<4, 4, false, 1>(b, s);

@@ -589,17 +589,19 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
   // in that order (hipcc on its own either sinks the loads to the end of the iteration — zero lookahead —
   // or, with plain order pinning, issues the 3 x 2NB staging instructions as a block with the MFMA pipe idle)
   constexpr int NOPS = 2 * NB, NMF = 8 * NACC;
-  constexpr int MW = (NMF >= 5 * NOPS) ? 2 : 1, ML = MW, MR = 1;
-  constexpr bool SGB = PIN && (NMF >= 3 * NOPS);
+  constexpr int MW = (NMF >= 5 * NOPS) ? 2 : 1, ML = (NMF >= 5 * NOPS) ? 2 : (NMF >= 2 * NOPS ? 1 : 0),
+                MR = (NMF >= 3 * NOPS) ? 1 : 0;          // small tiles: fewer MFMAs than staging instructions
+  constexpr bool SGB = PIN && (NMF >= NOPS);
 #define L_SCHED_(HASLD)                                                                 \
   { if constexpr (SGB) {                                                                \
       _Pragma("unroll") for (int i_ = 0; i_ < NOPS; ++i_) {                             \
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, MW, 0); } \
       if (HASLD) { _Pragma("unroll") for (int i_ = 0; i_ < NOPS; ++i_) {                \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, ML, 0); } } \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); if (ML > 0) __builtin_amdgcn_sched_group_barrier(0x008, ML, 0); } } \
       _Pragma("unroll") for (int i_ = 0; i_ < NOPS; ++i_) {                             \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, MR, 0); } \
-      __builtin_amdgcn_sched_group_barrier(0x008, NMF - (MW + (HASLD ? ML : 0) + MR) * NOPS, 0); } }
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); if (MR > 0) __builtin_amdgcn_sched_group_barrier(0x008, MR, 0); } \
+      if (NMF - (MW + (HASLD ? ML : 0) + MR) * NOPS > 0)                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - (MW + (HASLD ? ML : 0) + MR) * NOPS, 0); } }
 #define L_SCHED() L_SCHED_(true)
 
   // (pinned prologue: the waitcnt pass merges the prologue's load order into the loop header, so an

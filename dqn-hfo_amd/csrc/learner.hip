@@ -318,7 +318,7 @@ int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, 
   // acting-time batches (<= 128 rows, e.g. 64 env workers): 16x16 tiles so that one layer still spreads
   // over 256 workgroups (64 rows x 1024 outputs = 256 tiles) instead of 64
   static const bool kSmallTiles = !getenv("DQNHIP_NO_SMALL_TILES");
-  if (n == 1 && rows <= 128 && lds_ok && kSmallTiles) HIPCHK((fwd_lds_launch<1, 1, false>(b, st)));
+  if (n == 1 && rows <= 128 && lds_ok && kSmallTiles) HIPCHK((fwd_lds_launch<1, 1, true>(b, st)));
   else if (n == 1 && rows >= 512 && lds_ok && l.dims[i + 1] % 64 == 0) HIPCHK((fwd_lds_launch<4, 2, true>(b, st)));   // enough rows to fill the chip with 64x32 tiles (fewer bytes per FLOP)
   else if (n == 1) { if (lds_ok) HIPCHK((fwd_lds_launch<2, 2, true>(b, st))); else HIPCHK((fwd_direct_launch<2, 2>(b, st))); }
   else { if (lds_ok) HIPCHK((fwd_lds_launch<4, 2, true>(b, st))); else HIPCHK((fwd_direct_launch<4, 2>(b, st))); }

@@ -27,7 +27,7 @@ SHAPES = [(256, 1024, 1024), (32, 512, 1024), (32, 128, 256), (64, 1024, 64), (2
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("mode,variant", [(FWD, 1), (FWD, 2), (FWD, 10), (FWD, 12), (FWD, 15), (FWD, 16), (FWD, 17), (DGRAD, 1), (DGRAD, 2),
+@pytest.mark.parametrize("mode,variant", [(FWD, 1), (FWD, 2), (FWD, 10), (FWD, 12), (FWD, 15), (FWD, 16), (FWD, 17), (FWD, 20), (DGRAD, 1), (DGRAD, 2),
                                           (DGRAD, 5), (DGRAD, 6), (DGRAD, 7), (WGRAD, 1), (WGRAD, 2), (FWD, 0), (DGRAD, 0), (WGRAD, 0)])
 def test_gemm_variant_vs_naive(pkg, gpu, mode, variant, shape):
     rows, n_out, k_in = shape
@@ -38,7 +38,7 @@ def test_gemm_variant_vs_naive(pkg, gpu, mode, variant, shape):
         pytest.skip("LDS-staged family needs 64-multiples")
     if mode == DGRAD and variant in (2, 6) and rows % 32:
         pytest.skip("32-row Q tile")
-    if mode == FWD and variant in (10, 12, 15, 16, 17) and (k_in % 256 or k_in < 512 or (variant in (12, 17) and n_out % 64)):
+    if mode == FWD and variant in (10, 12, 15, 16, 17, 20) and (k_in % 256 or k_in < 512 or (variant in (12, 17) and n_out % 64)):
         pytest.skip("coalesced forward needs K % 256 == 0, K >= 512")
     if mode == DGRAD and variant in (5, 6) and (n_out % 256 or n_out < 512 or k_in % 64):
         pytest.skip("coalesced dgrad needs N % 256 == 0, N >= 512")
