@@ -593,23 +593,27 @@ __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int n
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
   __syncthreads();
+  // one lane per block evaluates the per-launch scalars (two double pow() are ~500 instructions: run by
+  // every thread they made this kernel VALU-bound: 733 VALU instructions per wave, 8 waves per SIMD)
   if (threadIdx.x == 0) {
     const float sumsq = (s[0] + s[1]) + (s[2] + s[3]);
     const float l2 = sqrtf(sumsq);
     s[4] = (a.clip >= 0.0f && l2 > a.clip) ? a.clip / l2 : 1.0f;
+    const int it_a = a.st->actor_iter, it_c = a.st->critic_iter;
+    const int t = (a.which == 0 ? it_a : it_c) + 1;      // t = iter_ + 1 (before increment)
+    // correction = sqrt(1 - beta2^t) / (1 - beta1^t), evaluated in double, rounded once
+    const float correction = (float)(sqrt(1.0 - pow((double)a.beta2, (double)t)) /
+                                     (1.0 - pow((double)a.beta1, (double)t)));
+    s[5] = a.lr * correction;
+    // soft update condition uses max_iter() AFTER both increments (src/dqn.cpp:967)
+    const int mx = (it_a + 1) > (it_c + 1) ? (it_a + 1) : (it_c + 1);
+    s[6] = ((mx % a.soft_update_freq) == 0) ? 1.0f : 0.0f;
   }
   __syncthreads();
   const float scale = s[4];
-  const int it_a = a.st->actor_iter, it_c = a.st->critic_iter;
-  const int t = (a.which == 0 ? it_a : it_c) + 1;      // t = iter_ + 1 (before increment)
-  // correction = sqrt(1 - beta2^t) / (1 - beta1^t), evaluated in double, rounded once
-  const float correction = (float)(sqrt(1.0 - pow((double)a.beta2, (double)t)) /
-                                   (1.0 - pow((double)a.beta1, (double)t)));
-  const float step = a.lr * correction;
+  const float step = s[5];
   const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
-  // soft update condition uses max_iter() AFTER both increments (src/dqn.cpp:967)
-  const int mx = (it_a + 1) > (it_c + 1) ? (it_a + 1) : (it_c + 1);
-  const bool soft = (mx % a.soft_update_freq) == 0;
+  const bool soft = s[6] != 0.0f;
   const float tau = a.tau, omt = 1 - a.tau;
   for (size_t i = (size_t)blk * 256 + threadIdx.x; i < a.n4; i += (size_t)nblk * 256) {
     f32x4 g = reinterpret_cast<f32x4*>(a.g)[i];
