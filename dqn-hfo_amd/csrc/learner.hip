@@ -339,6 +339,7 @@ int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows) 
 int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* garena, float* partial,
                    float** act, float** dZ, int rows, bool want_w, bool input_grad, int in_lo = 0, int in_hi = -1) {
   hipStream_t ax = aux_of(h);
+  static const bool kNarrowDgrad = !getenv("DQNHIP_NO_NARROW_DGRAD");
   const bool split = want_w && ax != st;
   for (int i = l.L - 1; i >= 0; --i) {
     GemmBatch bd{}, bw{};
@@ -376,7 +377,7 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
       if (kSeq) { if (lds_ok) HIPCHK((bwd_seq_launch<true>(b, st))); else HIPCHK((bwd_seq_launch<false>(b, st))); }
       else if (lds_ok) HIPCHK((bwd_pair_direct_launch<1, true>(b, st)));
       else HIPCHK(bwd_pair_direct_launch<1>(b, st));
-    } else if (need_dx && i == 0 && in_hi > in_lo && rows % 16 == 0 && !getenv("DQNHIP_NO_NARROW_DGRAD")) {
+    } else if (need_dx && i == 0 && in_hi > in_lo && rows % 16 == 0 && kNarrowDgrad) {
       GemmProblem& p = bd.prob[0];
       const int c0 = (in_lo / 16) * 16, c1 = std::min(l.kp[0], (in_hi + 15) / 16 * 16);
       p.P += c0; p.C += c0; p.Pdim = c1 - c0;
