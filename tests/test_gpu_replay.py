@@ -130,3 +130,33 @@ def test_graph_replay_equals_eager(pkg, gpu):
         dqn.close(); orc.close()
     for a, b in zip(*res):
         np.testing.assert_array_equal(a, b)
+
+
+def test_random_sequence_of_ring_operations(pkg, gpu):
+    """200 random AddTransitions / AddTransition / ClearReplayMemory calls against the oracle's deque model:
+    size and full contents (logical order) after every call."""
+    S, cap = 58, 257
+    rng = np.random.default_rng(99)
+    dqn = pkg.DQN(S, minibatch=32, hidden=(64,), memory=cap)
+    orc = c_oracle.Oracle(B=32, S=S, hidden=(64,), capacity=cap)
+    for step in range(200):
+        op = rng.random()
+        if op < 0.6:
+            n = int(rng.integers(1, cap))                     # up to cap-1 transitions at once
+            d = _mk(rng, n, S)
+            dqn.add_transitions_arrays(*d); orc.add_transitions(*d)
+        elif op < 0.95:
+            d = _mk(rng, 1, S)
+            t = pkg.Transition(d[0][0], d[1][0], float(d[2][0]), float(d[3][0]), None if d[5][0] else d[4][0])
+            dqn.AddTransition(t)
+            orc.add_transition(d[0][0], d[1][0], d[2][0], d[3][0], d[4][0], d[5][0])
+        else:
+            dqn.ClearReplayMemory(); orc.clear_memory()
+        n = orc.memory_size()
+        assert dqn.memory_size() == n <= cap
+        if n and step % 5 == 0:
+            for x, y in zip(dqn.read_memory(0, n), orc.read_memory(0, n)):
+                np.testing.assert_array_equal(x, y)
+    with pytest.raises(pkg.DQNFatal):
+        dqn.add_transitions_arrays(*_mk(rng, cap, S))          # a batch of `capacity` can never fit (src/dqn.cpp:776)
+    dqn.close(); orc.close()
