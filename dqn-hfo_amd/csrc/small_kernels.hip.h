@@ -243,6 +243,58 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
   }
 }
 
+// Large minibatches (rows >= 1024): one WAVE per row, no block-level synchronisation; the head weights
+// stay in registers across the rows of a wave (H <= 1024: NH x 4 float4 per lane).
+template <int NH, int MODE>
+__global__ __launch_bounds__(256) void k_head_fwd_rows(HeadArgs2 a2) {
+  const HeadArgs& a = a2.p[blockIdx.y];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  f32x4 wreg[NH][4];
+#pragma unroll
+  for (int j = 0; j < NH; ++j)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = lane * 4 + 256 * t;
+      wreg[j][t] = k < a.H ? *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+    const float* x = a.X + (size_t)row * a.ldx;
+    f32x4 xv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = lane * 4 + 256 * t;
+      xv[t] = k < a.H ? *reinterpret_cast<const f32x4*>(x + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float acc[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s = fmaf(xv[t].x, wreg[j][t].x, s); s = fmaf(xv[t].y, wreg[j][t].y, s);
+        s = fmaf(xv[t].z, wreg[j][t].z, s); s = fmaf(xv[t].w, wreg[j][t].w, s);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      acc[j] = s;
+    }
+    if (lane < kAP) {
+      float v = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NH; ++j) if (lane == j) v = acc[j] + a.b[j];
+      if constexpr (MODE == HEAD_ACTOR) {
+        a.out16[(size_t)row * kAP + lane] = v;
+        if (a.xc != nullptr && lane < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + lane] = v;
+      } else {
+        if (lane == 0) {
+          a.q[row] = v;
+          if constexpr (MODE == HEAD_Q_POLICY) a.qsum_partial[row] = (double)v;
+        }
+      }
+    }
+  }
+}
+
 // Both critic heads of the training step in one launch: q' = q_values(critic_target tower
 // top), q = q_values(critic tower top), then the TD target (src/dqn.cpp:892-900, doubles where
 // the reference has them) and the EuclideanLoss diff.  One wave per row.
