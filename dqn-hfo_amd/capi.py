@@ -2,9 +2,10 @@
 import ctypes as C
 import os
 
-from ._build import LIB, build
+from ._build import LIB, TEST_LIB, build
 
 MAX_HIDDEN = 8
+DP_ID_BYTES = 128        # DQNHIP_DP_ID_BYTES
 ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET = 0, 1, 2, 3
 KIND_W, KIND_M, KIND_V, KIND_G = 0, 1, 2, 3
 
@@ -41,6 +42,18 @@ SIGNATURES = {
     "dqnhip_update_phase": (C.c_int, [H, C.c_int32, ip]),
     "dqnhip_grad_buffer": (C.c_int, [H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "dqnhip_read_stats": (C.c_int, [H, fp, fp]),
+    "dqnhip_dp_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "dqnhip_dp_init": (C.c_int, [H, C.c_void_p, C.c_size_t, C.c_int32]),
+    "dqnhip_dp_init_file": (C.c_int, [H, C.c_char_p, C.c_int32, C.c_int32]),
+    "dqnhip_dp_broadcast_params": (C.c_int, [H, C.c_int32]),
+    "dqnhip_dp_update": (C.c_int, [H, ip]),
+    "dqnhip_dp_destroy": (C.c_int, [H]),
+    "dqnhip_skipped_steps": (C.c_int, [H, C.POINTER(C.c_int64)]),
+    "dqnhip_reduce_gradients_local": (C.c_int, [C.POINTER(H), C.c_int32, C.c_int32]),
+    "dqnhip_sample_states": (C.c_int, [H, ip, C.c_int32, fp]),
+    "dqnhip_get_actor_output": (C.c_int, [H, C.c_int32, C.c_int32, fp]),
+    "dqnhip_files_matching_regexp": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, ip]),
+    "dqnhip_remove_snapshots": (C.c_int, [C.c_char_p, C.c_int32]),
     "dqnhip_benchmark": (C.c_int, [H, C.c_int32, C.c_int32, fp]),
     "dqnhip_select_actions": (C.c_int, [H, fp, C.c_int32, fp]),
     "dqnhip_select_actions_device": (C.c_int, [H, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -112,3 +125,16 @@ def load(rebuild=False):
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+_test_lib = None
+
+
+def load_test():
+    """dlopen the test/tuning harness (libdqnhip_test.so: dqnhip_test_gemm / dqnhip_test_hgemm of
+    include/dqnhip_internal.h).  Tests and scripts only — the product path never loads it."""
+    global _test_lib
+    if _test_lib is None:
+        build()
+        _test_lib = C.CDLL(TEST_LIB)
+    return _test_lib

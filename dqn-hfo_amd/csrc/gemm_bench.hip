@@ -89,8 +89,6 @@ hipError_t launch_variant(int mode, int variant, GemmBatch& b, hipStream_t s) {
       case 2: return fwd_direct_launch<4, 2>(b, s);   // 64x32
       case 3: return fwd_direct_launch<2, 1>(b, s);   // 32x16
       case 4: return fwd_direct_launch<4, 4>(b, s);   // 64x64
-      case 5: return direct_launch(gemm_fwd_direct<2, 2, 1>, b, 32, 32, 4 * 4 * 64 * 16, s);  // ablation: no loads in loop
-      case 6: return direct_launch(gemm_fwd_direct<2, 2, 2>, b, 32, 32, 4 * 4 * 64 * 16, s);  // ablation: no MFMA
       case 10: return fwd_lds_launch<2, 2, false>(b, s);  // 32x32 coalesced+LDS transpose
       case 11: return fwd_lds_launch<2, 2, true>(b, s);
       case 12: return fwd_lds_launch<4, 2, false>(b, s);  // 64x32
@@ -102,9 +100,6 @@ hipError_t launch_variant(int mode, int variant, GemmBatch& b, hipStream_t s) {
       case 17: return fwd_lds_launch<4, 2, false, 1>(b, s);  // 64x32, one LDS image per wave (2 workgroups per CU)
       case 18: return fwd_lds_launch<2, 2, false, 1>(b, s);
       case 19: return fwd_lds_launch<4, 4, false, 1>(b, s);
-      case 9: return direct_launch(gemm_fwd_direct<2, 2, 3>, b, 32, 32, 4 * 4 * 64 * 16, s);  // ablation: coalesced loads only
-      case 7: return direct_launch(gemm_fwd_direct<4, 4, 1>, b, 64, 64, 4 * 16 * 64 * 16, s);
-      case 8: return direct_launch(gemm_fwd_direct<4, 4, 2>, b, 64, 64, 4 * 16 * 64 * 16, s);
     }
   } else if (mode == GEMM_DGRAD) {
     switch (variant) {
@@ -159,7 +154,6 @@ extern "C" int dqnhip_test_gemm(int32_t mode, int32_t variant, int32_t rows, int
     CK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4)); CK(direct_prepare(gemm_fwd_lds<4, 2, true>, 4 * 2 * 6 * 512 * 4));
     CK(direct_prepare(gemm_fwd_lds<4, 4, false>, 4 * 2 * 8 * 512 * 4));
     CK(direct_prepare((gemm_fwd_lds<4, 4, false, 1>), (fwd_lds_bytes<4, 4, false, 1>())));
-    CK(direct_prepare(gemm_fwd_direct<4, 4, 1>, 4 * 16 * 64 * 16)); CK(direct_prepare(gemm_fwd_direct<4, 4, 2>, 4 * 16 * 64 * 16));
     CK(direct_prepare(gemm_dgrad_direct<1, 4>, 4 * 16 * 64 * 16));
     prepared = true;
   }

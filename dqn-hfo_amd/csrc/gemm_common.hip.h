@@ -1,0 +1,56 @@
+// gemm_common.hip.h — types shared by the fp32 MFMA GEMM kernels of the learner
+// (gemm_direct.hip.h) and the head / optimiser kernels (small_kernels.hip.h).
+//
+// Every tower GEMM computes C[q][p] = sum_k Pop(p,k) * Qop(q,k) with `p` the contiguous
+// output dimension; the three modes replace the Caffe InnerProduct forward/backward GEMMs
+// the reference reaches from src/dqn.cpp:751, 904, 923, 963, 1013:
+//
+//   FWD   Y[m][n]  = lrelu(sum_k X[m][k] W[n][k] + b[n])         P=W  Q=X
+//   DGRAD dX[m][j] = (sum_n dY[m][n] W[n][j]) * lrelu'(Xp[m][j])  P=W  Q=dY
+//   WGRAD dW[n][j] = sum_m dY[m][n] X[m][j] ; db[n] = sum_m dY[m][n]   P=X  Q=dY
+//
+// with the ReLU(negative_slope=0.01) forward/backward (src/dqn.cpp:292-301) fused into the
+// epilogues.  A launch may carry up to 4 independent problems (grouped GEMM).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dqnhip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum GemmMode { GEMM_FWD = 0, GEMM_DGRAD = 1, GEMM_WGRAD = 2 };
+
+constexpr float kLeakySlope = 0.01f;  // src/dqn.cpp:300
+
+struct GemmProblem {
+  const float* P; int ldp;   // operand that indexes the contiguous output dim
+  const float* Q; int ldq;   // operand that indexes the output rows
+  float* C; int ldc;         // C[q*ldc + p]
+  int Pdim, Qdim, Kred;      // Pdim % BP == 0, Qdim % BQ == 0
+  const float* bias;         // FWD: bias[p] (may be null)
+  const float* mask; int ldm;// DGRAD: previous activation [q][p] for lrelu' (null: none)
+  float* db;                 // WGRAD: bias gradient [q] (null: skip)
+  float* partial;            // WGRAD: one sum-of-squares partial per tile (null: skip)
+  int relu;                  // FWD: apply leaky ReLU
+  int mode;                  // mixed-mode launches (gemm_bwd_pair_direct): GEMM_DGRAD / GEMM_WGRAD
+  int tiles_p, tiles_q, tile_base;
+};
+
+constexpr int kMaxGroup = 4;
+struct GemmBatch {
+  GemmProblem prob[kMaxGroup];
+  int n;
+  int total_tiles;
+};
+
+__device__ __forceinline__ float lrelu_fwd(float x) {
+  // Caffe ReLULayer::Forward: max(x,0) + slope*min(x,0)
+  return fmaxf(x, 0.0f) + kLeakySlope * fminf(x, 0.0f);
+}
+__device__ __forceinline__ float lrelu_mask(float y) {
+  // Caffe ReLULayer::Backward (in-place: bottom_data is the output y)
+  return (y > 0.0f ? 1.0f : 0.0f) + kLeakySlope * (y <= 0.0f ? 1.0f : 0.0f);
+}
+
+}  // namespace dqnhip

@@ -31,7 +31,7 @@
 
 #include <cstdlib>
 
-#include "gemm_mfma.hip.h"
+#include "gemm_common.hip.h"
 
 namespace dqnhip {
 
@@ -84,7 +84,7 @@ __device__ __forceinline__ f32x4 reduce_accumulator(const float* smem, int e, in
 // ================================ FWD ================================================
 // Y[m][n] = lrelu(sum_k X[m][k] W[n][k] + b[n]).  P = W (KC, 16-row blocks), Q = X (KC).
 // Tile = (16*TP) x (16*TQ).  Kred % 64 == 0.
-template <int TP, int TQ, int ABL = 0>
+template <int TP, int TQ>
 __device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
   constexpr int NACC = TP * TQ;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -98,13 +98,6 @@ __device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_
   for (int c = 0; c < TP; ++c) pp[c] = pr.P + (size_t)(p0 + c * 16 + li) * pr.ldp + wave * Kw + lg * 4;
 #pragma unroll
   for (int a = 0; a < TQ; ++a) qp[a] = pr.Q + (size_t)(q0 + a * 16 + li) * pr.ldq + wave * Kw + lg * 4;
-  if (ABL == 3) {   // ablation: same bytes, but 8 rows x 128 B per wave instruction (full lines)
-#pragma unroll
-    for (int c = 0; c < TP; ++c) pp[c] = pr.P + (size_t)(p0 + c * 16 + (lane >> 3)) * pr.ldp + wave * Kw + (lane & 7) * 4;
-#pragma unroll
-    for (int a = 0; a < TQ; ++a) qp[a] = pr.Q + (size_t)(q0 + a * 16 + (lane >> 3)) * pr.ldq + wave * Kw + (lane & 7) * 4;
-  }
-  const size_t abl_p8 = (size_t)8 * pr.ldp, abl_q8 = (size_t)8 * pr.ldq;
 
   f32x4 acc[NACC];
 #pragma unroll
@@ -112,28 +105,18 @@ __device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_
   f32x4 rp[4][TP], rq[4][TQ];
 
 #define FWD_LOAD(slot, kb)                                                              \
-  if (ABL == 3) {                                                                       \
-    _Pragma("unroll") for (int c = 0; c < TP; ++c)                                      \
-        rp[slot][c] = *reinterpret_cast<const f32x4*>(pp[c] + ((kb) & 1) * abl_p8 + (((kb) >> 1) << 5)); \
-    _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
-        rq[slot][a] = *reinterpret_cast<const f32x4*>(qp[a] + ((kb) & 1) * abl_q8 + (((kb) >> 1) << 5)); \
-  } else if (ABL != 1 || (kb) < 4) {                                                    \
+  {                                                                                     \
     _Pragma("unroll") for (int c = 0; c < TP; ++c)                                      \
         rp[slot][c] = *reinterpret_cast<const f32x4*>(pp[c] + ((kb) << 4));            \
     _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
         rq[slot][a] = *reinterpret_cast<const f32x4*>(qp[a] + ((kb) << 4));            \
   }
 #define FWD_COMPUTE(slot)                                                               \
-  if (ABL != 2 && ABL != 3) {                                                           \
+  {                                                                                     \
     _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
     _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
     _Pragma("unroll") for (int c = 0; c < TP; ++c)                                      \
         acc[a * TP + c] = DQN_MFMA(rp[slot][c][s], rq[slot][a][s], acc[a * TP + c]);    \
-  } else {                                                                              \
-    _Pragma("unroll") for (int a = 0; a < TQ; ++a)                                      \
-    _Pragma("unroll") for (int c = 0; c < TP; ++c) {                                    \
-        acc[a * TP + c].x += rp[slot][c].x + rq[slot][a].y;                             \
-        acc[a * TP + c].y += rp[slot][c].z + rq[slot][a].w; }                           \
   }
 
   const int nkb4 = nkb & ~3;
@@ -803,12 +786,12 @@ __device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p
 }
 
 // ---- kernels: thin wrappers over the bodies --------------------------------------------
-template <int TP, int TQ, int ABL = 0>
+template <int TP, int TQ>
 __global__ __launch_bounds__(256) void gemm_fwd_direct(const GemmBatch batch) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int pi, tile_p, tile_q;
   tile_of_block(batch, pi, tile_p, tile_q);
-  fwd_direct_body<TP, TQ, ABL>(batch.prob[pi], tile_p, tile_q, smem);
+  fwd_direct_body<TP, TQ>(batch.prob[pi], tile_p, tile_q, smem);
 }
 template <int TP, int TQ, bool PIN, int NSLOT = 2>
 __global__ __launch_bounds__(256) void gemm_fwd_lds(const GemmBatch batch) {

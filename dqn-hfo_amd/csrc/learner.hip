@@ -5,7 +5,9 @@
 // nothing crosses PCIe per update except (optionally) B sampled indices in and
 // two floats out.  See DESIGN.md for the data layout and the kernel list.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <zlib.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -17,12 +19,13 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <chrono>
+#include <thread>
 
 #include "../../include/dqnhip.h"
 #include "../../include/dqnhip_env.h"
 #include "env.hip.h"
 #include "gemm_direct.hip.h"
-#include "gemm_mfma.hip.h"
 #include "hgemm.hip.h"
 #include "small_kernels.hip.h"
 
@@ -126,6 +129,13 @@ struct dqnhip_learner {
   hipEvent_t ring_ev = nullptr; hipStream_t ring_last = nullptr; bool ring_ev_valid = false;
   std::mutex ring_mu;
   int h_actor_iter = 0, h_critic_iter = 0;
+  unsigned long long sample_states_calls = 0;
+  // native data parallelism (dqnhip_dp_*): one RCCL communicator per learner
+  ncclComm_t comm = nullptr;
+  bool dp_per_layer = false;            // bucket the gradient all-reduce per layer on comm_stream
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ev[2] = {nullptr, nullptr};
+  int next_phase = 0;                   // dqnhip_update_phase order check (0: an update may start)
   // minibatch panels / activations: pass 0 AT, 1 A, 2 CT, 3 C1, 4 C2
   float* Xa_s = nullptr; float* Xa_n = nullptr; float* Xc_tr = nullptr; float* Xc_pl = nullptr; float* Xc_nx = nullptr;
   float* act[5][kMaxL + 1] = {{nullptr}};
@@ -336,6 +346,10 @@ int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows) 
 // On return the aux stream may still be running wgrads: the caller joins before using them.
 // in_lo / in_hi: when only these input columns of dZ[0] are consumed (the critic's action columns), the
 // first layer's dgrad computes just the 16-column tiles that cover them.
+// RCCL sum all-reduce of one slice of a gradient arena on the communication stream, ordered after
+// everything enqueued on `st` so far (per-layer bucketing; defined with dqnhip_dp_*)
+int dp_reduce_slice(H* h, hipStream_t st, float* ptr, size_t count);
+
 int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* garena, float* partial,
                    float** act, float** dZ, int rows, bool want_w, bool input_grad, int in_lo = 0, int in_hi = -1) {
   hipStream_t ax = aux_of(h);
@@ -396,6 +410,9 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
       if (kNarrow) HIPCHK((wgrad_narrow_launch<1>(bw, st)));
       else HIPCHK((wgrad_direct_launch<1, 1>(bw, st)));
     }
+    // data parallel, bucketed: layer i's dW/db are final once this launch has run -> start their
+    // all-reduce on the communication stream while the chain continues with layer i-1
+    if (want_w && h->comm && h->dp_per_layer) RC(dp_reduce_slice(h, st, garena + l.w_off[i], (i + 1 < l.L ? l.w_off[i + 1] : l.hw_off) - l.w_off[i]));
   }
   return 0;
 }
@@ -574,6 +591,11 @@ int head_grad16(H* h, hipStream_t st, int kind, const float* dZL, int rows, floa
   return 0;
 }
 
+// Philox key of SampleTransitionsFromMemory: cfg.seed on rank 0 (what oracle/c_oracle.philox_indices
+// reproduces); data-parallel ranks get distinct streams from the SAME cfg.seed, so that the weight
+// initialisation (also keyed by cfg.seed) stays identical across the group
+inline uint64_t sample_key(const H* h) { return (uint64_t)h->cfg.seed + 0x9E3779B97F4A7C15ull * (uint64_t)h->cfg.dp_rank; }
+
 int run_phase16(H* h, int phase, const int* idx_dev) {
   const int B = h->B, L = h->L;
   const NetLayout &la = h->la, &lc = h->lc;
@@ -599,7 +621,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
                  h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
     hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
-                       (const DevState*)h->st, idx_dev, (uint64_t)h->cfg.seed, go, B);
+                       (const DevState*)h->st, idx_dev, sample_key(h), go, B);
     HIPCHK(hipGetLastError());
     {
       Cvt16Batch b{};
@@ -632,7 +654,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       t.X = h->act[3][L]; t.W = wat(h, DQNHIP_CRITIC, lc.hw_off); t.b = wat(h, DQNHIP_CRITIC, lc.hb_off);
       t.H = Hc; t.rows = B; t.reward = h->mb_reward; t.mc = h->mb_mc; t.term = h->mb_term;
       t.q_target = h->q_t; t.q = h->q1; t.y = h->y; t.dq = h->dq; t.loss_partial = h->loss_partial;
-      t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch;
+      t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch; t.st = h->st;
       hipLaunchKernelGGL(k_head_q_train, dim3((B + 3) / 4), dim3(256), 0, st, t);
       HIPCHK(hipGetLastError());
     }
@@ -731,8 +753,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
                  h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
     hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
-                       (const DevState*)h->st, idx_dev,
-                       (uint64_t)h->cfg.seed, go, B);
+                       (const DevState*)h->st, idx_dev, sample_key(h), go, B);
     HIPCHK(hipGetLastError());
     FwdPass pAT{DQNHIP_ACTOR_TARGET, &la, h->act[0]}, pA{DQNHIP_ACTOR, &la, h->act[1]};
     FwdPass pCT{DQNHIP_CRITIC_TARGET, &lc, h->act[2]}, pC1{DQNHIP_CRITIC, &lc, h->act[3]};
@@ -773,7 +794,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       t.X = h->act[3][L]; t.W = wat(h, DQNHIP_CRITIC, lc.hw_off); t.b = wat(h, DQNHIP_CRITIC, lc.hb_off);
       t.H = Hc; t.rows = B; t.reward = h->mb_reward; t.mc = h->mb_mc; t.term = h->mb_term;
       t.q_target = h->q_t; t.q = h->q1; t.y = h->y; t.dq = h->dq; t.loss_partial = h->loss_partial;
-      t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch;
+      t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch; t.st = h->st;
       hipLaunchKernelGGL(k_head_q_train, dim3((B + 3) / 4), dim3(256), 0, st, t);
       HIPCHK(hipGetLastError());
     }
@@ -949,6 +970,7 @@ size_t dqnhip_grad_arena_bytes(const dqnhip_config* cfg) {
 }
 
 static int create_impl(H* h, const dqnhip_config* cfg);
+static void drop_graphs_fwd(H* h) { for (int i = 0; i < 2; ++i) if (h->graph_exec[i]) { hipGraphExecDestroy(h->graph_exec[i]); h->graph_exec[i] = nullptr; } }
 
 int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   if (!out) return fail("out is null");
@@ -1115,6 +1137,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   if (h->ring_owner) h->ring_owner->sharers -= 1;
   if (h->ring_ev) hipEventDestroy(h->ring_ev);
   hipSetDevice(h->cfg.device);
+  dqnhip_dp_destroy(h);
   hipStreamSynchronize(h->stream);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (int i = 0; i < 2; ++i) if (h->graph_exec[i]) hipGraphExecDestroy(h->graph_exec[i]);
@@ -1170,7 +1193,8 @@ static int capture_graph(H* h, int which) {
 int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
-  if (h->cfg.dp_world > 1) return fail("dqnhip_update_async: dp_world > 1 requires dqnhip_update_phase + all-reduce");
+  if (h->cfg.dp_world > 1) return fail("dqnhip_update_async: dp_world > 1 requires dqnhip_update_phase + all-reduce (or dqnhip_dp_update)");
+  if (h->next_phase != 0) return fail("dqnhip_update_async: a phased update is in progress (next phase %d)", h->next_phase);
   RingUse ring_use(h);
   RC(sync_dirty16(h));
   if (h->cfg.use_graph && !h->timing && !h->graph_failed) {
@@ -1201,23 +1225,52 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
 int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
+  // 0 -> 1 -> 2 or 10 -> 11 -> 1 -> 2: a phase run out of order would apply stale gradients
+  // and advance the iteration counters
+  const int expect = h->next_phase;
+  const bool ok = (phase == 0 || phase == 10) ? (expect == 0) : (phase == expect);
+  if (!ok) return fail("dqnhip_update_phase: phase %d out of order (expected %s)", phase,
+                       expect == 0 ? "0 or 10" : expect == 1 ? "1" : expect == 2 ? "2" : "11");
   const int* idx_dev = nullptr;
-  if (phase != 0 && phase != 10) return run_phase(h, phase, idx_dev);
-  RingUse ring_use(h);
-  RC(sync_dirty16(h));
-  RC(stage_indices(h, idx_host, &idx_dev));
-  return run_phase(h, phase, idx_dev);
+  int rc;
+  if (phase != 0 && phase != 10) rc = run_phase(h, phase, idx_dev);
+  else {
+    RingUse ring_use(h);
+    RC(sync_dirty16(h));
+    RC(stage_indices(h, idx_host, &idx_dev));
+    rc = run_phase(h, phase, idx_dev);
+  }
+  if (!rc) h->next_phase = phase == 0 ? 1 : phase == 10 ? 11 : phase == 11 ? 1 : phase == 1 ? 2 : 0;
+  return rc;
 }
 
 int dqnhip_read_stats(dqnhip_handle h, float* critic_loss, float* avg_q) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipMemcpyAsync(h->pinned_stats, &h->st->critic_loss, 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  // {critic_loss, avg_q, flags, skipped_steps} are contiguous in DevState
+  HIPCHK(hipMemcpyAsync(h->pinned_stats, &h->st->critic_loss, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (critic_loss) *critic_loss = h->pinned_stats[0];
   if (avg_q) *avg_q = h->pinned_stats[1];
-  // CHECK(std::isfinite(critic_loss)) (src/dqn.cpp:906) — reported as an error code
+  int flags = 0; memcpy(&flags, &h->pinned_stats[2], sizeof flags);
+  if (flags) HIPCHK(hipMemsetAsync(&h->st->flags, 0, sizeof(int), h->stream));   // sticky until reported
+  // CHECK(std::isfinite(target)) (src/dqn.cpp:898) and CHECK(std::isfinite(critic_loss)) (:906) — the
+  // reference aborts; here: an error code from the first read after the offending update, whichever
+  // entry point (blocking, async, phased, hipGraph) ran it
+  if (flags & kFlagTarget) return fail("Target not finite!");
+  if (flags & kFlagGradNorm) return fail("Gradient norm not finite: the clip+Adam step was skipped (fp16: lower cfg.loss_scale)");
   if (!std::isfinite(h->pinned_stats[0])) return fail("Critic loss not finite!");
+  return 0;
+}
+
+int dqnhip_skipped_steps(dqnhip_handle h, int64_t* count) {
+  if (!h || !count) return fail("null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  int v = 0;
+  HIPCHK(hipMemcpyAsync(h->pinned_stats + 8, &h->st->skipped_steps, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  memcpy(&v, h->pinned_stats + 8, sizeof v);
+  *count = v;
   return 0;
 }
 
@@ -1250,6 +1303,149 @@ int dqnhip_benchmark(dqnhip_handle h, int32_t warmup, int32_t iterations, float*
   HIPCHK(hipEventElapsedTime(&ms, a, b));
   hipEventDestroy(a); hipEventDestroy(b);
   if (avg_ms) *avg_ms = ms / iterations;
+  return 0;
+}
+
+
+// ---- native data parallelism: RCCL over xGMI inside the library --------------------
+// The reference has no collective (threads + one mutex, src/dqn_main.cpp:62-63, 359-363).  Here a
+// data-parallel group is one learner per GPU; each rank gathers its own minibatch slice from its
+// own replay shard, and the update has exactly two exchange points (the actor step reads the
+// UPDATED critic, src/dqn.cpp:904 -> 914): a sum all-reduce of the critic gradient arena after
+// phase 0 and of the actor's after phase 1, in place, on the learner's stream — no host sync, no
+// Python in the loop.  (q - y)/B uses the global B, the actor gradient is an un-normalised sum
+// (src/dqn.cpp:918-921), the clip norm is recomputed on the reduced gradient: every rank applies
+// the identical Adam step.  [loss_sum, q_sum] ride in the 4-float arena tails.
+
+#define NCCLCHK(expr)                                                                     \
+  do {                                                                                    \
+    ncclResult_t r__ = (expr);                                                            \
+    if (r__ != ncclSuccess)                                                               \
+      return fail("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r__), __FILE__, __LINE__); \
+  } while (0)
+
+}  // extern "C"
+
+namespace {
+int dp_broadcast(H* h, int root) {
+  for (int net = 0; net < 4; ++net) NCCLCHK(ncclBroadcast(h->w[net], h->w[net], layout_of(h, net).arena, ncclFloat, root, h->comm, h->stream));
+  for (int net = 0; net < 2; ++net) {
+    NCCLCHK(ncclBroadcast(h->m[net], h->m[net], layout_of(h, net).arena, ncclFloat, root, h->comm, h->stream));
+    NCCLCHK(ncclBroadcast(h->v[net], h->v[net], layout_of(h, net).arena, ncclFloat, root, h->comm, h->stream));
+  }
+  NCCLCHK(ncclBroadcast(&h->st->actor_iter, &h->st->actor_iter, 2, ncclInt32, root, h->comm, h->stream));
+  int it[2];
+  HIPCHK(hipMemcpyAsync(it, &h->st->actor_iter, sizeof it, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->h_actor_iter = it[0]; h->h_critic_iter = it[1];
+  for (int net = 0; net < 4; ++net) h->w16_dirty[net] = true;
+  return 0;
+}
+
+int dp_reduce_slice(H* h, hipStream_t st, float* ptr, size_t count) {
+  HIPCHK(hipEventRecord(h->comm_ev[0], st));
+  HIPCHK(hipStreamWaitEvent(h->comm_stream, h->comm_ev[0], 0));
+  NCCLCHK(ncclAllReduce(ptr, ptr, count, ncclFloat, ncclSum, h->comm, h->comm_stream));
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int dqnhip_dp_unique_id(void* id_out, size_t bytes) {
+  if (!id_out) return fail("null argument");
+  if (bytes != sizeof(ncclUniqueId)) return fail("dp_unique_id: buffer must be DQNHIP_DP_ID_BYTES = %zu bytes", sizeof(ncclUniqueId));
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  memcpy(id_out, &id, sizeof id);
+  return 0;
+}
+
+int dqnhip_dp_init(dqnhip_handle h, const void* id, size_t bytes, int32_t flags) {
+  if (!h || !id) return fail("null argument");
+  if (bytes != sizeof(ncclUniqueId)) return fail("dp_init: id must be DQNHIP_DP_ID_BYTES = %zu bytes", sizeof(ncclUniqueId));
+  if (h->comm) return fail("dp_init: this learner already has a communicator");
+  if (h->w_owner || h->sharers) return fail("dp_init: learners that share layers cannot join a data-parallel group");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  ncclUniqueId uid; memcpy(&uid, id, sizeof uid);
+  NCCLCHK(ncclCommInitRank(&h->comm, h->cfg.dp_world, uid, h->cfg.dp_rank));
+  h->dp_per_layer = (flags & DQNHIP_DP_PER_LAYER) != 0;
+  HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  for (auto& e : h->comm_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  drop_graphs_fwd(h);
+  // replicas start from rank 0's state: weights of the four nets, Adam history, iterations
+  return dp_broadcast(h, 0);
+}
+
+// Single-node rendezvous without any launcher support: rank 0 publishes the RCCL id in a file,
+// the other ranks wait for it.  (A launcher that has its own channel — MPI, torch.distributed's
+// store — passes the id to dqnhip_dp_init directly.)
+int dqnhip_dp_init_file(dqnhip_handle h, const char* path, int32_t flags, int32_t timeout_s) {
+  if (!h || !path) return fail("null argument");
+  ncclUniqueId uid;
+  const std::string p(path), tmp = p + ".tmp";
+  if (h->cfg.dp_rank == 0) {
+    RC(dqnhip_dp_unique_id(&uid, sizeof uid));
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(&uid, sizeof uid, 1, f) != 1) { if (f) fclose(f); return fail("dp_init_file: cannot write %s", tmp.c_str()); }
+    fclose(f);
+    if (rename(tmp.c_str(), p.c_str())) return fail("dp_init_file: cannot publish %s", path);
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      FILE* f = fopen(p.c_str(), "rb");
+      if (f) { const size_t n = fread(&uid, 1, sizeof uid, f); fclose(f); if (n == sizeof uid) break; }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+        return fail("dp_init_file: rank %d timed out after %d s waiting for %s", h->cfg.dp_rank, timeout_s, path);
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+  }
+  return dqnhip_dp_init(h, &uid, sizeof uid, flags);
+}
+
+int dqnhip_dp_broadcast_params(dqnhip_handle h, int32_t root) {
+  if (!h) return fail("null handle");
+  if (!h->comm) return fail("dp_broadcast_params: no communicator (call dqnhip_dp_init first)");
+  if (root < 0 || root >= h->cfg.dp_world) return fail("bad root %d", root);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  return dp_broadcast(h, root);
+}
+
+int dqnhip_dp_update(dqnhip_handle h, const int32_t* idx_host) {
+  if (!h) return fail("null handle");
+  if (!h->comm) return fail("dp_update: no communicator (call dqnhip_dp_init first)");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const NetLayout &la = h->la, &lc = h->lc;
+  hipStream_t st = h->stream;
+  // with per-layer buckets the tower slices are already in flight on comm_stream; what is left is the
+  // head + tail slice, then the main stream waits for the communication stream
+  auto finish = [&](int net) -> int {
+    const NetLayout& l = net ? lc : la;
+    if (h->dp_per_layer) {
+      RC(dp_reduce_slice(h, st, h->g[net] + l.hw_off, l.arena + 4 - l.hw_off));
+      HIPCHK(hipEventRecord(h->comm_ev[1], h->comm_stream));
+      HIPCHK(hipStreamWaitEvent(st, h->comm_ev[1], 0));
+    } else {
+      NCCLCHK(ncclAllReduce(h->g[net], h->g[net], l.arena + 4, ncclFloat, ncclSum, h->comm, st));
+    }
+    return 0;
+  };
+  RC(dqnhip_update_phase(h, 0, idx_host));
+  RC(finish(1));
+  RC(dqnhip_update_phase(h, 1, nullptr));
+  RC(finish(0));
+  return dqnhip_update_phase(h, 2, nullptr);
+}
+
+int dqnhip_dp_destroy(dqnhip_handle h) {
+  if (!h || !h->comm) return 0;
+  hipSetDevice(h->cfg.device);
+  hipStreamSynchronize(h->stream);
+  hipStreamSynchronize(h->comm_stream);
+  ncclCommDestroy(h->comm); h->comm = nullptr;
+  hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr;
+  for (auto& e : h->comm_ev) { if (e) hipEventDestroy(e); e = nullptr; }
   return 0;
 }
 
@@ -1427,14 +1623,12 @@ int dqnhip_clear_memory(dqnhip_handle h) {
   return 0;
 }
 
-int dqnhip_read_memory(dqnhip_handle h, int32_t first, int32_t n, float* states, float* actor_out, float* rewards,
-                       float* on_policy_targets, float* next_states, uint8_t* terminal) {
-  if (!h) return fail("null handle");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  RingUse ring_use(h);
-  RC(refresh_ring(h));
+static bool same_nets(const dqnhip_learner* a, const dqnhip_learner* b);
+
+// caller holds the RingUse of h and has refreshed (head,size)
+static int read_memory_impl(H* h, int32_t first, int32_t n, float* states, float* actor_out, float* rewards,
+                            float* on_policy_targets, float* next_states, uint8_t* terminal) {
   if (n < 1 || first < 0 || (long long)first + n > RO(h)->h_size) return fail("read_memory range [%d,%d) outside [0,%lld)", first, first + n, RO(h)->h_size);
-  HIPCHK(hipSetDevice(h->cfg.device));
   const size_t sb = round_up_z((size_t)n * h->S * 4, 256), ab = round_up_z((size_t)n * kNO * 4, 256), vb = round_up_z((size_t)n * 4, 256);
   HIPCHK(hipStreamSynchronize(h->stream));
   RC(ensure_stage(h, 2 * sb + ab + 3 * vb));
@@ -1455,11 +1649,87 @@ int dqnhip_read_memory(dqnhip_handle h, int32_t first, int32_t n, float* states,
   return 0;
 }
 
+int dqnhip_read_memory(dqnhip_handle h, int32_t first, int32_t n, float* states, float* actor_out, float* rewards,
+                       float* on_policy_targets, float* next_states, uint8_t* terminal) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RingUse ring_use(h);
+  RC(refresh_ring(h));
+  return read_memory_impl(h, first, n, states, actor_out, rewards, on_policy_targets, next_states, terminal);
+}
+
+// DQN::SampleStatesFromMemory (src/dqn.cpp:511-523): n states of uniformly sampled transitions.
+// idx_host = the explicit form of SampleTransitionsFromMemory (as in dqnhip_update); NULL draws on
+// the device from the counter-based generator (its own key stream, one counter tick per call).
+int dqnhip_sample_states(dqnhip_handle h, const int32_t* idx_host, int32_t n, float* states_host) {
+  if (!h || !states_host) return fail("null argument");
+  if (n < 1) return fail("n must be >= 1");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RingUse ring_use(h);
+  RC(refresh_ring(h));
+  const long long size = RO(h)->h_size;
+  if (size < 1) return fail("replay memory is empty");
+  const size_t ib = round_up_z((size_t)n * sizeof(int), 256), sb = (size_t)n * h->S * sizeof(float);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  RC(ensure_stage(h, ib + sb));
+  int* di = (int*)h->stage_dev; float* ds = (float*)((char*)h->stage_dev + ib);
+  if (idx_host) {
+    for (int i = 0; i < n; ++i)
+      if (idx_host[i] < 0 || idx_host[i] >= size) return fail("sampled index %d = %d out of range [0,%lld)", i, idx_host[i], size);
+    HIPCHK(hipMemcpyAsync(di, idx_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  hipLaunchKernelGGL(k_sample_states, dim3((n + 3) / 4), dim3(256), 0, h->stream, RO(h)->ring, (const DevState*)RO(h)->st,
+                     idx_host ? (const int*)di : (const int*)nullptr, sample_key(h) ^ 0x5354415445535F5Full, h->sample_states_calls, n, ds);
+  HIPCHK(hipGetLastError());
+  if (!idx_host) h->sample_states_calls += 1;
+  HIPCHK(hipMemcpyAsync(states_host, ds, sb, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// getActorOutput (src/dqn.cpp:719-732): the first `batch_size` rows of an actor's output blobs as
+// left by its last forward — here the last update's minibatch forward (ACTOR: mu(s), ACTOR_TARGET: mu'(s')).
+int dqnhip_get_actor_output(dqnhip_handle h, int32_t net, int32_t batch_size, float* actor_out_host) {
+  if (!h || !actor_out_host) return fail("null argument");
+  if (net != DQNHIP_ACTOR && net != DQNHIP_ACTOR_TARGET) return fail("net must be an actor");
+  if (batch_size < 1 || batch_size > h->B) return fail("batch_size %d outside [1, %d]", batch_size, h->B);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  std::vector<float> tmp((size_t)batch_size * kAP);
+  HIPCHK(hipMemcpyAsync(tmp.data(), net == DQNHIP_ACTOR ? h->aout16 : h->aout_t16, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int r = 0; r < batch_size; ++r) memcpy(actor_out_host + (size_t)r * kNO, &tmp[(size_t)r * kAP], kNO * sizeof(float));
+  return 0;
+}
+
+// Sum the gradient arenas (4-float tails included) of n co-located learners of one data-parallel
+// group in rank order and leave the sum in every one of them: the exchange step of
+// dqnhip_update_phase for learners that share a device (multi-agent layouts, and the one-GPU parity
+// test of the dp_world > 1 code path).  Cross-device groups use dqnhip_dp_* (RCCL).
+int dqnhip_reduce_gradients_local(dqnhip_handle* hs, int32_t n, int32_t net) {
+  if (!hs || n < 1 || n > 8) return fail("reduce_gradients_local: 1..8 learners");
+  if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return fail("net must be ACTOR or CRITIC");
+  LocalReduce a{}; a.n = n;
+  for (int i = 0; i < n; ++i) {
+    if (!hs[i]) return fail("null handle");
+    if (hs[i]->cfg.device != hs[0]->cfg.device || !same_nets(hs[i], hs[0])) return fail("reduce_gradients_local: learners must share a device and a shape");
+    a.g[i] = hs[i]->g[net];
+  }
+  a.n4 = (layout_of(hs[0], net).arena + 4) / 4;
+  HIPCHK(hipSetDevice(hs[0]->cfg.device));
+  for (int i = 1; i < n; ++i) HIPCHK(hipStreamSynchronize(hs[i]->stream));   // their phase must be complete
+  hipLaunchKernelGGL(k_local_reduce, dim3(1024), dim3(256), 0, hs[0]->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(hs[0]->stream));
+  return 0;
+}
 
 // ---- .replaymemory files (src/dqn.cpp:1146-1226) --------------------------------------------
 int dqnhip_snapshot_replay_memory(dqnhip_handle h, const char* filename) {
   if (!h || !filename) return fail("null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
+  // one RingUse for the whole file: with a shared ring another agent's AddTransitions must not
+  // move the head between chunks (the file would hold shifted / duplicated transitions)
+  RingUse ring_use(h);
   RC(refresh_ring(h));
   gzFile f = gzopen(filename, "wb");
   if (!f) return fail("cannot open %s for writing", filename);
@@ -1471,7 +1741,7 @@ int dqnhip_snapshot_replay_memory(dqnhip_handle h, const char* filename) {
   std::vector<uint8_t> term(chunk), rec;
   for (int first = 0; first < n && ok; first += chunk) {
     const int m = std::min(chunk, n - first);
-    if (dqnhip_read_memory(h, first, m, s.data(), a.data(), r.data(), mc.data(), nullptr, term.data())) { gzclose(f); return 1; }
+    if (read_memory_impl(h, first, m, s.data(), a.data(), r.data(), mc.data(), nullptr, term.data())) { gzclose(f); return 1; }
     const size_t rb = S * 4 + kNO * 4 + 4 + 4 + 1;
     rec.resize((size_t)m * rb);
     for (int i = 0; i < m; ++i) {

@@ -7,7 +7,7 @@
 #include <stdint.h>
 
 #include "gemm_direct.hip.h"
-#include "gemm_mfma.hip.h"
+#include "gemm_common.hip.h"
 
 namespace dqnhip {
 
@@ -26,8 +26,13 @@ struct DevState {
   unsigned long long update_counter;  // Philox counter for on-device sampling
   float critic_loss;    // last update's return value .first
   float avg_q;          // .second
-  int pad;
+  // sticky until dqnhip_read_stats reports and clears them (the reference aborts instead:
+  // CHECK(std::isfinite(target)) src/dqn.cpp:898, CHECK(std::isfinite(critic_loss)) :906)
+  int flags;            // kFlagTarget | kFlagGradNorm
+  int skipped_steps;    // optimiser steps skipped because the gradient norm was not finite
 };
+constexpr int kFlagTarget = 1;     // a TD target of the last update(s) was not finite
+constexpr int kFlagGradNorm = 2;   // a gradient L2 norm was not finite: that clip+Adam step was skipped
 
 // ---- counter-based RNG (Philox-4x32-10) for SampleTransitionsFromMemory ------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -117,6 +122,19 @@ __global__ void k_read_memory(Ring ring, const DevState* st, int first, int n, f
     if (mc) mc[row] = ring.mc[slot];
     if (term) term[row] = ring.term[slot];
   }
+}
+
+// DQN::SampleStatesFromMemory (src/dqn.cpp:511-523): one wave per sampled transition, dense [n][S] out
+__global__ void k_sample_states(Ring ring, const DevState* rs, const int* __restrict__ idx_in, uint64_t key,
+                                unsigned long long counter, int n, float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const int size = rs->ring_size;
+  int li = idx_in ? idx_in[row] : (int)(((uint64_t)philox_u32(key, counter, (uint32_t)row) * (uint64_t)size) >> 32);
+  li = li < 0 ? 0 : (li >= size ? size - 1 : li);
+  const long long slot = ((long long)rs->ring_head + li) % ring.cap;
+  for (int c = lane; c < ring.S; c += 64) out[(size_t)row * ring.S + c] = ring.state[slot * ring.SP + c];
 }
 
 // Minibatch gather (src/dqn.cpp:846-887): one wave per sampled transition; each
@@ -305,6 +323,7 @@ struct HeadTrainArgs {
   const float* reward; const float* mc; const float* term;
   float* q_target; float* q; float* y; float* dq; float* loss_partial;
   double gamma, beta; float inv_batch;
+  DevState* st;                                         // non-finite target flag (src/dqn.cpp:898)
 };
 __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -331,6 +350,7 @@ __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
     const float off_policy = a.term[row] != 0.0f ? r : (float)((double)r + a.gamma * (double)qt);
     const float target = (float)(a.beta * (double)a.mc[row] + (1 - a.beta) * (double)off_policy);
     a.y[row] = target;
+    if (!isfinite(target)) atomicOr(&a.st->flags, kFlagTarget);   // CHECK(std::isfinite(target)), src/dqn.cpp:898
     const float d = q - target;
     a.dq[row] = a.inv_batch * d;
     d2 = d * d;
@@ -632,11 +652,11 @@ struct AdamArgs {
   float lr, beta1, beta2, eps, clip, tau;
   int soft_update_freq;
   int which;                      // 0 actor, 1 critic (selects the iter counter)
-  const DevState* st;
+  DevState* st;
 };
 // body shared by the stand-alone kernel and the mixed GEMM+Adam launch: block `blk` of
 // `nblk` 256-thread blocks strides over the arena slice
-__device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int nblk, float* s /*>= 5 floats*/) {
+__device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int nblk, float* s /*>= 8 floats*/) {
   // every block re-derives the same global L2 norm from the partials, in the
   // same order -> bit-identical scale everywhere, no extra launch
   float acc = 0.0f;
@@ -660,8 +680,14 @@ __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int n
     // soft update condition uses max_iter() AFTER both increments (src/dqn.cpp:967)
     const int mx = (it_a + 1) > (it_c + 1) ? (it_a + 1) : (it_c + 1);
     s[6] = ((mx % a.soft_update_freq) == 0) ? 1.0f : 0.0f;
+    // A non-finite norm (fp16 mode: an overflowed dZ panel) would give scale = clip/inf = 0 and
+    // g*0 = NaN in m, v, w and the targets for good.  Every block derives the same norm, so every
+    // block takes the same decision: skip the whole step and raise the sticky flag.
+    s[7] = isfinite(sumsq) ? 0.0f : 1.0f;
+    if (s[7] != 0.0f && blk == 0) { atomicOr(&a.st->flags, kFlagGradNorm); atomicAdd(&a.st->skipped_steps, 1); }
   }
   __syncthreads();
+  if (s[7] != 0.0f) return;
   const float scale = s[4];
   const float step = s[5];
   const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
@@ -702,6 +728,16 @@ __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int n
 __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   __shared__ float s[8];
   adam_soft_body(a, blockIdx.x, gridDim.x, s);
+}
+
+// Sum of up to 8 co-located gradient arenas in rank order, written back to all (dqnhip_reduce_gradients_local)
+struct LocalReduce { float* g[8]; int n; size_t n4; };
+__global__ __launch_bounds__(256) void k_local_reduce(LocalReduce a) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) {
+    f32x4 s = reinterpret_cast<const f32x4*>(a.g[0])[i];
+    for (int r = 1; r < a.n; ++r) { const f32x4 v = reinterpret_cast<const f32x4*>(a.g[r])[i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    for (int r = 0; r < a.n; ++r) reinterpret_cast<f32x4*>(a.g[r])[i] = s;
+  }
 }
 
 // Reduce the per-block loss / q partials into the gradient-arena tails

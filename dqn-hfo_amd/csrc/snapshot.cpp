@@ -329,4 +329,29 @@ int dqnhip_remove_files_matching_regexp(const char* regexp) {
   return 0;
 }
 
+// FilesMatchingRegexp (src/dqn.hpp:213-216, src/dqn.cpp:559-580): the regular files of the regexp's
+// directory whose NAME matches its last path component, '\n'-separated into buf.
+int dqnhip_files_matching_regexp(const char* regexp, char* buf, size_t buf_len, int32_t* count) {
+  if (!regexp || !buf || buf_len == 0) return fail("null argument");
+  std::vector<std::string> files;
+  try { files = files_matching_regexp(regexp); }
+  catch (const std::regex_error& e) { return fail(std::string("bad regexp '") + regexp + "': " + e.what()); }
+  std::sort(files.begin(), files.end());       // directory order is unspecified; make the listing stable
+  std::string joined;
+  for (auto& f : files) { if (!joined.empty()) joined += '\n'; joined += f; }
+  if (joined.size() + 1 > buf_len) return fail("files_matching_regexp: buffer too small (" + std::to_string(joined.size() + 1) + " bytes needed)");
+  memcpy(buf, joined.c_str(), joined.size() + 1);
+  if (count) *count = (int32_t)files.size();
+  return 0;
+}
+
+// RemoveSnapshots (src/dqn.hpp:222-224, src/dqn.cpp:100-109): remove the matching files whose
+// "_<iter>." suffix is below min_iter.
+int dqnhip_remove_snapshots(const char* regexp, int32_t min_iter) {
+  if (!regexp) return fail("null argument");
+  try { remove_snapshots(regexp, min_iter); }
+  catch (const std::exception& e) { return fail(std::string("RemoveSnapshots(") + regexp + "): " + e.what()); }
+  return 0;
+}
+
 }  // extern "C"

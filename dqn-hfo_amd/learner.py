@@ -314,6 +314,25 @@ class DQN:
         o1, o2 = GetParamOffset(act, 0), GetParamOffset(act, 1)
         return Action(act, float(ao[kActionSize + o1]), 0.0 if o2 < 0 else float(ao[kActionSize + o2]))
 
+    def SampleStatesFromMemory(self, n, idx=None):
+        """src/dqn.cpp:511-523: the states of n uniformly sampled transitions ([n,S]); idx = the
+        explicit form of SampleTransitionsFromMemory, None = device draw."""
+        out = np.empty((n, self.state_size_), np.float32)
+        ip = None
+        if idx is not None:
+            i = np.ascontiguousarray(idx, dtype=np.int32)
+            if i.size != n:
+                raise DQNFatal("need %d indices" % n)
+            ip = i.ctypes.data_as(capi.ip)
+        self._ck(self.lib.dqnhip_sample_states(self.h, ip, n, _p(out)))
+        return out
+
+    def getActorOutput(self, batch_size, net=ACTOR):
+        """src/dqn.cpp:719-732: the actor's output blobs as its last minibatch forward left them."""
+        out = np.empty((batch_size, 10), np.float32)
+        self._ck(self.lib.dqnhip_get_actor_output(self.h, net, batch_size, _p(out)))
+        return out
+
     def CriticForward(self, states_batch, action_batch, net=CRITIC):
         s = _f32(states_batch).reshape(-1, self.state_size_)
         a = _f32(action_batch).reshape(-1, 10)
@@ -332,28 +351,55 @@ class DQN:
         """One update; idx = explicit sampled indices or None for on-device
         sampling.  Returns (critic_loss, avg_q) like the reference."""
         loss, avgq = C.c_float(), C.c_float()
-        ip = None
-        if idx is not None:
-            i = np.ascontiguousarray(idx, dtype=np.int32)
-            if i.size != self.kMinibatchSize:
-                raise DQNFatal("need %d indices" % self.kMinibatchSize)
-            ip = i.ctypes.data_as(capi.ip)
+        keep, ip = self._idx(idx)
         self._ck(self.lib.dqnhip_update(self.h, ip, C.byref(loss), C.byref(avgq)))
         return loss.value, avgq.value
 
+    def _idx(self, idx):
+        """B explicit sampled indices as an int32 pointer (the C side reads exactly kMinibatchSize)."""
+        if idx is None:
+            return None, None
+        i = np.ascontiguousarray(idx, dtype=np.int32)
+        if i.size != self.kMinibatchSize:
+            raise DQNFatal("need %d indices, got %d" % (self.kMinibatchSize, i.size))
+        return i, i.ctypes.data_as(capi.ip)
+
     def update_async(self, idx=None):
-        ip = None
-        if idx is not None:
-            i = np.ascontiguousarray(idx, dtype=np.int32)
-            ip = i.ctypes.data_as(capi.ip)
+        keep, ip = self._idx(idx)
         self._ck(self.lib.dqnhip_update_async(self.h, ip))
 
     def update_phase(self, phase, idx=None):
-        ip = None
-        if idx is not None:
-            i = np.ascontiguousarray(idx, dtype=np.int32)
-            ip = i.ctypes.data_as(capi.ip)
+        keep, ip = self._idx(idx)
         self._ck(self.lib.dqnhip_update_phase(self.h, phase, ip))
+
+    # -- native data parallelism (RCCL inside the library, include/dqnhip.h dqnhip_dp_*) -------
+    @staticmethod
+    def dp_unique_id():
+        lib = capi.load()
+        buf = C.create_string_buffer(capi.DP_ID_BYTES)
+        if lib.dqnhip_dp_unique_id(buf, capi.DP_ID_BYTES) != 0:
+            raise DQNFatal(lib.dqnhip_last_error().decode())
+        return buf.raw
+
+    def dp_init(self, unique_id, per_layer=False):
+        assert len(unique_id) == capi.DP_ID_BYTES
+        buf = C.create_string_buffer(bytes(unique_id), capi.DP_ID_BYTES)
+        self._ck(self.lib.dqnhip_dp_init(self.h, buf, capi.DP_ID_BYTES, 1 if per_layer else 0))
+
+    def dp_init_file(self, path, per_layer=False, timeout_s=120):
+        self._ck(self.lib.dqnhip_dp_init_file(self.h, os.fsencode(path), 1 if per_layer else 0, int(timeout_s)))
+
+    def dp_broadcast_params(self, root=0):
+        self._ck(self.lib.dqnhip_dp_broadcast_params(self.h, int(root)))
+
+    def dp_update(self, idx=None):
+        keep, ip = self._idx(idx)
+        self._ck(self.lib.dqnhip_dp_update(self.h, ip))
+
+    def skipped_steps(self):
+        n = C.c_int64()
+        self._ck(self.lib.dqnhip_skipped_steps(self.h, C.byref(n)))
+        return n.value
 
     def read_stats(self):
         loss, avgq = C.c_float(), C.c_float()
@@ -466,6 +512,36 @@ def RemoveFilesMatchingRegexp(regexp):
     """src/dqn.cpp:92-98."""
     lib = capi.load()
     if lib.dqnhip_remove_files_matching_regexp(os.fsencode(regexp)) != 0:
+        raise DQNFatal(lib.dqnhip_last_error().decode())
+
+
+def FilesMatchingRegexp(regexp):
+    """src/dqn.hpp:213-216: regular files in the regexp's directory whose name matches its last component."""
+    lib = capi.load()
+    n = C.c_int32()
+    size = 1 << 16
+    while True:
+        buf = C.create_string_buffer(size)
+        if lib.dqnhip_files_matching_regexp(os.fsencode(regexp), buf, size, C.byref(n)) == 0:
+            return [os.fsdecode(x) for x in buf.value.split(b"\n") if x]
+        msg = lib.dqnhip_last_error().decode()
+        if "buffer too small" not in msg or size > (1 << 26):
+            raise DQNFatal(msg)
+        size *= 4
+
+
+def RemoveSnapshots(regexp, min_iter):
+    """src/dqn.hpp:222-224, src/dqn.cpp:100-109."""
+    lib = capi.load()
+    if lib.dqnhip_remove_snapshots(os.fsencode(regexp), int(min_iter)) != 0:
+        raise DQNFatal(lib.dqnhip_last_error().decode())
+
+
+def reduce_gradients_local(learners, net):
+    """Sum the gradient arenas of co-located learners of one data-parallel group (rank order)."""
+    lib = capi.load()
+    arr = (capi.H * len(learners))(*[l.h for l in learners])
+    if lib.dqnhip_reduce_gradients_local(arr, len(learners), net) != 0:
         raise DQNFatal(lib.dqnhip_last_error().decode())
 
 

@@ -1,5 +1,14 @@
-"""Data-parallel form of the update: one process per GPU, gradients summed with
-torch.distributed (backend "nccl" == RCCL over xGMI on ROCm).
+"""Data-parallel form of the update: one process per GPU.
+
+Two transports:
+  * NATIVE (default on GPUs): RCCL inside libdqnhip.so (include/dqnhip.h dqnhip_dp_*): the two
+    gradient all-reduces are ncclAllReduce calls on the learner's own stream, issued by
+    dqnhip_dp_update — no Python between the phases.  torch.distributed is only the rendezvous
+    channel that carries rank 0's 128-byte RCCL id to the other ranks (a C++ host uses
+    dqnhip_dp_init_file or its own launcher instead) — make_native_data_parallel().
+  * torch.distributed all-reduce between dqnhip_update_phase calls (DataParallelUpdate): what the
+    CPU/gloo tests drive with the oracle as the backend, and the fallback transport when two
+    ranks must share one GPU (RCCL refuses duplicate devices).
 
 The reference has no collective at all (threads + a mutex, src/dqn_main.cpp:62-63,
 359-363); this is the MI355X-native addition of SURVEY.md §8e.  The update has exactly
@@ -74,4 +83,44 @@ def make_hip_data_parallel(pkg, state_size, rank, world, device, group=None, ove
     dp = DataParallelUpdate(dqn, critic_grad=views[1], actor_grad=views[0], group=group,
                             overlap=overlap)
     dp.arena = arena       # keep the storage alive
+    if world > 1:
+        sync_params_from_rank0(dqn, group)
     return dqn, dp
+
+
+def sync_params_from_rank0(dqn, group=None):
+    """Replicas must start identical: broadcast rank 0's weights (4 nets), Adam history and
+    iterations (torch.distributed transport; the native path does this inside dqnhip_dp_init)."""
+    import numpy as np
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    for net in range(4):
+        for kind in ((0, 1, 2) if net < 2 else (0,)):
+            t = torch.from_numpy(dqn.get_params(net, kind)).to(dev)
+            dist.broadcast(t, src=0, group=group)
+            dqn.set_params(net, t.cpu().numpy(), kind)
+    it = torch.tensor([dqn.actor_iter(), dqn.critic_iter()], dtype=torch.int64, device=dev)
+    dist.broadcast(it, src=0, group=group)
+    dqn.set_iters(int(it[0]), int(it[1]))
+
+
+class NativeDataParallel:
+    """dqnhip_dp_update: phase 0 -> ncclAllReduce(critic grads) -> phase 1 -> ncclAllReduce(actor
+    grads) -> phase 2, enqueued by the library on the learner's stream."""
+    overlap = False
+
+    def __init__(self, dqn):
+        self.backend = dqn
+
+    def update(self, idx=None):
+        self.backend.dp_update(idx)
+
+
+def make_native_data_parallel(pkg, state_size, rank, world, device, group=None, per_layer=False, **dqn_kwargs):
+    """One learner per rank with an RCCL communicator inside the library.  Needs an initialised
+    torch.distributed group only to ship the id when world > 1."""
+    dqn = pkg.DQN(state_size, device=device, dp_world=world, dp_rank=rank, **dqn_kwargs)
+    box = [pkg.DQN.dp_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    dqn.dp_init(box[0], per_layer=per_layer)
+    return dqn, NativeDataParallel(dqn)

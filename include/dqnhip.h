@@ -163,8 +163,41 @@ int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host)
  * same all-reduce.  net = DQNHIP_ACTOR or DQNHIP_CRITIC. */
 int dqnhip_grad_buffer(dqnhip_handle h, int32_t net, void** dptr, size_t* nfloats);
 
-/* Waits for the stream and returns the scalars of the last update. */
+/* ---- native data parallelism: RCCL over xGMI inside the library --------------
+ * The reference scales with threads + one mutex (src/dqn_main.cpp:62-63, 359-363); there is no
+ * collective to replace.  One learner per GPU (cfg.dp_world / cfg.dp_rank), each with its own
+ * replay shard; dqnhip_dp_update runs phase 0, sum-all-reduces the critic gradient arena, phase 1,
+ * all-reduces the actor's, phase 2 — all on the learner's stream, no host sync.
+ *   dqnhip_dp_unique_id   rank 0 creates the RCCL id (DQNHIP_DP_ID_BYTES); the launcher ships it
+ *   dqnhip_dp_init        every rank: ncclCommInitRank, then rank 0's weights (4 nets), Adam
+ *                         history and iterations are broadcast so the replicas start identical
+ *   dqnhip_dp_init_file   the same with a file as the rendezvous (one node, no launcher support)
+ * flags: DQNHIP_DP_PER_LAYER buckets each all-reduce per tower layer on a communication stream,
+ * started as soon as that layer's wgrad has run (backward order), head + tail last. */
+#define DQNHIP_DP_ID_BYTES 128
+#define DQNHIP_DP_PER_LAYER 1
+int dqnhip_dp_unique_id(void* id_out, size_t bytes);
+int dqnhip_dp_init(dqnhip_handle h, const void* id, size_t bytes, int32_t flags);
+int dqnhip_dp_init_file(dqnhip_handle h, const char* path, int32_t flags, int32_t timeout_s);
+int dqnhip_dp_broadcast_params(dqnhip_handle h, int32_t root);
+int dqnhip_dp_update(dqnhip_handle h, const int32_t* idx_host);
+int dqnhip_dp_destroy(dqnhip_handle h);
+
+/* Waits for the stream and returns the scalars of the last update.  Fails — the reference
+ * aborts: CHECK(std::isfinite(target)) src/dqn.cpp:898, CHECK(std::isfinite(critic_loss)) :906 —
+ * with "Target not finite!" / "Critic loss not finite!" if any update since the last call
+ * (blocking, async, phased or graph-replayed alike: the flags are raised on the device and are
+ * sticky until reported here) produced a non-finite TD target or loss, or if a clip+Adam step was
+ * skipped because the gradient norm was not finite (fp16 overflow; weights are left untouched). */
 int dqnhip_read_stats(dqnhip_handle h, float* critic_loss, float* avg_q);
+/* Optimiser steps skipped so far because of a non-finite gradient norm. */
+int dqnhip_skipped_steps(dqnhip_handle h, int64_t* count);
+
+/* Sum-reduce the gradient arenas (tails included) of n learners of one data-parallel group that
+ * live on ONE device, in rank order, leaving the sum in each: the exchange step between
+ * dqnhip_update_phase calls without a communicator (co-located agents; the one-GPU test of the
+ * dp_world > 1 arithmetic).  Groups that span devices use dqnhip_dp_* (RCCL over xGMI). */
+int dqnhip_reduce_gradients_local(dqnhip_handle* learners, int32_t n, int32_t net);
 
 /* Replaces DQN::Benchmark (src/dqn.cpp:487-498): times `iterations` updates
  * (after `warmup` untimed ones) with HIP events on the learner's stream and
@@ -214,6 +247,15 @@ int dqnhip_add_transitions_device(dqnhip_handle h, const float* states, const fl
  * (gamma double, result rounded to float). */
 int dqnhip_label_transitions(double gamma, const float* rewards, int32_t n,
                              float* on_policy_targets);
+
+/* Replaces DQN::SampleStatesFromMemory (src/dqn.cpp:511-523): the states ([n,S], host) of n
+ * transitions sampled uniformly with replacement.  idx_host: explicit logical indices (the
+ * SampleTransitionsFromMemory part, src/dqn.cpp:501-509) or NULL = counter-based draw on the device. */
+int dqnhip_sample_states(dqnhip_handle h, const int32_t* idx_host, int32_t n, float* states_host);
+/* Replaces getActorOutput (src/dqn.cpp:719-732): the first batch_size rows [batch_size,10] of the
+ * output blobs an actor's last minibatch forward left behind (ACTOR: mu(s) of the last update,
+ * ACTOR_TARGET: mu'(s')). */
+int dqnhip_get_actor_output(dqnhip_handle h, int32_t net, int32_t batch_size, float* actor_out_host);
 
 /* DQN::memory_size / ClearReplayMemory (src/dqn.hpp:106,112). */
 int dqnhip_memory_size(dqnhip_handle h, int32_t* size);
@@ -303,6 +345,13 @@ int dqnhip_find_latest_snapshot(const char* snapshot_prefix, char* actor, char* 
 int dqnhip_find_hiscore(const char* snapshot_prefix, int32_t* score);
 /* RemoveFilesMatchingRegexp (src/dqn.cpp:92-98) */
 int dqnhip_remove_files_matching_regexp(const char* regexp);
+/* FilesMatchingRegexp (src/dqn.hpp:213-216; src/dqn.cpp:559-580): regular files in the regexp's
+ * directory whose file NAME matches its last path component; paths '\n'-separated (sorted) in
+ * buf, their number in *count.  Fails if buf is too small. */
+int dqnhip_files_matching_regexp(const char* regexp, char* buf, size_t buf_len, int32_t* count);
+/* RemoveSnapshots (src/dqn.hpp:222-224; src/dqn.cpp:100-109): removes the matching files whose
+ * iteration (the number between the last '_' and the last '.') is < min_iter. */
+int dqnhip_remove_snapshots(const char* regexp, int32_t min_iter);
 
 /* ---- introspection for parity tests ------------------------------------ */
 

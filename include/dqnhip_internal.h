@@ -1,5 +1,5 @@
 /*
- * dqnhip_internal.h — test / tuning hooks exported by libdqnhip.so.  Not part of the
+ * dqnhip_internal.h — test / tuning hooks exported by libdqnhip_test.so (csrc/gemm_bench.hip).  Not part of the
  * drop-in boundary (include/dqnhip.h); used by tests/ and scripts/gemm_tune.py only.
  */
 #ifndef DQNHIP_INTERNAL_H_

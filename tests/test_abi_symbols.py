@@ -10,9 +10,14 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
+INTERNAL = "dqnhip_internal.h"      # test/tuning hooks: exported by libdqnhip_test.so, not by the product library
+
+
+def declared_functions(internal=False):
     names = set()
     for hdr in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        if (os.path.basename(hdr) == INTERNAL) != internal:
+            continue
         src = open(hdr).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         src = re.sub(r"//[^\n]*", "", src)
@@ -31,10 +36,19 @@ def test_every_declared_symbol_is_exported(pkg):
     out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\b(dqnhip_[a-z_0-9]+)\b", out))
     assert decl <= exported
+    # the test hooks live in their own library and are NOT in the product library
+    tdecl = declared_functions(internal=True)
+    assert tdecl == {"dqnhip_test_gemm", "dqnhip_test_hgemm"}
+    assert not (tdecl & exported)
+    tlib = pkg.capi.load_test()
+    assert all(hasattr(tlib, n) for n in tdecl)
+    # the product library links RCCL itself (native data parallelism, dqnhip_dp_*)
+    needed = subprocess.run(["readelf", "-d", lib_path], capture_output=True, text=True).stdout
+    assert "librccl" in needed
 
 
 def test_ctypes_table_matches_header(pkg):
-    decl = {n for n in declared_functions() if n not in ("dqnhip_test_gemm", "dqnhip_test_hgemm")}   # dqnhip_internal.h
+    decl = declared_functions()
     assert set(pkg.capi.SIGNATURES) == decl
 
 

@@ -10,9 +10,13 @@ from oracle import c_oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("workers,eps", [(5, 0.0), (64, 0.3), (100, 1.0)])
-def test_env_front_end_matches_oracle(pkg, gpu, workers, eps):
-    dqn, orc, data, rng = make_pair(pkg, B=32, S=59, hidden=(128, 64, 64, 64), n_replay=100, capacity=20000)
+@pytest.mark.parametrize("workers,eps,S,hidden,wscale", [
+    (5, 0.0, 59, (128, 64, 64, 64), 10.0), (64, 0.3, 59, (128, 64, 64, 64), 10.0), (100, 1.0, 59, (128, 64, 64, 64), 10.0),
+    (64, 0.3, 68, (1024, 1024, 1024, 1024), 3.0),      # BASELINE.json configs[2]: 1v1 (S = 68), 64 workers, the 4x1024 tower
+    (64, 0.1, 77, (1024, 1024, 1024, 1024), 3.0),      # configs[3]'s state size (2v1, S = 77)
+])
+def test_env_front_end_matches_oracle(pkg, gpu, workers, eps, S, hidden, wscale):
+    dqn, orc, data, rng = make_pair(pkg, B=32, S=S, hidden=hidden, n_replay=100, capacity=20000, wscale=wscale)
     kw = dict(max_steps=40, unum=7, p_end=0.05, p_goal=0.4, seed=11)
     env = pkg.EnvFrontEnd(dqn, workers, **kw)
     oenv = c_oracle.OracleEnv(orc, workers, **kw)

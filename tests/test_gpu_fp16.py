@@ -70,7 +70,7 @@ def close16(got, want, name=""):
 
 
 def test_hgemm_kernels(pkg, gpu):
-    lib = pkg.capi.load()
+    lib = pkg.capi.load_test()
     lib.dqnhip_test_hgemm.restype = C.c_int
 
     def run(mode, tile, M, N, K):
@@ -97,6 +97,7 @@ def test_hgemm_kernels(pkg, gpu):
     dict(B=128, S=77, hidden=(128, 256), wscale=5.0),
     dict(B=1024, S=58, hidden=(256, 256), wscale=4.0),      # large minibatch: head kernels emit the fp16 panels
     dict(B=128, S=58, hidden=(2048, 1536), wscale=2.0),     # wider than 1024
+    dict(B=4096, S=58, hidden=(1024, 1024, 1024, 1024), wscale=2.0),   # BASELINE.json configs[4]: its own shape
 ])
 def test_fp16_pipeline_matches_emulation(pkg, gpu, shape):
     shape = dict(shape)
@@ -183,6 +184,40 @@ def test_fp16_update_tracks_fp32_oracle(pkg, gpu, use_graph):
     # acting uses the fp32 master weights with the exact-fp32 kernels
     st = data[0][:50]
     np.testing.assert_allclose(dqn.SelectActionGreedily(st), _actor32(dqn, st, S, hid), rtol=1e-4, atol=1e-5)
+    dqn.close(); orc.close()
+
+
+def test_fp16_config5_shape_vs_float64(pkg, gpu):
+    """BASELINE.json configs[4] on its own shape (minibatch 4096, 4x1024, S=58): one update of the fp16
+    learner against the float64 autograd restatement — loose by construction (an fp16 forward moves
+    pre-activations by ~1e-3 and flips ReLU' of the units nearest zero), but every Q within 2 %, the
+    gradients within a few % Frobenius, nothing overflowed."""
+    B, S, hid = 4096, 58, (1024, 1024, 1024, 1024)
+    dqn, orc, data, rng = make_pair(pkg, B=B, S=S, hidden=hid, n_replay=8192, capacity=16384, wscale=2.0, precision="fp16")
+    s, a, r, mc, nx, term = data
+    t64 = torch_ref.TorchRef(B=B, S=S, hidden=hid)
+    for net in range(4):
+        t64.set_params(net, dqn.get_params(net))
+    idx = rng.integers(0, 8192, size=B)
+    l64, q64 = t64.update(s[idx], a[idx], r[idx], mc[idx], nx[idx], term[idx])
+    dqn.update_phase(0, idx)
+    gc = dqn.get_params(1, 3)
+    dqn.update_phase(1)
+    ga = dqn.get_params(0, 3)
+    dqn.update_phase(2)
+    l1, q1 = dqn.read_stats()                                # fails on a non-finite target / loss / gradient norm
+    assert dqn.skipped_steps() == 0
+
+    def fro(x, y):
+        return np.linalg.norm(np.asarray(x, np.float64) - y) / max(np.linalg.norm(y), 1e-300)
+
+    e_c, e_a = fro(gc, t64.g[1].numpy()), fro(ga, t64.g[0].numpy())
+    assert e_c <= 0.05 and e_a <= 0.1, (e_c, e_a)
+    for name in ("q_target", "q_train", "q_policy", "y"):
+        ref = t64.dbg[name].numpy()
+        assert np.abs(dqn.debug_read(name) - ref).max() <= 2e-2 * max(1.0, np.abs(ref).max()), name
+    assert abs(l1 - l64) <= 5e-3 * max(1.0, abs(l64)), (l1, l64)
+    assert abs(q1 - q64) <= 5e-3 * max(1.0, abs(q64)), (q1, q64)
     dqn.close(); orc.close()
 
 

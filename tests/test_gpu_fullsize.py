@@ -39,11 +39,15 @@ def test_ring_holds_capacity_minus_one(big):
 
 
 def test_device_sampling_is_uniform_and_gathers_the_sampled_rows(big):
+    from oracle import c_oracle
     dqn, _ = big
     seen = []
-    for _ in range(40):
+    u0 = dqn.actor_iter()                 # the sampling counter ticks once per update, like the iterations
+    for u in range(40):
         dqn.UpdateActorCritic()
         idx = dqn.debug_read("idx").astype(np.int64)
+        # the on-device sampler IS its CPU twin (oracle/dqn_oracle.c orc_philox_index): exact
+        np.testing.assert_array_equal(idx, c_oracle.philox_indices(4, u0 + u, B, CAP - 1))
         assert idx.min() >= 0 and idx.max() < CAP - 1
         seen.append(idx)
         term_gathered = dqn.debug_read("terminal")

@@ -11,7 +11,7 @@ FWD, DGRAD, WGRAD = 0, 1, 2
 
 
 def _run(pkg, mode, variant, rows, n_out, k_in, groups=1):
-    lib = pkg.capi.load()
+    lib = pkg.capi.load_test()
     fn = lib.dqnhip_test_gemm
     fn.restype = C.c_int
     fn.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 3

@@ -2,6 +2,8 @@
 RemoveFilesMatchingRegexp with the reference's naming (src/dqn.cpp:80-158)."""
 import os
 
+import pytest
+
 
 def touch(p):
     open(p, "wb").close()
@@ -32,3 +34,21 @@ def test_find_hiscore_and_remove(pkg, tmp_path):
     pkg.RemoveFilesMatchingRegexp(pre + "_HiScore.*")                        # src/dqn_main.cpp:371
     left = sorted(os.listdir(tmp_path))
     assert left == ["run_agent1_actor_iter_5.caffemodel"]
+
+
+def test_files_matching_regexp_and_remove_snapshots(pkg, tmp_path):
+    names = ["dqn_agent0_actor_iter_100.caffemodel", "dqn_agent0_actor_iter_2000.caffemodel",
+             "dqn_agent0_actor_iter_30000.solverstate", "dqn_agent0_critic_iter_100.caffemodel", "other.txt"]
+    for nme in names:
+        (tmp_path / nme).write_bytes(b"x")
+    (tmp_path / "dqn_agent0_actor_iter_7.caffemodel").mkdir()            # directories never match (is_regular_file)
+    rx = str(tmp_path / r"dqn_agent0_actor_iter_[0-9]+\.caffemodel")
+    got = pkg.FilesMatchingRegexp(rx)
+    assert [os.path.basename(g) for g in got] == ["dqn_agent0_actor_iter_100.caffemodel", "dqn_agent0_actor_iter_2000.caffemodel"]
+    assert pkg.FilesMatchingRegexp(str(tmp_path / "nothing.*")) == []
+    assert pkg.FilesMatchingRegexp(str(tmp_path / "missing_dir" / ".*")) == []
+    pkg.RemoveSnapshots(rx, 2000)                                         # iter < min_iter goes (src/dqn.cpp:100-109)
+    assert [os.path.basename(g) for g in pkg.FilesMatchingRegexp(rx)] == ["dqn_agent0_actor_iter_2000.caffemodel"]
+    assert (tmp_path / "dqn_agent0_critic_iter_100.caffemodel").exists() and (tmp_path / "other.txt").exists()
+    with pytest.raises(pkg.DQNFatal):
+        pkg.FilesMatchingRegexp(str(tmp_path / "bad[regexp"))
