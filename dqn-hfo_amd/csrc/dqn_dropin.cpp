@@ -1,0 +1,406 @@
+// dqn_dropin.cpp — what replaces the reference's src/dqn.cpp in its build: the out-of-line part
+// of include/dqn.hpp's `dqn::DQN` (src/dqn.hpp:56-134) and the free functions (:204-242) as a thin
+// host adaptor over the C-ABI of libdqnhip.so.  It uses the same glog / gflags / boost / caffe
+// NAMES as the file it replaces, so it builds against the real libraries in the reference's
+// environment and against include/shim/ where they are absent (this image).  All arithmetic is in
+// the library; what stays here is what must stay on the host to keep the reference's behaviour:
+// the std::mt19937 draws in the reference's call order (epsilon per SelectActions call :700,
+// GetRandomActorOutput :664-682, SampleTransitionsFromMemory :501-509, SampleAction :180-194),
+// the Update() gate / smoothed logs / snapshot cadence (:799-826), and the 11 learner gflags
+// (:21-31), which must be DEFINED here because the driver's ParseCommandLineFlags owns the single
+// flag namespace (src/dqn_main.cpp:393).
+#include "dqn.hpp"
+
+#include <glog/logging.h>
+#include <gflags/gflags.h>
+
+#include <chrono>
+#include <cstdio>
+#include <sstream>
+
+namespace dqn {
+
+using namespace hfo;
+
+// the reference's learner flags, same names / defaults / help (src/dqn.cpp:21-31)
+DEFINE_int32(seed, 0, "Seed the RNG. Default: time");
+DEFINE_double(tau, .001, "Step size for soft updates.");
+DEFINE_int32(soft_update_freq, 1, "Do SoftUpdateNet this frequently");
+DEFINE_double(gamma, .99, "Discount factor of future rewards (0,1]");
+DEFINE_int32(memory, 500000, "Capacity of replay memory");
+DEFINE_int32(memory_threshold, 1000, "Number of transitions required to start learning");
+DEFINE_int32(loss_display_iter, 1000, "Frequency of loss display");
+DEFINE_int32(snapshot_freq, 10000, "Frequency (steps) snapshots");
+DEFINE_bool(remove_old_snapshots, true, "Remove old snapshots when writing more recent ones.");
+DEFINE_bool(snapshot_memory, true, "Snapshot the replay memory along with the network.");
+DEFINE_double(beta, .5, "Mix between off-policy and on-policy updates.");
+// MI355X learner flags (no counterpart in the reference; defaults reproduce its behaviour)
+DEFINE_int32(minibatch, kMinibatchSize, "Minibatch size of the HIP learner (reference: kMinibatchSize = 32); multiple of 32.");
+DEFINE_int32(hip_device, 0, "HIP device ordinal of this process's learners.");
+DEFINE_bool(hip_graph, true, "Replay each update as one captured hipGraph.");
+DEFINE_string(precision, "fp32", "fp32 (exact-fp32 MFMA, the parity path) or fp16 (fp16 MFMA operands, fp32 accumulate).");
+DEFINE_bool(device_sampling, false, "Sample minibatch indices on the device (counter-based) instead of the host std::mt19937.");
+
+#define DQNHIP_CK(call) CHECK((call) == 0) << dqnhip_last_error()
+
+namespace {
+
+// tower widths = num_output of the InnerProduct layers named ip<i>_layer (src/dqn.cpp:406)
+std::vector<int> TowerWidths(const caffe::NetParameter& np) {
+  std::vector<int> widths;
+  for (int i = 0; i < np.layer_size(); ++i) {
+    const auto& l = np.layer(i);
+    if (l.type() != "InnerProduct") continue;
+    const std::string want = "ip" + std::to_string(widths.size() + 1) + "_layer";
+    if (l.name() == want) widths.push_back(l.inner_product_param().num_output());
+  }
+  return widths;
+}
+
+void AddLayer(caffe::NetParameter& np, const std::string& name, const std::string& type,
+              const std::vector<std::string>& bottoms, const std::vector<std::string>& tops) {
+  caffe::LayerParameter* l = np.add_layer();
+  l->set_name(name); l->set_type(type);
+  for (const auto& b : bottoms) l->add_bottom(b);
+  for (const auto& t : tops) l->add_top(t);
+}
+void AddMemoryData(caffe::NetParameter& np, const std::string& name, const std::vector<std::string>& tops, int n, int c, int h, int w) {
+  AddLayer(np, name, "MemoryData", {}, tops);
+  auto* p = np.mutable_layer(np.layer_size() - 1)->mutable_memory_data_param();
+  p->set_batch_size(n); p->set_channels(c); p->set_height(h); p->set_width(w);
+}
+void AddInnerProduct(caffe::NetParameter& np, const std::string& name, const std::string& bottom, const std::string& top, int num_output) {
+  AddLayer(np, name, "InnerProduct", {bottom}, {top});
+  np.mutable_layer(np.layer_size() - 1)->mutable_inner_product_param()->set_num_output(num_output);   // gaussian(0.01) filler, :348-352
+}
+// ip<i>_layer (InnerProduct) + ip<i>_relu_layer (ReLU 0.01, in place) per width (src/dqn.cpp:400-416)
+std::string AddTower(caffe::NetParameter& np, std::string input, const std::vector<int>& widths) {
+  for (size_t i = 1; i <= widths.size(); ++i) {
+    const std::string top = "ip" + std::to_string(i);
+    AddInnerProduct(np, top + "_layer", input, top, widths[i - 1]);
+    AddLayer(np, top + "_relu_layer", "ReLU", {top}, {top});
+    np.mutable_layer(np.layer_size() - 1)->mutable_relu_param()->set_negative_slope(0.01f);
+    input = top;
+  }
+  return input;
+}
+const std::vector<int> kDefaultTower = {1024, 512, 256, 128};     // src/dqn.cpp:425, 449
+
+}  // namespace
+
+caffe::NetParameter CreateActorNet(int state_size) {
+  caffe::NetParameter np;
+  np.set_name("Actor");
+  np.set_force_backward(true);
+  AddMemoryData(np, state_input_layer_name, {states_blob_name, "dummy1"}, kMinibatchSize, kStateInputCount, state_size, 1);
+  AddLayer(np, "silence", "Silence", {"dummy1"}, {});
+  const std::string top = AddTower(np, states_blob_name, kDefaultTower);
+  AddInnerProduct(np, "action_layer", top, actions_blob_name, kActionSize);
+  AddInnerProduct(np, "actionpara_layer", top, action_params_blob_name, kActionParamSize);
+  return np;
+}
+
+caffe::NetParameter CreateCriticNet(int state_size) {
+  caffe::NetParameter np;
+  np.set_name("Critic");
+  np.set_force_backward(true);
+  AddMemoryData(np, state_input_layer_name, {states_blob_name, "dummy1"}, kMinibatchSize, kStateInputCount, state_size, 1);
+  AddMemoryData(np, action_input_layer_name, {actions_blob_name, "dummy2"}, kMinibatchSize, kStateInputCount, kActionSize, 1);
+  AddMemoryData(np, action_params_input_layer_name, {action_params_blob_name, "dummy3"}, kMinibatchSize, kStateInputCount, kActionParamSize, 1);
+  AddMemoryData(np, target_input_layer_name, {targets_blob_name, "dummy4"}, kMinibatchSize, 1, 1, 1);
+  AddLayer(np, "silence", "Silence", {"dummy1", "dummy2", "dummy3", "dummy4"}, {});
+  AddLayer(np, "concat", "Concat", {states_blob_name, actions_blob_name, action_params_blob_name}, {"state_actions"});
+  np.mutable_layer(np.layer_size() - 1)->mutable_concat_param()->set_axis(2);
+  const std::string top = AddTower(np, "state_actions", kDefaultTower);
+  AddInnerProduct(np, q_values_layer_name, top, q_values_blob_name, 1);
+  AddLayer(np, "loss", "EuclideanLoss", {q_values_blob_name, targets_blob_name}, {loss_blob_name});
+  return np;
+}
+
+int GetParamOffset(const action_t action, const int arg_num) {
+  if (arg_num < 0 || arg_num > 1) return -1;
+  switch (action) {
+    case DASH: return arg_num;
+    case TURN: return arg_num == 0 ? 2 : -1;
+    case TACKLE: return arg_num == 0 ? 3 : -1;
+    case KICK: return 4 + arg_num;
+    default: LOG(FATAL) << "Unrecognized action: " << action;
+  }
+  return -1;
+}
+
+Action GetAction(const ActorOutput& actor_output) {
+  ActorOutput logits(actor_output);
+  logits[TACKLE] = -99999;                                    // TACKLE is never chosen (src/dqn.cpp:198)
+  const action_t best = (action_t)std::distance(logits.begin(), std::max_element(logits.begin(), logits.begin() + kActionSize));
+  const int o1 = GetParamOffset(best, 0), o2 = GetParamOffset(best, 1);
+  CHECK_GE(o1, 0);
+  Action a;
+  a.action = best;
+  a.arg1 = actor_output[kActionSize + o1];
+  a.arg2 = o2 < 0 ? 0 : actor_output[kActionSize + o2];
+  return a;
+}
+
+std::string PrintActorOutput(const ActorOutput& o) {
+  auto s = [](float v) { return std::to_string(v); };
+  return "Dash(" + s(o[4]) + ", " + s(o[5]) + ")=" + s(o[0]) + ", Turn(" + s(o[6]) + ")=" + s(o[1]) + ", Tackle(" + s(o[7]) + ")=" + s(o[2]) +
+         ", Kick(" + s(o[8]) + ", " + s(o[9]) + ")=" + s(o[3]);
+}
+
+std::vector<std::string> FilesMatchingRegexp(const std::string& regexp) {
+  std::vector<char> buf(1 << 16);
+  int32_t n = 0;
+  while (dqnhip_files_matching_regexp(regexp.c_str(), buf.data(), buf.size(), &n) != 0) {
+    CHECK(std::string(dqnhip_last_error()).find("buffer too small") != std::string::npos && buf.size() < (1u << 28)) << dqnhip_last_error();
+    buf.resize(buf.size() * 4);
+  }
+  std::vector<std::string> out;
+  std::istringstream ss(buf.data());
+  for (std::string line; std::getline(ss, line);) if (!line.empty()) out.push_back(line);
+  return out;
+}
+void RemoveFilesMatchingRegexp(const std::string& regexp) { DQNHIP_CK(dqnhip_remove_files_matching_regexp(regexp.c_str())); }
+void RemoveSnapshots(const std::string& regexp, int min_iter) { DQNHIP_CK(dqnhip_remove_snapshots(regexp.c_str(), min_iter)); }
+void FindLatestSnapshot(const std::string& snapshot_prefix, std::string& actor_snapshot, std::string& critic_snapshot,
+                        std::string& memory_snapshot) {
+  char a[4096], c[4096], m[4096];
+  DQNHIP_CK(dqnhip_find_latest_snapshot(snapshot_prefix.c_str(), a, c, m, sizeof a));
+  if (a[0]) actor_snapshot = a;
+  if (c[0]) critic_snapshot = c;
+  if (m[0]) memory_snapshot = m;
+}
+int FindHiScore(const std::string& snapshot_prefix) {
+  int32_t s = 0;
+  DQNHIP_CK(dqnhip_find_hiscore(snapshot_prefix.c_str(), &s));
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+DQN::DQN(caffe::SolverParameter& actor_solver_param, caffe::SolverParameter& critic_solver_param, std::string save_path,
+         int state_size, int tid)
+    : actor_solver_param_(actor_solver_param), critic_solver_param_(critic_solver_param), replay_memory_capacity_(FLAGS_memory),
+      gamma_(FLAGS_gamma), random_engine(), smoothed_critic_loss_(0), smoothed_actor_loss_(0), last_snapshot_iter_(0),
+      save_path_(save_path), state_size_(state_size), tid_(tid), unum_(0), minibatch_(FLAGS_minibatch), h_(nullptr) {
+  unsigned seed;
+  if (FLAGS_seed <= 0) {
+    seed = (unsigned)std::chrono::system_clock::now().time_since_epoch().count();
+    LOG(INFO) << "Seeding RNG to time (seed = " << seed << ")";
+  } else {
+    seed = (unsigned)FLAGS_seed;
+    LOG(INFO) << "Seeding RNG with seed = " << FLAGS_seed;
+  }
+  random_engine.seed(seed);
+  // -gpu=false selects Caffe's CPU mode in the reference (src/dqn_main.cpp:208-212); this learner is
+  // the MI355X path and has no CPU fallback by design
+  CHECK(caffe::Caffe::mode() == caffe::Caffe::GPU) << "the HIP learner needs -gpu=true (there is no CPU backend)";
+  std::vector<int> wa = TowerWidths(actor_solver_param_.net_param()), wc = TowerWidths(critic_solver_param_.net_param());
+  if (wa.empty()) wa = kDefaultTower;
+  if (wc.empty()) wc = kDefaultTower;
+  CHECK(wa == wc) << "actor and critic towers must have the same widths";
+  CHECK_LE(wa.size(), (size_t)DQNHIP_MAX_HIDDEN);
+  dqnhip_config c;
+  dqnhip_default_config(&c, state_size);
+  c.minibatch = FLAGS_minibatch;
+  c.num_hidden = (int)wa.size();
+  for (size_t i = 0; i < wa.size(); ++i) c.hidden[i] = wa[i];
+  c.replay_capacity = FLAGS_memory;
+  c.soft_update_freq = FLAGS_soft_update_freq;
+  c.gamma = FLAGS_gamma; c.beta = FLAGS_beta; c.tau = FLAGS_tau;
+  // each solver's own hyper-parameters; the fused optimiser pass takes ONE (momentum, momentum2,
+  // delta, clip) pair, so the two solvers must agree on those (the driver sets them from the same flags)
+  c.actor_lr = actor_solver_param_.base_lr(); c.critic_lr = critic_solver_param_.base_lr();
+  CHECK(actor_solver_param_.momentum() == critic_solver_param_.momentum() && actor_solver_param_.momentum2() == critic_solver_param_.momentum2() &&
+        actor_solver_param_.clip_gradients() == critic_solver_param_.clip_gradients() && actor_solver_param_.delta() == critic_solver_param_.delta())
+      << "actor and critic solvers must share momentum / momentum2 / delta / clip_gradients";
+  c.momentum = critic_solver_param_.momentum(); c.momentum2 = critic_solver_param_.momentum2();
+  c.delta = critic_solver_param_.delta(); c.clip_gradients = critic_solver_param_.clip_gradients();
+  CHECK(actor_solver_param_.type() == "Adam" && critic_solver_param_.type() == "Adam") << "only the Adam solver is implemented (-solver Adam, the reference's default)";
+  c.device = FLAGS_hip_device;
+  c.use_graph = FLAGS_hip_graph ? 1 : 0;
+  c.seed = seed;
+  CHECK(FLAGS_precision == "fp32" || FLAGS_precision == "fp16") << "-precision must be fp32 or fp16";
+  c.precision = FLAGS_precision == "fp16" ? DQNHIP_FP16 : DQNHIP_FP32;
+  DQNHIP_CK(dqnhip_create(&c, &h_));
+}
+
+DQN::~DQN() { DQNHIP_CK(dqnhip_destroy(h_)); }
+
+void DQN::Benchmark(int iterations) {
+  LOG(INFO) << "*** Benchmark begins ***";
+  float ms = 0;
+  DQNHIP_CK(dqnhip_benchmark(h_, 0, iterations, &ms));
+  LOG(INFO) << "Average Update: " << ms << " ms.";
+  LOG(INFO) << "*** Benchmark ends ***";
+}
+
+void DQN::RestoreActorSolver(const std::string& f) { DQNHIP_CK(dqnhip_solver_restore(h_, DQNHIP_ACTOR, f.c_str())); last_snapshot_iter_ = max_iter(); }
+void DQN::RestoreCriticSolver(const std::string& f) { DQNHIP_CK(dqnhip_solver_restore(h_, DQNHIP_CRITIC, f.c_str())); last_snapshot_iter_ = max_iter(); }
+void DQN::LoadActorWeights(const std::string& f) { DQNHIP_CK(dqnhip_load_caffemodel(h_, DQNHIP_ACTOR, f.c_str())); }
+void DQN::LoadCriticWeights(const std::string& f) { DQNHIP_CK(dqnhip_load_caffemodel(h_, DQNHIP_CRITIC, f.c_str())); }
+void DQN::LoadReplayMemory(const std::string& f) {
+  LOG(INFO) << "Loading replay memory from " << f;
+  DQNHIP_CK(dqnhip_load_replay_memory(h_, f.c_str()));
+  LOG(INFO) << "replay_mem_size = " << memory_size();
+}
+void DQN::SnapshotReplayMemory(const std::string& f) { DQNHIP_CK(dqnhip_snapshot_replay_memory(h_, f.c_str())); }
+
+void DQN::Snapshot() { Snapshot(save_path_, FLAGS_remove_old_snapshots, FLAGS_snapshot_memory); }
+void DQN::Snapshot(const std::string& snapshot_prefix, bool remove_old, bool snapshot_memory) {
+  if (snapshot_memory) LOG(INFO) << "Snapshotting memory to " << snapshot_prefix << "_iter_" << max_iter() << ".replaymemory";
+  DQNHIP_CK(dqnhip_snapshot(h_, save_path_.c_str(), snapshot_prefix.c_str(), remove_old, snapshot_memory));
+  LOG(INFO) << "Snapshotting Finished!";
+}
+
+ActorOutput DQN::GetRandomActorOutput() {
+  auto u = [this](float lo, float hi) { return std::uniform_real_distribution<float>(lo, hi)(random_engine); };
+  ActorOutput o;
+  for (int i = 0; i < kActionSize; ++i) o[i] = u(-1.0, 1.0);
+  o[kActionSize + 0] = u(-100.0, 100.0);      // Dash Power   (draw order = src/dqn.cpp:669-680)
+  o[kActionSize + 1] = u(-180.0, 180.0);      // Dash Angle
+  o[kActionSize + 2] = u(-180.0, 180.0);      // Turn Angle
+  o[kActionSize + 3] = u(-180.0, 180.0);      // Tackle Angle
+  o[kActionSize + 4] = u(0.0, 100.0);         // Kick Power
+  o[kActionSize + 5] = u(-180.0, 180.0);      // Kick Angle
+  return o;
+}
+
+ActorOutput DQN::SelectAction(const InputStates& last_states, const double epsilon) {
+  return SelectActions(std::vector<InputStates>{{last_states}}, epsilon)[0];
+}
+
+std::vector<ActorOutput> DQN::SelectActions(const std::vector<InputStates>& states_batch, const double epsilon) {
+  CHECK(epsilon >= 0.0 && epsilon <= 1.0);
+  // (the reference caps the batch at kMinibatchSize, :699, because its MemoryData layer is that wide; the
+  // device path takes any n)
+  std::vector<ActorOutput> out(states_batch.size());
+  if (std::uniform_real_distribution<double>(0.0, 1.0)(random_engine) < epsilon) {      // ONE draw per call (:700)
+    for (auto& o : out) o = GetRandomActorOutput();
+    return out;
+  }
+  std::vector<float> s(states_batch.size() * (size_t)state_size_);
+  for (size_t n = 0; n < states_batch.size(); ++n) {
+    const StateDataSp& sp = states_batch[n][0];
+    CHECK(sp) << "null state";
+    CHECK_EQ((int)sp->size(), state_size_);
+    std::copy(sp->begin(), sp->end(), s.begin() + n * state_size_);
+  }
+  DQNHIP_CK(dqnhip_select_actions(h_, s.data(), (int)states_batch.size(), out[0].data()));
+  return out;
+}
+
+Action DQN::SampleAction(const ActorOutput& actor_output) {
+  const float dash = std::max(0., actor_output[DASH] + 1.0), turn = std::max(0., actor_output[TURN] + 1.0);
+  const float kick = std::max(0., actor_output[KICK] + 1.0);
+  std::discrete_distribution<int> dist{dash, turn, 0 /* tackle removed */, kick};
+  const action_t act = (action_t)dist(random_engine);
+  const int o1 = GetParamOffset(act, 0), o2 = GetParamOffset(act, 1);
+  CHECK_GE(o1, 0);
+  Action a;
+  a.action = act;
+  a.arg1 = actor_output[kActionSize + o1];
+  a.arg2 = o2 < 0 ? 0 : actor_output[kActionSize + o2];
+  return a;
+}
+
+float DQN::EvaluateAction(const InputStates& input_states, const ActorOutput& action) {
+  float q = 0;
+  DQNHIP_CK(dqnhip_critic_forward(h_, DQNHIP_CRITIC, input_states[0]->data(), action.data(), 1, &q));
+  return q;
+}
+
+void DQN::AddTransition(const Transition& t) {
+  const auto& next = std::get<4>(t);
+  DQNHIP_CK(dqnhip_add_transition(h_, std::get<0>(t)[0]->data(), std::get<1>(t).data(), std::get<2>(t), std::get<3>(t),
+                                  next ? (*next)->data() : nullptr, next ? 0 : 1));
+}
+
+void DQN::AddTransitions(const std::vector<Transition>& ts) {
+  const size_t n = ts.size(), S = (size_t)state_size_;
+  if (n == 0) return;
+  std::vector<float> s(n * S), nx(n * S, 0.f), a(n * (kActionSize + kActionParamSize)), r(n), mc(n);
+  std::vector<uint8_t> term(n);
+  for (size_t i = 0; i < n; ++i) {
+    const Transition& t = ts[i];
+    std::copy(std::get<0>(t)[0]->begin(), std::get<0>(t)[0]->end(), s.begin() + i * S);
+    std::copy(std::get<1>(t).begin(), std::get<1>(t).end(), a.begin() + i * (kActionSize + kActionParamSize));
+    r[i] = std::get<2>(t); mc[i] = std::get<3>(t);
+    const auto& next = std::get<4>(t);
+    term[i] = next ? 0 : 1;                                  // terminal <=> next_state is none (:878)
+    if (next) std::copy((*next)->begin(), (*next)->end(), nx.begin() + i * S);
+  }
+  DQNHIP_CK(dqnhip_add_transitions(h_, s.data(), a.data(), r.data(), mc.data(), nx.data(), term.data(), (int)n));
+}
+
+void DQN::LabelTransitions(std::vector<Transition>& ts) {
+  CHECK_GT(ts.size(), 0u) << "Need at least one transition to label.";
+  std::vector<float> r(ts.size()), mc(ts.size());
+  for (size_t i = 0; i < ts.size(); ++i) r[i] = std::get<2>(ts[i]);
+  DQNHIP_CK(dqnhip_label_transitions(gamma_, r.data(), (int)ts.size(), mc.data()));
+  for (size_t i = 0; i < ts.size(); ++i) std::get<3>(ts[i]) = mc[i];
+}
+
+void DQN::Update() {
+  if (memory_size() < FLAGS_memory_threshold) return;
+  const std::pair<float, float> res = UpdateActorCritic();
+  if (critic_iter() % FLAGS_loss_display_iter == 0) {
+    LOG(INFO) << "[Agent" << tid_ << "] Critic Iteration " << critic_iter() << ", loss = " << smoothed_critic_loss_;
+    smoothed_critic_loss_ = 0;
+  }
+  smoothed_critic_loss_ += res.first / float(FLAGS_loss_display_iter);
+  if (actor_iter() % FLAGS_loss_display_iter == 0) {
+    LOG(INFO) << "[Agent" << tid_ << "] Actor Iteration " << actor_iter() << ", avg_q_value = " << smoothed_actor_loss_;
+    smoothed_actor_loss_ = 0;
+  }
+  smoothed_actor_loss_ += res.second / float(FLAGS_loss_display_iter);
+  if (critic_iter() >= last_snapshot_iter_ + FLAGS_snapshot_freq || actor_iter() >= last_snapshot_iter_ + FLAGS_snapshot_freq) {
+    Snapshot();
+    last_snapshot_iter_ = max_iter();
+  }
+}
+
+std::vector<int> DQN::SampleTransitionsFromMemory(int n) {
+  std::vector<int> idx(n);
+  const int size = memory_size();
+  for (int& i : idx) i = std::uniform_int_distribution<int>(0, size - 1)(random_engine);
+  return idx;
+}
+
+std::vector<InputStates> DQN::SampleStatesFromMemory(int n) {
+  const std::vector<int> idx = SampleTransitionsFromMemory(n);
+  std::vector<float> flat((size_t)n * state_size_);
+  DQNHIP_CK(dqnhip_sample_states(h_, idx.data(), n, flat.data()));
+  std::vector<InputStates> out(n);
+  for (int i = 0; i < n; ++i)
+    out[i][0] = std::make_shared<StateData>(flat.begin() + (size_t)i * state_size_, flat.begin() + (size_t)(i + 1) * state_size_);
+  return out;
+}
+
+std::pair<float, float> DQN::UpdateActorCritic() {
+  if (FLAGS_device_sampling) {
+    float loss = 0, avgq = 0;
+    DQNHIP_CK(dqnhip_update(h_, nullptr, &loss, &avgq));                      // CHECK(isfinite(target / loss)): the call fails
+    return std::make_pair(loss, avgq);
+  }
+  return UpdateActorCritic(SampleTransitionsFromMemory(minibatch_));
+}
+
+std::pair<float, float> DQN::UpdateActorCritic(const std::vector<int>& transitions) {
+  CHECK_EQ((int)transitions.size(), minibatch_);
+  float loss = 0, avgq = 0;
+  static_assert(sizeof(int) == sizeof(int32_t), "indices travel as int32");
+  DQNHIP_CK(dqnhip_update(h_, reinterpret_cast<const int32_t*>(transitions.data()), &loss, &avgq));
+  return std::make_pair(loss, avgq);
+}
+
+void DQN::ClearReplayMemory() { DQNHIP_CK(dqnhip_clear_memory(h_)); }
+int DQN::memory_size() const { int32_t n = 0; DQNHIP_CK(dqnhip_memory_size(h_, &n)); return n; }
+int DQN::critic_iter() const { int32_t a = 0, c = 0; DQNHIP_CK(dqnhip_get_iters(h_, &a, &c)); return c; }
+int DQN::actor_iter() const { int32_t a = 0, c = 0; DQNHIP_CK(dqnhip_get_iters(h_, &a, &c)); return a; }
+
+void DQN::ShareParameters(DQN& other, int num_actor_layers_to_share, int num_critic_layers_to_share) {
+  DQNHIP_CK(dqnhip_share_parameters(h_, other.h_, num_actor_layers_to_share, num_critic_layers_to_share));
+}
+void DQN::ShareReplayMemory(DQN& other) { DQNHIP_CK(dqnhip_share_replay_memory(h_, other.h_)); }
+
+}  // namespace dqn

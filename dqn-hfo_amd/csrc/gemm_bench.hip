@@ -375,3 +375,67 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
   hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
   return 0;
 }
+
+
+// ======================= optimiser pass probe ===================================================
+#include "small_kernels.hip.h"
+
+namespace {
+__global__ void k_touch(float* p, size_t n4) {        // stand-in for the traffic between two Adam passes of an update
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<f32x4*>(p)[i]; v.x += 1.0f; reinterpret_cast<f32x4*>(p)[i] = v;
+  }
+}
+}  // namespace
+
+// Times the fused clip+Adam+soft-update pass (k_adam_soft) on n_params random parameters.
+//   variant  10*U + NT: U = float4s in flight per array per thread (1, 2, 4), NT = non-temporal gradient loads
+//   blocks   grid size;  touch_mb: MB of unrelated read-modify-write traffic issued between two passes
+//            (0: back-to-back passes over an Infinity-Cache-resident working set)
+// avg_us = mean kernel time from the dispatch packets' own timestamps.
+extern "C" int dqnhip_test_adam(int64_t n_params, int32_t variant, int32_t blocks, int32_t iters, int32_t touch_mb, float* avg_us) {
+  if (n_params < 1024 || n_params % 4 || iters < 1 || blocks < 1) return 1;
+  hipStream_t s; CK(hipStreamCreate(&s));
+  float *w, *g, *m, *v, *wt, *part, *junk = nullptr;
+  DevState* st;
+  const size_t nb = (size_t)n_params * 4;
+  CK(hipMalloc(&w, nb)); CK(hipMalloc(&g, nb)); CK(hipMalloc(&m, nb)); CK(hipMalloc(&v, nb)); CK(hipMalloc(&wt, nb));
+  CK(hipMalloc(&part, 1024 * 4)); CK(hipMalloc(&st, sizeof(DevState)));
+  CK(hipMemsetAsync(st, 0, sizeof(DevState), s)); CK(hipMemsetAsync(part, 0, 1024 * 4, s));
+  CK(hipMemsetAsync(m, 0, nb, s)); CK(hipMemsetAsync(v, 0, nb, s));
+  hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, w, (size_t)n_params, 1u, -0.1f, 0.1f);
+  hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, wt, (size_t)n_params, 2u, -0.1f, 0.1f);
+  hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, g, (size_t)n_params, 3u, -1e-3f, 1e-3f);
+  const size_t junk4 = (size_t)touch_mb * (1 << 20) / 16;
+  if (touch_mb > 0) { CK(hipMalloc(&junk, junk4 * 16)); CK(hipMemsetAsync(junk, 0, junk4 * 16, s)); }
+  AdamArgs a{};
+  a.w = w; a.g = g; a.m = m; a.v = v; a.wt = wt; a.n4 = (size_t)n_params / 4; a.partial = part; a.n_partial = 1024;
+  a.lr = 1e-3f; a.beta1 = .95f; a.beta2 = .999f; a.eps = 1e-8f; a.clip = 10.f; a.tau = .001f; a.soft_update_freq = 1; a.which = 1; a.st = st;
+  std::vector<hipEvent_t> ev(2 * (size_t)iters);
+  for (auto& e : ev) CK(hipEventCreate(&e));
+  auto launch = [&](hipEvent_t e0, hipEvent_t e1) {
+    switch (variant) {
+      case 10: hipExtLaunchKernelGGL((k_adam_soft_t<1, 0>), dim3(blocks), dim3(256), 0, s, e0, e1, 0, a); break;
+      case 11: hipExtLaunchKernelGGL((k_adam_soft_t<1, 1>), dim3(blocks), dim3(256), 0, s, e0, e1, 0, a); break;
+      case 20: hipExtLaunchKernelGGL((k_adam_soft_t<2, 0>), dim3(blocks), dim3(256), 0, s, e0, e1, 0, a); break;
+      case 21: hipExtLaunchKernelGGL((k_adam_soft_t<2, 1>), dim3(blocks), dim3(256), 0, s, e0, e1, 0, a); break;
+      case 40: hipExtLaunchKernelGGL((k_adam_soft_t<4, 0>), dim3(blocks), dim3(256), 0, s, e0, e1, 0, a); break;
+      case 41: hipExtLaunchKernelGGL((k_adam_soft_t<4, 1>), dim3(blocks), dim3(256), 0, s, e0, e1, 0, a); break;
+      default: return 1;
+    }
+    return 0;
+  };
+  for (int i = 0; i < 3; ++i) { if (launch(nullptr, nullptr)) return 1; }
+  for (int i = 0; i < iters; ++i) {
+    if (touch_mb > 0) hipLaunchKernelGGL(k_touch, dim3(2048), dim3(256), 0, s, junk, junk4);
+    if (launch(ev[2 * i], ev[2 * i + 1])) return 1;
+  }
+  CK(hipStreamSynchronize(s));
+  double tot = 0;
+  for (int i = 0; i < iters; ++i) { float ms = 0; CK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); tot += ms; }
+  if (avg_us) *avg_us = (float)(tot * 1000.0 / iters);
+  for (auto& e : ev) hipEventDestroy(e);
+  hipFree(w); hipFree(g); hipFree(m); hipFree(v); hipFree(wt); hipFree(part); hipFree(st); if (junk) hipFree(junk);
+  hipStreamDestroy(s);
+  return 0;
+}

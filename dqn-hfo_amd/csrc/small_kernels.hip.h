@@ -656,6 +656,7 @@ struct AdamArgs {
 };
 // body shared by the stand-alone kernel and the mixed GEMM+Adam launch: block `blk` of
 // `nblk` 256-thread blocks strides over the arena slice
+template <int U = 1, int NT = 0>
 __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int nblk, float* s /*>= 8 floats*/) {
   // every block re-derives the same global L2 norm from the partials, in the
   // same order -> bit-identical scale everywhere, no extra launch
@@ -693,41 +694,61 @@ __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int n
   const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
   const bool soft = s[6] != 0.0f;
   const float tau = a.tau, omt = 1 - a.tau;
-  for (size_t i = (size_t)blk * 256 + threadIdx.x; i < a.n4; i += (size_t)nblk * 256) {
-    f32x4 g = reinterpret_cast<f32x4*>(a.g)[i];
-    f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
-    f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
-    f32x4* wq = reinterpret_cast<f32x4*>(i < a.n4_sh ? a.w_sh : a.w) + i;
-    f32x4* tq = reinterpret_cast<f32x4*>(i < a.n4_sh ? a.wt_sh : a.wt) + i;
-    f32x4 w = *wq;
-    f32x4 wt = *tq;
-    float* gp = reinterpret_cast<float*>(&g); float* mp = reinterpret_cast<float*>(&m);
-    float* vp = reinterpret_cast<float*>(&v); float* wp = reinterpret_cast<float*>(&w);
-    float* tp = reinterpret_cast<float*>(&wt);
+  // U float4 per array in flight per thread (U * 5 x 16-B loads before the first use); NT: the gradient is
+  // read exactly once per update and never again -> non-temporal
+  for (size_t i0 = (size_t)blk * (256 * U) + threadIdx.x; i0 < a.n4; i0 += (size_t)nblk * (256 * U)) {
+    f32x4 g[U], m[U], v[U], w[U], wt[U];
+    f32x4* wq[U]; f32x4* tq[U];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float gi = gp[e] * scale;
-      const float mi = fmaf(omb1, gi, a.beta1 * mp[e]);
-      const float vi = fmaf(omb2, gi * gi, a.beta2 * vp[e]);
-      const float upd = step * (mi / (sqrtf(vi) + a.eps));
-      const float wi = wp[e] - upd;
-      mp[e] = mi; vp[e] = vi; wp[e] = wi;
-      if (soft) tp[e] = fmaf(tau, wi, omt * tp[e]);
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + (size_t)u * 256;
+      if (i < a.n4) {
+        wq[u] = reinterpret_cast<f32x4*>(i < a.n4_sh ? a.w_sh : a.w) + i;
+        tq[u] = reinterpret_cast<f32x4*>(i < a.n4_sh ? a.wt_sh : a.wt) + i;
+        g[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g) + i) : reinterpret_cast<const f32x4*>(a.g)[i];
+        m[u] = reinterpret_cast<const f32x4*>(a.m)[i];
+        v[u] = reinterpret_cast<const f32x4*>(a.v)[i];
+        w[u] = *wq[u];
+        wt[u] = *tq[u];
+      }
     }
-    reinterpret_cast<f32x4*>(a.m)[i] = m;
-    reinterpret_cast<f32x4*>(a.v)[i] = v;
-    *wq = w;
-    if (soft) *tq = wt;
-    if (a.w16 != nullptr) {
-      typedef __attribute__((ext_vector_type(4))) _Float16 h16x4_t;
-      reinterpret_cast<h16x4_t*>(a.w16)[i] = h16x4_t{(_Float16)wp[0], (_Float16)wp[1], (_Float16)wp[2], (_Float16)wp[3]};
-      if (soft) reinterpret_cast<h16x4_t*>(a.wt16)[i] = h16x4_t{(_Float16)tp[0], (_Float16)tp[1], (_Float16)tp[2], (_Float16)tp[3]};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + (size_t)u * 256;
+      if (i >= a.n4) continue;
+      float* gp = reinterpret_cast<float*>(&g[u]); float* mp = reinterpret_cast<float*>(&m[u]);
+      float* vp = reinterpret_cast<float*>(&v[u]); float* wp = reinterpret_cast<float*>(&w[u]);
+      float* tp = reinterpret_cast<float*>(&wt[u]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gi = gp[e] * scale;
+        const float mi = fmaf(omb1, gi, a.beta1 * mp[e]);
+        const float vi = fmaf(omb2, gi * gi, a.beta2 * vp[e]);
+        const float upd = step * (mi / (sqrtf(vi) + a.eps));
+        const float wi = wp[e] - upd;
+        mp[e] = mi; vp[e] = vi; wp[e] = wi;
+        if (soft) tp[e] = fmaf(tau, wi, omt * tp[e]);
+      }
+      reinterpret_cast<f32x4*>(a.m)[i] = m[u];
+      reinterpret_cast<f32x4*>(a.v)[i] = v[u];
+      *wq[u] = w[u];
+      if (soft) *tq[u] = wt[u];
+      if (a.w16 != nullptr) {
+        typedef __attribute__((ext_vector_type(4))) _Float16 h16x4_t;
+        reinterpret_cast<h16x4_t*>(a.w16)[i] = h16x4_t{(_Float16)wp[0], (_Float16)wp[1], (_Float16)wp[2], (_Float16)wp[3]};
+        if (soft) reinterpret_cast<h16x4_t*>(a.wt16)[i] = h16x4_t{(_Float16)tp[0], (_Float16)tp[1], (_Float16)tp[2], (_Float16)tp[3]};
+      }
     }
   }
 }
+template <int U, int NT>
+__global__ __launch_bounds__(256) void k_adam_soft_t(AdamArgs a) {
+  __shared__ float s[8];
+  adam_soft_body<U, NT>(a, blockIdx.x, gridDim.x, s);
+}
 __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   __shared__ float s[8];
-  adam_soft_body(a, blockIdx.x, gridDim.x, s);
+  adam_soft_body<1, 0>(a, blockIdx.x, gridDim.x, s);
 }
 
 // Sum of up to 8 co-located gradient arenas in rank order, written back to all (dqnhip_reduce_gradients_local)

@@ -34,6 +34,11 @@ int dqnhip_test_gemm(int32_t mode, int32_t variant, int32_t rows, int32_t n_out,
 int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t N, int32_t K, int32_t iters,
                       float* avg_us, float* max_abs_err, float* max_ref);
 
+/* Times the fused clip+Adam+soft-update pass on n_params random parameters (see gemm_bench.hip).
+ * variant = 10*U + NT (U in {1,2,4} float4 per array in flight per thread, NT = non-temporal
+ * gradient loads); touch_mb = MB of unrelated traffic between two passes (0: back to back). */
+int dqnhip_test_adam(int64_t n_params, int32_t variant, int32_t blocks, int32_t iters, int32_t touch_mb, float* avg_us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,18 +1,42 @@
-// Drives the C++ `dqn::DQN` adaptor the way src/dqn_main.cpp drives the reference class
-// (PlayOneEpisode :97-153 + the update burst :357-363), with a synthetic environment.
-// Built by tests/test_cpp_adaptor.py with g++ against libdqnhip.so; run only on the GPU box.
+// Drives include/dqn.hpp's `dqn::DQN` (+ dqn-hfo_amd/csrc/dqn_dropin.cpp) the way src/dqn_main.cpp drives
+// the reference class (solver parameters :221-262, PlayOneEpisode :97-153, the update burst :357-363,
+// resume :213-220 + 268-286, sharing :305-323), with a synthetic environment and a narrower tower taken
+// from an edited prototxt.  Built by tests/test_cpp_adaptor.py with g++ against libdqnhip.so and
+// include/shim/ (no reference sources involved); run only on the GPU box.
 #include <cmath>
 #include <cstdio>
 
-#include "../../dqn-hfo_amd/csrc/dqn_adaptor.hpp"
+#include <gflags/gflags.h>
 
-int main() {
-  dqn::Flags flags;
-  flags.seed = 7; flags.memory = 5000; flags.memory_threshold = 100; flags.hidden = {128, 64, 64, 64};
-  dqn::SolverParams actor_sp, critic_sp;
-  actor_sp.base_lr = 1e-5f;
+#include "dqn.hpp"
+
+using namespace hfo;
+
+// a subclass reaches the protected update, as a white-box test of the reference would
+struct TestDQN : dqn::DQN {
+  using dqn::DQN::DQN;
+  std::pair<float, float> Step() { return UpdateActorCritic(); }
+  std::vector<dqn::InputStates> States(int n) { return SampleStatesFromMemory(n); }
+};
+
+int main(int argc, char** argv) {
+  gflags::ParseCommandLineFlags(&argc, &argv, true);     // the learner flags are defined by dqn_dropin.cpp
+  caffe::Caffe::set_mode(caffe::Caffe::GPU);
   const int num_features = 59;                      // NumStateFeatures(1), src/hfo_game.hpp:13-16
-  dqn::DQN dqn(actor_sp, critic_sp, "/tmp/dqnhip_adaptor_smoke_run_agent0", num_features, 0, flags);
+  caffe::SolverParameter actor_sp, critic_sp;
+  // tower 128-64-64-64: what a user gets by editing <save>_actor.prototxt / _critic.prototxt
+  const int widths[4] = {128, 64, 64, 64};
+  caffe::NetParameter an = dqn::CreateActorNet(num_features), cn = dqn::CreateCriticNet(num_features);
+  for (caffe::NetParameter* np : {&an, &cn})
+    for (int i = 0, k = 0; i < np->layer_size(); ++i)
+      if (np->layer(i).type() == "InnerProduct" && np->layer(i).name().rfind("ip", 0) == 0)
+        np->mutable_layer(i)->mutable_inner_product_param()->set_num_output(widths[k++]);
+  actor_sp.mutable_net_param()->CopyFrom(an); critic_sp.mutable_net_param()->CopyFrom(cn);
+  for (caffe::SolverParameter* sp : {&actor_sp, &critic_sp}) {
+    sp->set_type("Adam"); sp->set_momentum(.95f); sp->set_momentum2(.999f); sp->set_clip_gradients(10); sp->set_lr_policy("fixed");
+  }
+  actor_sp.set_base_lr(1e-5f); critic_sp.set_base_lr(1e-3f);
+  TestDQN dqn(actor_sp, critic_sp, "/tmp/dqnhip_adaptor_smoke_run_agent0", num_features, 0);
   std::mt19937 env(1);
   std::uniform_real_distribution<float> U(-1.f, 1.f);
   int total_steps = 0;
@@ -30,7 +54,7 @@ int main() {
       for (auto& v : *next) v = U(env);
       const float reward = 0.1f * U(env);
       if (t + 1 < len) ep.emplace_back(in, ao, reward, 0.f, next);
-      else ep.emplace_back(in, ao, reward + 5.f, 0.f, std::nullopt);
+      else ep.emplace_back(in, ao, reward + 5.f, 0.f, boost::none);
       state = next;
     }
     dqn.LabelTransitions(ep);
@@ -49,14 +73,14 @@ int main() {
   dqn::FindLatestSnapshot(prefix, a_snap, c_snap, m_snap);
   if (a_snap.empty() || c_snap.empty() || m_snap.empty()) { std::fprintf(stderr, "FindLatestSnapshot found nothing\n"); return 5; }
   {
-    dqn::DQN resumed(actor_sp, critic_sp, prefix, num_features, 0, flags);
+    dqn::DQN resumed(actor_sp, critic_sp, prefix, num_features, 0);
     resumed.RestoreActorSolver(a_snap); resumed.RestoreCriticSolver(c_snap); resumed.LoadReplayMemory(m_snap);
     if (resumed.actor_iter() != dqn.actor_iter() || resumed.memory_size() != dqn.memory_size()) return 6;
     resumed.Update();
   }
   {
     // a teammate sharing the first layers and the replay memory (src/dqn_main.cpp:305-323)
-    dqn::DQN mate(actor_sp, critic_sp, prefix + "_mate", num_features, 1, flags);
+    dqn::DQN mate(actor_sp, critic_sp, prefix + "_mate", num_features, 1);
     dqn.ShareParameters(mate, 2, 1);
     dqn.ShareReplayMemory(mate);
     if (mate.memory_size() != dqn.memory_size()) return 8;
@@ -68,8 +92,10 @@ int main() {
   dqn::RemoveFilesMatchingRegexp(prefix + "_.*");
   Action sampled = dqn.SampleAction(dqn.GetRandomActorOutput());
   if (sampled.action == TACKLE) return 7;
-  auto res = dqn.UpdateActorCritic();
+  auto res = dqn.Step();
   if (!std::isfinite(res.first) || !std::isfinite(res.second)) return 4;
+  if (dqn.States(5).size() != 5 || (int)dqn.States(3)[2][0]->size() != num_features) return 10;
+  if (dqn::FilesMatchingRegexp("/tmp/dqnhip_adaptor_smoke_agent0_.*").size() != 0) return 11;
   std::printf("adaptor smoke OK: %d transitions, %d updates, loss %g avg_q %g\n", dqn.memory_size(), dqn.actor_iter(), res.first, res.second);
   return 0;
 }
