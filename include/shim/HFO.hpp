@@ -74,7 +74,7 @@ class HFOEnvironment {
     draw_state();
     std::uniform_real_distribution<double> U(0.0, 1.0);
     if (t_ >= frames_) status_ = OUT_OF_TIME;
-    else if (U(rng_) < p_end_) {
+    else if (t_ >= 2 && U(rng_) < p_end_) {             // never on the first step: src/dqn_main.cpp:106 CHECKs that
       const double u = U(rng_);
       status_ = u < p_goal_ ? GOAL : (u < p_goal_ + (1 - p_goal_) / 2 ? OUT_OF_BOUNDS : CAPTURED_BY_DEFENSE);
     }
