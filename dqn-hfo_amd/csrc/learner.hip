@@ -149,6 +149,7 @@ struct dqnhip_learner {
   float* loss_partial = nullptr; double* q_partial = nullptr; int n_head_blocks = 0;
   float* part[2] = {nullptr, nullptr};  // GEMM-epilogue sumsq partials per net
   float* part_dp = nullptr; int n_part_dp = 0;
+  int* tick_ticket = nullptr;                                // arrival counter of the update's last launch (k_adam_soft + tick)
   float* head_slab = nullptr; int* head_ticket = nullptr;   // k_head_bwd cross-block reduction
   float* head_slab2 = nullptr;                               // k_head_bwd_big row-chunk slabs (minibatch >= 1024)
   // mixed precision (cfg.precision == DQNHIP_FP16): fp16 copies of the tower weights in both
@@ -454,13 +455,15 @@ int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
   const int rows_c = (a.rows + RC - 1) / RC;
   const size_t lds = ((size_t)rows_c * NH + 16 * NH * 64 + 16) * sizeof(float);
   a.slab = h->head_slab; a.ticket = h->head_ticket;
-  hipLaunchKernelGGL((k_head_bwd<NH>), dim3(a.H / 64, RC), dim3(1024), lds, st, a);
+  int ry = 0;                                               // extra grid rows for the q rider (16 rows per block)
+  if (a.q_out != nullptr) { a.rc_blocks = RC; ry = ((a.rows + 15) / 16 + a.H / 64 - 1) / (a.H / 64); }
+  hipLaunchKernelGGL((k_head_bwd<NH>), dim3(a.H / 64, RC + ry), dim3(1024), lds, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 // clip + Adam + Net::Update + soft target update over arena floats [begin, end)
-int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end) {
+int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick = nullptr) {
   AdamArgs a{};
   a.w = h->w[net] + begin; a.g = h->g[net] + begin; a.m = h->m[net] + begin; a.v = h->v[net] + begin;
   a.wt = h->w[net + 2] + begin;
@@ -475,6 +478,7 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   a.beta1 = h->cfg.momentum; a.beta2 = h->cfg.momentum2; a.eps = h->cfg.delta;
   a.clip = h->cfg.clip_gradients; a.tau = (float)h->cfg.tau;
   a.soft_update_freq = h->cfg.soft_update_freq; a.which = net; a.st = h->st;
+  if (tick) { a.tick_ticket = h->tick_ticket; a.tick = *tick; }
   static const int kAdamCap = getenv("DQNHIP_ADAM_BLOCKS") ? atoi(getenv("DQNHIP_ADAM_BLOCKS")) : 2048;
   int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)kAdamCap);
   ScopedTiming t(h, 3, st);
@@ -707,14 +711,11 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     return 0;
   }
   if (phase == 2) {
+    const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
+                        dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world)};
     RC(sumsq_launch(h, 0));
-    RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena));
+    RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena, &tick));   // + iteration counters / statistics (k_tick's work)
     RC(sync_w16(h, st, DQNHIP_ACTOR, true));
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(256), 0, st, h->st, critic_tail, actor_tail,
-                       (const float*)h->loss_partial, h->n_head_blocks,
-                       dp ? (const double*)nullptr : (const double*)h->q_partial, B,
-                       (float)(B * h->cfg.dp_world));
-    HIPCHK(hipGetLastError());
     h->h_actor_iter += 1; h->h_critic_iter += 1;
     return 0;
   }
@@ -836,17 +837,19 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       RC(adam_launch(h, st, 1, part, n_part, 0, lc.arena));
       RC(tower_forward(h, st, &pC2, 1, B));
     }
-    {
+    // q(s, mu(s)) with the updated critic [:913-916] and, in the same launch, the seed of
+    // BackwardFrom(q_values_layer): q diff = -1 per row, input gradient only (the reference's
+    // discarded critic dW, SURVEY a11, is never computed).  The seed does not depend on q.
+    if (head_big_ok(h, B, Hc)) {
       HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
       a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.b = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q = h->q2;
       a.qsum_partial = h->q_partial;
       RC((head_forward<1, HEAD_Q_POLICY>(h, st, a)));
     }
-    // q diff = -1 per row, BackwardFrom(q_values_layer) — input gradient only; the
-    // reference's discarded critic dW is never computed
     {
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
+      if (!head_big_ok(h, B, Hc)) { a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial; }
       RC(head_backward<1>(h, st, a));
     }
     RC(tower_backward(h, st, lc, DQNHIP_CRITIC, nullptr, nullptr, h->act[4], h->dZc, B, false, true, h->S, h->S + kNO));
@@ -867,13 +870,12 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     return 0;
   }
   if (phase == 2) {
-    if (dp) { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena)); }
-    else RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena));
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(256), 0, st, h->st, critic_tail, actor_tail,
-                       (const float*)h->loss_partial, h->n_head_blocks,
-                       dp ? (const double*)nullptr : (const double*)h->q_partial, B,
-                       (float)(B * h->cfg.dp_world));
-    HIPCHK(hipGetLastError());
+    // the actor's optimiser pass is the update's last launch: its last-arriving block also publishes
+    // (critic_loss, avg_q) and advances the iteration / sampling counters (what k_tick did in its own launch)
+    const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
+                        dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world)};
+    if (dp) { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena, &tick)); }
+    else RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick));
     h->h_actor_iter += 1; h->h_critic_iter += 1;
     return 0;
   }
@@ -1050,6 +1052,7 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
     const int Hmax = std::max(h->la.dims[L], h->lc.dims[L]);
     RC(dalloc(&h->head_slab, (size_t)64 * (Hmax / 64) * kNO * 64 + 64 * 16));
     if (B >= 1024 && B % 64 == 0) RC(dalloc(&h->head_slab2, (size_t)(B / 64) * kNO * Hmax + (size_t)(B / 64) * 16));
+    HIPCHK(hipMalloc(&h->tick_ticket, sizeof(int))); HIPCHK(hipMemsetAsync(h->tick_ticket, 0, sizeof(int), h->stream));
     HIPCHK(hipMalloc(&h->head_ticket, (Hmax / 64) * sizeof(int)));
     HIPCHK(hipMemsetAsync(h->head_ticket, 0, (Hmax / 64) * sizeof(int), h->stream));
   }
@@ -1153,7 +1156,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   hipHostFree(h->idx_pinned); hipHostFree(h->pinned_stats);
   hipFree(h->aout_t16); hipFree(h->aout16); hipFree(h->dA16);
   hipFree(h->q_t); hipFree(h->q1); hipFree(h->q2); hipFree(h->y); hipFree(h->dq);
-  hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp); hipFree(h->head_slab); hipFree(h->head_ticket); if (h->head_slab2) hipFree(h->head_slab2);
+  hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp); hipFree(h->head_slab); hipFree(h->head_ticket); hipFree(h->tick_ticket); if (h->head_slab2) hipFree(h->head_slab2);
   for (void* p : h->allocs16) hipFree(p);
   if (h->stage_dev) hipFree(h->stage_dev);
   if (h->act_buf) hipFree(h->act_buf);

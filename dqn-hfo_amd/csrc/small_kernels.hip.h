@@ -376,8 +376,13 @@ struct HeadBwdArgs {
   float* dA16;                         // actor: post-invert head diffs (debug / parity)
   const float* W; const float* X4; int H; int rows;
   float* dZ; float* dW; float* db; float* partial;
-  float* slab;                         // [gridDim.y][H/64][NH][64] per-row-chunk partial dW
+  float* slab;                         // [RC][H/64][NH][64] per-row-chunk partial dW
   int* ticket;                         // [H/64] arrival counters, zero before and after every launch
+  // rider (NH == 1, dq = -1 pass): the y-rows >= rc_blocks of the grid compute q = head(X4) + avg-Q partials
+  // — the critic(s, mu(s)) head forward (src/dqn.cpp:913-916).  The -1 seed does not depend on q, so the
+  // two used to be separate dependent launches for no reason.
+  int rc_blocks;                       // row chunks of the backward part (0: gridDim.y)
+  const float* q_bias; float* q_out; double* qsum_partial;
 };
 // Grid = (H/64 column blocks) x (RC row chunks); block = 64 columns x 16 row groups.  Each block
 // writes its dZ rows directly and a partial dW slab; the LAST block to arrive for a column block
@@ -386,7 +391,22 @@ struct HeadBwdArgs {
 template <int NH>
 __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int RC = gridDim.y, rc = blockIdx.y, nkb = gridDim.x;
+  const int RC = a.rc_blocks > 0 ? a.rc_blocks : gridDim.y, rc = blockIdx.y, nkb = gridDim.x;
+  if (NH == 1 && rc >= RC) {                           // rider blocks: one wave per row, k-strips of float4
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = (((int)blockIdx.y - RC) * (int)gridDim.x + (int)blockIdx.x) * 16 + wave;
+    if (row >= a.rows) return;
+    const float* x = a.X4 + (size_t)row * a.H;
+    float acc = 0.0f;
+    for (int k = lane * 4; k < a.H; k += 256) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k), wv = *reinterpret_cast<const f32x4*>(a.W + k);
+      acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) { const float v = acc + a.q_bias[0]; a.q_out[row] = v; a.qsum_partial[row] = (double)v; }
+    return;
+  }
   const int rows_c = (a.rows + RC - 1) / RC;           // rows of this chunk
   const int r0 = rc * rows_c, r1 = min(a.rows, r0 + rows_c);
   float* s_dy = sm;                                    // [rows_c][NH]
@@ -643,6 +663,10 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, size
 // (Caffe sgd_solver.cpp/adam_solver.cpp @2ef5847; src/dqn.cpp:
 // 904, 964, 967-970, 1085-1096).  36 B/param of HBM traffic instead of Caffe's
 // ~7 separate param-sized passes plus the separate soft-update pass.
+struct TickArgs {
+  DevState* st; float* critic_tail; float* actor_tail;
+  const float* loss_partial; int n_loss; const double* q_partial; int n_q; float batch;
+};
 struct AdamArgs {
   float* w; float* g; float* m; float* v; float* wt;
   _Float16* w16; _Float16* wt16;             // fp16 mode: fp16 mirrors of w / wt, same offsets (null otherwise)
@@ -653,6 +677,11 @@ struct AdamArgs {
   int soft_update_freq;
   int which;                      // 0 actor, 1 critic (selects the iter counter)
   DevState* st;
+  // the update's last launch also does k_tick's work: the block that finishes last (arrival
+  // ticket; no fence needed — it consumes nothing the other blocks of THIS launch produced, and
+  // by then every block has read the iteration counters it is about to advance) runs tick_body
+  int* tick_ticket;               // null: no tick duty
+  TickArgs tick;
 };
 // body shared by the stand-alone kernel and the mixed GEMM+Adam launch: block `blk` of
 // `nblk` 256-thread blocks strides over the arena slice
@@ -746,9 +775,21 @@ __global__ __launch_bounds__(256) void k_adam_soft_t(AdamArgs a) {
   __shared__ float s[8];
   adam_soft_body<U, NT>(a, blockIdx.x, gridDim.x, s);
 }
+__device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot, double* sq);   // below
 __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   __shared__ float s[8];
+  __shared__ double sq[4];
+  __shared__ int s_last;
   adam_soft_body<1, 0>(a, blockIdx.x, gridDim.x, s);
+  if (a.tick_ticket == nullptr) return;
+  __syncthreads();                                       // this block's last reads of DevState are done
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(a.tick_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (int)gridDim.x - 1);
+    if (s_last) *a.tick_ticket = 0;                      // re-arm for the next launch
+  }
+  __syncthreads();
+  if (s_last) tick_body(a.tick, s, sq);
 }
 
 // Sum of up to 8 co-located gradient arenas in rank order, written back to all (dqnhip_reduce_gradients_local)
@@ -793,17 +834,14 @@ __global__ __launch_bounds__(256) void k_tails(const float* loss_partial, int n_
 // avg_q = std::accumulate(q, 0.0) / float(B) (src/dqn.cpp:915-916): the double sum
 // is taken from the per-block double partials when they are local (single GPU),
 // from the all-reduced float tail under data parallelism.
-__global__ __launch_bounds__(256) void k_tick(DevState* st, float* critic_tail, float* actor_tail, const float* loss_partial,
-                                              int n_loss, const double* q_partial, int n_q, float batch) {
-  // one block: strided partial sums, fixed butterfly + fixed cross-wave order -> deterministic
-  __shared__ float sdot[4];
-  __shared__ double sq[4];
+// One block of 256 threads: strided partial sums, fixed butterfly + fixed cross-wave order.
+__device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot /*[4]*/, double* sq /*[4]*/) {
   const int t = threadIdx.x;
   double qs = 0.0;
-  if (q_partial != nullptr) {          // single GPU: reduce the per-block partials here
+  if (a.q_partial != nullptr) {          // single GPU: reduce the per-block partials here
     float dot = 0.0f;
-    for (int i = t; i < n_loss; i += 256) dot += loss_partial[i];
-    for (int i = t; i < n_q; i += 256) qs += q_partial[i];
+    for (int i = t; i < a.n_loss; i += 256) dot += a.loss_partial[i];
+    for (int i = t; i < a.n_q; i += 256) qs += a.q_partial[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { dot += __shfl_xor(dot, off, 64); qs += __shfl_xor(qs, off, 64); }
     if ((t & 63) == 0) { sdot[t >> 6] = dot; sq[t >> 6] = qs; }
@@ -811,13 +849,18 @@ __global__ __launch_bounds__(256) void k_tick(DevState* st, float* critic_tail, 
     if (t == 0) {
       dot = (sdot[0] + sdot[1]) + (sdot[2] + sdot[3]);
       qs = (sq[0] + sq[1]) + (sq[2] + sq[3]);
-      critic_tail[0] = dot / batch / 2.0f; actor_tail[1] = (float)qs;     // EuclideanLoss: dot / num / 2
+      a.critic_tail[0] = dot / a.batch / 2.0f; a.actor_tail[1] = (float)qs;     // EuclideanLoss: dot / num / 2
     }
-  } else qs = (double)actor_tail[1];   // data parallel: tails were all-reduced
+  } else qs = (double)a.actor_tail[1];   // data parallel: tails were all-reduced
   if (t != 0) return;
-  st->critic_loss = critic_tail[0];
-  st->avg_q = (float)(qs / (double)batch);
-  st->actor_iter += 1; st->critic_iter += 1; st->update_counter += 1;
+  a.st->critic_loss = a.critic_tail[0];
+  a.st->avg_q = (float)(qs / (double)a.batch);
+  a.st->actor_iter += 1; a.st->critic_iter += 1; a.st->update_counter += 1;
+}
+__global__ __launch_bounds__(256) void k_tick(TickArgs a) {
+  __shared__ float sdot[4];
+  __shared__ double sq[4];
+  tick_body(a, sdot, sq);
 }
 
 // ---- acting-time helpers ---------------------------------------------------------
