@@ -85,16 +85,21 @@ KERNEL_NAMES = {"hgemm_fwd": "hgemm_nt<2,2>/<1,1> (forward epilogue)", "hgemm_dg
                 "gemm_dgrad": "gemm_dgrad_lds<1,1>", "gemm_wgrad": "gemm_wgrad_direct<1,1>"}
 
 
+PMC_SUMMARY = "profiles/r02_pmc_summary.json"
+
+
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/): separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE is doubled as MI355X_MICROARCH.md
-    §HBM prescribes for wide coalesced reads on gfx950.  None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    """HBM-side bytes per launch of `kernel`.  PMC counters cannot be read from inside this process
+    (rocprofv3 wraps the command), so the figure comes from the committed PMC passes of the SAME
+    kernels (scripts/pmc_fetch.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    bench.py; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads on
+    gfx950) and is labelled with its source.  (None, None) if that kernel is not in the file."""
     try:
-        d = json.load(open(path))["kernels"][kernel]
-        return int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
+        j = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
+        d = j["kernels"][kernel.replace(" ", "")]
+        return int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024), "%s (%s)" % (PMC_SUMMARY, j.get("kernels_version", "kernel version not recorded"))
     except Exception:
-        return None
+        return None, None
 
 
 def prefill(dqn, n, seed, chunk=131072):
@@ -159,6 +164,73 @@ def cpu_baseline(budget_s=12.0):
                     "affinity capped by the cgroup quota"}
 
 
+def timed(step, sync, n, warm):
+    for _ in range(warm):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    sync()
+    return (time.perf_counter() - t0) / n
+
+
+def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
+    """Per-config records next to the headline (BASELINE.json configs[2] and [4]; strong scaling when N > 1).
+    Small replay memories: these time kernels, not prefill."""
+    import torch
+    out = {}
+    GB, n_it = 4096, 100
+    if world == 1:
+        # configs[4] on ONE GPU: minibatch 4096, fp16 MFMA operands / fp32 accumulate, 4x1024
+        for prec in ("fp16", "fp32"):
+            d = pkg.DQN(S, minibatch=GB, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, use_graph=True, precision=prec)
+            prefill(d, 150000, seed=7)
+            dt = timed(lambda: d.update_async(None), torch.cuda.synchronize, n_it, 20)
+            fl = sum((family_flops16 if prec == "fp16" else family_flops)(GB, S, HIDDEN).values())
+            peak = MFMA_F16_PEAK_TF if prec == "fp16" else MFMA_F32_PEAK_TF
+            out["configs4_1gpu_b4096_%s" % prec] = {"ms_per_update": round(dt * 1e3, 4), "updates_per_s": round(1 / dt, 1),
+                                                    "samples_per_s": round(GB / dt), "update_mfma_frac": round(fl / dt / 1e12 / peak, 4)}
+            d.read_stats(); d.close()
+        # configs[2]: 1v1 (S = 68), 64 parallel workers feeding one replay buffer
+        d = pkg.DQN(68, minibatch=B, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, use_graph=True)
+        env = pkg.EnvFrontEnd(d, 64, max_steps=500, p_end=0.01, seed=5)
+        env.step(0.1, 20); env.stats()
+        t1 = time.perf_counter(); env.step(0.1, 200); env.stats(); dt = (time.perf_counter() - t1) / 200
+        out["configs2_64workers_s68"] = {"env_steps_per_s": round(64 / dt, 1), "us_per_batched_step": round(dt * 1e6, 2)}
+        env.close(); d.close()
+        return out
+    if not native:
+        return None
+    # N > 1: STRONG scaling of a global minibatch of 4096 (SURVEY 8e: where the batch warrants DP)
+    for prec in ("fp32", "fp16"):
+        rows = GB // world
+        if rows % (128 if prec == "fp16" else 32):
+            continue
+        d, dp = par.make_native_data_parallel(pkg, S, rank, world, local_rank, minibatch=rows, hidden=HIDDEN, memory=200000,
+                                              seed=1, precision=prec, per_layer=args.dp_per_layer)
+        prefill(d, 150000, seed=7 + rank)
+        t_dp = timed(lambda: dp.update(None), barrier, n_it, 20)
+
+        def local_only():                 # the same kernels without the two collectives (timing only)
+            d.update_phase(0); d.update_phase(1); d.update_phase(2)
+        t_loc = timed(local_only, barrier, n_it, 10)
+        d.close()
+        t_one = None
+        if rank == 0:                     # the single-GPU reference for the speed-up: whole global minibatch on rank 0
+            one = pkg.DQN(S, minibatch=GB, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, use_graph=True, precision=prec)
+            prefill(one, 150000, seed=7)
+            t_one = timed(lambda: one.update_async(None), torch.cuda.synchronize, n_it, 20)
+            one.close()
+        barrier()
+        if rank == 0:
+            out["strong_b4096_%s" % prec] = {"n_gpus": world, "rows_per_gpu": rows, "ms_per_update": round(t_dp * 1e3, 4),
+                                             "ms_per_update_without_collectives": round(t_loc * 1e3, 4),
+                                             "allreduce_us_per_update": round((t_dp - t_loc) * 1e6, 1),
+                                             "ms_per_update_1gpu": round(t_one * 1e3, 4), "speedup_vs_1gpu": round(t_one / t_dp, 3)}
+    return out if rank == 0 else None
+
+
 def main():
     global B
     ap = argparse.ArgumentParser()
@@ -180,6 +252,8 @@ def main():
                     help="torch.distributed backend (nccl = RCCL; gloo only for the 2-ranks-on-one-GPU flow test)")
     ap.add_argument("--share-device0", action="store_true",
                     help="testing: every rank uses GPU 0 (needs --backend gloo; RCCL refuses duplicate devices)")
+    ap.add_argument("--dp-per-layer", action="store_true", help="native DP: bucket each all-reduce per tower layer on a communication stream")
+    ap.add_argument("--no-subrecords", action="store_true", help="skip the per-config sub-records (configs #3, #5; strong scaling under N > 1)")
     ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],
                     help="N>1: dp = gradient all-reduce (weak scaling), replicas = independent learners")
     args = ap.parse_args()
@@ -211,11 +285,17 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     use_dp = dist_on and args.mode == "dp"
+    native = use_dp and args.backend == "nccl"     # RCCL inside libdqnhip.so; gloo: torch.distributed between the phases
+    par = None
     if use_dp:
         from importlib import import_module
         par = import_module("dqn_hfo_amd.parallel")
-        dqn, dp = par.make_hip_data_parallel(pkg, S, rank, world, local_rank, minibatch=B, hidden=HIDDEN,
-                                             memory=args.replay, seed=1 + rank, precision=args.precision)
+        # ONE seed for the whole group: identical initialisation (rank 0's state is broadcast anyway), the
+        # per-shard sample streams are decorrelated by dp_rank inside the library
+        make = par.make_native_data_parallel if native else par.make_hip_data_parallel
+        kw = dict(per_layer=args.dp_per_layer) if native else {}
+        dqn, dp = make(pkg, S, rank, world, local_rank, minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1,
+                       precision=args.precision, **kw)
         step = lambda: dp.update(None)
     else:
         dqn = pkg.DQN(S, minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1 + rank, device=local_rank,
@@ -270,7 +350,8 @@ def main():
         flops_per_launch = fam_flops[dom] / per_update_launches
         ach = flops_per_launch / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(KERNEL_NAMES[dom]),
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(KERNEL_NAMES[dom])[0],
+                "traffic_source": pmc_traffic(KERNEL_NAMES[dom])[1],
                 "avg_launch_us": round(ms * 1e3, 2), "launches_per_update": per_update_launches,
                 "flops_per_launch": flops_per_launch,
                 "families_us": {f: [round(stats[f][0] * 1e3, 2), stats[f][1] / n_t] for f in stats}}
@@ -310,6 +391,10 @@ def main():
             env_res["cpu_port_workers_64"] = {"env_steps_per_s": round(64 * 10 / dt, 1), "cores": c_oracle.usable_cores()}
             oenv.close(); orc.close()
 
+    sub = None
+    if not args.no_subrecords and not args.strong and args.precision == "fp32" and B == 256:
+        sub = sub_records(pkg, par, args, rank, world, local_rank, native, barrier)
+
     if rank == 0:
         ups = args.steps / elapsed
         value = ups if args.strong else ups * (world if world > 1 else 1)
@@ -326,7 +411,7 @@ def main():
                                    % (B, args.replay),
                        "minibatch_per_gpu": B, "global_minibatch": B * (world if use_dp else 1),
                        "parallelism": ("dp%d (%s all-reduce of critic then actor gradients); value counts %s"
-                                       % (world, "RCCL" if args.backend == "nccl" else args.backend,
+                                       % (world, "RCCL inside libdqnhip.so (dqnhip_dp_update)" if native else args.backend + " via torch.distributed",
                                           "global-minibatch updates" if args.strong else "minibatch-%d updates" % B)) if use_dp else
                                       ("replicas x%d" % world if world > 1 else "single"),
                        "hip_graph": (not args.no_graph) and not use_dp,
@@ -336,6 +421,7 @@ def main():
             "last_critic_loss": loss, "last_avg_q": avgq,
             "roofline": roof,
             "env_steps": env_res,
+            "sub_records": sub,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

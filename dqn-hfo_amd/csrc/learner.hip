@@ -478,7 +478,8 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   a.beta1 = h->cfg.momentum; a.beta2 = h->cfg.momentum2; a.eps = h->cfg.delta;
   a.clip = h->cfg.clip_gradients; a.tau = (float)h->cfg.tau;
   a.soft_update_freq = h->cfg.soft_update_freq; a.which = net; a.st = h->st;
-  if (tick) { a.tick_ticket = h->tick_ticket; a.tick = *tick; }
+  static const bool kTickInAdam = !getenv("DQNHIP_SEPARATE_TICK");
+  if (tick && kTickInAdam) { a.tick_ticket = h->tick_ticket; a.tick = *tick; }
   static const int kAdamCap = getenv("DQNHIP_ADAM_BLOCKS") ? atoi(getenv("DQNHIP_ADAM_BLOCKS")) : 2048;
   int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)kAdamCap);
   ScopedTiming t(h, 3, st);
@@ -486,6 +487,10 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
   else hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
+  if (tick && !kTickInAdam) {
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(256), 0, st, *tick);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 
@@ -840,7 +845,9 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // q(s, mu(s)) with the updated critic [:913-916] and, in the same launch, the seed of
     // BackwardFrom(q_values_layer): q diff = -1 per row, input gradient only (the reference's
     // discarded critic dW, SURVEY a11, is never computed).  The seed does not depend on q.
-    if (head_big_ok(h, B, Hc)) {
+    static const bool kQRider = !getenv("DQNHIP_SEPARATE_QHEAD");
+    const bool q_sep = head_big_ok(h, B, Hc) || !kQRider;
+    if (q_sep) {
       HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
       a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.b = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q = h->q2;
       a.qsum_partial = h->q_partial;
@@ -849,7 +856,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     {
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
-      if (!head_big_ok(h, B, Hc)) { a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial; }
+      if (!q_sep) { a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial; }
       RC(head_backward<1>(h, st, a));
     }
     RC(tower_backward(h, st, lc, DQNHIP_CRITIC, nullptr, nullptr, h->act[4], h->dZc, B, false, true, h->S, h->S + kNO));
@@ -1052,7 +1059,7 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
     const int Hmax = std::max(h->la.dims[L], h->lc.dims[L]);
     RC(dalloc(&h->head_slab, (size_t)64 * (Hmax / 64) * kNO * 64 + 64 * 16));
     if (B >= 1024 && B % 64 == 0) RC(dalloc(&h->head_slab2, (size_t)(B / 64) * kNO * Hmax + (size_t)(B / 64) * 16));
-    HIPCHK(hipMalloc(&h->tick_ticket, sizeof(int))); HIPCHK(hipMemsetAsync(h->tick_ticket, 0, sizeof(int), h->stream));
+    HIPCHK(hipMalloc(&h->tick_ticket, 17 * 32 * sizeof(int))); HIPCHK(hipMemsetAsync(h->tick_ticket, 0, 17 * 32 * sizeof(int), h->stream));
     HIPCHK(hipMalloc(&h->head_ticket, (Hmax / 64) * sizeof(int)));
     HIPCHK(hipMemsetAsync(h->head_ticket, 0, (Hmax / 64) * sizeof(int), h->stream));
   }

@@ -783,10 +783,21 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   adam_soft_body<1, 0>(a, blockIdx.x, gridDim.x, s);
   if (a.tick_ticket == nullptr) return;
   __syncthreads();                                       // this block's last reads of DevState are done
+  // Two-level arrival count: atomics on ONE word serialise at ~12 ns each (2048 blocks = 25 us,
+  // measured); 16 sub-counters on separate 128-B lines, then one top counter: <= 128 + 16 in a row.
   if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(a.tick_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (int)gridDim.x - 1);
-    if (s_last) *a.tick_ticket = 0;                      // re-arm for the next launch
+    constexpr int kSub = 16;
+    const int G = (int)gridDim.x, sub = (int)blockIdx.x % kSub;
+    const int expect = (G + kSub - 1 - sub) / kSub;      // blocks with blockIdx % kSub == sub
+    int* c = a.tick_ticket + sub * 32;
+    int last = 0;
+    if (__hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1) {
+      *c = 0;                                            // re-arm for the next launch
+      int* top = a.tick_ticket + kSub * 32;
+      const int groups = G < kSub ? G : kSub;
+      if (__hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) { *top = 0; last = 1; }
+    }
+    s_last = last;
   }
   __syncthreads();
   if (s_last) tick_body(a.tick, s, sq);
