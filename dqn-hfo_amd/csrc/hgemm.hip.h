@@ -53,6 +53,11 @@ struct HGemm {
   float scale32;               // the fp32 output is multiplied by this (loss-scale removal)
 };
 
+// Up to two independent problems of the same tile configuration in one launch (the two actors' /
+// the two critics' same-depth layers, or a layer's dgrad + wgrad at small minibatches): blocks
+// [0, tiles0) work on g[0], the rest on g[1].
+struct HGemmBatch { HGemm g[2]; int n; int tiles0; };
+
 __device__ __forceinline__ int hg_tile_of_block(int bid, int total) {
   // XCD x (= bid % 8) gets a contiguous run of row-major tiles: they share A row panels and
   // sweep all of B, so each XCD's L2 holds its A panels + B once (bijective for any total)
@@ -85,15 +90,18 @@ template <int N> __device__ __forceinline__ void hg_wait_vm() { asm volatile("s_
 #define HG_PIN() __builtin_amdgcn_sched_barrier(0)
 
 template <int WM, int WN>
-__global__ __launch_bounds__(256, 1) void hgemm_nt(HGemm g) {
+__global__ __launch_bounds__(256, 1) void hgemm_nt(HGemmBatch batch) {
   using Cfg = HGCfg<WM, WN>;
+  const int sel = (batch.n > 1 && (int)blockIdx.x >= batch.tiles0) ? 1 : 0;      // wave-uniform
+  const HGemm& g = batch.g[sel];
+  const int bid = (int)blockIdx.x - sel * batch.tiles0;
   constexpr int WK = Cfg::WK, BM = Cfg::BM, BN = Cfg::BN, STAGES = Cfg::STAGES, TLD = Cfg::TLD;
   constexpr int NSUB = Cfg::NSUB, LOADS = Cfg::LOADS, KSTEP = Cfg::KSTEP;
   extern __shared__ __attribute__((aligned(1024))) unsigned char hg_smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (WK == 1) ? (w >> 1) : 0, wn = (WK == 1) ? (w & 1) : 0;
   const int tiles_n = g.N / BN, tiles_m = g.M / BM;
-  const int T = hg_tile_of_block(blockIdx.x, tiles_m * tiles_n);
+  const int T = hg_tile_of_block(bid, tiles_m * tiles_n);
   const int m0 = (T / tiles_n) * BM, n0 = (T % tiles_n) * BN;
   const int nk = g.K / KSTEP;
 
@@ -301,23 +309,37 @@ inline hipError_t hgemm_prepare() {
 }
 
 // picks the tile: 128x128 when that fills the chip, else 64x64 with in-workgroup split-K
-inline hipError_t hgemm_launch(const HGemm& g, hipStream_t st, int force = 0, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-  const bool big_ok = (g.M % 128 == 0) && (g.N % 128 == 0);
-  const long tiles_big = big_ok ? (long)(g.M / 128) * (g.N / 128) : 0;
-  const bool big = force == 1 || (force == 0 && tiles_big >= 192);
-  if (g.K % 64 || g.K < 64) return hipErrorInvalidValue;
+inline bool hgemm_big_ok(const HGemm& g) { return (g.M % 128 == 0) && (g.N % 128 == 0); }
+inline long hgemm_tiles(const HGemm& g, bool big) { return big ? (long)(g.M / 128) * (g.N / 128) : (long)(g.M / 64) * (g.N / 64); }
+
+inline hipError_t hgemm_launch_batch(const HGemm* gs, int n, hipStream_t st, int force = 0, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+  if (n < 1 || n > 2) return hipErrorInvalidValue;
+  bool big_ok = true; long tiles_big = 0;
+  for (int i = 0; i < n; ++i) { big_ok = big_ok && hgemm_big_ok(gs[i]); if (gs[i].K % 64 || gs[i].K < 64) return hipErrorInvalidValue; }
+  if (big_ok) for (int i = 0; i < n; ++i) tiles_big += hgemm_tiles(gs[i], true);
+  const bool big = force == 1 || (force == 0 && big_ok && tiles_big >= 192);
+  HGemmBatch b{};
+  b.n = n;
+  for (int i = 0; i < n; ++i) b.g[i] = gs[i];
   if (big) {
     if (!big_ok) return hipErrorInvalidValue;
-    if (t0) hipExtLaunchKernelGGL((hgemm_nt<2, 2>), dim3((unsigned)tiles_big), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, g);
-    else hipLaunchKernelGGL((hgemm_nt<2, 2>), dim3((unsigned)tiles_big), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, g);
+    b.tiles0 = (int)hgemm_tiles(gs[0], true);
+    if (t0) hipExtLaunchKernelGGL((hgemm_nt<2, 2>), dim3((unsigned)tiles_big), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, b);
+    else hipLaunchKernelGGL((hgemm_nt<2, 2>), dim3((unsigned)tiles_big), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, b);
   } else {
-    if (g.M % 64 || g.N % 64 || g.K % 128) return hipErrorInvalidValue;
-    const unsigned nb = (unsigned)((g.M / 64) * (g.N / 64));
-    if (t0) hipExtLaunchKernelGGL((hgemm_nt<1, 1>), dim3(nb), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, g);
-    else hipLaunchKernelGGL((hgemm_nt<1, 1>), dim3(nb), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, g);
+    long nb = 0;
+    for (int i = 0; i < n; ++i) { if (gs[i].M % 64 || gs[i].N % 64 || gs[i].K % 128) return hipErrorInvalidValue; nb += hgemm_tiles(gs[i], false); }
+    b.tiles0 = (int)hgemm_tiles(gs[0], false);
+    if (t0) hipExtLaunchKernelGGL((hgemm_nt<1, 1>), dim3((unsigned)nb), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, b);
+    else hipLaunchKernelGGL((hgemm_nt<1, 1>), dim3((unsigned)nb), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, b);
   }
   return hipGetLastError();
 }
+inline hipError_t hgemm_launch(const HGemm& g, hipStream_t st, int force = 0, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+  return hgemm_launch_batch(&g, 1, st, force, t0, t1);
+}
+// would a stand-alone launch of g use the 64x64 split-K tile?
+inline bool hgemm_uses_small_tile(const HGemm& g) { return !(hgemm_big_ok(g) && hgemm_tiles(g, true) >= 192); }
 
 // ---------------------------------------------------------------------------------------------
 // fp32 [rows][ld_src] -> fp16 [rows][ld16] (+ transposed fp16 [ld16][ldT]) glue: minibatch panels,

@@ -505,14 +505,16 @@ int sumsq_launch(H* h, int net);
 
 // ---- mixed-precision building blocks (hgemm.hip.h) --------------------------------------------
 
-int hgemm_timed(H* h, hipStream_t st, const HGemm& g, int fam) {
+int hgemm_timed(H* h, hipStream_t st, const HGemm* gs, int n, int fam) {
   ScopedTiming t(h, fam, st);
   LaunchTimer& lt = launch_timer();
   hipEvent_t a = lt.start, b = lt.stop;
   lt.start = lt.stop = nullptr;
-  HIPCHK(hgemm_launch(g, st, 0, a, b));
+  HIPCHK(hgemm_launch_batch(gs, n, st, 0, a, b));
   return 0;
 }
+int hgemm_timed(H* h, hipStream_t st, const HGemm& g, int fam) { return hgemm_timed(h, st, &g, 1, fam); }
+static const bool kHgemmPairs = !getenv("DQNHIP_NO_HGEMM_PAIRS");
 
 // fp32 master weights of `net` -> fp16 mirror [N][kp] (unless only_t) + transposed copies for the
 // online nets.  The Adam pass keeps the mirrors current by itself; after it only the transposes
@@ -532,20 +534,33 @@ int sync_w16(H* h, hipStream_t st, int net, bool only_t = false) {
   return 0;
 }
 
-int tower_forward16(H* h, hipStream_t st, int p, int net, int rows) {
+HGemm fwd16_problem(H* h, int p, int net, int rows, int i) {
   const NetLayout& l = layout_of(h, net);
   const int kind = net & 1;
   const bool needT = (p == 1 || p == 3);
+  HGemm g{};
+  g.A = h->act16[p][i]; g.lda = h->k16[kind][i];
+  g.B = h->w16[net][i]; g.ldb = h->k16[kind][i];
+  g.M = rows; g.N = l.dims[i + 1]; g.K = h->k16[kind][i];
+  g.C16 = h->act16[p][i + 1]; g.ldc16 = l.dims[i + 1];
+  if (needT) { g.CT16 = h->actT16[p][i + 1]; g.ldct16 = rows; }
+  if (i == l.L - 1) { g.C32 = h->act[p][l.L]; g.ldc32 = l.kp[l.L]; g.n_valid32 = l.dims[l.L]; }
+  g.bias = h->w[net] + l.b_off[i]; g.relu = 1; g.scale32 = 1.0f;
+  return g;
+}
+int tower_forward16(H* h, hipStream_t st, int p, int net, int rows) {
+  const NetLayout& l = layout_of(h, net);
+  for (int i = 0; i < l.L; ++i) RC(hgemm_timed(h, st, fwd16_problem(h, p, net, rows, i), 7));
+  return 0;
+}
+// two independent passes of the same net kind, layer by layer in ONE launch each (the target and
+// the online net: same shapes, different weights and inputs)
+int tower_forward16_pair(H* h, hipStream_t st, int p0, int net0, int p1, int net1, int rows) {
+  if (!kHgemmPairs) { RC(tower_forward16(h, st, p0, net0, rows)); return tower_forward16(h, st, p1, net1, rows); }
+  const NetLayout& l = layout_of(h, net0);
   for (int i = 0; i < l.L; ++i) {
-    HGemm g{};
-    g.A = h->act16[p][i]; g.lda = h->k16[kind][i];
-    g.B = h->w16[net][i]; g.ldb = h->k16[kind][i];
-    g.M = rows; g.N = l.dims[i + 1]; g.K = h->k16[kind][i];
-    g.C16 = h->act16[p][i + 1]; g.ldc16 = l.dims[i + 1];
-    if (needT) { g.CT16 = h->actT16[p][i + 1]; g.ldct16 = rows; }
-    if (i == l.L - 1) { g.C32 = h->act[p][l.L]; g.ldc32 = l.kp[l.L]; g.n_valid32 = l.dims[l.L]; }
-    g.bias = h->w[net] + l.b_off[i]; g.relu = 1; g.scale32 = 1.0f;
-    RC(hgemm_timed(h, st, g, 7));
+    const HGemm gs[2] = {fwd16_problem(h, p0, net0, rows, i), fwd16_problem(h, p1, net1, rows, i)};
+    RC(hgemm_timed(h, st, gs, 2, 7));
   }
   return 0;
 }
@@ -558,8 +573,10 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
   const int kind = net & 1;
   h16** dZ = h->dZ16[kind]; h16** dZT = h->dZT16[kind];
   for (int i = l.L - 1; i >= 0; --i) {
-    if (i > 0 || input_grad) {             // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
-      HGemm g{};
+    HGemm gd{}, gw{};
+    const bool need_dx = i > 0 || input_grad;
+    if (need_dx) {                         // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
+      HGemm& g = gd;
       g.A = dZ[i + 1]; g.lda = l.dims[i + 1];
       g.B = h->wt16[net][i]; g.ldb = l.dims[i + 1];
       g.M = rows; g.N = h->k16[kind][i]; g.K = l.dims[i + 1];
@@ -570,15 +587,22 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
       } else {
         g.C32 = dZ32_0; g.ldc32 = l.kp[0]; g.n_valid32 = l.kp[0]; g.scale32 = 1.0f / ls;
       }
-      RC(hgemm_timed(h, st, g, 8));
     }
     if (want_w) {                          // dW_i = dZ[i+1]^T . act[i]
-      HGemm g{};
+      HGemm& g = gw;
       g.A = dZT[i + 1]; g.lda = rows;
       g.B = h->actT16[p][i]; g.ldb = rows;
       g.M = l.dims[i + 1]; g.N = h->k16[kind][i]; g.K = rows;
       g.C32 = garena + l.w_off[i]; g.ldc32 = l.kp[i]; g.n_valid32 = l.kp[i]; g.scale32 = 1.0f / ls;
-      RC(hgemm_timed(h, st, g, 9));
+    }
+    // both read dZ[i+1] and neither reads the other's output: at small minibatches (both on the
+    // 64x64 split-K tile) they share one launch
+    if (need_dx && want_w && kHgemmPairs && hgemm_uses_small_tile(gd) && hgemm_uses_small_tile(gw) && gd.K % 128 == 0 && gw.K % 128 == 0) {
+      const HGemm gs[2] = {gd, gw};
+      RC(hgemm_timed(h, st, gs, 2, 8));
+    } else {
+      if (need_dx) RC(hgemm_timed(h, st, gd, 8));
+      if (want_w) RC(hgemm_timed(h, st, gw, 9));
     }
   }
   if (want_w) {                            // db_i = colsum(dZ[i+1]) for all layers in one launch
@@ -639,8 +663,8 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       cvt16_add(b, h->Xc_tr, lc.kp[0], B, lc.kp[0], h->act16[3][0], h->k16[1][0], h->actT16[3][0], B, 1.0f);
       HIPCHK(cvt16_launch(b, st));
     }
-    RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B));
-    if (!split) RC(tower_forward16(h, st, 1, DQNHIP_ACTOR, B));
+    if (split) RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B));
+    else RC(tower_forward16_pair(h, st, 0, DQNHIP_ACTOR_TARGET, 1, DQNHIP_ACTOR, B));
     HeadArgs hAT{}; hAT.X = h->act[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
     hAT.W = wat(h, DQNHIP_ACTOR_TARGET, la.hw_off); hAT.b = wat(h, DQNHIP_ACTOR_TARGET, la.hb_off);
     hAT.out16 = h->aout_t16; hAT.xc = h->Xc_nx; hAT.ldxc = lc.kp[0]; hAT.xc_col = h->S;
@@ -655,8 +679,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       if (!split) cvt16_add(b, h->Xc_pl, lc.kp[0], B, lc.kp[0], h->act16[4][0], h->k16[1][0], nullptr, B, 1.0f);
       HIPCHK(cvt16_launch(b, st));
     }
-    RC(tower_forward16(h, st, 2, DQNHIP_CRITIC_TARGET, B));
-    RC(tower_forward16(h, st, 3, DQNHIP_CRITIC, B));
+    RC(tower_forward16_pair(h, st, 2, DQNHIP_CRITIC_TARGET, 3, DQNHIP_CRITIC, B));
     {
       HeadTrainArgs t{};
       t.Xt = h->act[2][L]; t.Wt = wat(h, DQNHIP_CRITIC_TARGET, lc.hw_off); t.bt = wat(h, DQNHIP_CRITIC_TARGET, lc.hb_off);
