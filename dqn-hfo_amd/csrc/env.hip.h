@@ -36,6 +36,10 @@ struct EnvDev {
   // totals
   unsigned long long* n_steps; unsigned long long* n_episodes; unsigned long long* n_goals; double* reward_sum;
   const float* eps;                // device scalar: this call's epsilon (not a kernel argument, so a captured step replays)
+  // fused actor heads (action_layer + actionpara_layer on this worker's tower-top row): null -> out16 was
+  // written by a separate head launch
+  const float* head_x; const float* head_w; const float* head_b; int head_h;
+  int* commit_ticket;              // arrival counter of k_env_flush (its last block publishes the ring bookkeeping); null: k_env_commit does
 };
 
 __device__ __forceinline__ float env_u01(unsigned long long seed, unsigned long long g, int w, int k) {
@@ -132,6 +136,34 @@ __global__ void k_env_step(EnvDev e) {
   const unsigned long long g = e.g[w];
   // SelectAction(state, epsilon): ONE epsilon draw per call (src/dqn.cpp:700)
   const bool rnd = env_u01(e.seed, g, w, 0) < epsilon;
+  if (e.head_x != nullptr) {
+    // SelectActionGreedily's last step for this worker: the 10 head outputs of its tower-top row (one wave:
+    // float4 k-strips, butterfly) — the separate head launch of the batched step folded in
+    const float* x = e.head_x + (size_t)w * e.head_h;
+    float acc[kNO];
+#pragma unroll
+    for (int j = 0; j < kNO; ++j) acc[j] = 0.0f;
+    for (int k = lane * 4; k < e.head_h; k += 256) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
+#pragma unroll
+      for (int j = 0; j < kNO; ++j) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(e.head_w + (size_t)j * e.head_h + k);
+        acc[j] = fmaf(xv.x, wv.x, acc[j]); acc[j] = fmaf(xv.y, wv.y, acc[j]); acc[j] = fmaf(xv.z, wv.z, acc[j]); acc[j] = fmaf(xv.w, wv.w, acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kNO; ++j) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
+    }
+    if (lane < kAP) {
+      float v = 0.0f;
+#pragma unroll
+      for (int j = 0; j < kNO; ++j) if (lane == j) v = acc[j] + e.head_b[j];
+      e.out16[(size_t)w * kAP + lane] = v;
+    }
+    __syncthreads();               // one wave: orders the out16 stores before the loads below
+  }
   if (lane < kAP) {
     float v = 0.0f;
     if (lane < kNO) {
@@ -191,13 +223,35 @@ __device__ __forceinline__ void ring_add_plan(int cap, int n, int& head, int& si
   head = (int)(((long long)head + pops) % cap); size -= pops;
 }
 
+__device__ __forceinline__ void env_flush_worker(const EnvDev& e, const Ring& ring, const DevState* st, double gamma, int w, int len,
+                                                 float* sm, int* s_start_p);
+__device__ __forceinline__ void env_commit_body(const EnvDev& e, const Ring& ring, DevState* st);
+
 // finished episodes: LabelTransitions + AddTransitions, in worker order; then reset the worker
 __global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const DevState* st, double gamma) {
   extern __shared__ float sm[];          // [T] mc labels, then [SP] reset row
   __shared__ int s_start;
   const int w = blockIdx.x;
   const int len = e.done[w];
-  if (len == 0) return;
+  if (len != 0) env_flush_worker(e, ring, st, gamma, w, len, sm, &s_start);
+  if (e.commit_ticket == nullptr) return;
+  // Every block has now read what it needs of done[] and (head,size); the LAST one to get here publishes the
+  // ring bookkeeping (what k_env_commit did in its own launch).  It consumes nothing the other blocks of this
+  // launch wrote, so the arrival count needs no fence.
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(e.commit_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (int)gridDim.x - 1);
+    if (s_last) *e.commit_ticket = 0;
+  }
+  __syncthreads();
+  if (s_last) env_commit_body(e, ring, const_cast<DevState*>(st));
+}
+
+__device__ __forceinline__ void env_flush_worker(const EnvDev& e, const Ring& ring, const DevState* st, double gamma, int w, int len,
+                                                 float* sm, int* s_start_p) {
+  int& s_start = *s_start_p;
   // AddTransitions of the workers before us, in worker order.  Every AddTransitions(n) (n <= cap-1)
   // moves the deque's tail by exactly n and leaves size = min(size + n, cap - 1), so this worker's
   // first slot is tail0 + (transitions flushed by lower-numbered workers): a parallel prefix sum
@@ -274,7 +328,7 @@ __global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const De
 template <int UNUSED = 0>
 __global__ void k_set_float(float* p, float v) { *p = v; }
 
-__global__ __launch_bounds__(256) void k_env_commit(EnvDev e, Ring ring, DevState* st) {
+__device__ __forceinline__ void env_commit_body(const EnvDev& e, const Ring& ring, DevState* st) {
   // the closed form of the same sequence of AddTransitions (see k_env_flush): tail += total,
   // size = min(size + total, cap - 1)
   __shared__ int s_tot[4];
@@ -293,5 +347,6 @@ __global__ __launch_bounds__(256) void k_env_commit(EnvDev e, Ring ring, DevStat
   st->ring_head = (int)((tail - size) % ring.cap);
   st->ring_size = (int)size;
 }
+__global__ __launch_bounds__(256) void k_env_commit(EnvDev e, Ring ring, DevState* st) { env_commit_body(e, ring, st); }
 
 }  // namespace dqnhip

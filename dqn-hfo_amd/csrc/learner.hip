@@ -2052,6 +2052,7 @@ struct dqnhip_env {
   float* acts[kMaxL + 1] = {nullptr};
   std::vector<void*> allocs;
   float* eps_dev = nullptr;
+  int* commit_ticket = nullptr;
   hipGraphExec_t graph[2] = {nullptr, nullptr};   // one batched step / kEnvUnroll steps, captured on first use
   bool graph_failed = false;
 };
@@ -2105,6 +2106,7 @@ static int env_create_impl(dqnhip_env* e) {
   e->acts[0] = d.cur;
   for (int i = 1; i <= h->L; ++i) RC(env_alloc(e, &e->acts[i], Np * h->la.kp[i]));
   RC(env_alloc(e, &e->eps_dev, 16)); d.eps = e->eps_dev;
+  RC(env_alloc(e, &e->commit_ticket, 32));
   hipLaunchKernelGGL(k_env_init, dim3(d.N), dim3(64), d.SP * sizeof(float), h->stream, d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -2125,21 +2127,35 @@ int dqnhip_env_destroy(dqnhip_env_handle e) {
 // per-worker epsilon draw / GetAction / reward / episode bookkeeping / AddTransitions
 static int env_one_step(dqnhip_env* e) {
   dqnhip_learner* h = e->h;
-  const EnvDev& d = e->d;
+  EnvDev d = e->d;
   hipStream_t st = h->stream;
   const NetLayout& la = h->la;
   FwdPass fp{DQNHIP_ACTOR, &la, e->acts};
   RC(tower_forward(h, st, &fp, 1, e->Npad));
-  HeadArgs a{}; a.X = e->acts[la.L]; a.ldx = la.dims[la.L]; a.H = la.dims[la.L]; a.rows = e->Npad;
-  a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.b = wat(h, DQNHIP_ACTOR, la.hb_off); a.out16 = d.out16;
-  RC((head_forward<kNO, HEAD_ACTOR>(h, st, a)));
+  // 6 launches per batched step at L = 4: the actor heads ride in k_env_step (one wave per worker computes
+  // its own 10 outputs) and the ring bookkeeping in k_env_flush's last block; DQNHIP_ENV_SEPARATE=1 restores
+  // the 8-launch form (head kernel + k_env_commit) for A/B measurements
+  static const bool kFused = !getenv("DQNHIP_ENV_SEPARATE");
+  // (beyond a few hundred workers the dedicated head kernel and a separate commit win: one wave per head row is
+  // slower than the tiled head kernel there, and N arrivals on one counter serialise at ~12 ns each)
+  if (kFused && la.dims[la.L] % 4 == 0 && d.N <= 512) {
+    d.head_x = e->acts[la.L]; d.head_h = la.dims[la.L];
+    d.head_w = wat(h, DQNHIP_ACTOR, la.hw_off); d.head_b = wat(h, DQNHIP_ACTOR, la.hb_off);
+    d.commit_ticket = e->commit_ticket;
+  } else {
+    HeadArgs a{}; a.X = e->acts[la.L]; a.ldx = la.dims[la.L]; a.H = la.dims[la.L]; a.rows = e->Npad;
+    a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.b = wat(h, DQNHIP_ACTOR, la.hb_off); a.out16 = d.out16;
+    RC((head_forward<kNO, HEAD_ACTOR>(h, st, a)));
+  }
   hipLaunchKernelGGL(k_env_step, dim3(d.N), dim3(64), d.SP * sizeof(float), st, d);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), (d.T + d.SP) * sizeof(float), st, d, RO(h)->ring,
                      (const DevState*)RO(h)->st, h->cfg.gamma);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(k_env_commit, dim3(1), dim3(256), 0, st, d, RO(h)->ring, RO(h)->st);
-  HIPCHK(hipGetLastError());
+  if (d.commit_ticket == nullptr) {
+    hipLaunchKernelGGL(k_env_commit, dim3(1), dim3(256), 0, st, d, RO(h)->ring, RO(h)->st);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 
