@@ -439,3 +439,130 @@ extern "C" int dqnhip_test_adam(int64_t n_params, int32_t variant, int32_t block
   hipStreamDestroy(s);
   return 0;
 }
+
+
+// ======================= persistent forward chain probe ==========================================
+// VERDICT r1 item 2 asked for "one persistent kernel per phase with per-row-tile ready flags".  This probe
+// measures exactly that seam on the learner's own forward kernel: L dependent 256 x 1024 x 1024 layers
+//   (a) as L launches of gemm_fwd_lds<2,2> (what the learner does), and
+//   (b) as ONE launch of 256 co-resident workgroups that run the same fwd_lds_body per layer and hand the
+//       32-row slabs over through per-(layer, slab) arrival counters: producer plain stores ->
+//       s_waitcnt vmcnt(0) -> __syncthreads -> lane-0 agent release -> relaxed counter add; consumer: one lane
+//       polls (relaxed, agent) -> agent acquire -> __syncthreads -> plain loads (guide G16's valid form).
+//       map = 0: the learner's tile map (a slab's 32 column tiles spread over the 8 XCDs);
+//       map = 1: slab s on XCD s (hand-offs stay inside one XCD's L2, every XCD streams all of W).
+// Spins are bounded: a give-up sets err and the results are wrong, but nothing can hang.
+namespace {
+struct ChainArgs {
+  const float* W[8]; const float* bias[8]; float* act[9];     // act[0] = input, act[l+1] = output of layer l
+  int L, rows, width;
+  int* counters;                                               // [L][rows/32], monotone: target = 32 * epoch
+  int epoch, map;
+  int* err;
+};
+
+__global__ __launch_bounds__(256) void k_fwd_chain(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_fail;
+  const int slabs = a.rows / 32, ctiles = a.width / 32;
+  int tile_p, tile_q;
+  if (a.map == 0) { const int b = blockIdx.x, xcd = b & 7, j = b >> 3; tile_q = j % slabs; tile_p = (j / slabs) * 8 + xcd; }
+  else { const int b = blockIdx.x; tile_q = b & 7; tile_p = b >> 3; }       // rows/32 == 8 slabs <-> 8 XCDs
+  if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // an earlier launch gave up: do nothing
+  for (int l = 0; l < a.L; ++l) {
+    if (l > 0) {
+      if (threadIdx.x == 0) {
+        const int* c = a.counters + (l - 1) * slabs + tile_q;
+        const int target = ctiles * a.epoch;
+        int spins = 0, fail = 0;
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > 400000) { fail = 1; break; }
+          if ((spins & 1023) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fail = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_fail = fail;
+        if (fail) *a.err = 1;
+      }
+      __syncthreads();
+    }
+    GemmProblem pr{};
+    pr.P = a.W[l]; pr.ldp = a.width; pr.Q = a.act[l]; pr.ldq = a.width; pr.C = a.act[l + 1]; pr.ldc = a.width;
+    pr.Pdim = a.width; pr.Qdim = a.rows; pr.Kred = a.width; pr.bias = a.bias[l]; pr.relu = 1;
+    fwd_lds_body<2, 2, true>(pr, tile_p, tile_q, smem);
+    if (l + 1 < a.L) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(a.counters + l * slabs + tile_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, float* us_launches, float* us_persistent,
+                                 float* max_abs_diff, int32_t* gave_up) {
+  if (layers < 1 || layers > 8 || iters < 1) return 1;
+  const int rows = 256, width = 1024;
+  hipStream_t s; CK(hipStreamCreate(&s));
+  ChainArgs a{}; a.L = layers; a.rows = rows; a.width = width; a.map = map;
+  float* ref[9];
+  for (int l = 0; l < layers; ++l) {
+    float *w, *b;
+    CK(hipMalloc(&w, (size_t)width * width * 4)); CK(hipMalloc(&b, width * 4));
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, w, (size_t)width * width, 100u + l, -0.05f, 0.05f);
+    hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, s, b, (size_t)width, 200u + l, -0.1f, 0.1f);
+    a.W[l] = w; a.bias[l] = b;
+  }
+  for (int l = 0; l <= layers; ++l) { CK(hipMalloc(&a.act[l], (size_t)rows * width * 4)); CK(hipMalloc(&ref[l], (size_t)rows * width * 4)); }
+  hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, s, a.act[0], (size_t)rows * width, 7u, -1.f, 1.f);
+  CK(hipMemcpyAsync(ref[0], a.act[0], (size_t)rows * width * 4, hipMemcpyDeviceToDevice, s));
+  CK(hipMalloc(&a.counters, 8 * 8 * sizeof(int))); CK(hipMemsetAsync(a.counters, 0, 8 * 8 * sizeof(int), s));
+  CK(hipMalloc(&a.err, sizeof(int))); CK(hipMemsetAsync(a.err, 0, sizeof(int), s));
+  const int lds = fwd_lds_bytes<2, 2, true>();
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_chain), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  auto run_launches = [&]() -> hipError_t {
+    for (int l = 0; l < layers; ++l) {
+      GemmBatch b{}; b.n = 1;
+      GemmProblem& p = b.prob[0];
+      p.P = a.W[l]; p.ldp = width; p.Q = ref[l]; p.ldq = width; p.C = ref[l + 1]; p.ldc = width;
+      p.Pdim = width; p.Qdim = rows; p.Kred = width; p.bias = a.bias[l]; p.relu = 1;
+      hipError_t e = fwd_lds_launch<2, 2, true>(b, s);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  };
+  int epoch = 0;
+  auto run_persistent = [&]() -> hipError_t {
+    a.epoch = ++epoch;
+    hipLaunchKernelGGL(k_fwd_chain, dim3(256), dim3(256), lds, s, a);
+    return hipGetLastError();
+  };
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float ms = 0;
+  for (int i = 0; i < 3; ++i) CK(run_launches());
+  CK(hipStreamSynchronize(s)); CK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) CK(run_launches());
+  CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+  if (us_launches) *us_launches = ms * 1000.f / iters;
+  for (int i = 0; i < 3; ++i) CK(run_persistent());
+  CK(hipStreamSynchronize(s)); CK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) CK(run_persistent());
+  CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+  if (us_persistent) *us_persistent = ms * 1000.f / iters;
+  float* dres; CK(hipMalloc(&dres, 8)); CK(hipMemsetAsync(dres, 0, 8, s));
+  hipLaunchKernelGGL(k_maxdiff, dim3(1), dim3(256), 0, s, a.act[layers], ref[layers], (size_t)rows * width, dres);
+  float hres[2] = {0, 0}; int herr = 0;
+  CK(hipMemcpyAsync(hres, dres, 8, hipMemcpyDeviceToHost, s));
+  CK(hipMemcpyAsync(&herr, a.err, sizeof(int), hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  if (max_abs_diff) *max_abs_diff = hres[0];
+  if (gave_up) *gave_up = herr;
+  for (int l = 0; l < layers; ++l) { hipFree((void*)a.W[l]); hipFree((void*)a.bias[l]); }
+  for (int l = 0; l <= layers; ++l) { hipFree(a.act[l]); hipFree(ref[l]); }
+  hipFree(a.counters); hipFree(a.err); hipFree(dres); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+  return 0;
+}
