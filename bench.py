@@ -292,10 +292,11 @@ def main():
         par = import_module("dqn_hfo_amd.parallel")
         # ONE seed for the whole group: identical initialisation (rank 0's state is broadcast anyway), the
         # per-shard sample streams are decorrelated by dp_rank inside the library
-        make = par.make_native_data_parallel if native else par.make_hip_data_parallel
-        kw = dict(per_layer=args.dp_per_layer) if native else {}
-        dqn, dp = make(pkg, S, rank, world, local_rank, minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1,
-                       precision=args.precision, **kw)
+        common = dict(minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1, precision=args.precision)
+        if native:
+            dqn, dp = par.make_native_data_parallel(pkg, S, rank, world, local_rank, per_layer=args.dp_per_layer, **common)
+        else:
+            dqn, dp = par.make_hip_data_parallel(pkg, S, rank, world, local_rank, **common)
         step = lambda: dp.update(None)
     else:
         dqn = pkg.DQN(S, minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1 + rank, device=local_rank,
@@ -391,10 +392,7 @@ def main():
             env_res["cpu_port_workers_64"] = {"env_steps_per_s": round(64 * 10 / dt, 1), "cores": c_oracle.usable_cores()}
             oenv.close(); orc.close()
 
-    sub = None
-    if not args.no_subrecords and not args.strong and args.precision == "fp32" and B == 256:
-        sub = sub_records(pkg, par, args, rank, world, local_rank, native, barrier)
-
+    out = None
     if rank == 0:
         ups = args.steps / elapsed
         value = ups if args.strong else ups * (world if world > 1 else 1)
@@ -421,12 +419,43 @@ def main():
             "last_critic_loss": loss, "last_avg_q": avgq,
             "roofline": roof,
             "env_steps": env_res,
-            "sub_records": sub,
+            "sub_records": None,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
+
+    def emit_and_exit(note=None):
+        """The ONE JSON line (rank 0), then leave without running the communication libraries' exit handlers."""
+        if rank == 0:
+            if note:
+                out["sub_records"] = {"error": note}
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)      # RCCL's banner goes through C stdio: push it out first
+            except Exception:
+                pass
+            sys.stdout.flush()
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    # side records (configs[2], configs[4]; strong scaling under N > 1).  They must never cost the headline:
+    # a watchdog on every rank prints the line without them if they do not finish (e.g. one rank stuck in a
+    # collective the others never entered), and an exception only drops the side records.
+    if not args.no_subrecords and not args.strong and args.precision == "fp32" and B == 256:
+        import threading
+        dog = threading.Timer(240.0, emit_and_exit, kwargs={"note": "side records did not finish within 240 s"})
+        dog.daemon = True
+        dog.start()
+        try:
+            sub = sub_records(pkg, par, args, rank, world, local_rank, native, barrier)
+        except Exception as ex:
+            sub = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        dog.cancel()
+        if rank == 0:
+            out["sub_records"] = sub
+    if rank == 0:
         final_line = json.dumps(out)
     if dist_on:
         import torch.distributed as dist
