@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 68
-for workers in (64, 256, 2048):
+WORKERS = [int(x) for x in sys.argv[2:]] or [64, 256, 2048]
+for workers in WORKERS:
     d = pkg.DQN(S, minibatch=256, hidden=(1024,) * 4, memory=1200000, seed=1, use_graph=True)
     env = pkg.EnvFrontEnd(d, workers, max_steps=500, p_end=0.01, seed=5)
     env.step(0.1, 40); env.stats()

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU"; do
   out=/tmp/pmcb_$RANDOM
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -- python bench.py --no-cpu-baseline --no-env --steps 60 --warmup 10 --replay 100000 --no-graph > /tmp/pmcb.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -- python bench.py --no-cpu-baseline --no-env --no-subrecords --steps 60 --warmup 10 --replay 100000 --no-graph > /tmp/pmcb.log 2>&1
   f=$(find $out -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv, sys, collections

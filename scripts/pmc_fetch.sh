@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "pass $c"; rm -rf /tmp/pf_$c
-  timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pf_$c -- python bench.py --steps 30 --warmup 5 --no-graph --no-cpu-baseline --no-env --replay 100000 > /tmp/pf_$c.log 2>&1; echo "  rc=$?"
+  timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pf_$c -- python bench.py --steps 30 --warmup 5 --no-graph --no-cpu-baseline --no-env --no-subrecords --replay 100000 > /tmp/pf_$c.log 2>&1; echo "  rc=$?"
 done
 python - <<'PY'
 import csv, glob, json, collections

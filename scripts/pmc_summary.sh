@@ -7,7 +7,7 @@ rm -rf /tmp/pmcs; mkdir -p /tmp/pmcs
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   i=$((i+1))
-  echo "pass $i: $grp"; timeout 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmcs/p$i -- python bench.py --steps 60 --warmup 10 --no-graph --no-cpu-baseline --no-env --replay 200000 > /tmp/pmcs/log$i.txt 2>&1; echo "  rc=$?"
+  echo "pass $i: $grp"; timeout 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmcs/p$i -- python bench.py --steps 60 --warmup 10 --no-graph --no-cpu-baseline --no-env --no-subrecords --replay 200000 > /tmp/pmcs/log$i.txt 2>&1; echo "  rc=$?"
 done
 python - <<'PY'
 import csv, glob, json, collections, re
@@ -21,7 +21,7 @@ for f in glob.glob("/tmp/pmcs/p*/**/*counter_collection.csv", recursive=True):
         n = n[:n.index("(")] if "(" in n else n
         n = n.replace(" ", "")
         acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"source": "rocprofv3 --kernel-trace --pmc <one pass per counter group> -- python bench.py --steps 60 --warmup 10 --no-graph --no-cpu-baseline --no-env --replay 200000 (MI355X, round 1, scripts/pmc_summary.sh)",
+out = {"source": "rocprofv3 --kernel-trace --pmc <one pass per counter group> -- python bench.py --steps 60 --warmup 10 --no-graph --no-cpu-baseline --no-env --no-subrecords --replay 200000 (MI355X, round 1, scripts/pmc_summary.sh)",
        "units": {"FETCH_SIZE": "KB as reported (double it for wide coalesced reads on gfx950, MI355X_MICROARCH.md §HBM)", "WRITE_SIZE": "KB",
                  "SQ_VALU_MFMA_BUSY_CYCLES": "cycles summed over SIMDs (32 per v_mfma_f32_16x16x4_f32)",
                  "SQ_WAVE_CYCLES/SQ_WAIT_*": "quad-cycles summed over waves"},
