@@ -268,43 +268,69 @@ __device__ __forceinline__ void env_flush_worker(const EnvDev& e, const Ring& ri
   // global-memory latency inside its dependent chain
   for (int i = threadIdx.x; i < len; i += 256) sm[i] = e.ep_r[(size_t)w * e.T + i];
   __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (threadIdx.x == 0) {
     const long long tail0 = (long long)st->ring_head + st->ring_size;
     s_start = (int)((tail0 + ((s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]))) % ring.cap);
-    // LabelTransitions (src/dqn.cpp:783-797): reverse scan, gamma double, float store — the
-    // float rounding of every step makes the chain inherently serial; in place: sm[i] r -> mc
-    float target = sm[len - 1];
-    int i = len - 2;
-    for (; i >= 3; i -= 4) {
-      const float r0 = sm[i], r1 = sm[i - 1], r2 = sm[i - 2], r3 = sm[i - 3];
-      target = (float)((double)r0 + gamma * (double)target); sm[i] = target;
-      target = (float)((double)r1 + gamma * (double)target); sm[i - 1] = target;
-      target = (float)((double)r2 + gamma * (double)target); sm[i - 2] = target;
-      target = (float)((double)r3 + gamma * (double)target); sm[i - 3] = target;
-    }
-    for (; i >= 0; --i) { target = (float)((double)sm[i] + gamma * (double)target); sm[i] = target; }
-    e.n_episodes[w] += 1;
   }
   __syncthreads();
   const int start = s_start;
   const int SP = e.SP;                   // episode-buffer row = the actor's input panel width
   const int RSP = ring.SP;               // ring row (<= SP: the fp16 learner pads its panels to 128)
-  for (int i = threadIdx.x; i < len * RSP; i += 256) {
-    const int t = i / RSP, c = i % RSP;
-    const long long slot = ((long long)start + t) % ring.cap;
-    ring.state[slot * RSP + c] = e.ep_s[((size_t)w * e.T + t) * SP + c];
-    ring.next[slot * RSP + c] = (t + 1 < len) ? e.ep_s[((size_t)w * e.T + t + 1) * SP + c] : 0.0f;
+  if (wave == 0) {
+    // LabelTransitions (src/dqn.cpp:783-797): reverse scan, gamma double, float store — the float rounding
+    // of every step makes the chain inherently serial (one lane); it runs BESIDE the row copies of waves 1-3
+    // instead of in front of them.  In place: sm[i] r -> mc
+    if (lane == 0) {
+      float target = sm[len - 1];
+      int i = len - 2;
+      for (; i >= 3; i -= 4) {
+        const float r0 = sm[i], r1 = sm[i - 1], r2 = sm[i - 2], r3 = sm[i - 3];
+        target = (float)((double)r0 + gamma * (double)target); sm[i] = target;
+        target = (float)((double)r1 + gamma * (double)target); sm[i - 1] = target;
+        target = (float)((double)r2 + gamma * (double)target); sm[i - 2] = target;
+        target = (float)((double)r3 + gamma * (double)target); sm[i - 3] = target;
+      }
+      for (; i >= 0; --i) { target = (float)((double)sm[i] + gamma * (double)target); sm[i] = target; }
+      e.n_episodes[w] += 1;
+    }
+  } else {
+    // 192 threads copy the episode as float4s (RSP/4 = 16 or 32 per row: shifts, no division); the ring slot
+    // needs one conditional subtraction (start < cap, t < len < cap) instead of a 64-bit modulo per element;
+    // four independent float4 pairs in flight per thread
+    const int q4 = RSP >> 2, sh = (q4 == 16) ? 4 : (q4 == 32 ? 5 : 0);
+    const int tid3 = threadIdx.x - 64, n4 = len * q4;
+    auto copy1 = [&](int idx) {
+      const int t = sh ? (idx >> sh) : (idx / q4), c4 = sh ? (idx & (q4 - 1)) : (idx % q4);
+      long long slot = (long long)start + t;
+      if (slot >= ring.cap) slot -= ring.cap;
+      const f32x4* src = reinterpret_cast<const f32x4*>(e.ep_s + ((size_t)w * e.T + t) * SP) + c4;
+      const f32x4 sv = src[0];
+      const f32x4 nv = (t + 1 < len) ? src[SP >> 2] : f32x4{0.f, 0.f, 0.f, 0.f};
+      reinterpret_cast<f32x4*>(ring.state + slot * RSP)[c4] = sv;
+      reinterpret_cast<f32x4*>(ring.next + slot * RSP)[c4] = nv;
+    };
+    int idx = tid3;
+    for (; idx + 3 * 192 < n4; idx += 4 * 192) { copy1(idx); copy1(idx + 192); copy1(idx + 2 * 192); copy1(idx + 3 * 192); }
+    for (; idx < n4; idx += 192) copy1(idx);
+    for (int i = tid3; i < len * (kAP / 4); i += 192) {            // actor outputs: 4 float4 per transition
+      const int t = i >> 2, c4 = i & 3;
+      long long slot = (long long)start + t;
+      if (slot >= ring.cap) slot -= ring.cap;
+      reinterpret_cast<f32x4*>(ring.act + slot * kAP)[c4] = reinterpret_cast<const f32x4*>(e.ep_a + ((size_t)w * e.T + t) * kAP)[c4];
+    }
+    for (int t = tid3; t < len; t += 192) {
+      long long slot = (long long)start + t;
+      if (slot >= ring.cap) slot -= ring.cap;
+      ring.reward[slot] = e.ep_r[(size_t)w * e.T + t];
+      ring.term[slot] = (t + 1 < len) ? 0 : 1;                     // terminal <=> next_state == none
+    }
   }
-  for (int i = threadIdx.x; i < len * kAP; i += 256) {
-    const int t = i / kAP, c = i % kAP;
-    const long long slot = ((long long)start + t) % ring.cap;
-    ring.act[slot * kAP + c] = e.ep_a[((size_t)w * e.T + t) * kAP + c];
-  }
+  __syncthreads();
   for (int t = threadIdx.x; t < len; t += 256) {
-    const long long slot = ((long long)start + t) % ring.cap;
-    ring.reward[slot] = e.ep_r[(size_t)w * e.T + t];
+    long long slot = (long long)start + t;
+    if (slot >= ring.cap) slot -= ring.cap;
     ring.mc[slot] = sm[t];
-    ring.term[slot] = (t + 1 == len) ? 1 : 0;       // terminal <=> next_state == none
   }
   __syncthreads();
   // new episode for this worker (same steps as env_reset_worker, 256 threads wide)
