@@ -165,6 +165,7 @@ struct dqnhip_learner {
   h16* dZ16[2][kMaxL + 1] = {{nullptr}};     // [B][k16]   per net kind
   h16* dZT16[2][kMaxL + 1] = {{nullptr}};    // [k16][B]
   bool w16_dirty[4] = {true, true, true, true};
+  bool wt16_by_adam = false;                 // the last optimiser launch wrote wt16 itself (tiled form)
   std::vector<void*> allocs16;
   // host-staging for add_transitions / acting
   void* stage_dev = nullptr; size_t stage_bytes = 0;
@@ -481,11 +482,31 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   static const bool kTickInAdam = !getenv("DQNHIP_SEPARATE_TICK");
   if (tick && kTickInAdam) { a.tick_ticket = h->tick_ticket; a.tick = *tick; }
   static const int kAdamCap = getenv("DQNHIP_ADAM_BLOCKS") ? atoi(getenv("DQNHIP_ADAM_BLOCKS")) : 2048;
-  int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)kAdamCap);
+  static const bool kTiled = !getenv("DQNHIP_ADAM_FLAT");
+  const NetLayout& l = layout_of(h, net);
+  const bool tiled = h->fp16 && kTiled && begin == 0 && end == l.arena;
   ScopedTiming t(h, 3, st);
   LaunchTimer& lt = launch_timer();
-  if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
-  else hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, a);
+  if (tiled) {
+    // fp16 mode: the pass writes wt16 (the transposed fp16 weights the dgrad GEMMs read) itself
+    a.n_tseg = l.L; a.n_fseg = 0; a.n_tiles = 0;
+    for (int i = 0; i < l.L; ++i) {
+      a.tseg[i] = {l.w_off[i], l.dims[i + 1], l.kp[i], h->wt16[net][i], l.dims[i + 1], a.n_tiles};
+      a.n_tiles += (l.dims[i + 1] / 64) * (l.kp[i] / 64);
+      const size_t b0 = l.b_off[i], b1 = i + 1 < l.L ? l.w_off[i + 1] : l.hw_off;
+      a.fseg[a.n_fseg++] = {b0 / 4, (b1 - b0) / 4};
+    }
+    a.fseg[a.n_fseg++] = {l.hw_off / 4, (l.arena - l.hw_off) / 4};
+    const int blocks = a.n_tiles + 8;
+    if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft_tiled, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
+    else hipLaunchKernelGGL(k_adam_soft_tiled, dim3(blocks), dim3(256), 0, st, a);
+    h->wt16_by_adam = true;
+  } else {
+    int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)kAdamCap);
+    if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
+    else hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, a);
+    h->wt16_by_adam = false;
+  }
   HIPCHK(hipGetLastError());
   if (tick && !kTickInAdam) {
     hipLaunchKernelGGL(k_tick, dim3(1), dim3(256), 0, st, *tick);
@@ -523,6 +544,7 @@ int sync_w16(H* h, hipStream_t st, int net, bool only_t = false) {
   const NetLayout& l = layout_of(h, net);
   const int kind = net & 1;
   if (only_t && net >= 2) return 0;
+  if (only_t && h->wt16_by_adam) return 0;   // k_adam_soft_tiled already wrote the transposes
   Cvt16Batch b{};
   for (int i = 0; i < l.L; ++i) {
     cvt16_add(b, h->w[net] + l.w_off[i], l.kp[i], l.dims[i + 1], l.kp[i], only_t ? nullptr : h->w16[net][i], h->k16[kind][i],

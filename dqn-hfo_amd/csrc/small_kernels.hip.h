@@ -682,11 +682,18 @@ struct AdamArgs {
   // by then every block has read the iteration counters it is about to advance) runs tick_body
   int* tick_ticket;               // null: no tick duty
   TickArgs tick;
+  // fp16 mode, tiled form (k_adam_soft_tiled): the tower weight matrices are walked in 64 x 64 tiles so that the
+  // pass can also write the TRANSPOSED fp16 copy the dgrad GEMMs read (wt16[k][n]) through an LDS tile — what a
+  // separate transposing conversion launch per net did before.  Everything else (biases, heads) stays flat.
+  int n_tseg, n_fseg, n_tiles;
+  struct TileSeg { size_t off; int N, Kp; _Float16* wT; int ldT; int tile_base; } tseg[8];
+  struct FlatSeg { size_t off4, n4; } fseg[10];
 };
 // body shared by the stand-alone kernel and the mixed GEMM+Adam launch: block `blk` of
 // `nblk` 256-thread blocks strides over the arena slice
-template <int U = 1, int NT = 0>
-__device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int nblk, float* s /*>= 8 floats*/) {
+// per-launch scalars of the optimiser pass into s[4..7]: clip scale, lr * Adam correction, soft-update
+// switch, skip flag.  Every block re-derives them from the same partials in the same order.
+__device__ __forceinline__ void adam_scalars(const AdamArgs& a, int blk, float* s /*>= 8 floats*/) {
   // every block re-derives the same global L2 norm from the partials, in the
   // same order -> bit-identical scale everywhere, no extra launch
   float acc = 0.0f;
@@ -717,6 +724,10 @@ __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int n
     if (s[7] != 0.0f && blk == 0) { atomicOr(&a.st->flags, kFlagGradNorm); atomicAdd(&a.st->skipped_steps, 1); }
   }
   __syncthreads();
+}
+template <int U = 1, int NT = 0>
+__device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int nblk, float* s /*>= 8 floats*/) {
+  adam_scalars(a, blk, s);
   if (s[7] != 0.0f) return;
   const float scale = s[4];
   const float step = s[5];
@@ -776,6 +787,118 @@ __global__ __launch_bounds__(256) void k_adam_soft_t(AdamArgs a) {
   adam_soft_body<U, NT>(a, blockIdx.x, gridDim.x, s);
 }
 __device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot, double* sq);   // below
+
+// one float4 of every array: the same arithmetic as adam_soft_body's inner loop
+__device__ __forceinline__ void adam_elem4(const AdamArgs& a, size_t i, float scale, float step, bool soft, f32x4& w_out) {
+  const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2, tau = a.tau, omt = 1 - a.tau;
+  f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i], m = reinterpret_cast<const f32x4*>(a.m)[i], v = reinterpret_cast<const f32x4*>(a.v)[i];
+  f32x4 w = reinterpret_cast<const f32x4*>(a.w)[i], wt = reinterpret_cast<const f32x4*>(a.wt)[i];
+  float* gp = reinterpret_cast<float*>(&g); float* mp = reinterpret_cast<float*>(&m); float* vp = reinterpret_cast<float*>(&v);
+  float* wp = reinterpret_cast<float*>(&w); float* tp = reinterpret_cast<float*>(&wt);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gi = gp[e] * scale;
+    const float mi = fmaf(omb1, gi, a.beta1 * mp[e]);
+    const float vi = fmaf(omb2, gi * gi, a.beta2 * vp[e]);
+    const float upd = step * (mi / (sqrtf(vi) + a.eps));
+    const float wi = wp[e] - upd;
+    mp[e] = mi; vp[e] = vi; wp[e] = wi;
+    if (soft) tp[e] = fmaf(tau, wi, omt * tp[e]);
+  }
+  reinterpret_cast<f32x4*>(a.m)[i] = m; reinterpret_cast<f32x4*>(a.v)[i] = v; reinterpret_cast<f32x4*>(a.w)[i] = w;
+  if (soft) reinterpret_cast<f32x4*>(a.wt)[i] = wt;
+  typedef __attribute__((ext_vector_type(4))) _Float16 h16x4_t;
+  reinterpret_cast<h16x4_t*>(a.w16)[i] = h16x4_t{(_Float16)wp[0], (_Float16)wp[1], (_Float16)wp[2], (_Float16)wp[3]};
+  if (soft) reinterpret_cast<h16x4_t*>(a.wt16)[i] = h16x4_t{(_Float16)tp[0], (_Float16)tp[1], (_Float16)tp[2], (_Float16)tp[3]};
+  w_out = w;
+}
+
+// fp16 mode: blocks [0, n_tiles) own one 64 x 64 tile of a tower weight matrix each; the blocks after them
+// stride over the flat segments (biases, heads).
+__global__ __launch_bounds__(256) void k_adam_soft_tiled(AdamArgs a) {
+  __shared__ float s[8];
+  __shared__ double sq[4];
+  __shared__ int s_last;
+  __shared__ _Float16 sT[64][72];                         // [k][n] halves, 144-B rows (16-B aligned chunks)
+  adam_scalars(a, blockIdx.x, s);
+  if (s[7] == 0.0f) {
+    const float scale = s[4], step = s[5];
+    const bool soft = s[6] != 0.0f;
+    const int b = blockIdx.x;
+    if (b < a.n_tiles) {
+      int j = 0;
+      while (j + 1 < a.n_tseg && b >= a.tseg[j + 1].tile_base) ++j;
+      const AdamArgs::TileSeg& t = a.tseg[j];
+      const int tl = b - t.tile_base, tk_n = t.Kp >> 6;
+      const int n0 = (tl / tk_n) << 6, k0 = (tl % tk_n) << 6;
+      // 16 lanes cover one 256-B row segment, a wave 4 rows per instruction (whole lines); all 20 float4 loads
+      // of the thread's four rows are issued before the first use
+      const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+      const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2, tau = a.tau, omt = 1 - a.tau;
+      f32x4 g[4], m[4], v[4], w[4], wt[4];
+      size_t idx[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        idx[q] = (t.off + (size_t)(n0 + r0 + 16 * q) * t.Kp + k0) / 4 + c4;
+        g[q] = reinterpret_cast<const f32x4*>(a.g)[idx[q]]; m[q] = reinterpret_cast<const f32x4*>(a.m)[idx[q]];
+        v[q] = reinterpret_cast<const f32x4*>(a.v)[idx[q]]; w[q] = reinterpret_cast<const f32x4*>(a.w)[idx[q]];
+        wt[q] = reinterpret_cast<const f32x4*>(a.wt)[idx[q]];
+      }
+      typedef __attribute__((ext_vector_type(4))) _Float16 h16x4_t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float* gp = reinterpret_cast<float*>(&g[q]); float* mp = reinterpret_cast<float*>(&m[q]); float* vp = reinterpret_cast<float*>(&v[q]);
+        float* wp = reinterpret_cast<float*>(&w[q]); float* tp = reinterpret_cast<float*>(&wt[q]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gi = gp[e] * scale;
+          const float mi = fmaf(omb1, gi, a.beta1 * mp[e]);
+          const float vi = fmaf(omb2, gi * gi, a.beta2 * vp[e]);
+          const float upd = step * (mi / (sqrtf(vi) + a.eps));
+          const float wi = wp[e] - upd;
+          mp[e] = mi; vp[e] = vi; wp[e] = wi;
+          if (soft) tp[e] = fmaf(tau, wi, omt * tp[e]);
+          sT[c4 * 4 + e][r0 + 16 * q] = (_Float16)wi;
+        }
+        reinterpret_cast<f32x4*>(a.m)[idx[q]] = m[q]; reinterpret_cast<f32x4*>(a.v)[idx[q]] = v[q]; reinterpret_cast<f32x4*>(a.w)[idx[q]] = w[q];
+        if (soft) reinterpret_cast<f32x4*>(a.wt)[idx[q]] = wt[q];
+        reinterpret_cast<h16x4_t*>(a.w16)[idx[q]] = h16x4_t{(_Float16)wp[0], (_Float16)wp[1], (_Float16)wp[2], (_Float16)wp[3]};
+        if (soft) reinterpret_cast<h16x4_t*>(a.wt16)[idx[q]] = h16x4_t{(_Float16)tp[0], (_Float16)tp[1], (_Float16)tp[2], (_Float16)tp[3]};
+      }
+      __syncthreads();
+      typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+      const int kk = threadIdx.x >> 2, part = threadIdx.x & 3;   // one transposed row = 64 halves = 4 x 32 B
+      h8* dst = reinterpret_cast<h8*>(t.wT + (size_t)(k0 + kk) * t.ldT + n0 + part * 16);
+      dst[0] = *reinterpret_cast<const h8*>(&sT[kk][part * 16]);
+      dst[1] = *reinterpret_cast<const h8*>(&sT[kk][part * 16 + 8]);
+    } else {
+      const int fb = b - a.n_tiles, nfb = (int)gridDim.x - a.n_tiles;
+      for (int f = 0; f < a.n_fseg; ++f)
+        for (size_t i = (size_t)fb * 256 + threadIdx.x; i < a.fseg[f].n4; i += (size_t)nfb * 256) {
+          f32x4 w;
+          adam_elem4(a, a.fseg[f].off4 + i, scale, step, soft, w);
+        }
+    }
+  }
+  if (a.tick_ticket == nullptr) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    constexpr int kSub = 16;
+    const int G = (int)gridDim.x, sub = (int)blockIdx.x % kSub;
+    const int expect = (G + kSub - 1 - sub) / kSub;
+    int* c = a.tick_ticket + sub * 32;
+    int last = 0;
+    if (__hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1) {
+      *c = 0;
+      int* top = a.tick_ticket + kSub * 32;
+      const int groups = G < kSub ? G : kSub;
+      if (__hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) { *top = 0; last = 1; }
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last) tick_body(a.tick, s, sq);
+}
 __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   __shared__ float s[8];
   __shared__ double sq[4];
