@@ -454,7 +454,8 @@ int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
   // row chunks: enough blocks to cover the chip a few times over, <= 64 rows per chunk
   const int RC = std::max(1, std::min(16, a.rows / 64));   // (64 chunks measured slower at B=4096: the last arriver's slab walk)
   const int rows_c = (a.rows + RC - 1) / RC;
-  const size_t lds = ((size_t)rows_c * NH + 16 * NH * 64 + 16) * sizeof(float);
+  size_t lds = ((size_t)rows_c * NH + 16 * NH * 64 + 16) * sizeof(float);
+  if (a.dZT16 != nullptr) lds += (size_t)64 * (rows_c + 8) * sizeof(h16);
   a.slab = h->head_slab; a.ticket = h->head_ticket;
   int ry = 0;                                               // extra grid rows for the q rider (16 rows per block)
   if (a.q_out != nullptr) { a.rc_blocks = RC; ry = ((a.rows + 15) / 16 + a.H / 64 - 1) / (a.H / 64); }
@@ -717,7 +718,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L]; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
       if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->dZT16[1][L], h->ls_c)); }
-      else { RC(head_backward<1>(h, st, a)); RC(head_grad16(h, st, 1, h->dZc[L], B, h->ls_c, true)); }
+      else { a.dZ16 = h->dZ16[1][L]; a.dZT16 = h->dZT16[1][L]; a.ldT = B; a.scale16 = h->ls_c; RC(head_backward<1>(h, st, a)); }
     }
     RC(tower_backward16(h, st, DQNHIP_CRITIC, 3, h->g[1], nullptr, B, true, false, h->ls_c));
     if (dp) {
@@ -742,7 +743,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
       if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], nullptr, h->ls_q)); }
-      else { RC(head_backward<1>(h, st, a)); RC(head_grad16(h, st, 1, h->dZc[L], B, h->ls_q, false)); }
+      else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_q; RC(head_backward<1>(h, st, a)); }
     }
     RC(tower_backward16(h, st, DQNHIP_CRITIC, 4, nullptr, h->dZc[0], B, false, true, h->ls_q));
     {
@@ -750,7 +751,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.X4 = h->act[1][L]; a.H = Hh; a.rows = B; a.dZ = h->dZa[L];
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
       if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->dZT16[0][L], h->ls_a)); }
-      else { RC(head_backward<kNO>(h, st, a)); RC(head_grad16(h, st, 0, h->dZa[L], B, h->ls_a, true)); }
+      else { a.dZ16 = h->dZ16[0][L]; a.dZT16 = h->dZT16[0][L]; a.ldT = B; a.scale16 = h->ls_a; RC(head_backward<kNO>(h, st, a)); }
     }
     RC(tower_backward16(h, st, DQNHIP_ACTOR, 1, h->g[0], nullptr, B, true, false, h->ls_a));
     if (dp) {

@@ -383,6 +383,9 @@ struct HeadBwdArgs {
   // two used to be separate dependent launches for no reason.
   int rc_blocks;                       // row chunks of the backward part (0: gridDim.y)
   const float* q_bias; float* q_out; double* qsum_partial;
+  // fp16 learner: also emit the tower-top gradient as the scaled fp16 panel(s) the fp16 GEMMs read —
+  // dZ16 [rows][H] and (wgrad operand) dZT16 [H][ldT] — instead of a separate conversion launch
+  _Float16* dZ16; _Float16* dZT16; int ldT; float scale16;
 };
 // Grid = (H/64 column blocks) x (RC row chunks); block = 64 columns x 16 row groups.  Each block
 // writes its dZ rows directly and a partial dW slab; the LAST block to arrive for a column block
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   const int r0 = rc * rows_c, r1 = min(a.rows, r0 + rows_c);
   float* s_dy = sm;                                    // [rows_c][NH]
   float* s_acc = sm + rows_c * NH;                     // [16][NH][64]
+  _Float16* s_t = reinterpret_cast<_Float16*>(s_acc + 16 * NH * 64 + 16);   // fp16 mode: [64][rows_c + 8] halves
   __shared__ int s_last;
   const int tid = threadIdx.x;
   const bool want_w = a.dW != nullptr;
@@ -455,7 +459,23 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
       acc[j] = fmaf(d, xv, acc[j]);
     }
     if (NH == kNO) s0 += s1;
-    a.dZ[(size_t)m * a.H + k] = s0 * lrelu_mask(xv);
+    const float dz = s0 * lrelu_mask(xv);
+    a.dZ[(size_t)m * a.H + k] = dz;
+    if (a.dZ16 != nullptr) {
+      const _Float16 hz = (_Float16)(dz * a.scale16);
+      a.dZ16[(size_t)m * a.H + k] = hz;
+      if (a.dZT16 != nullptr) s_t[kc * (rows_c + 8) + (m - r0)] = hz;
+    }
+  }
+  if (a.dZT16 != nullptr) {                             // [64 columns][rows of this chunk] -> 16-B pieces of the transposed panel
+    __syncthreads();
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    const int per_row = (r1 - r0) >> 3;                 // rows_c is a multiple of 8 (minibatch % 128 == 0 in fp16 mode)
+    for (int q = tid; q < 64 * per_row; q += 1024) {
+      const int col = q / per_row, c8 = q % per_row;
+      *reinterpret_cast<h8*>(a.dZT16 + (size_t)(blockIdx.x * 64 + col) * a.ldT + r0 + c8 * 8) =
+          *reinterpret_cast<const h8*>(s_t + col * (rows_c + 8) + c8 * 8);
+    }
   }
   if (!want_w) return;
 #pragma unroll
