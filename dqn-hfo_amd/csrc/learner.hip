@@ -1426,7 +1426,9 @@ int dqnhip_dp_init(dqnhip_handle h, const void* id, size_t bytes, int32_t flags)
   HIPCHK(hipStreamSynchronize(h->stream));
   ncclUniqueId uid; memcpy(&uid, id, sizeof uid);
   NCCLCHK(ncclCommInitRank(&h->comm, h->cfg.dp_world, uid, h->cfg.dp_rank));
-  h->dp_per_layer = (flags & DQNHIP_DP_PER_LAYER) != 0;
+  // per-layer buckets need each layer's dW AND db final when its wgrad launch has run: true for the fp32 path on
+  // one stream; the fp16 path writes all bias gradients at the end (k_db16) and keeps one collective per net
+  h->dp_per_layer = (flags & DQNHIP_DP_PER_LAYER) != 0 && !h->fp16 && h->aux == nullptr;
   HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
   for (auto& e : h->comm_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   drop_graphs_fwd(h);

@@ -173,7 +173,8 @@ int dqnhip_grad_buffer(dqnhip_handle h, int32_t net, void** dptr, size_t* nfloat
  *                         history and iterations are broadcast so the replicas start identical
  *   dqnhip_dp_init_file   the same with a file as the rendezvous (one node, no launcher support)
  * flags: DQNHIP_DP_PER_LAYER buckets each all-reduce per tower layer on a communication stream,
- * started as soon as that layer's wgrad has run (backward order), head + tail last. */
+ * started as soon as that layer's wgrad has run (backward order), head + tail last (fp32 learner only; the
+ * fp16 learner keeps one collective per net). */
 #define DQNHIP_DP_ID_BYTES 128
 #define DQNHIP_DP_PER_LAYER 1
 int dqnhip_dp_unique_id(void* id_out, size_t bytes);
