@@ -109,6 +109,39 @@ def test_hip_dp2_matches_single_learner_and_oracle(pkg, gpu, shape):
     orc.close()
 
 
+def test_two_agents_with_a_two_rank_group_each(pkg, gpu):
+    """BASELINE.json configs[3]'s layout (2v1: S = 77; two agents, each a 2-rank data-parallel group with its own
+    replay shards) with all four learners on one GPU: the groups exchange nothing with each other (the reference's
+    agents are independent DQNs, src/dqn_main.cpp:264), each group's ranks stay bit-identical and each group
+    reproduces ITS single learner on the concatenated minibatch."""
+    Bl, S, hid = 32, 77, (128, 64, 64)
+    groups = [_group(pkg, Bl, S, hid, 5.0, "fp32", seed=3 + 10 * a) for a in range(2)]
+    for it in range(3):
+        for a, (ranks, one, orc, rng) in enumerate(groups):
+            idx_local = [rng.integers(0, N_SHARD, size=Bl) for _ in ranks]
+            idx_global = np.concatenate([i + r * N_SHARD for r, i in enumerate(idx_local)])
+            one.update_phase(0, idx_global); gc_one = one.get_params(1, pkg.KIND_G)
+            one.update_phase(1); ga_one = one.get_params(0, pkg.KIND_G)
+            one.update_phase(2)
+            # interleave the two agents' phases on the device: agent 0 phase p, agent 1 phase p, ... is what two
+            # agent threads produce; here agent a runs to completion per iteration, the other agent's learners
+            # sit between its collectives with their own gradient arenas
+            g_c, g_a = _dp_step(pkg, ranks, idx_local)
+            np.testing.assert_array_equal(g_c[0], g_c[1]); np.testing.assert_array_equal(g_a[0], g_a[1])
+            assert _fro(g_c[0], gc_one) <= 1e-5 and _fro(g_a[0], ga_one) <= 1e-5
+            assert ranks[0].read_stats() == ranks[1].read_stats()
+    # different agents, different weights (different seeds): nothing leaked across the groups
+    assert not np.array_equal(groups[0][0][0].get_params(0), groups[1][0][0].get_params(0))
+    for ranks, one, orc, rng in groups:
+        for net in range(4):
+            np.testing.assert_array_equal(ranks[0].get_params(net), ranks[1].get_params(net))
+            d = np.abs(ranks[0].get_params(net) - one.get_params(net))
+            assert d.mean() <= 1e-7, (net, d.mean())
+        for d in ranks + [one]:
+            d.close()
+        orc.close()
+
+
 def test_hip_dp2_fp16_ranks_bit_identical(pkg, gpu):
     """Mixed-precision learner under data parallelism: the loss scale uses the GLOBAL batch; both
     ranks hold the same bits after every update and track one fp16 learner on the concatenation."""
