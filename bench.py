@@ -192,6 +192,20 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
             out["configs4_1gpu_b4096_%s" % prec] = {"ms_per_update": round(dt * 1e3, 4), "updates_per_s": round(1 / dt, 1),
                                                     "samples_per_s": round(GB / dt), "update_mfma_frac": round(fl / dt / 1e12 / peak, 4)}
             d.read_stats(); d.close()
+        # two independent agents (learners) on this one GPU, each on its own stream with its own captured update —
+        # how the reference packs a multi-agent team onto one device (one DQN per agent thread, src/dqn_main.cpp:62, 264)
+        agents = [pkg.DQN(S, minibatch=B, hidden=HIDDEN, memory=100000, seed=11 + i, device=local_rank, use_graph=True) for i in range(2)]
+        for i, d in enumerate(agents):
+            prefill(d, 60000, seed=21 + i)
+
+        def both():
+            for d in agents:
+                d.update_async(None)
+        dt = timed(both, torch.cuda.synchronize, 500, 50)
+        out["two_agents_one_gpu_b256_fp32"] = {"aggregate_updates_per_s": round(2 / dt, 1), "per_agent_updates_per_s": round(1 / dt, 1),
+                                               "note": "independent streams overlap each other's launch floors"}
+        for d in agents:
+            d.read_stats(); d.close()
         # configs[2]: 1v1 (S = 68), 64 parallel workers feeding one replay buffer
         d = pkg.DQN(68, minibatch=B, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, use_graph=True)
         env = pkg.EnvFrontEnd(d, 64, max_steps=500, p_end=0.01, seed=5)
