@@ -134,6 +134,8 @@ __global__ void k_env_step(EnvDev e) {
   const int w = blockIdx.x, lane = threadIdx.x;
   const int len = e.len[w];
   const unsigned long long g = e.g[w];
+  GameState gs;                                      // fetched now, used at the end: its latency hides behind the heads
+  if (lane == 0) gs = e.game[w];
   // SelectAction(state, epsilon): ONE epsilon draw per call (src/dqn.cpp:700)
   const bool rnd = env_u01(e.seed, g, w, 0) < epsilon;
   if (e.head_x != nullptr) {
@@ -203,7 +205,6 @@ __global__ void k_env_step(EnvDev e) {
     if (env_u01(e.seed, g, w, 11) < e.p_end) status = env_u01(e.seed, g, w, 12) < e.p_goal ? 1 : 2;   // GOAL / CAPTURED_BY_DEFENSE
     if (status == 0 && len + 1 >= e.T) status = 4;                                                   // OUT_OF_TIME
     const int pob = env_u01(e.seed, g, w, 13) < 0.5f ? e.unum : -1;
-    GameState gs = e.game[w];
     game_update(gs, s_next, status, pob);
     int goal = 0;
     const float r = game_reward(gs, e.unum, &goal);
@@ -294,6 +295,22 @@ __device__ __forceinline__ void env_flush_worker(const EnvDev& e, const Ring& ri
       for (; i >= 0; --i) { target = (float)((double)sm[i] + gamma * (double)target); sm[i] = target; }
       e.n_episodes[w] += 1;
     }
+    // new episode for this worker (env_reset_worker's steps), also beside the copies: the episode buffers the
+    // other waves are reading are not touched (cur / game / len / g only)
+    {
+      float* s_state = sm + e.T;
+      const unsigned long long g = e.g[w];
+      for (int f = lane; f < e.SP; f += 64) {
+        const float v = f < e.S ? env_feature(e, g, w, f) : 0.0f;
+        s_state[f] = v; e.cur[(size_t)w * e.SP + f] = v;
+      }
+      __builtin_amdgcn_wave_barrier();                     // one wave wrote s_state; its lane 0 reads it (LDS ops of a wave are in order)
+      if (lane == 0) {
+        GameState gs; game_reset(gs);
+        game_update(gs, s_state, 0, 0);
+        e.game[w] = gs; e.len[w] = 0; e.g[w] = g + 1;
+      }
+    }
   } else {
     // 192 threads copy the episode as float4s (RSP/4 = 16 or 32 per row: shifts, no division); the ring slot
     // needs one conditional subtraction (start < cap, t < len < cap) instead of a 64-bit modulo per element;
@@ -331,22 +348,6 @@ __device__ __forceinline__ void env_flush_worker(const EnvDev& e, const Ring& ri
     long long slot = (long long)start + t;
     if (slot >= ring.cap) slot -= ring.cap;
     ring.mc[slot] = sm[t];
-  }
-  __syncthreads();
-  // new episode for this worker (same steps as env_reset_worker, 256 threads wide)
-  {
-    float* s_state = sm + e.T;
-    const unsigned long long g = e.g[w];
-    for (int f = threadIdx.x; f < e.SP; f += 256) {
-      const float v = f < e.S ? env_feature(e, g, w, f) : 0.0f;
-      s_state[f] = v; e.cur[(size_t)w * e.SP + f] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      GameState gs; game_reset(gs);
-      game_update(gs, s_state, 0, 0);
-      e.game[w] = gs; e.len[w] = 0; e.g[w] = g + 1;
-    }
   }
 }
 
