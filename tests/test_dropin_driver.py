@@ -132,3 +132,14 @@ def test_unchanged_driver_trains_on_the_gpu(pkg, gpu, tmp_path):
     r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
     log2 = r2.stderr + "".join(open(f).read() for f in glob.glob(save + "_INFO_*"))
     assert r2.returncode == 0 and "Found Resumable(s): [" in log2 and "_actor_iter_%d.solverstate" % it in log2
+    # the driver's other branches on the resumed state: -learn_offline (updates on the loaded replay memory only,
+    # src/dqn_main.cpp:340-348), -evaluate (:325-331), -benchmark (DQN::Benchmark, :332-339)
+    r3 = subprocess.run(cmd[:cmd.index("-max_iter")] + ["-max_iter", str(it + 40), "-learn_offline"] + cmd[cmd.index("-max_iter") + 2:],
+                        capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    assert any(("_actor_iter_%d.solverstate" % (it + 40)) in f for f in os.listdir(str(tmp_path)))
+    r4 = subprocess.run(cmd + ["-evaluate"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r4.returncode == 0 and "Evaluation: actor_iter = %d" % (it + 40) in r4.stderr, r4.stderr[-2000:]
+    r5 = subprocess.run(cmd + ["-benchmark", "-minibatch", "256"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    log5 = r5.stderr + "".join(open(f).read() for f in glob.glob(save + "_INFO_*"))
+    assert r5.returncode == 0 and "*** Benchmark begins ***" in log5 and "Average Update: " in log5, log5[-2000:]
