@@ -2,8 +2,13 @@
 import csv, sys
 f, n_upd, title, cmd = sys.argv[1], float(sys.argv[2]), sys.argv[3], sys.argv[4]
 rows = list(csv.DictReader(open(f)))
+if n_upd <= 0:      # derive the number of updates (or env steps) in the trace from a once-or-twice-per-unit kernel
+    calls = {r["Name"]: int(r["Calls"]) for r in rows}
+    adam = sum(v for k, v in calls.items() if "k_adam_soft" in k)
+    env = sum(v for k, v in calls.items() if "k_env_step" in k)
+    n_upd = adam / 2.0 if adam else float(env)
 print("# %s\n" % title)
-print("Command: `%s` (MI355X, via gpurun).  %d updates in the trace (warm-up + timed + the 20-update event-timing pass).\n" % (cmd, n_upd))
+print("Command: `%s` (MI355X, via gpurun).  %d updates (env probe: batched steps) in the trace (pre-warm + warm-up + timed + the 20-update event-timing pass; counted from the optimiser / env-step launches).\n" % (cmd, n_upd))
 print("| kernel | calls | calls/update | avg (us) | us/update | % |")
 print("|---|---|---|---|---|---|")
 tot = 0.0
