@@ -458,6 +458,7 @@ struct ChainArgs {
   int L, rows, width;
   int* counters;                                               // [L][rows/32], monotone: target = 32 * epoch
   int epoch, map;
+  int wt;                                                      // 1: sc1 write-through tile stores, no release fence (guide G16 R1)
   int* err;
 };
 
@@ -489,13 +490,16 @@ __global__ __launch_bounds__(256) void k_fwd_chain(ChainArgs a) {
     GemmProblem pr{};
     pr.P = a.W[l]; pr.ldp = a.width; pr.Q = a.act[l]; pr.ldq = a.width; pr.C = a.act[l + 1]; pr.ldc = a.width;
     pr.Pdim = a.width; pr.Qdim = a.rows; pr.Kred = a.width; pr.bias = a.bias[l]; pr.relu = 1;
-    fwd_lds_body<2, 2, true>(pr, tile_p, tile_q, smem);
+    if (a.wt) fwd_lds_body<2, 2, true, 2, true>(pr, tile_p, tile_q, smem);
+    else fwd_lds_body<2, 2, true>(pr, tile_p, tile_q, smem);
     if (l + 1 < a.L) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its stores
       __syncthreads();
       if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!a.wt) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __hip_atomic_fetch_add(a.counters + l * slabs + tile_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -505,10 +509,12 @@ __global__ __launch_bounds__(256) void k_fwd_chain(ChainArgs a) {
 
 extern "C" int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, float* us_launches, float* us_persistent,
                                  float* max_abs_diff, int32_t* gave_up) {
+  // map bit 0: tile -> XCD map (0 learner's, 1 slab per XCD); bit 1: write-through (sc1) hand-off without a release fence
+  const int wt = (map >> 1) & 1; map &= 1;
   if (layers < 1 || layers > 8 || iters < 1) return 1;
   const int rows = 256, width = 1024;
   hipStream_t s; CK(hipStreamCreate(&s));
-  ChainArgs a{}; a.L = layers; a.rows = rows; a.width = width; a.map = map;
+  ChainArgs a{}; a.L = layers; a.rows = rows; a.width = width; a.map = map; a.wt = wt;
   float* ref[9];
   for (int l = 0; l < layers; ++l) {
     float *w, *b;

@@ -515,7 +515,9 @@ __device__ __forceinline__ void wgrad_narrow_body(const GemmProblem& pr, int til
 // The LDS image is private to the wave (no barrier anywhere in the main loop); two images
 // ping-pong, global loads run two 32-k steps ahead in registers.
 // Requires Kred % 256 == 0 and Kred >= 512 (>= 4 steps of 32 k per wave, even count).
-template <int TP, int TQ, bool PIN, int NSLOT = 2>
+// WT (probe only, csrc/gemm_bench.hip): the output tile is stored write-through (`sc1`), the producer side of an
+// in-launch hand-off without a release fence (guide G16 R1).  The learner instantiates WT = false.
+template <int TP, int TQ, bool PIN, int NSLOT = 2, bool WT = false>
 __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
   constexpr int NB = TP + TQ;
   constexpr int NACC = TP * TQ;
@@ -648,7 +650,13 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
       }
       if (pr.relu) { v.x = lrelu_fwd(v.x); v.y = lrelu_fwd(v.y); v.z = lrelu_fwd(v.z); v.w = lrelu_fwd(v.w); }
-      *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
+      if constexpr (WT) {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, pr.Qdim * pr.ldc * 4, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)(((size_t)q * pr.ldc + p) * 4), 0, 16 /* sc1 */);
+      } else {
+        *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
+      }
     }
   }
 }

@@ -9,7 +9,7 @@ fn.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.POINTER(C.c_float)] * 3 + [
 print("layers map  us(launches)  us(persistent)  per-layer: launches / persistent   max|diff|  gave_up")
 for rep in range(2):
     for layers in (1, 2, 4, 8):
-        for mp in (0, 1):
+        for mp in (0, 1, 2, 3):        # bit 0: slab per XCD, bit 1: sc1 write-through hand-off (no release fence)
             a, b, d = C.c_float(), C.c_float(), C.c_float(); g = C.c_int32()
             rc = fn(layers, mp, 200, C.byref(a), C.byref(b), C.byref(d), C.byref(g))
             print("%4d %4d %12.2f %14.2f %14.2f / %.2f %14.3g %6d  rc=%d" % (layers, mp, a.value, b.value, a.value / layers, b.value / layers, d.value, g.value, rc), flush=True)
