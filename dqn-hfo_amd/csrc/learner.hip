@@ -733,7 +733,9 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     RC(adam_launch(h, st, 1, h->part_dp, h->n_part_dp, 0, lc.arena));
     RC(sync_w16(h, st, DQNHIP_CRITIC, true));          // the Adam pass wrote the fp16 mirrors of critic and target
     RC(tower_forward16(h, st, 4, DQNHIP_CRITIC, B));
-    {
+    static const bool kQRider16 = !getenv("DQNHIP_SEPARATE_QHEAD");
+    const bool q_sep16 = head_big_ok(h, B, Hc) || !kQRider16;     // small minibatches: q(s, mu(s)) rides in the dq = -1 head launch, as on the fp32 path
+    if (q_sep16) {
       HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
       a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.b = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q = h->q2;
       a.qsum_partial = h->q_partial;
@@ -742,6 +744,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     {
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
+      if (!q_sep16) { a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial; }
       if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], nullptr, h->ls_q)); }
       else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_q; RC(head_backward<1>(h, st, a)); }
     }
