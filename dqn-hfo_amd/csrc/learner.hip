@@ -679,11 +679,19 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
                        (const DevState*)h->st, idx_dev, sample_key(h), go, B);
     HIPCHK(hipGetLastError());
+    // the state parts of the two critic panels whose action columns the actor heads fill (still zero here) are
+    // converted in the same launch; the heads then write mu / mu' straight into the fp16 panels as well
+    static const bool kHeads16 = !getenv("DQNHIP_SEPARATE_CVT2");
+    const bool heads16 = kHeads16 && !split;
     {
       Cvt16Batch b{};
       cvt16_add(b, h->Xa_n, la.kp[0], B, la.kp[0], h->act16[0][0], h->k16[0][0], nullptr, B, 1.0f);
       cvt16_add(b, h->Xa_s, la.kp[0], B, la.kp[0], h->act16[1][0], h->k16[0][0], h->actT16[1][0], B, 1.0f);
       cvt16_add(b, h->Xc_tr, lc.kp[0], B, lc.kp[0], h->act16[3][0], h->k16[1][0], h->actT16[3][0], B, 1.0f);
+      if (heads16) {
+        cvt16_add(b, h->Xc_nx, lc.kp[0], B, lc.kp[0], h->act16[2][0], h->k16[1][0], nullptr, B, 1.0f);
+        cvt16_add(b, h->Xc_pl, lc.kp[0], B, lc.kp[0], h->act16[4][0], h->k16[1][0], nullptr, B, 1.0f);
+      }
       HIPCHK(cvt16_launch(b, st));
     }
     if (split) RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B));
@@ -694,9 +702,10 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
     hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
+    if (heads16) { hAT.xc16 = h->act16[2][0]; hAT.ldxc16 = h->k16[1][0]; hA.xc16 = h->act16[4][0]; hA.ldxc16 = h->k16[1][0]; }
     if (split) RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT)));
     else RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));
-    {
+    if (!heads16) {
       Cvt16Batch b{};
       cvt16_add(b, h->Xc_nx, lc.kp[0], B, lc.kp[0], h->act16[2][0], h->k16[1][0], nullptr, B, 1.0f);
       if (!split) cvt16_add(b, h->Xc_pl, lc.kp[0], B, lc.kp[0], h->act16[4][0], h->k16[1][0], nullptr, B, 1.0f);

@@ -195,6 +195,7 @@ struct HeadArgs {
   // HEAD_ACTOR
   float* out16;                        // [rows][16]
   float* xc; int ldxc; int xc_col;     // also written into a critic input panel (may be null)
+  _Float16* xc16; int ldxc16;          // fp16 learner: and into that panel's fp16 copy (may be null)
   // HEAD_Q*
   float* q;                            // [rows]
   // HEAD_Q_TRAIN: TD target + Euclidean loss
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
       if constexpr (MODE == HEAD_ACTOR) {
         a.out16[(size_t)row * kAP + j] = v;
         if (a.xc != nullptr && j < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + j] = v;
+        if (a.xc16 != nullptr && j < NH) a.xc16[(size_t)row * a.ldxc16 + a.xc_col + j] = (_Float16)v;
       } else {
         if (j == 0) {
           a.q[row] = v;
@@ -303,6 +305,7 @@ __global__ __launch_bounds__(256) void k_head_fwd_rows(HeadArgs2 a2) {
       if constexpr (MODE == HEAD_ACTOR) {
         a.out16[(size_t)row * kAP + lane] = v;
         if (a.xc != nullptr && lane < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + lane] = v;
+        if (a.xc16 != nullptr && lane < NH) a.xc16[(size_t)row * a.ldxc16 + a.xc_col + lane] = (_Float16)v;
       } else {
         if (lane == 0) {
           a.q[row] = v;
