@@ -527,12 +527,12 @@ int sumsq_launch(H* h, int net);
 
 // ---- mixed-precision building blocks (hgemm.hip.h) --------------------------------------------
 
-int hgemm_timed(H* h, hipStream_t st, const HGemm* gs, int n, int fam) {
+int hgemm_timed(H* h, hipStream_t st, const HGemm* gs, int n, int fam, int force = 0) {
   ScopedTiming t(h, fam, st);
   LaunchTimer& lt = launch_timer();
   hipEvent_t a = lt.start, b = lt.stop;
   lt.start = lt.stop = nullptr;
-  HIPCHK(hgemm_launch_batch(gs, n, st, 0, a, b));
+  HIPCHK(hgemm_launch_batch(gs, n, st, force, a, b));
   return 0;
 }
 int hgemm_timed(H* h, hipStream_t st, const HGemm& g, int fam) { return hgemm_timed(h, st, &g, 1, fam); }
@@ -622,7 +622,7 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
     // 64x64 split-K tile) they share one launch
     if (need_dx && want_w && kHgemmPairs && hgemm_uses_small_tile(gd) && hgemm_uses_small_tile(gw) && gd.K % 128 == 0 && gw.K % 128 == 0) {
       const HGemm gs[2] = {gd, gw};
-      RC(hgemm_timed(h, st, gs, 2, 8));
+      RC(hgemm_timed(h, st, gs, 2, 8, 2));      // both on the 64x64 tile, as each would be alone
     } else {
       if (need_dx) RC(hgemm_timed(h, st, gd, 8));
       if (want_w) RC(hgemm_timed(h, st, gw, 9));
@@ -1456,6 +1456,9 @@ int dqnhip_dp_init_file(dqnhip_handle h, const char* path, int32_t flags, int32_
   ncclUniqueId uid;
   const std::string p(path), tmp = p + ".tmp";
   if (h->cfg.dp_rank == 0) {
+    // a file left over from an earlier job would hand the other ranks a dead id (they would sit in
+    // ncclCommInitRank until its time-out): refuse to start over it
+    if (FILE* old = fopen(p.c_str(), "rb")) { fclose(old); return fail("dp_init_file: %s already exists (left over from an earlier job?): remove it or use a fresh path", path); }
     RC(dqnhip_dp_unique_id(&uid, sizeof uid));
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f || fwrite(&uid, sizeof uid, 1, f) != 1) { if (f) fclose(f); return fail("dp_init_file: cannot write %s", tmp.c_str()); }

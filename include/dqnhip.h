@@ -171,7 +171,8 @@ int dqnhip_grad_buffer(dqnhip_handle h, int32_t net, void** dptr, size_t* nfloat
  *   dqnhip_dp_unique_id   rank 0 creates the RCCL id (DQNHIP_DP_ID_BYTES); the launcher ships it
  *   dqnhip_dp_init        every rank: ncclCommInitRank, then rank 0's weights (4 nets), Adam
  *                         history and iterations are broadcast so the replicas start identical
- *   dqnhip_dp_init_file   the same with a file as the rendezvous (one node, no launcher support)
+ *   dqnhip_dp_init_file   the same with a file as the rendezvous (one node, no launcher support); the path must
+ *                         not exist beforehand (rank 0 refuses a leftover file) and is the caller's to remove
  * flags: DQNHIP_DP_PER_LAYER buckets each all-reduce per tower layer on a communication stream,
  * started as soon as that layer's wgrad has run (backward order), head + tail last (fp32 learner only; the
  * fp16 learner keeps one collective per net). */

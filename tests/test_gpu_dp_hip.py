@@ -251,3 +251,7 @@ def test_native_rccl_file_rendezvous(pkg, gpu, tmp_path):
     d.dp_update(np.arange(32))
     assert all(np.isfinite(d.read_stats()))
     d.close()
+    d2 = pkg.DQN(59, minibatch=32, hidden=(64,), memory=2048, dp_world=1, dp_rank=0)
+    with pytest.raises(pkg.DQNFatal, match="already exists"):
+        d2.dp_init_file(str(tmp_path / "rccl_id"), timeout_s=5)       # a leftover file is refused, not reused
+    d2.close()
