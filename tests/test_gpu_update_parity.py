@@ -18,7 +18,7 @@ def _fro(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def _check_grads(dqn, orc, net, ref64=None):
+def _check_grads(dqn, orc, net, ref64=None, c_tol=1e-5):
     """Raw gradients (before clip/Adam).
 
     Two fp32 implementations with different summation orders can disagree on the sign of a
@@ -29,14 +29,12 @@ def _check_grads(dqn, orc, net, ref64=None):
     where no flip occurs (the small shapes, deterministic), tight against the float64 autograd
     restatement at the BASELINE shape, and a loose 5e-3 bound against the C oracle there."""
     g1, g2 = dqn.get_params(net, 3), orc.grad_view(net).copy()
-    if ref64 is None:
-        assert _fro(g1, g2) <= 1e-5, (net, _fro(g1, g2))
-    else:
+    if ref64 is not None:
         assert _fro(g1, ref64) <= 1e-5, (net, _fro(g1, ref64))
-        assert _fro(g1, g2) <= 5e-3, (net, _fro(g1, g2))
+    assert _fro(g1, g2) <= c_tol, (net, _fro(g1, g2))
 
 
-def _check_update(dqn, orc, idx, t64=None, data=None):
+def _check_update(dqn, orc, idx, t64=None, data=None, c_tol=1e-5):
     """One update, phase by phase (the phases are where gradients are complete)."""
     g64 = [None, None]
     if t64 is not None:
@@ -44,9 +42,9 @@ def _check_update(dqn, orc, idx, t64=None, data=None):
         t64.update(s[idx], a[idx], r[idx], mc[idx], nx[idx], term[idx])
         g64 = [t64.g[0].numpy(), t64.g[1].numpy()]
     dqn.update_phase(0, idx); orc.update_phase(0, idx)
-    _check_grads(dqn, orc, 1, g64[1])               # critic dW/db of Step(1)
+    _check_grads(dqn, orc, 1, g64[1], c_tol)        # critic dW/db of Step(1)
     dqn.update_phase(1); orc.update_phase(1, idx)
-    _check_grads(dqn, orc, 0, g64[0])               # actor dW/db
+    _check_grads(dqn, orc, 0, g64[0], c_tol)        # actor dW/db
     dqn.update_phase(2); orc.update_phase(2, idx)
     l1, q1 = dqn.read_stats()
     l2, q2 = orc.last_stats()
@@ -63,14 +61,20 @@ def _check_update(dqn, orc, idx, t64=None, data=None):
     if t64 is not None:
         for name in ("q_target", "y", "q_train", "q_policy"):
             np.testing.assert_allclose(dqn.debug_read(name), t64.dbg[name].numpy(), rtol=QRTOL, atol=QTOL, err_msg=name)
+        # against float64 the per-row quantities are TIGHT (no shared fp32 rounding to flip a ReLU the same way twice):
+        # mu(s) to 1e-5 of its scale, the post-invert dQ/da to 1e-4 of its scale per element
+        for name, tol in (("actor_out", 1e-5), ("dq_da", 1e-4)):
+            ref = t64.dbg[name].numpy()
+            err = np.abs(dqn.debug_read(name) - ref).max()
+            assert err <= tol * max(np.abs(ref).max(), 1e-30), (name, err, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("shape", [
-    dict(B=32, S=59, hidden=(1024, 512, 256, 128)),        # reference defaults (src/dqn.hpp:19, dqn.cpp:425)
-    dict(B=32, S=68, hidden=(128, 64, 64, 64)),            # 1v1 state size, small tower
-    dict(B=64, S=77, hidden=(256, 128), ),                 # 2v1 state size, 2-layer tower
+    dict(B=32, S=59, hidden=(1024, 512, 256, 128), f64=True),   # reference defaults (src/dqn.hpp:19, dqn.cpp:425)
+    dict(B=32, S=68, hidden=(128, 64, 64, 64), f64=True),  # 1v1 state size, small tower
+    dict(B=64, S=77, hidden=(256, 128), f64=True),         # 2v1 state size, 2-layer tower
     dict(B=1024, S=58, hidden=(256, 256), wscale=3.0),     # large minibatch: the bandwidth-tiled head kernels
-    dict(B=96, S=61, hidden=(192, 320, 64), wscale=5.0),   # ragged: no dimension a multiple of 128, 3 layers
+    dict(B=96, S=61, hidden=(192, 320, 64), wscale=5.0, f64=True),   # ragged: no dimension a multiple of 128, 3 layers
     dict(B=32, S=120, hidden=(64,), wscale=5.0),           # one hidden layer, 130-wide critic input (3 K panels)
     dict(B=64, S=59, hidden=(128, 64, 64, 128, 64, 64), wscale=8.0),   # six layers
     dict(B=32, S=58, hidden=(2048, 1536), wscale=2.0),     # wider than the 1024-column head strips
@@ -84,6 +88,8 @@ def test_update_matches_oracle(pkg, gpu, shape):
     shape = dict(shape)
     shape.setdefault("wscale", 5.0)
     use64 = shape.pop("f64", False)
+    big = shape["hidden"][0] >= 1024 and len(shape["hidden"]) == 4 and shape["hidden"][-1] >= 1024     # the BASELINE shape
+    c_tol = 5e-3 if big else 1e-5             # C oracle: loose only where its own ReLU flips relative to float64 were measured
     dqn, orc, data, rng = make_pair(pkg, n_replay=2048, **shape)
     B = shape["B"]
     t64 = None
@@ -95,16 +101,17 @@ def test_update_matches_oracle(pkg, gpu, shape):
     n_it = 3 if use64 else 4
     for it in range(n_it):
         idx = rng.integers(0, 2048, size=B)
-        _check_update(dqn, orc, idx, t64, data)
+        _check_update(dqn, orc, idx, t64, data, c_tol)
     # Adam's normalised step m/(sqrt(v)+eps) is O(1) whatever |g| is, so an element whose gradient
     # is at fp32-roundoff level may legitimately move differently by up to lr per update; on
     # average the parameters must agree to 1% of a step.
     lr = {0: 1e-5, 1: 1e-3, 2: 1e-5 * 1e-3, 3: 1e-3 * 1e-3}
     for net in range(4):
-        ref = t64.get_params(net) if use64 else orc.get_params(net)
-        d = np.abs(dqn.get_params(net) - ref)
-        assert d.max() <= n_it * lr[net] + 1e-6, (net, d.max())
-        assert d.mean() <= 0.01 * lr[net] + 1e-8, (net, d.mean())
+        refs = ([t64.get_params(net)] if use64 else []) + ([] if big else [orc.get_params(net)])
+        for ref in refs:
+            d = np.abs(dqn.get_params(net) - ref)
+            assert d.max() <= n_it * lr[net] + 1e-6, (net, d.max())
+            assert d.mean() <= 0.01 * lr[net] + 1e-8, (net, d.mean())
     for kind in (1, 2):   # Adam m, v
         for net in (0, 1):
             a, b = dqn.get_params(net, kind), (t64 if use64 else orc).get_params(net, kind)
