@@ -190,8 +190,8 @@ def test_fp16_update_tracks_fp32_oracle(pkg, gpu, use_graph):
 def test_fp16_config5_shape_vs_float64(pkg, gpu):
     """BASELINE.json configs[4] on its own shape (minibatch 4096, 4x1024, S=58): one update of the fp16
     learner against the float64 autograd restatement — loose by construction (an fp16 forward moves
-    pre-activations by ~1e-3 and flips ReLU' of the units nearest zero), but every Q within 2 %, the
-    gradients within a few % Frobenius, nothing overflowed."""
+    pre-activations by ~1e-3 and flips ReLU' of the units nearest zero), but every Q within 2 %, the critic
+    gradient within 0.5 % and the actor gradient within 2 % Frobenius, nothing overflowed."""
     B, S, hid = 4096, 58, (1024, 1024, 1024, 1024)
     dqn, orc, data, rng = make_pair(pkg, B=B, S=S, hidden=hid, n_replay=8192, capacity=16384, wscale=2.0, precision="fp16")
     s, a, r, mc, nx, term = data
@@ -212,7 +212,8 @@ def test_fp16_config5_shape_vs_float64(pkg, gpu):
         return np.linalg.norm(np.asarray(x, np.float64) - y) / max(np.linalg.norm(y), 1e-300)
 
     e_c, e_a = fro(gc, t64.g[1].numpy()), fro(ga, t64.g[0].numpy())
-    assert e_c <= 0.05 and e_a <= 0.1, (e_c, e_a)
+    print("fp16 B=4096 4x1024 vs float64: critic grad fro %.4g, actor grad fro %.4g" % (e_c, e_a))
+    assert e_c <= 5e-3 and e_a <= 2e-2, (e_c, e_a)          # measured 1.1e-3 / 4.5e-3: 4096 rows average the per-row ReLU flips out
     for name in ("q_target", "q_train", "q_policy", "y"):
         ref = t64.dbg[name].numpy()
         assert np.abs(dqn.debug_read(name) - ref).max() <= 2e-2 * max(1.0, np.abs(ref).max()), name
