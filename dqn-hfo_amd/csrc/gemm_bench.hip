@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/dqnhip_internal.h"
@@ -78,6 +79,33 @@ __global__ __launch_bounds__(256) void k_mfma_peak(float* out, int iters, float 
   reinterpret_cast<f32x4*>(out)[blockIdx.x * 256 + threadIdx.x] = r;
 }
 
+// the same for v_mfma_f32_32x32x16_f16 (the fp16 learner's instruction): NACC independent 32x32 accumulators
+typedef __attribute__((ext_vector_type(8))) _Float16 pk_h16x8;
+typedef __attribute__((ext_vector_type(16))) float pk_f32x16;
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_peak_h(float* out, int iters) {
+  pk_f32x16 acc[NACC];
+#pragma unroll
+  for (int e = 0; e < NACC; ++e)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[e][j] = 0.f;
+  pk_h16x8 a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(0.001f * (threadIdx.x + j)); b[j] = (_Float16)(0.002f * (threadIdx.x - j)); }
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < NACC; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[e], 0, 0, 0);
+  }
+  float r = 0.f;
+#pragma unroll
+  for (int e = 0; e < NACC; ++e)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) r += acc[e][j];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
 #define CK(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { fprintf(stderr, "dqnhip_test_gemm: %s -> %s\n", #e, hipGetErrorString(e__)); return 2; } } while (0)
 
 hipError_t launch_variant(int mode, int variant, GemmBatch& b, hipStream_t s) {
@@ -133,7 +161,10 @@ extern "C" int dqnhip_test_gemm(int32_t mode, int32_t variant, int32_t rows, int
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(e0, s));
       for (int i = 0; i < iters; ++i) {
-        if (variant == 1) hipLaunchKernelGGL(k_mfma_peak<1>, dim3(rows), dim3(256), 0, s, out, n_out, 0.5f, 0.25f);
+        if (variant == 11) hipLaunchKernelGGL(k_mfma_peak_h<1>, dim3(rows), dim3(256), 0, s, out, n_out);
+        else if (variant == 12) hipLaunchKernelGGL(k_mfma_peak_h<2>, dim3(rows), dim3(256), 0, s, out, n_out);
+        else if (variant == 14) hipLaunchKernelGGL(k_mfma_peak_h<4>, dim3(rows), dim3(256), 0, s, out, n_out);
+        else if (variant == 1) hipLaunchKernelGGL(k_mfma_peak<1>, dim3(rows), dim3(256), 0, s, out, n_out, 0.5f, 0.25f);
         else if (variant == 2) hipLaunchKernelGGL(k_mfma_peak<2>, dim3(rows), dim3(256), 0, s, out, n_out, 0.5f, 0.25f);
         else hipLaunchKernelGGL(k_mfma_peak<4>, dim3(rows), dim3(256), 0, s, out, n_out, 0.5f, 0.25f);
       }
@@ -241,6 +272,7 @@ extern "C" int dqnhip_test_gemm(int32_t mode, int32_t variant, int32_t rows, int
 }
 
 // ======================= fp16-input family (hgemm.hip.h) ========================================
+#define HG_CLOCKPROBE 1
 #include "hgemm.hip.h"
 
 namespace {
@@ -294,12 +326,13 @@ __global__ void k_cmp_h(const float* ref, int M, int N, const h16* C16, int ldc1
 //                     mode 1: DGRAD-like (ReLU' mask; fp16 + transposed fp16 + scaled fp32 outputs)
 //                     mode 2: WGRAD-like (scaled fp32 output only, the upper half of the columns not written)
 //                     mode 3: k_cvt16 + k_db16 glue check (M x N panel)
-// tile: 0 auto, 1 force 128x128, 2 force 64x64 split-K.  max_abs_err excludes one fp16 rounding of the result.
+// tile: 0 auto, 1 force 128x128, 2 force 64x64 split-K, 3 force 256x128 (8 waves); +10: two problems in one launch.
+// max_abs_err excludes one fp16 rounding of the result.
 extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t N, int32_t K, int32_t iters,
                                  float* avg_us, float* max_abs_err, float* max_ref) {
   if (iters < 1 || M % 64 || N % 64 || K % 64) return 1;
   static bool prepared = false;
-  if (!prepared) { CK((hgemm_prepare<2, 2>())); CK((hgemm_prepare<1, 1>())); prepared = true; }
+  if (!prepared) { CK((hgemm_prepare<2, 2>())); CK((hgemm_prepare<1, 1>())); CK((hgemm_prepare<4, 2>())); prepared = true; }
   hipStream_t s; CK(hipStreamCreate(&s));
   float* dres; CK(hipMalloc(&dres, 8)); CK(hipMemsetAsync(dres, 0, 8, s));
   float hres[2] = {0, 0};
@@ -335,30 +368,43 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
     return 0;
   }
   h16 *A, *B, *mask, *C16, *CT16; float *bias, *C32, *ref;
-  CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&mask, (size_t)M * N * 2));
+  // DQNHIP_TEST_LDPAD=<halves>: leading-dimension padding of both operands (L2 channel-camping probe)
+  const int ldpad = getenv("DQNHIP_TEST_LDPAD") ? atoi(getenv("DQNHIP_TEST_LDPAD")) : 0;
+  const int ldk = K + ldpad;
+  CK(hipMalloc(&A, (size_t)M * ldk * 2)); CK(hipMalloc(&B, (size_t)N * ldk * 2)); CK(hipMalloc(&mask, (size_t)M * N * 2));
   CK(hipMalloc(&C16, (size_t)M * N * 2)); CK(hipMalloc(&CT16, (size_t)M * N * 2)); CK(hipMalloc(&bias, N * 4));
   CK(hipMalloc(&C32, (size_t)M * N * 4)); CK(hipMalloc(&ref, (size_t)M * N * 4));
-  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, A, (size_t)M * K, 11u, -1.f, 1.f);
-  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, B, (size_t)N * K, 23u, -1.f, 1.f);
+  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, A, (size_t)M * ldk, 11u, -1.f, 1.f);
+  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, B, (size_t)N * ldk, 23u, -1.f, 1.f);
   hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, mask, (size_t)M * N, 31u, -1.f, 1.f);
   hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, s, bias, (size_t)N, 41u, -1.f, 1.f);
   CK(hipMemsetAsync(C16, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(CT16, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(C32, 0xff, (size_t)M * N * 4, s));
   HGemm g{};
-  g.A = A; g.lda = K; g.B = B; g.ldb = K; g.M = M; g.N = N; g.K = K; g.scale32 = 1.0f; g.n_valid32 = N;
+  g.A = A; g.lda = ldk; g.B = B; g.ldb = ldk; g.M = M; g.N = N; g.K = K; g.scale32 = 1.0f; g.n_valid32 = N;
   if (mode == 0) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; g.C32 = C32; g.ldc32 = N; }
   else if (mode == 4) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; }
   else if (mode == 5) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; }
   else if (mode == 1) { g.mask = mask; g.ldm = N; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 64.0f; }
   else { g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 1024.0f; g.n_valid32 = N / 2; }
-  for (int i = 0; i < 3; ++i) CK(hgemm_launch(g, s, tile));
+  // tile >= 10: TWO problems in one launch (the second one a copy with its own outputs), tile - 10 = the forced shape
+  const bool pair = tile >= 10;
+  if (pair) tile -= 10;
+  HGemm gp[2] = {g, g};
+  h16 *C16b = nullptr, *CT16b = nullptr; float* C32b = nullptr;
+  if (pair) {
+    CK(hipMalloc(&C16b, (size_t)M * N * 2)); CK(hipMalloc(&CT16b, (size_t)M * N * 2)); CK(hipMalloc(&C32b, (size_t)M * N * 4));
+    CK(hipMemsetAsync(C16b, 0xff, (size_t)M * N * 2, s));
+    if (g.C16) gp[1].C16 = C16b; if (g.CT16) gp[1].CT16 = CT16b; if (g.C32) gp[1].C32 = C32b;
+  }
+  for (int i = 0; i < 3; ++i) CK(hgemm_launch_batch(gp, pair ? 2 : 1, s, tile));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipStreamSynchronize(s));
   CK(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) CK(hgemm_launch(g, s, tile));
+  for (int i = 0; i < iters; ++i) CK(hgemm_launch_batch(gp, pair ? 2 : 1, s, tile));
   CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   if (avg_us) *avg_us = ms * 1000.0f / iters;
-  hipLaunchKernelGGL(k_ref_h, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, (const h16*)A, K, (const h16*)B, K, M, N, K,
+  hipLaunchKernelGGL(k_ref_h, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, (const h16*)A, ldk, (const h16*)B, ldk, M, N, K,
                      (const float*)g.bias, g.relu, g.mask, g.ldm, ref);
   hipLaunchKernelGGL(k_cmp_h, dim3(256), dim3(256), 0, s, (const float*)ref, M, N, (const h16*)g.C16, N, (const h16*)g.CT16, M, (const float*)g.C32, N,
                      g.n_valid32, g.scale32, dres);
@@ -369,6 +415,18 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
     CK(hipMemcpy(row.data(), C32, N * 4, hipMemcpyDeviceToHost));
     for (int n = N / 2; n < N; ++n) if (row[n] != 0xffffffffu) hres[0] = 1e30f;
   }
+  if (getenv("DQNHIP_TEST_CLOCK")) {
+    unsigned long long hc[2] = {0, 0};
+    CK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(hg_clk), sizeof(hc)));
+    fprintf(stderr, "hgemm main loop of block 17: %llu shader cycles in %.2f us -> %.0f MHz, %.0f cycles per 64-deep K tile\n", hc[0], hc[1] / 100.0,
+            hc[1] ? hc[0] / (hc[1] / 100.0) : 0.0, (double)hc[0] / (K / 64));
+  }
+  if (pair && g.C16) {   // the second problem of the launch must have produced the same fp16 panel, bit for bit
+    std::vector<uint16_t> a((size_t)M * N), b((size_t)M * N);
+    CK(hipMemcpy(a.data(), C16, a.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), C16b, b.size() * 2, hipMemcpyDeviceToHost));
+    if (memcmp(a.data(), b.data(), a.size() * 2) != 0) hres[0] = 1e30f;
+  }
+  if (C16b) { hipFree(C16b); hipFree(CT16b); hipFree(C32b); }
   if (max_abs_err) *max_abs_err = hres[0];
   if (max_ref) *max_ref = hres[1];
   hipFree(A); hipFree(B); hipFree(mask); hipFree(C16); hipFree(CT16); hipFree(bias); hipFree(C32); hipFree(ref); hipFree(dres);
@@ -570,5 +628,237 @@ extern "C" int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, flo
   for (int l = 0; l < layers; ++l) { hipFree((void*)a.W[l]); hipFree((void*)a.bias[l]); }
   for (int l = 0; l <= layers; ++l) { hipFree(a.act[l]); hipFree(ref[l]); }
   hipFree(a.counters); hipFree(a.err); hipFree(dres); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+  return 0;
+}
+
+// ---- CU load-path probe: how many bytes per clock one CU can pull from its XCD's L2 ------------------------------------
+// Every workgroup streams `iters` 32-KiB pieces (8 x 1 KiB per wave, 16 B per lane — the fp16 GEMM's stage shape) from a
+// region that all workgroups of its XCD share (region_kb per XCD: <= 2 MiB stays L2-resident, 16 KiB stays in the L1).
+//   mode 0  global_load_dwordx4 into registers (8 in flight per wave)
+//   mode 1  global_load_lds_dwordx4 (LDS-DMA) into a 4-stage ring, counted vmcnt, no consumer
+//   mode 2  as 1, plus every wave reads 16 KiB of each landed stage with ds_read_b128 (the GEMM's fragment traffic)
+//   mode 3  the fragment reads alone (no DMA)
+//   mode 4  global -> registers -> ds_write_b128 (two register sets in flight) + the fragment reads;  5: without the reads
+//   mode 6  half of each stage by LDS-DMA, half straight into registers, + the fragment reads;  7: without the reads
+//   mode 8  a fifth wave issues all the LDS-DMA of a stage, waves 0-3 only read fragments (loader / consumer split)
+//   mode 9  fragment reads alone with the GEMM's swizzled fragment addresses
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(MODE == 8 ? 320 : 256, 1) void k_loadpath(const unsigned char* src, uint32_t region_bytes, int iters, uint32_t* sink) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lp_smem[];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const unsigned char* base = src + (size_t)xcd * region_bytes;
+  const uint32_t npieces = region_bytes / 32768u;               // 32-KiB pieces in the region
+  uint32_t piece = (uint32_t)(slot * 7) % npieces;
+  uint32_t acc = 0;
+  if constexpr (MODE == 0) {
+    for (int it = 0; it < iters; ++it) {
+      const uint4* p = reinterpret_cast<const uint4*>(base + (size_t)piece * 32768u + w * 8192 + lane * 16);
+      uint4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = p[i * 64];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+      piece = piece + 1 == npieces ? 0 : piece + 1;
+    }
+  } else if constexpr (MODE == 4 || MODE == 5) {
+    // global -> registers -> ds_write_b128, two register sets (two stages of loads in flight), 4 LDS slots
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lp_smem;
+    uint4 r0[8], r1[8];
+    auto gload = [&](uint4 (&r)[8]) {
+      const uint4* p = reinterpret_cast<const uint4*>(base + (size_t)piece * 32768u + w * 8192 + lane * 16);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r[i] = p[i * 64];
+      piece = piece + 1 == npieces ? 0 : piece + 1;
+    };
+    auto swrite = [&](const uint4 (&r)[8], int it) {
+      uint4* d = reinterpret_cast<uint4*>(lp_smem + (it & 3) * 32768 + w * 8192) + lane;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[i * 64] = r[i];
+    };
+    auto sread = [&](int it) {
+      if constexpr (MODE == 4) {
+        const uint32_t a0 = lds0 + (uint32_t)((it & 3) * 32768 + (w & 1) * 16384 + lane * 16);
+        uint4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[i]) : "v"(a0), "n"(i * 1024));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) acc ^= v[i].x;
+      }
+    };
+    gload(r0); gload(r1);
+    swrite(r0, 0); gload(r0);
+    for (int it = 0; it < iters; it += 2) {
+      __syncthreads();
+      swrite(r1, it + 1); gload(r1);
+      sread(it);
+      __syncthreads();
+      swrite(r0, it + 2); gload(r0);
+      sread(it + 1);
+    }
+    acc ^= r0[0].x ^ r1[0].x;
+  } else if constexpr (MODE == 8) {
+    // loader wave: wave 4 (of 5) issues every LDS-DMA piece of a stage (32 x 1 KiB) and owns the counted vmcnt;
+    // waves 0-3 only read fragments.  One barrier per stage, as in the GEMM.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lp_smem;
+    const uint32_t voff = lane * 16;
+    auto issue = [&](int it) {
+      const unsigned char* b = base + (size_t)piece * 32768u;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const uint32_t dst = lds0 + (uint32_t)((it & 3) * 32768 + i * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voff), "s"(b + i * 1024), "s"(dst) : "memory");
+      }
+      piece = piece + 1 == npieces ? 0 : piece + 1;
+    };
+    if (w == 4) {
+      issue(0); issue(1);
+      for (int it = 0; it < iters; ++it) {
+        if (it + 2 < iters) { issue(it + 2); asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); }   // stage `it` landed
+        else if (it + 1 < iters) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      for (int it = 0; it < iters; ++it) {
+        __builtin_amdgcn_s_barrier();
+        const uint32_t a0 = lds0 + (uint32_t)((it & 3) * 32768 + (w & 1) * 16384 + lane * 16);
+        uint4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[i]) : "v"(a0), "n"(i * 1024));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) acc ^= v[i].x;
+      }
+    }
+  } else if constexpr (MODE == 6 || MODE == 7) {
+    // split path: half of every 32-KiB stage by LDS-DMA (the LDS operand), half straight into registers (an operand stored
+    // in fragment order needs no LDS); 8 vector-memory operations per wave per stage as before, 3 stages in flight
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lp_smem;
+    const uint32_t voff = lane * 16;
+    uint4 rb[4];
+    auto issue = [&](int it) {
+      const unsigned char* b = base + (size_t)piece * 32768u + w * 8192;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t dst = lds0 + (uint32_t)((it & 3) * 16384 + (w * 4 + i) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voff), "s"(b + i * 1024), "s"(dst) : "memory");
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[i]) : "v"(voff), "s"(b + 4096 + i * 1024) : "memory");
+      piece = piece + 1 == npieces ? 0 : piece + 1;
+    };
+    issue(0); issue(1); issue(2);
+    for (int it = 0; it < iters; ++it) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      __syncthreads();
+      if (it + 3 < iters) issue(it + 3);
+      if constexpr (MODE == 6) {
+        const uint32_t a0 = lds0 + (uint32_t)((it & 3) * 16384 + lane * 16);
+        uint4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[i]) : "v"(a0), "n"(i * 1024));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) acc ^= v[i].x;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    acc ^= rb[0].x;
+  } else {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lp_smem;
+    const uint32_t voff = lane * 16;
+    auto issue = [&](int it) {
+      const unsigned char* b = base + (size_t)piece * 32768u + w * 8192;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t dst = lds0 + (uint32_t)((it & 3) * 32768 + (w * 8 + i) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voff), "s"(b + i * 1024), "s"(dst) : "memory");
+      }
+      piece = piece + 1 == npieces ? 0 : piece + 1;
+    };
+    if constexpr (MODE != 3 && MODE != 9) { issue(0); issue(1); issue(2); }
+    for (int it = 0; it < iters; ++it) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // stage `it` landed (two later stages may be in flight)
+      __syncthreads();
+      if constexpr (MODE != 3 && MODE != 9) { if (it + 3 < iters) issue(it + 3); }
+      if constexpr (MODE == 9) {
+        // the GEMM's fragment pattern: 32 rows of 128 B, chunk (2s+hi) ^ ((row>>1)&7); 4 sub-steps x (2 A + 2 B) blocks
+        const int l31 = lane & 31, hi = lane >> 5, sw = (l31 >> 1) & 7;
+        uint4 v[16];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const uint32_t o = lds0 + (uint32_t)((it & 3) * 32768 + (((2 * sub + hi) ^ sw) << 4) + l31 * 128);
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[sub * 4 + 0]) : "v"(o), "n"(0));
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[sub * 4 + 1]) : "v"(o), "n"(4096));
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[sub * 4 + 2]) : "v"(o), "n"(16384));
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[sub * 4 + 3]) : "v"(o), "n"(16384 + 4096));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) acc ^= v[i].x;
+      } else if constexpr (MODE >= 2) {
+        const uint32_t a0 = lds0 + (uint32_t)((it & 3) * 32768 + (w & 1) * 16384 + lane * 16);
+        uint4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[i]) : "v"(a0), "n"(i * 1024));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) acc ^= v[i].x;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+}  // namespace
+
+extern "C" int dqnhip_test_loadpath(int32_t mode, int32_t blocks, int32_t region_kb, int32_t iters, int32_t launches,
+                                    float* avg_us, float* tb_per_s) {
+  if (mode < 0 || mode > 9 || blocks < 8 || region_kb < 32 || (region_kb & 31) || iters < 4 || launches < 1) return 1;
+  hipStream_t s; CK(hipStreamCreate(&s));
+  const size_t region = (size_t)region_kb * 1024;
+  unsigned char* src; uint32_t* sink;
+  CK(hipMalloc(&src, region * 8)); CK(hipMalloc(&sink, 64));
+  CK(hipMemsetAsync(src, 1, region * 8, s));
+  auto launch = [&]() {
+    const int lds = mode == 0 ? 0 : 4 * 32768;
+    if (mode == 0) hipLaunchKernelGGL(k_loadpath<0>, dim3(blocks), dim3(256), lds, s, src, (uint32_t)region, iters, sink);
+    else if (mode == 1) hipLaunchKernelGGL(k_loadpath<1>, dim3(blocks), dim3(256), lds, s, src, (uint32_t)region, iters, sink);
+    else if (mode == 2) hipLaunchKernelGGL(k_loadpath<2>, dim3(blocks), dim3(256), lds, s, src, (uint32_t)region, iters, sink);
+    else if (mode == 3) hipLaunchKernelGGL(k_loadpath<3>, dim3(blocks), dim3(256), lds, s, src, (uint32_t)region, iters, sink);
+    else if (mode == 4) hipLaunchKernelGGL(k_loadpath<4>, dim3(blocks), dim3(256), lds, s, src, (uint32_t)region, iters, sink);
+    else if (mode == 5) hipLaunchKernelGGL(k_loadpath<5>, dim3(blocks), dim3(256), lds, s, src, (uint32_t)region, iters, sink);
+    else if (mode == 6) hipLaunchKernelGGL(k_loadpath<6>, dim3(blocks), dim3(256), lds, s, src, (uint32_t)region, iters, sink);
+    else if (mode == 7) hipLaunchKernelGGL(k_loadpath<7>, dim3(blocks), dim3(256), lds, s, src, (uint32_t)region, iters, sink);
+    else if (mode == 8) hipLaunchKernelGGL(k_loadpath<8>, dim3(blocks), dim3(320), lds, s, src, (uint32_t)region, iters, sink);
+    else hipLaunchKernelGGL(k_loadpath<9>, dim3(blocks), dim3(256), lds, s, src, (uint32_t)region, iters, sink);
+  };
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loadpath<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loadpath<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loadpath<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loadpath<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loadpath<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loadpath<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loadpath<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loadpath<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loadpath<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) launch();
+  CK(hipStreamSynchronize(s)); CK(hipEventRecord(e0, s));
+  for (int i = 0; i < launches; ++i) launch();
+  CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipGetLastError());
+  const float us = ms * 1000.f / launches;
+  if (avg_us) *avg_us = us;
+  if (tb_per_s) *tb_per_s = (float)((double)blocks * iters * 32768.0 / (us * 1e-6) / 1e12);
+  hipFree(src); hipFree(sink); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
   return 0;
 }

@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace dqnhip {
@@ -66,18 +67,26 @@ __device__ __forceinline__ int hg_tile_of_block(int bid, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+#ifdef HG_CLOCKPROBE
+__device__ unsigned long long hg_clk[2];   // shader cycles / 100 MHz ticks of block 17's main loop (test build only)
+#endif
+
 template <int WM, int WN>
 struct HGCfg {
-  static constexpr int WK = 4 / (WM * WN);
+  static constexpr int NW = (WM * WN >= 4) ? WM * WN : 4;                   // waves per workgroup (4, or 8 for <4,2>)
+  static constexpr int NT = NW * 64;
+  static constexpr int WK = (WM * WN >= 4) ? 1 : 4 / (WM * WN);
   static constexpr int BM = WM * 64, BN = WN * 64;
-  // A stage is 256 row slots of 128 B (32 KiB).  <2,2>: slots 0-127 = A rows, 128-255 = B rows of one
-  // 64-deep K tile.  <1,1>: two 64-deep sub-tiles, each 64 A rows + 64 B rows (K step 128).
+  // <2,2>: a stage is 256 row slots of 128 B (32 KiB): slots 0-127 = A rows, 128-255 = B rows of one 64-deep K tile.
+  // <4,2>: 384 row slots (48 KiB): 256 A rows + 128 B rows.  <1,1>: two 64-deep sub-tiles, each 64 A rows + 64 B rows
+  // (K step 128).
   static constexpr int KSTEP = (WK == 1) ? 64 : 128;
 #ifndef HG_STAGES
 #define HG_STAGES 4
 #endif
-  static constexpr int STAGE = 32768, STAGES = HG_STAGES;
-  static constexpr int LOADS = 8;                                           // 1-KiB pieces per wave per stage
+  static constexpr int STAGE = (WK == 1) ? (BM + BN) * 128 : 32768;
+  static constexpr int STAGES = (STAGE > 32768) ? 3 : HG_STAGES;
+  static constexpr int LOADS = STAGE / 1024 / NW;                           // 1-KiB pieces per wave per stage (8; 6 for <4,2>)
   static constexpr int NSUB = (WK == 1) ? 4 : 2;                            // k16 steps per wave per stage
   static constexpr int TLD = BN + 4;                                        // fp32 epilogue tile row stride
   static constexpr int T_BYTES = WK * BM * TLD * 4;
@@ -90,8 +99,12 @@ template <int N> __device__ __forceinline__ void hg_wait_vm() { asm volatile("s_
 #define HG_PIN() __builtin_amdgcn_sched_barrier(0)
 
 template <int WM, int WN>
-__global__ __launch_bounds__(256, 1) void hgemm_nt(HGemmBatch batch) {
+__global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch batch) {
   using Cfg = HGCfg<WM, WN>;
+  constexpr int NW = Cfg::NW, NT = Cfg::NT;
+#ifdef HG_CLOCKPROBE
+  const unsigned long long hg_c0 = clock64(), hg_r0 = wall_clock64();
+#endif
   const int sel = (batch.n > 1 && (int)blockIdx.x >= batch.tiles0) ? 1 : 0;      // wave-uniform
   const HGemm& g = batch.g[sel];
   const int bid = (int)blockIdx.x - sel * batch.tiles0;
@@ -105,31 +118,52 @@ __global__ __launch_bounds__(256, 1) void hgemm_nt(HGemmBatch batch) {
   const int m0 = (T / tiles_n) * BM, n0 = (T % tiles_n) * BN;
   const int nk = g.K / KSTEP;
 
-  // ---- LDS-DMA source addresses.  Wave w owns pieces w*8 .. w*8+7 of every stage; piece p = row
-  // slots p*8 .. p*8+7; lane -> (slot R, physical chunk pc) fetches logical chunk pc ^ ((R>>1)&7).
-  // A wave's 64 slots belong to ONE matrix (waves {0,1}/{2,3} = A/B for <2,2>; even/odd for <1,1>),
-  // so the source is a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset.
+  // ---- LDS-DMA source addresses.  A piece is 8 row slots (1 KiB); lane -> (slot R, physical chunk pc) fetches logical
+  // chunk pc ^ ((R>>1)&7).  A piece belongs to ONE matrix, so its source is a wave-uniform 64-bit base (SGPR pair) +
+  // a 32-bit per-lane byte offset.
+  //   4 waves: wave w owns pieces w*8 .. w*8+7 of every stage (waves {0,1}/{2,3} = A/B for <2,2>; even/odd for <1,1>).
+  //   8 waves (<4,2>): wave w owns A pieces w*4 .. w*4+3 (A rows w*32 ..) and B pieces w*2, w*2+1 (B rows w*16 ..).
   const int r8 = lane >> 3, pc = lane & 7;
   const int wu = __builtin_amdgcn_readfirstlane(w);
-  const bool from_a = (WK == 1) ? (wu < 2) : ((wu & 1) == 0);
-  const int row_w = (WK == 1) ? (wu & 1) * 64 : 0;              // first matrix row (inside the tile) of this wave's slots
-  const int ld = from_a ? g.lda : g.ldb;
-  const h16* wbase = (from_a ? g.A + (size_t)m0 * g.lda : g.B + (size_t)n0 * g.ldb) + (size_t)row_w * ld +
-                     ((WK == 1) ? 0 : (wu >> 1) * 64);
-  uint32_t voff[LOADS];
-#pragma unroll
-  for (int i = 0; i < LOADS; ++i) {
-    const int R = (wu * LOADS + i) * 8 + r8;                    // stage slot
-    const int c = pc ^ ((R >> 1) & 7);
-    voff[i] = (uint32_t)(((i * 8 + r8) * ld + c * 8) * 2);
-  }
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)hg_smem;
+  const h16* wbase = nullptr; const h16* wbase_b = nullptr;
+  uint32_t voff[LOADS];
+  if constexpr (NW == 4) {
+    const bool from_a = (WK == 1) ? (wu < 2) : ((wu & 1) == 0);
+    const int row_w = (WK == 1) ? (wu & 1) * 64 : 0;            // first matrix row (inside the tile) of this wave's slots
+    const int ld = from_a ? g.lda : g.ldb;
+    wbase = (from_a ? g.A + (size_t)m0 * g.lda : g.B + (size_t)n0 * g.ldb) + (size_t)row_w * ld +
+            ((WK == 1) ? 0 : (wu >> 1) * 64);
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int R = (wu * LOADS + i) * 8 + r8;                  // stage slot
+      const int c = pc ^ ((R >> 1) & 7);
+      voff[i] = (uint32_t)(((i * 8 + r8) * ld + c * 8) * 2);
+    }
+  } else {
+    wbase = g.A + (size_t)(m0 + wu * 32) * g.lda;
+    wbase_b = g.B + (size_t)(n0 + wu * 16) * g.ldb;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const bool pa = i < 4;
+      const int rl = pa ? i * 8 : (i - 4) * 8;                  // row inside this wave's run of the matrix
+      const int R = (pa ? wu * 32 : BM + wu * 16) + rl + r8;    // stage slot
+      const int c = pc ^ ((R >> 1) & 7);
+      voff[i] = (uint32_t)(((rl + r8) * (pa ? g.lda : g.ldb) + c * 8) * 2);
+    }
+  }
   // one piece of stage kt.  Inline asm: the compiler's waitcnt pass models a global_load_lds as a FLAT
   // operation that may touch LDS and then turns every later lgkmcnt wait into lgkmcnt(0), which
   // serialises the fragment prefetch; all ordering of the DMA is done by hand (counted vmcnt + barrier).
   auto issue1 = [&](int kt, int i) {
-    const h16* base = wbase + (size_t)kt * KSTEP;
-    const uint32_t dst = lds0 + (uint32_t)((kt % STAGES) * Cfg::STAGE + (wu * LOADS + i) * 1024);
+    const h16* base; uint32_t dst;
+    if constexpr (NW == 4) {
+      base = wbase + (size_t)kt * KSTEP;
+      dst = lds0 + (uint32_t)((kt % STAGES) * Cfg::STAGE + (wu * LOADS + i) * 1024);
+    } else {
+      base = (i < 4 ? wbase : wbase_b) + (size_t)kt * KSTEP;
+      dst = lds0 + (uint32_t)((kt % STAGES) * Cfg::STAGE + (i < 4 ? (wu * 4 + i) : (BM / 8 + wu * 2 + (i - 4))) * 1024);
+    }
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :: "v"(voff[i]), "s"(base), "s"(dst) : "memory");
   };
@@ -141,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_nt(HGemmBatch batch) {
   for (int s = 0; s < NSUB; ++s) {
     if constexpr (WK == 1) {
       const int o = (((2 * s + hi) ^ sw) << 4) + l31 * 128;
-      offa[s] = wm * 64 * 128 + o; offb[s] = (128 + wn * 64) * 128 + o;
+      offa[s] = wm * 64 * 128 + o; offb[s] = (BM + wn * 64) * 128 + o;
     } else {
       const int o = (((2 * w + hi) ^ sw) << 4) + l31 * 128;     // this wave's k16 slice of each sub-tile
       offa[s] = s * 16384 + o; offb[s] = s * 16384 + 8192 + o;
@@ -195,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_nt(HGemmBatch batch) {
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
       const int cur = s & 1;                // NSUB is even: register buffer 0 again at s = 0 of the next stage
-      constexpr int PPS = LOADS / NSUB;     // pieces per sub-step
+      const int p_lo = s * LOADS / NSUB, p_hi = (s + 1) * LOADS / NSUB, p_mid = (p_lo + p_hi + 1) / 2;   // this sub-step's pieces
       HG_PIN();
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
       HG_PIN();
@@ -204,14 +238,14 @@ __global__ __launch_bounds__(256, 1) void hgemm_nt(HGemmBatch batch) {
       HG_PIN();
       if constexpr (more) {
 #pragma unroll
-        for (int i = 0; i < PPS / 2; ++i) issue1(kt + STAGES - 1, s * PPS + i);
+        for (int i = 0; i < LOADS; ++i) if (i >= p_lo && i < p_mid) issue1(kt + STAGES - 1, i);
       }
       HG_PIN();
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
       HG_PIN();
       if constexpr (more) {
 #pragma unroll
-        for (int i = PPS / 2; i < PPS; ++i) issue1(kt + STAGES - 1, s * PPS + i);
+        for (int i = 0; i < LOADS; ++i) if (i >= p_mid && i < p_hi) issue1(kt + STAGES - 1, i);
       }
       HG_PIN();
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
@@ -222,6 +256,9 @@ __global__ __launch_bounds__(256, 1) void hgemm_nt(HGemmBatch batch) {
   for (; kt + STAGES - 1 < nk; ++kt) stage_body(kt, std::true_type{});
   for (; kt < nk; ++kt) stage_body(kt, std::false_type{});
   __syncthreads();                          // pipeline buffers are dead: reuse them as the fp32 tile
+#ifdef HG_CLOCKPROBE
+  if (blockIdx.x == 17 && threadIdx.x == 0) { hg_clk[0] = clock64() - hg_c0; hg_clk[1] = wall_clock64() - hg_r0; }
+#endif
 
   // ---- epilogue 1: accumulators -> fp32 tile  Tt[wk][m][n]   (C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
   float* Tt = reinterpret_cast<float*>(hg_smem);
@@ -242,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_nt(HGemmBatch batch) {
 
   // ---- epilogue 2: m-major outputs, 8 consecutive n per thread
   constexpr int CPR = BN / 8;               // chunks per row
-  for (int q = tid; q < BM * CPR; q += 256) {
+  for (int q = tid; q < BM * CPR; q += NT) {
     const int row = q / CPR, c8 = q % CPR;
     float v[8];
     {
@@ -292,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_nt(HGemmBatch batch) {
   __syncthreads();
   // ---- epilogue 3: transposed output  CT16[n][m]: 4 lanes cover 32 consecutive m of one n (64 B)
   constexpr int CPC = BM / 8;               // 8-m chunks per column
-  for (int q = tid; q < BN * CPC; q += 256) {
+  for (int q = tid; q < BN * CPC; q += NT) {
     const int clo = q & 3, n = (q >> 2) % BN, chi = (q >> 2) / BN;
     const int c8 = chi * 4 + clo;
     h16x8 o;
@@ -308,20 +345,33 @@ inline hipError_t hgemm_prepare() {
                              HGCfg<WM, WN>::LDS_BYTES);
 }
 
-// picks the tile: 128x128 when that fills the chip, else 64x64 with in-workgroup split-K
+// picks the tile: 256x128 (8 waves) when THAT fills the chip (two 4096-row problems in one launch), 128x128 when that
+// does, else 64x64 with in-workgroup split-K.  force: 0 auto, 1 128x128, 2 64x64, 3 256x128.
 inline bool hgemm_big_ok(const HGemm& g) { return (g.M % 128 == 0) && (g.N % 128 == 0); }
+inline bool hgemm_huge_ok(const HGemm& g) { return (g.M % 256 == 0) && (g.N % 128 == 0); }
 inline long hgemm_tiles(const HGemm& g, bool big) { return big ? (long)(g.M / 128) * (g.N / 128) : (long)(g.M / 64) * (g.N / 64); }
+inline bool hgemm_huge_enabled() { static const bool on = getenv("DQNHIP_NO_HGEMM_256") == nullptr; return on; }
 
 inline hipError_t hgemm_launch_batch(const HGemm* gs, int n, hipStream_t st, int force = 0, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
   if (n < 1 || n > 2) return hipErrorInvalidValue;
-  bool big_ok = true; long tiles_big = 0;
-  for (int i = 0; i < n; ++i) { big_ok = big_ok && hgemm_big_ok(gs[i]); if (gs[i].K % 64 || gs[i].K < 64) return hipErrorInvalidValue; }
+  bool big_ok = true, huge_ok = true; long tiles_big = 0, tiles_huge = 0;
+  for (int i = 0; i < n; ++i) {
+    big_ok = big_ok && hgemm_big_ok(gs[i]); huge_ok = huge_ok && hgemm_huge_ok(gs[i]);
+    if (gs[i].K % 64 || gs[i].K < 64) return hipErrorInvalidValue;
+  }
   if (big_ok) for (int i = 0; i < n; ++i) tiles_big += hgemm_tiles(gs[i], true);
-  const bool big = force == 1 || (force == 0 && big_ok && tiles_big >= 192);
+  if (huge_ok) for (int i = 0; i < n; ++i) tiles_huge += (long)(gs[i].M / 256) * (gs[i].N / 128);
+  const bool huge = force == 3 || (force == 0 && huge_ok && tiles_huge >= 192 && hgemm_huge_enabled());
+  const bool big = !huge && (force == 1 || (force == 0 && big_ok && tiles_big >= 192));
   HGemmBatch b{};
   b.n = n;
   for (int i = 0; i < n; ++i) b.g[i] = gs[i];
-  if (big) {
+  if (huge) {
+    if (!huge_ok) return hipErrorInvalidValue;
+    b.tiles0 = (int)((long)(gs[0].M / 256) * (gs[0].N / 128));
+    if (t0) hipExtLaunchKernelGGL((hgemm_nt<4, 2>), dim3((unsigned)tiles_huge), dim3(512), (HGCfg<4, 2>::LDS_BYTES), st, t0, t1, 0, b);
+    else hipLaunchKernelGGL((hgemm_nt<4, 2>), dim3((unsigned)tiles_huge), dim3(512), (HGCfg<4, 2>::LDS_BYTES), st, b);
+  } else if (big) {
     if (!big_ok) return hipErrorInvalidValue;
     b.tiles0 = (int)hgemm_tiles(gs[0], true);
     if (t0) hipExtLaunchKernelGGL((hgemm_nt<2, 2>), dim3((unsigned)tiles_big), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, b);

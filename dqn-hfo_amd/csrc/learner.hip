@@ -1157,7 +1157,7 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
         RC(halloc(&h->dZ16[kind][i], (size_t)B * h->k16[kind][i]));
         RC(halloc(&h->dZT16[kind][i], (size_t)h->k16[kind][i] * B));
       }
-    HIPCHK((hgemm_prepare<2, 2>())); HIPCHK((hgemm_prepare<1, 1>()));
+    HIPCHK((hgemm_prepare<2, 2>())); HIPCHK((hgemm_prepare<1, 1>())); HIPCHK((hgemm_prepare<4, 2>()));
   }
   // weights: gaussian(std 0.01), zero bias (src/dqn.cpp:350-352); targets = hard copy (:660-661)
   {

@@ -47,6 +47,12 @@ int dqnhip_test_adam(int64_t n_params, int32_t variant, int32_t blocks, int32_t 
 int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, float* us_launches, float* us_persistent,
                       float* max_abs_diff, int32_t* gave_up);
 
+/* CU load-path probe (see gemm_bench.hip): `blocks` workgroups of 256 threads each stream `iters` 32-KiB pieces from a
+ * region of region_kb KiB shared by the workgroups of one XCD.  mode 0 register loads, 1 LDS-DMA, 2 LDS-DMA + fragment
+ * reads.  tb_per_s = bytes delivered to the CUs per second, chip-wide. */
+int dqnhip_test_loadpath(int32_t mode, int32_t blocks, int32_t region_kb, int32_t iters, int32_t launches,
+                         float* avg_us, float* tb_per_s);
+
 #ifdef __cplusplus
 }
 #endif

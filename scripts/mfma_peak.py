@@ -15,3 +15,13 @@ for nacc in (1, 2, 4):
             tf = nm * 2048 / (us.value * 1e-6) / 1e12
             cyc = us.value * 1e-6 * 2.4e9 / (nm / 1024)  # cycles per MFMA per SIMD at 2.4 GHz if all 1024 SIMDs busy
             print("nacc %d blocks %4d loops %4d: %8.2f us  %6.1f TF  (%.1f cyc@2.4GHz per MFMA per SIMD)" % (nacc, blocks, loops, us.value, tf, cyc), flush=True)
+print("v_mfma_f32_32x32x16_f16:")
+for nacc in (1, 2, 4):
+    for blocks in (256, 512):
+        for loops in (256, 4096):
+            us = C.c_float()
+            fn(99, 10 + nacc, blocks, loops, 0, 1, 20, C.byref(us), None, None)
+            nm = blocks * 4 * loops * 4 * nacc
+            tf = nm * 32768 / (us.value * 1e-6) / 1e12
+            cyc = us.value * 1e-6 * 2.4e9 / (nm / 1024)
+            print("nacc %d blocks %4d loops %4d: %8.2f us  %7.1f TF  (%.1f cyc@2.4GHz per MFMA per SIMD)" % (nacc, blocks, loops, us.value, tf, cyc), flush=True)

@@ -38,7 +38,8 @@ def test_every_declared_symbol_is_exported(pkg):
     assert decl <= exported
     # the test hooks live in their own library and are NOT in the product library
     tdecl = declared_functions(internal=True)
-    assert tdecl == {"dqnhip_test_gemm", "dqnhip_test_hgemm", "dqnhip_test_adam", "dqnhip_test_chain"}
+    assert tdecl == {"dqnhip_test_gemm", "dqnhip_test_hgemm", "dqnhip_test_adam", "dqnhip_test_chain",
+                     "dqnhip_test_loadpath"}
     assert not (tdecl & exported)
     tlib = pkg.capi.load_test()
     assert all(hasattr(tlib, n) for n in tdecl)
