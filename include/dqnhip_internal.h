@@ -29,7 +29,8 @@ int dqnhip_test_gemm(int32_t mode, int32_t variant, int32_t rows, int32_t n_out,
  *        2 WGRAD-like scaled fp32 output, only the first N/2 columns written
  *        4 / 5   as 0 with the fp16 output only / fp16 + transposed fp16 (the common layer cases)
  *        3 glue check: k_cvt16 (fp32 -> fp16 + transposed, zero padding) and k_db16 on an M x N panel
- *   tile 0 auto, 1 128x128, 2 64x64 with in-workgroup split-K
+ *   tile 0 auto, 1 128x128, 2 64x64 with in-workgroup split-K, 3 256x128 on eight waves; +10: two problems (the second a
+ *        copy with its own outputs, which must come out bit-identical) in one launch
  * max_abs_err excludes one fp16 rounding of each fp16 result. */
 int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t N, int32_t K, int32_t iters,
                       float* avg_us, float* max_abs_err, float* max_ref);

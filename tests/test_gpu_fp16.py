@@ -81,7 +81,12 @@ def test_hgemm_kernels(pkg, gpu):
     cases = [(0, 1, 128, 128, 64), (0, 1, 256, 384, 192), (0, 2, 64, 64, 128), (0, 2, 128, 192, 256),
              (1, 1, 256, 128, 128), (1, 2, 128, 128, 128), (2, 2, 128, 128, 512), (2, 1, 128, 256, 512),
              (4, 1, 512, 256, 1024), (5, 2, 256, 256, 384), (0, 0, 1024, 1024, 128), (2, 0, 1024, 128, 512),
-             (0, 1, 4096, 1024, 1024), (2, 2, 1024, 1024, 4096), (3, 0, 256, 192, 64)]
+             (0, 1, 4096, 1024, 1024), (2, 2, 1024, 1024, 4096), (3, 0, 256, 192, 64),
+             # 256x128 eight-wave tile (tile 3), alone and as the two-problem launch the learner uses at 4096 rows (+10);
+             # K = 64 / 128 / 192 exercise the 3-stage ring's prologue and tail; pairs also of the other shapes
+             (0, 3, 256, 128, 64), (0, 3, 512, 256, 128), (1, 3, 256, 256, 192), (5, 3, 1024, 384, 1024), (2, 3, 512, 128, 512),
+             (0, 13, 256, 128, 64), (1, 13, 512, 256, 320), (5, 13, 4096, 1024, 1024), (4, 10, 4096, 1024, 1024),
+             (5, 11, 512, 256, 256), (1, 12, 128, 128, 256)]
     for c in cases:
         rc, err, ref = run(*c)
         assert rc == 0, c
@@ -89,6 +94,7 @@ def test_hgemm_kernels(pkg, gpu):
         assert err <= 2e-5 * max(ref, 1.0), (c, err, ref)
     assert run(0, 2, 64, 64, 64)[0] != 0           # the split-K tile needs K % 128 == 0: refused, not wrong
     assert run(0, 1, 192, 128, 64)[0] != 0          # 128x128 tile on M = 192: refused
+    assert run(0, 3, 384, 128, 64)[0] != 0          # 256x128 tile on M = 384: refused
 
 
 @pytest.mark.parametrize("shape", [
