@@ -182,13 +182,23 @@ __global__ void k_env_step(EnvDev e) {
   }
   float* eps_row = e.ep_s + ((size_t)w * e.T + len) * e.SP;
   float* cur = e.cur + (size_t)w * e.SP;
+  // synthetic server: does the episode end on this step, and how (every lane evaluates the same two draws: the
+  // wave needs the answer to know which state the worker shows the actor next)
+  int status = 0;
+  if (env_u01(e.seed, g, w, 11) < e.p_end) status = env_u01(e.seed, g, w, 12) < e.p_goal ? 1 : 2;   // GOAL / CAPTURED_BY_DEFENSE
+  if (status == 0 && len + 1 >= e.T) status = 4;                                                   // OUT_OF_TIME
+  float* s_first = s_next + e.SP;                    // first state of the next episode (only if this one ends)
   for (int f = lane; f < e.SP; f += 64) {
     eps_row[f] = cur[f];
     const float v = f < e.S ? env_feature(e, g, w, f) : 0.0f;
     s_next[f] = v;
+    if (status != 0) s_first[f] = f < e.S ? env_feature(e, g + 1, w, f) : 0.0f;
   }
   __syncthreads();
-  for (int f = lane; f < e.SP; f += 64) cur[f] = s_next[f];
+  // the actor's next input row: the next state, or — the episode is over — the first state of the new one
+  // (src/dqn_main.cpp:97-105; the finished episode's transitions are labelled and added by k_env_flush, which
+  // no longer has to run before the next forward pass)
+  for (int f = lane; f < e.SP; f += 64) cur[f] = status != 0 ? s_first[f] : s_next[f];
   if (lane == 0) {
     // GetAction (src/dqn.cpp:196-208)
     float c0 = s_ao[0], c1 = s_ao[1], c3 = s_ao[3];
@@ -200,17 +210,19 @@ __global__ void k_env_step(EnvDev e) {
     const int o1 = best == 0 ? 0 : best == 1 ? 2 : best == 2 ? 3 : 4;
     const int o2 = best == 0 ? 1 : best == 3 ? 5 : -1;
     e.act[w] = best; e.arg1[w] = s_ao[kNA + o1]; e.arg2[w] = o2 < 0 ? 0.0f : s_ao[kNA + o2];
-    // synthetic server: does the episode end on this step, and how
-    int status = 0;
-    if (env_u01(e.seed, g, w, 11) < e.p_end) status = env_u01(e.seed, g, w, 12) < e.p_goal ? 1 : 2;   // GOAL / CAPTURED_BY_DEFENSE
-    if (status == 0 && len + 1 >= e.T) status = 4;                                                   // OUT_OF_TIME
     const int pob = env_u01(e.seed, g, w, 13) < 0.5f ? e.unum : -1;
     game_update(gs, s_next, status, pob);
     int goal = 0;
     const float r = game_reward(gs, e.unum, &goal);
-    e.game[w] = gs;
     e.ep_r[(size_t)w * e.T + len] = r; e.rew[w] = r;
-    e.len[w] = len + 1; e.g[w] = g + 1;
+    if (status != 0) {
+      // new episode: HFOGameState() and the initial update after the forced DASH(0,0) (src/dqn_main.cpp:103-105)
+      GameState g0; game_reset(g0);
+      game_update(g0, s_first, 0, 0);
+      e.game[w] = g0; e.len[w] = 0; e.g[w] = g + 2;
+    } else {
+      e.game[w] = gs; e.len[w] = len + 1; e.g[w] = g + 1;
+    }
     e.done[w] = status != 0 ? len + 1 : 0;           // length of the finished episode (0: still open)
     e.n_steps[w] += 1; e.reward_sum[w] += (double)r; e.n_goals[w] += goal;
   }
@@ -228,11 +240,11 @@ __device__ __forceinline__ void env_flush_worker(const EnvDev& e, const Ring& ri
                                                  float* sm, int* s_start_p);
 __device__ __forceinline__ void env_commit_body(const EnvDev& e, const Ring& ring, DevState* st);
 
-// finished episodes: LabelTransitions + AddTransitions, in worker order; then reset the worker
-__global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const DevState* st, double gamma) {
-  extern __shared__ float sm[];          // [T] mc labels, then [SP] reset row
+// finished episodes: LabelTransitions + AddTransitions, in worker order (the worker itself was reset by k_env_step:
+// this launch only reads done[] and the episode buffers, so it runs beside the next step's forward pass)
+// one block of the flush: worker w of n_workers blocks (sm: [T] floats of LDS)
+__device__ __forceinline__ void env_flush_block(const EnvDev& e, const Ring& ring, const DevState* st, double gamma, int w, int n_workers, float* sm) {
   __shared__ int s_start;
-  const int w = blockIdx.x;
   const int len = e.done[w];
   if (len != 0) env_flush_worker(e, ring, st, gamma, w, len, sm, &s_start);
   if (e.commit_ticket == nullptr) return;
@@ -243,11 +255,15 @@ __global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const De
   __syncthreads();
   if (threadIdx.x == 0) {
     const int t = __hip_atomic_fetch_add(e.commit_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (int)gridDim.x - 1);
+    s_last = (t == n_workers - 1);
     if (s_last) *e.commit_ticket = 0;
   }
   __syncthreads();
   if (s_last) env_commit_body(e, ring, const_cast<DevState*>(st));
+}
+__global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const DevState* st, double gamma) {
+  extern __shared__ float sm[];          // [T] mc labels
+  env_flush_block(e, ring, st, gamma, blockIdx.x, gridDim.x, sm);
 }
 
 __device__ __forceinline__ void env_flush_worker(const EnvDev& e, const Ring& ring, const DevState* st, double gamma, int w, int len,
@@ -294,22 +310,6 @@ __device__ __forceinline__ void env_flush_worker(const EnvDev& e, const Ring& ri
       }
       for (; i >= 0; --i) { target = (float)((double)sm[i] + gamma * (double)target); sm[i] = target; }
       e.n_episodes[w] += 1;
-    }
-    // new episode for this worker (env_reset_worker's steps), also beside the copies: the episode buffers the
-    // other waves are reading are not touched (cur / game / len / g only)
-    {
-      float* s_state = sm + e.T;
-      const unsigned long long g = e.g[w];
-      for (int f = lane; f < e.SP; f += 64) {
-        const float v = f < e.S ? env_feature(e, g, w, f) : 0.0f;
-        s_state[f] = v; e.cur[(size_t)w * e.SP + f] = v;
-      }
-      __builtin_amdgcn_wave_barrier();                     // one wave wrote s_state; its lane 0 reads it (LDS ops of a wave are in order)
-      if (lane == 0) {
-        GameState gs; game_reset(gs);
-        game_update(gs, s_state, 0, 0);
-        e.game[w] = gs; e.len[w] = 0; e.g[w] = g + 1;
-      }
     }
   } else {
     // 192 threads copy the episode as float4s (RSP/4 = 16 or 32 per row: shifts, no division); the ring slot

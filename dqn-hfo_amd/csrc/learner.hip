@@ -2095,6 +2095,10 @@ struct dqnhip_env {
   int* commit_ticket = nullptr;
   hipGraphExec_t graph[2] = {nullptr, nullptr};   // one batched step / kEnvUnroll steps, captured on first use
   bool graph_failed = false;
+  // inside a sequence of batched steps the episode flush of step t (LabelTransitions + AddTransitions of the
+  // finished episodes) rides as extra workgroups of step t+1's first-layer launch: k_env_step resets the worker
+  // itself, so nothing before the next k_env_step depends on the flush
+  bool flush_deferred = false;
 };
 constexpr int kEnvUnroll = 16;
 
@@ -2163,33 +2167,73 @@ int dqnhip_env_destroy(dqnhip_env_handle e) {
   return 0;
 }
 
+// First tower layer of batched step t+1 (the small-K direct kernel's 32x32 tiles) and the episode flush of step t
+// in ONE launch: blocks [0, tiles) are GEMM tiles, the next N blocks are k_env_flush's.  The two parts share no data
+// (the layer reads the state panel k_env_step(t) wrote, the flush reads done[] and the episode rows).  A side
+// stream was measured first (A/B in one call, 64 workers, S = 68): 48.0 us per step against 33.5 — every
+// cross-stream edge of a replayed graph costs more than the 7 us flush it would hide.
+__global__ __launch_bounds__(256) void k_env_l0_flush(const GemmBatch batch, EnvDev e, Ring ring, const DevState* st, double gamma) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < batch.total_tiles) {
+    int pi, tile_p, tile_q;
+    tile_of_block(batch, pi, tile_p, tile_q);
+    fwd_direct_body<2, 2>(batch.prob[pi], tile_p, tile_q, smem);
+    return;
+  }
+  env_flush_block(e, ring, st, gamma, (int)blockIdx.x - batch.total_tiles, (int)gridDim.x - batch.total_tiles, smem);
+}
+
 // one batched env step on the learner's stream: SelectActionGreedily for all workers, then the
 // per-worker epsilon draw / GetAction / reward / episode bookkeeping / AddTransitions
-static int env_one_step(dqnhip_env* e) {
+static int env_one_step(dqnhip_env* e, bool more_follow) {
   dqnhip_learner* h = e->h;
   EnvDev d = e->d;
   hipStream_t st = h->stream;
   const NetLayout& la = h->la;
   FwdPass fp{DQNHIP_ACTOR, &la, e->acts};
-  RC(tower_forward(h, st, &fp, 1, e->Npad));
-  // 6 launches per batched step at L = 4: the actor heads ride in k_env_step (one wave per worker computes
-  // its own 10 outputs) and the ring bookkeeping in k_env_flush's last block; DQNHIP_ENV_SEPARATE=1 restores
-  // the 8-launch form (head kernel + k_env_commit) for A/B measurements
+  // 5 launches per batched step at L = 4 inside a sequence: the actor heads ride in k_env_step (one wave per worker
+  // computes its own 10 outputs), the ring bookkeeping in the flush's last block, and the flush itself in the NEXT
+  // step's first-layer launch; DQNHIP_ENV_SEPARATE=1 restores the 8-launch form for A/B measurements
   static const bool kFused = !getenv("DQNHIP_ENV_SEPARATE");
+  static const bool kRide = !getenv("DQNHIP_ENV_NO_RIDER");
   // (beyond a few hundred workers the dedicated head kernel and a separate commit win: one wave per head row is
   // slower than the tiled head kernel there, and N arrivals on one counter serialise at ~12 ns each)
-  if (kFused && la.dims[la.L] % 4 == 0 && d.N <= 512) {
+  const bool fused = kFused && la.dims[la.L] % 4 == 0 && d.N <= 512;
+  if (fused) {
     d.head_x = e->acts[la.L]; d.head_h = la.dims[la.L];
     d.head_w = wat(h, DQNHIP_ACTOR, la.hw_off); d.head_b = wat(h, DQNHIP_ACTOR, la.hb_off);
     d.commit_ticket = e->commit_ticket;
-  } else {
+  }
+  const bool l0_direct = !((la.kp[0] >= 512) && (la.kp[0] % 256 == 0)) && la.dims[1] % 32 == 0 && e->Npad % 32 == 0;
+  int first = 0;
+  if (e->flush_deferred) {
+    // the previous step's flush + this step's first layer (the deferral below is only made when this holds)
+    GemmBatch b{}; b.n = 1;
+    GemmProblem& p = b.prob[0];
+    p.P = wat(h, DQNHIP_ACTOR, la.w_off[0]); p.ldp = la.kp[0];
+    p.Q = e->acts[0]; p.ldq = la.kp[0];
+    p.C = e->acts[1]; p.ldc = la.kp[1];
+    p.Pdim = la.dims[1]; p.Qdim = e->Npad; p.Kred = la.kp[0];
+    p.bias = wat(h, DQNHIP_ACTOR, la.b_off[0]); p.relu = 1;
+    p.tiles_p = p.Pdim / 32; p.tiles_q = p.Qdim / 32; p.tile_base = 0;
+    b.total_tiles = p.tiles_p * p.tiles_q;
+    const size_t lds = std::max<size_t>(4 * 2 * 2 * 64 * 16, d.T * sizeof(float));
+    hipLaunchKernelGGL(k_env_l0_flush, dim3(b.total_tiles + d.N), dim3(256), lds, st, b, d, RO(h)->ring,
+                       (const DevState*)RO(h)->st, h->cfg.gamma);
+    HIPCHK(hipGetLastError());
+    e->flush_deferred = false;
+    first = 1;
+  }
+  for (int i = first; i < la.L; ++i) RC(layer_forward(h, st, &fp, 1, e->Npad, i));
+  if (!fused) {
     HeadArgs a{}; a.X = e->acts[la.L]; a.ldx = la.dims[la.L]; a.H = la.dims[la.L]; a.rows = e->Npad;
     a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.b = wat(h, DQNHIP_ACTOR, la.hb_off); a.out16 = d.out16;
     RC((head_forward<kNO, HEAD_ACTOR>(h, st, a)));
   }
-  hipLaunchKernelGGL(k_env_step, dim3(d.N), dim3(64), d.SP * sizeof(float), st, d);
+  hipLaunchKernelGGL(k_env_step, dim3(d.N), dim3(64), 2 * d.SP * sizeof(float), st, d);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), (d.T + d.SP) * sizeof(float), st, d, RO(h)->ring,
+  if (more_follow && kRide && fused && l0_direct && !h->timing) { e->flush_deferred = true; return 0; }
+  hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), d.T * sizeof(float), st, d, RO(h)->ring,
                      (const DevState*)RO(h)->st, h->cfg.gamma);
   HIPCHK(hipGetLastError());
   if (d.commit_ticket == nullptr) {
@@ -2205,7 +2249,8 @@ static int env_capture(dqnhip_env* e, int which) {
   HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
   const int n = which ? kEnvUnroll : 1;
-  for (int s = 0; s < n && !rc; ++s) rc = env_one_step(e);
+  for (int s = 0; s < n && !rc; ++s) rc = env_one_step(e, s + 1 < n);
+  e->flush_deferred = false;                     // (only left set if a launch failed: the sequence is abandoned)
   hipError_t err = hipStreamEndCapture(h->stream, &graph);
   if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
   if (err != hipSuccess) return fail("hipStreamEndCapture (env): %s", hipGetErrorString(err));
@@ -2240,7 +2285,10 @@ int dqnhip_env_step(dqnhip_env_handle e, float epsilon, int32_t n_steps) {
       if (e->graph_failed) break;
     }
   }
-  for (; s < n_steps; ++s) RC(env_one_step(e));
+  for (; s < n_steps; ++s) {
+    const int rc = env_one_step(e, s + 1 < n_steps);
+    if (rc) { e->flush_deferred = false; return rc; }
+  }
   RO(h)->ring_stale = true;
   return 0;
 }
