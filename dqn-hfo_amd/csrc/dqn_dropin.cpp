@@ -278,6 +278,7 @@ std::vector<ActorOutput> DQN::SelectActions(const std::vector<InputStates>& stat
     for (auto& o : out) o = GetRandomActorOutput();
     return out;
   }
+  if (states_batch.empty()) return out;
   std::vector<float> s(states_batch.size() * (size_t)state_size_);
   for (size_t n = 0; n < states_batch.size(); ++n) {
     const StateDataSp& sp = states_batch[n][0];
