@@ -286,11 +286,14 @@ __global__ void k_fill_h(h16* p, size_t n, uint32_t seed, float lo, float hi) {
 }
 // naive reference of the whole epilogue, fp32 accumulation of the fp16 inputs in k order
 __global__ void k_ref_h(const h16* A, int lda, const h16* B, int ldb, int M, int N, int K, const float* bias, int relu,
-                        const h16* mask, int ldm, float* ref) {
+                        const h16* mask, int ldm, float* ref, int tn = 0) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * N) return;
   const int m = (int)(i / N), n = (int)(i % N);
   float acc = 0.f;
+  if (tn == 1) { for (int k = 0; k < K; ++k) acc = fmaf((float)A[(size_t)k * lda + m], (float)B[(size_t)k * ldb + n], acc); }
+  else if (tn == 2) { for (int k = 0; k < K; ++k) acc = fmaf((float)A[(size_t)m * lda + k], (float)B[(size_t)k * ldb + n], acc); }
+  else
   for (int k = 0; k < K; ++k) acc = fmaf((float)A[(size_t)m * lda + k], (float)B[(size_t)n * ldb + k], acc);
   if (bias) acc += bias[n];
   if (relu) acc = acc > 0.f ? acc : 0.01f * acc;
@@ -332,7 +335,7 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
                                  float* avg_us, float* max_abs_err, float* max_ref) {
   if (iters < 1 || M % 64 || N % 64 || K % 64) return 1;
   static bool prepared = false;
-  if (!prepared) { CK((hgemm_prepare<2, 2>())); CK((hgemm_prepare<1, 1>())); CK((hgemm_prepare<4, 2>())); prepared = true; }
+  if (!prepared) { CK(hgemm_prepare_all()); prepared = true; }
   hipStream_t s; CK(hipStreamCreate(&s));
   float* dres; CK(hipMalloc(&dres, 8)); CK(hipMemsetAsync(dres, 0, 8, s));
   float hres[2] = {0, 0};
@@ -371,11 +374,13 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
   // DQNHIP_TEST_LDPAD=<halves>: leading-dimension padding of both operands (L2 channel-camping probe)
   const int ldpad = getenv("DQNHIP_TEST_LDPAD") ? atoi(getenv("DQNHIP_TEST_LDPAD")) : 0;
   const int ldk = K + ldpad;
-  CK(hipMalloc(&A, (size_t)M * ldk * 2)); CK(hipMalloc(&B, (size_t)N * ldk * 2)); CK(hipMalloc(&mask, (size_t)M * N * 2));
+  const bool tn = mode == 6;           // mode 6: as 2, but both operands reduction-major ([K][M] and [K][N]) — the learner's wgrad
+  const size_t a_elems = tn ? (size_t)K * (M + ldpad) : (size_t)M * ldk, b_elems = tn ? (size_t)K * (N + ldpad) : (size_t)N * ldk;
+  CK(hipMalloc(&A, a_elems * 2)); CK(hipMalloc(&B, b_elems * 2)); CK(hipMalloc(&mask, (size_t)M * N * 2));
   CK(hipMalloc(&C16, (size_t)M * N * 2)); CK(hipMalloc(&CT16, (size_t)M * N * 2)); CK(hipMalloc(&bias, N * 4));
   CK(hipMalloc(&C32, (size_t)M * N * 4)); CK(hipMalloc(&ref, (size_t)M * N * 4));
-  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, A, (size_t)M * ldk, 11u, -1.f, 1.f);
-  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, B, (size_t)N * ldk, 23u, -1.f, 1.f);
+  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, A, a_elems, 11u, -1.f, 1.f);
+  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, B, b_elems, 23u, -1.f, 1.f);
   hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, mask, (size_t)M * N, 31u, -1.f, 1.f);
   hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, s, bias, (size_t)N, 41u, -1.f, 1.f);
   CK(hipMemsetAsync(C16, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(CT16, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(C32, 0xff, (size_t)M * N * 4, s));
@@ -386,6 +391,7 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
   else if (mode == 5) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; }
   else if (mode == 1) { g.mask = mask; g.ldm = N; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 64.0f; }
   else { g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 1024.0f; g.n_valid32 = N / 2; }
+  if (tn) { g.ta = g.tb = 1; g.lda = M + ldpad; g.ldb = N + ldpad; }
   // tile >= 10: TWO problems in one launch (the second one a copy with its own outputs), tile - 10 = the forced shape
   const bool pair = tile >= 10;
   if (pair) tile -= 10;
@@ -404,13 +410,13 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
   CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   if (avg_us) *avg_us = ms * 1000.0f / iters;
-  hipLaunchKernelGGL(k_ref_h, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, (const h16*)A, ldk, (const h16*)B, ldk, M, N, K,
-                     (const float*)g.bias, g.relu, g.mask, g.ldm, ref);
+  hipLaunchKernelGGL(k_ref_h, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, (const h16*)A, g.lda, (const h16*)B, g.ldb, M, N, K,
+                     (const float*)g.bias, g.relu, g.mask, g.ldm, ref, tn ? 1 : 0);
   hipLaunchKernelGGL(k_cmp_h, dim3(256), dim3(256), 0, s, (const float*)ref, M, N, (const h16*)g.C16, N, (const h16*)g.CT16, M, (const float*)g.C32, N,
                      g.n_valid32, g.scale32, dres);
   CK(hipMemcpyAsync(hres, dres, 8, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
-  if (mode == 2) {   // untouched upper columns must still hold the 0xff fill
+  if (mode == 2 || mode == 6) {   // untouched upper columns must still hold the 0xff fill
     std::vector<uint32_t> row(N);
     CK(hipMemcpy(row.data(), C32, N * 4, hipMemcpyDeviceToHost));
     for (int n = N / 2; n < N; ++n) if (row[n] != 0xffffffffu) hres[0] = 1e30f;
@@ -434,6 +440,75 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
   return 0;
 }
 
+
+// The layer backward as the learner launches it without transposed panels: a dgrad-oriented problem (A = dY [B][N_out]
+// k-major, B = W [N_out][K_in] reduction-major; ReLU' mask, fp16 + scaled fp32 outputs) and a wgrad-oriented one (A = dY
+// [B][N_out], B = X [B][K_in], both reduction-major; scaled fp32 output), sharing dY.  Each alone, then both in ONE
+// launch of the 64x64 split-K tile (hgemm_nt<1,1,2,3>); every result against the naive reference.
+//   rows = minibatch B, n_out, k_in (multiples of 128).  us[3] = dgrad alone, wgrad alone, pair.
+extern "C" int dqnhip_test_hgemm_backward(int32_t rows, int32_t n_out, int32_t k_in, int32_t iters, float* us, float* max_abs_err, float* max_ref) {
+  if (iters < 1 || rows % 128 || n_out % 128 || k_in % 128) return 1;
+  static bool prepared = false;
+  if (!prepared) { CK(hgemm_prepare_all()); prepared = true; }
+  hipStream_t s; CK(hipStreamCreate(&s));
+  h16 *dY, *W, *X, *mask, *dX16; float *dX32, *dW32, *refd, *refw, *dres;
+  CK(hipMalloc(&dY, (size_t)rows * n_out * 2)); CK(hipMalloc(&W, (size_t)n_out * k_in * 2)); CK(hipMalloc(&X, (size_t)rows * k_in * 2));
+  CK(hipMalloc(&mask, (size_t)rows * k_in * 2)); CK(hipMalloc(&dX16, (size_t)rows * k_in * 2)); CK(hipMalloc(&dX32, (size_t)rows * k_in * 4));
+  CK(hipMalloc(&dW32, (size_t)n_out * k_in * 4)); CK(hipMalloc(&refd, (size_t)rows * k_in * 4)); CK(hipMalloc(&refw, (size_t)n_out * k_in * 4));
+  CK(hipMalloc(&dres, 8));
+  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, dY, (size_t)rows * n_out, 3u, -1.f, 1.f);
+  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, W, (size_t)n_out * k_in, 5u, -1.f, 1.f);
+  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, X, (size_t)rows * k_in, 7u, -1.f, 1.f);
+  hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, mask, (size_t)rows * k_in, 9u, -1.f, 1.f);
+  HGemm gd{}, gw{};
+  gd.A = dY; gd.lda = n_out; gd.B = W; gd.ldb = k_in; gd.tb = 1; gd.M = rows; gd.N = k_in; gd.K = n_out;
+  gd.mask = mask; gd.ldm = k_in; gd.C16 = dX16; gd.ldc16 = k_in; gd.C32 = dX32; gd.ldc32 = k_in; gd.n_valid32 = k_in; gd.scale32 = 1.0f / 64.0f;
+  gw.A = dY; gw.lda = n_out; gw.ta = 1; gw.B = X; gw.ldb = k_in; gw.tb = 1; gw.M = n_out; gw.N = k_in; gw.K = rows;
+  gw.C32 = dW32; gw.ldc32 = k_in; gw.n_valid32 = k_in; gw.scale32 = 1.0f / 1024.0f;
+  hipLaunchKernelGGL(k_ref_h, dim3((unsigned)(((size_t)rows * k_in + 255) / 256)), dim3(256), 0, s, (const h16*)dY, n_out, (const h16*)W, k_in, rows, k_in, n_out,
+                     (const float*)nullptr, 0, (const h16*)mask, k_in, refd, 2);
+  hipLaunchKernelGGL(k_ref_h, dim3((unsigned)(((size_t)n_out * k_in + 255) / 256)), dim3(256), 0, s, (const h16*)dY, n_out, (const h16*)X, k_in, n_out, k_in, rows,
+                     (const float*)nullptr, 0, (const h16*)nullptr, 0, refw, 1);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float worst = 0.f, big = 0.f;
+  auto check = [&]() -> int {
+    float hres[2];
+    CK(hipMemsetAsync(dres, 0, 8, s));
+    hipLaunchKernelGGL(k_cmp_h, dim3(256), dim3(256), 0, s, (const float*)refd, rows, k_in, (const h16*)dX16, k_in, (const h16*)nullptr, 0, (const float*)dX32, k_in, k_in, gd.scale32, dres);
+    hipLaunchKernelGGL(k_cmp_h, dim3(256), dim3(256), 0, s, (const float*)refw, n_out, k_in, (const h16*)nullptr, 0, (const h16*)nullptr, 0, (const float*)dW32, k_in, k_in, gw.scale32, dres);
+    CK(hipMemcpyAsync(hres, dres, 8, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s));
+    worst = fmaxf(worst, hres[0]); big = fmaxf(big, hres[1]);
+    return 0;
+  };
+  auto clear = [&]() -> int {
+    CK(hipMemsetAsync(dX16, 0xff, (size_t)rows * k_in * 2, s)); CK(hipMemsetAsync(dX32, 0xff, (size_t)rows * k_in * 4, s));
+    CK(hipMemsetAsync(dW32, 0xff, (size_t)n_out * k_in * 4, s));
+    return 0;
+  };
+  for (int form = 0; form < 3; ++form) {        // 0: dgrad alone (+ wgrad once for the check), 1: wgrad alone, 2: the pair
+    if (clear()) return 2;
+    const HGemm pair[2] = {gd, gw};
+    auto run = [&]() -> hipError_t {
+      if (form == 0) return hgemm_launch(gd, s);
+      if (form == 1) return hgemm_launch(gw, s);
+      return hgemm_launch_batch(pair, 2, s, 2);
+    };
+    for (int i = 0; i < 3; ++i) CK(run());
+    CK(hipStreamSynchronize(s)); CK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) CK(run());
+    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (us) us[form] = ms * 1000.f / iters;
+    if (form == 0) CK(hgemm_launch(gw, s));
+    if (form == 1) CK(hgemm_launch(gd, s));
+    if (check()) return 2;
+  }
+  if (max_abs_err) *max_abs_err = worst;
+  if (max_ref) *max_ref = big;
+  hipFree(dY); hipFree(W); hipFree(X); hipFree(mask); hipFree(dX16); hipFree(dX32); hipFree(dW32); hipFree(refd); hipFree(refw); hipFree(dres);
+  hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+  return 0;
+}
 
 // ======================= optimiser pass probe ===================================================
 #include "small_kernels.hip.h"

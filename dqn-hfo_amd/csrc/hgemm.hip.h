@@ -52,6 +52,12 @@ struct HGemm {
   int relu;                    // leaky ReLU(0.01) on the result
   const h16* mask; int ldm;    // [M][ldm]: multiply by lrelu'(mask) = mask > 0 ? 1 : 0.01 (may be null)
   float scale32;               // the fp32 output is multiplied by this (loss-scale removal)
+  // Operand orientation in memory.  0: k-major — [rows][ld] with the reduction index contiguous (a lane's MFMA fragment
+  // is one 16-B piece).  1: REDUCTION-major — [K][ld] with the M (resp. N) index contiguous; fragments then come out of
+  // LDS through the transposing read ds_read_b64_tr_b16.  With it the three layer GEMMs read the SAME batch-major panels
+  // and the SAME weight mirror:  FWD  A = X[b][k] (0), B = W[n][k] (0);  DGRAD  A = dY[b][n] (0), B = W[n][k_in] (1: rows
+  // are the reduction index n);  WGRAD  A = dY[b][n] (1), B = X[b][k] (1) — no transposed copy of anything.
+  int ta, tb;
 };
 
 // Up to two independent problems of the same tile configuration in one launch (the two actors' /
@@ -98,16 +104,19 @@ struct HGCfg {
 template <int N> __device__ __forceinline__ void hg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #define HG_PIN() __builtin_amdgcn_sched_barrier(0)
 
-template <int WM, int WN>
-__global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch batch) {
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short hg_s16x4;
+typedef __attribute__((address_space(3))) hg_s16x4* hg_lds_s16x4_ptr;
+
+// MODE = ta | tb << 1 of the problem (compile time: the fragment loads of the main loop differ)
+template <int WM, int WN, int MODE>
+__device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
   using Cfg = HGCfg<WM, WN>;
   constexpr int NW = Cfg::NW, NT = Cfg::NT;
+  constexpr bool TA = (MODE & 1) != 0, TB = (MODE & 2) != 0;
+  static_assert(MODE == 0 || NW == 4, "reduction-major operands: 128x128 and 64x64 tiles only");
 #ifdef HG_CLOCKPROBE
   const unsigned long long hg_c0 = clock64(), hg_r0 = wall_clock64();
 #endif
-  const int sel = (batch.n > 1 && (int)blockIdx.x >= batch.tiles0) ? 1 : 0;      // wave-uniform
-  const HGemm& g = batch.g[sel];
-  const int bid = (int)blockIdx.x - sel * batch.tiles0;
   constexpr int WK = Cfg::WK, BM = Cfg::BM, BN = Cfg::BN, STAGES = Cfg::STAGES, TLD = Cfg::TLD;
   constexpr int NSUB = Cfg::NSUB, LOADS = Cfg::LOADS, KSTEP = Cfg::KSTEP;
   extern __shared__ __attribute__((aligned(1024))) unsigned char hg_smem[];
@@ -127,18 +136,36 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch ba
   const int wu = __builtin_amdgcn_readfirstlane(w);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)hg_smem;
   const h16* wbase = nullptr; const h16* wbase_b = nullptr;
+  size_t dma_step = KSTEP;                   // elements between two stages of this wave's source (KSTEP columns, or KSTEP rows)
   uint32_t voff[LOADS];
   if constexpr (NW == 4) {
     const bool from_a = (WK == 1) ? (wu < 2) : ((wu & 1) == 0);
-    const int row_w = (WK == 1) ? (wu & 1) * 64 : 0;            // first matrix row (inside the tile) of this wave's slots
-    const int ld = from_a ? g.lda : g.ldb;
-    wbase = (from_a ? g.A + (size_t)m0 * g.lda : g.B + (size_t)n0 * g.ldb) + (size_t)row_w * ld +
-            ((WK == 1) ? 0 : (wu >> 1) * 64);
+    const bool red = from_a ? TA : TB;                          // wave-uniform (a constant when TA == TB)
+    const int ld = __builtin_amdgcn_readfirstlane(from_a ? g.lda : g.ldb);
+    if (red) {
+      // reduction-major operand: the wave's 64 slots are 64 consecutive REDUCTION rows of one 64-column strip —
+      // <2,2>: strips {A cols 0-63, A cols 64-127, B cols 0-63, B cols 64-127} for waves 0..3; <1,1>: {A, B} x
+      // {first, second 64-deep sub-tile}.  Same 128-B rows as the k-major image, but the swizzle that keeps the
+      // transposing read conflict-free is chunk ^= ((row >> 1) & 1) << 2 (the four rows of a 32-lane cycle then
+      // cover four different 64-B quarters of the bank row; PMC: 0 conflicts).
+      wbase = (from_a ? g.A + m0 : g.B + n0) + ((WK == 1) ? (wu & 1) * 64 : 0) + (size_t)((WK == 1) ? 0 : (wu >> 1) * 64) * ld;
+      dma_step = (size_t)(KSTEP * ld);
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
-      const int R = (wu * LOADS + i) * 8 + r8;                  // stage slot
-      const int c = pc ^ ((R >> 1) & 7);
-      voff[i] = (uint32_t)(((i * 8 + r8) * ld + c * 8) * 2);
+      for (int i = 0; i < LOADS; ++i) {
+        const int c = pc ^ (((r8 >> 1) & 1) << 2);
+        voff[i] = (uint32_t)(((i * 8 + r8) * ld + c * 8) * 2);
+      }
+    } else {
+      const int row_w = (WK == 1) ? (wu & 1) * 64 : 0;          // first matrix row (inside the tile) of this wave's slots
+      wbase = (from_a ? g.A + (size_t)m0 * g.lda : g.B + (size_t)n0 * g.ldb) + (size_t)row_w * ld +
+              ((WK == 1) ? 0 : (wu >> 1) * 64);
+      dma_step = KSTEP;
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i) {
+        const int R = (wu * LOADS + i) * 8 + r8;                // stage slot
+        const int c = pc ^ ((R >> 1) & 7);
+        voff[i] = (uint32_t)(((i * 8 + r8) * ld + c * 8) * 2);
+      }
     }
   } else {
     wbase = g.A + (size_t)(m0 + wu * 32) * g.lda;
@@ -158,7 +185,7 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch ba
   auto issue1 = [&](int kt, int i) {
     const h16* base; uint32_t dst;
     if constexpr (NW == 4) {
-      base = wbase + (size_t)kt * KSTEP;
+      base = wbase + (size_t)kt * dma_step;
       dst = lds0 + (uint32_t)((kt % STAGES) * Cfg::STAGE + (wu * LOADS + i) * 1024);
     } else {
       base = (i < 4 ? wbase : wbase_b) + (size_t)kt * KSTEP;
@@ -190,13 +217,41 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch ba
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // reduction-major image: a lane's fragment (8 reduction values of one output row/column) is two transposing
+  // reads.  ds_read_b64_tr_b16 (semantics probed, profiles/r02_ds_read_tr_b16_probe.txt): within a 16-lane group
+  // out[lane i][j] = in[lane 4j + (i >> 2)][i & 3], in[t] = the 4 halves at lane t's address.  So lane t = 4j + q
+  // of group gq points at row (kb + j), columns 16 gq' + 4q of its 32-column block: the group then holds, per lane
+  // i, column 16 gq' + i at rows kb .. kb+3.  Lanes 0-31 take reduction rows kb = k16 + 0 (+4 for the second read),
+  // lanes 32-63 k16 + 8 (+12): the 32x32x16 operand layout.
+  int tro[2][2] = {{0, 0}, {0, 0}};          // [read r][operand 0 = A, 1 = B]: byte offset inside a stage, block 0, sub-step 0
+  if constexpr (TA || TB) {
+    const int t16 = lane & 15, j4 = t16 >> 2, q4 = t16 & 3, gq = (lane >> 4) & 1;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = ((WK == 1) ? 0 : 16 * w) + hi * 8 + 4 * r + j4;      // + 16 s for <2,2> sub-steps (keeps (row >> 1) & 1)
+      const int chunk = gq * 2 + (q4 >> 1);                                 // 16-B chunk inside the 64-B block
+      const int o = row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4) + (q4 & 1) * 8;
+      tro[r][0] = ((WK == 1) ? wm * 8192 : 0) + o;
+      tro[r][1] = ((WK == 1) ? (BM + wn * 64) * 128 : 8192) + o;
+    }
+  }
   h16x8 fa[2][2], fb[2][2];                 // [register buffer][32-row half]
   auto load_frags = [&](int buf, int kt, int s) {
     const unsigned char* st = hg_smem + (kt % STAGES) * Cfg::STAGE;
+    // reduction-major operand: block i (32 columns) = +64 B along the row, i.e. chunk bit 2: XOR 64 on the swizzled offset
+    const uint32_t sbase = lds0 + (uint32_t)((kt % STAGES) * Cfg::STAGE + ((WK == 1) ? s * 16 * 128 : s * 16384));
+    auto tr_frag = [&](int op, int i) -> h16x8 {
+      union { hg_s16x4 h[2]; h16x8 v; } u;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) u.h[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((hg_lds_s16x4_ptr)(sbase + (uint32_t)(tro[r][op] ^ (i * 64))));
+      return u.v;
+    };
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      fa[buf][i] = *reinterpret_cast<const h16x8*>(st + offa[s] + i * 32 * 128);
-      fb[buf][i] = *reinterpret_cast<const h16x8*>(st + offb[s] + i * 32 * 128);
+      if constexpr (TA) fa[buf][i] = tr_frag(0, i);
+      else fa[buf][i] = *reinterpret_cast<const h16x8*>(st + offa[s] + i * 32 * 128);
+      if constexpr (TB) fb[buf][i] = tr_frag(1, i);
+      else fb[buf][i] = *reinterpret_cast<const h16x8*>(st + offb[s] + i * 32 * 128);
     }
   };
 
@@ -339,18 +394,40 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch ba
   }
 }
 
-template <int WM, int WN>
-inline hipError_t hgemm_prepare() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_nt<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             HGCfg<WM, WN>::LDS_BYTES);
+// One launch carries one problem, or two of the same tile configuration; MODE0 / MODE1 = their operand orientations
+// (blocks [0, tiles0) work on g[0], the rest on g[1]).
+template <int WM, int WN, int MODE0, int MODE1>
+__global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch batch) {
+  const int sel = (batch.n > 1 && (int)blockIdx.x >= batch.tiles0) ? 1 : 0;      // wave-uniform
+  const int bid = (int)blockIdx.x - sel * batch.tiles0;
+  if constexpr (MODE0 == MODE1) hgemm_body<WM, WN, MODE0>(batch.g[sel], bid);
+  else if (sel == 0) hgemm_body<WM, WN, MODE0>(batch.g[0], bid);
+  else hgemm_body<WM, WN, MODE1>(batch.g[1], bid);
+}
+
+// the instantiations the learner uses: forward (0), dgrad (2 = B reduction-major), wgrad (3 = both), and a small-
+// minibatch layer's dgrad + wgrad in one launch (2, 3)
+#define HG_FOR_EACH_KERNEL(X) \
+  X(2, 2, 0, 0) X(2, 2, 2, 2) X(2, 2, 3, 3) X(1, 1, 0, 0) X(1, 1, 2, 2) X(1, 1, 3, 3) X(1, 1, 2, 3) X(4, 2, 0, 0)
+
+inline hipError_t hgemm_prepare_all() {
+  hipError_t e = hipSuccess;
+#define HG_PREP(WM, WN, M0, M1)                                                                                     \
+  if (e == hipSuccess)                                                                                               \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_nt<WM, WN, M0, M1>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            HGCfg<WM, WN>::LDS_BYTES);
+  HG_FOR_EACH_KERNEL(HG_PREP)
+#undef HG_PREP
+  return e;
 }
 
 // picks the tile: 256x128 (8 waves) when THAT fills the chip (two 4096-row problems in one launch), 128x128 when that
 // does, else 64x64 with in-workgroup split-K.  force: 0 auto, 1 128x128, 2 64x64, 3 256x128.
 inline bool hgemm_big_ok(const HGemm& g) { return (g.M % 128 == 0) && (g.N % 128 == 0); }
-inline bool hgemm_huge_ok(const HGemm& g) { return (g.M % 256 == 0) && (g.N % 128 == 0); }
+inline bool hgemm_huge_ok(const HGemm& g) { return (g.M % 256 == 0) && (g.N % 128 == 0) && !g.ta && !g.tb; }
 inline long hgemm_tiles(const HGemm& g, bool big) { return big ? (long)(g.M / 128) * (g.N / 128) : (long)(g.M / 64) * (g.N / 64); }
 inline bool hgemm_huge_enabled() { static const bool on = getenv("DQNHIP_NO_HGEMM_256") == nullptr; return on; }
+inline int hgemm_mode(const HGemm& g) { return (g.ta ? 1 : 0) | (g.tb ? 2 : 0); }
 
 inline hipError_t hgemm_launch_batch(const HGemm* gs, int n, hipStream_t st, int force = 0, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
   if (n < 1 || n > 2) return hipErrorInvalidValue;
@@ -363,26 +440,30 @@ inline hipError_t hgemm_launch_batch(const HGemm* gs, int n, hipStream_t st, int
   if (huge_ok) for (int i = 0; i < n; ++i) tiles_huge += (long)(gs[i].M / 256) * (gs[i].N / 128);
   const bool huge = force == 3 || (force == 0 && huge_ok && tiles_huge >= 192 && hgemm_huge_enabled());
   const bool big = !huge && (force == 1 || (force == 0 && big_ok && tiles_big >= 192));
+  if (huge && !huge_ok) return hipErrorInvalidValue;
+  if (big && !big_ok) return hipErrorInvalidValue;
   HGemmBatch b{};
   b.n = n;
   for (int i = 0; i < n; ++i) b.g[i] = gs[i];
-  if (huge) {
-    if (!huge_ok) return hipErrorInvalidValue;
-    b.tiles0 = (int)((long)(gs[0].M / 256) * (gs[0].N / 128));
-    if (t0) hipExtLaunchKernelGGL((hgemm_nt<4, 2>), dim3((unsigned)tiles_huge), dim3(512), (HGCfg<4, 2>::LDS_BYTES), st, t0, t1, 0, b);
-    else hipLaunchKernelGGL((hgemm_nt<4, 2>), dim3((unsigned)tiles_huge), dim3(512), (HGCfg<4, 2>::LDS_BYTES), st, b);
-  } else if (big) {
-    if (!big_ok) return hipErrorInvalidValue;
-    b.tiles0 = (int)hgemm_tiles(gs[0], true);
-    if (t0) hipExtLaunchKernelGGL((hgemm_nt<2, 2>), dim3((unsigned)tiles_big), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, b);
-    else hipLaunchKernelGGL((hgemm_nt<2, 2>), dim3((unsigned)tiles_big), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, b);
-  } else {
-    long nb = 0;
-    for (int i = 0; i < n; ++i) { if (gs[i].M % 64 || gs[i].N % 64 || gs[i].K % 128) return hipErrorInvalidValue; nb += hgemm_tiles(gs[i], false); }
+  long blocks = 0;
+  if (huge) { blocks = tiles_huge; b.tiles0 = (int)((long)(gs[0].M / 256) * (gs[0].N / 128)); }
+  else if (big) { blocks = tiles_big; b.tiles0 = (int)hgemm_tiles(gs[0], true); }
+  else {
+    for (int i = 0; i < n; ++i) { if (gs[i].M % 64 || gs[i].N % 64 || gs[i].K % 128) return hipErrorInvalidValue; blocks += hgemm_tiles(gs[i], false); }
     b.tiles0 = (int)hgemm_tiles(gs[0], false);
-    if (t0) hipExtLaunchKernelGGL((hgemm_nt<1, 1>), dim3((unsigned)nb), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, b);
-    else hipLaunchKernelGGL((hgemm_nt<1, 1>), dim3((unsigned)nb), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, b);
   }
+  const int wm = huge ? 4 : (big ? 2 : 1), wn = huge ? 2 : (big ? 2 : 1);
+  const int m0 = hgemm_mode(gs[0]), m1 = n > 1 ? hgemm_mode(gs[1]) : m0;
+  bool launched = false;
+#define HG_TRY(WM, WN, M0, M1)                                                                                                          \
+  if (!launched && wm == WM && wn == WN && m0 == M0 && m1 == M1) {                                                                      \
+    launched = true;                                                                                                                    \
+    if (t0) hipExtLaunchKernelGGL((hgemm_nt<WM, WN, M0, M1>), dim3((unsigned)blocks), dim3(HGCfg<WM, WN>::NT), (HGCfg<WM, WN>::LDS_BYTES), st, t0, t1, 0, b); \
+    else hipLaunchKernelGGL((hgemm_nt<WM, WN, M0, M1>), dim3((unsigned)blocks), dim3(HGCfg<WM, WN>::NT), (HGCfg<WM, WN>::LDS_BYTES), st, b);         \
+  }
+  HG_FOR_EACH_KERNEL(HG_TRY)
+#undef HG_TRY
+  if (!launched) return hipErrorInvalidValue;          // an orientation pair no kernel was built for
   return hipGetLastError();
 }
 inline hipError_t hgemm_launch(const HGemm& g, hipStream_t st, int force = 0, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
@@ -462,6 +543,44 @@ __global__ __launch_bounds__(256) void k_db16(Db16Batch b) {
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) d.db[n] = ((s[0] + s[1]) + (s[2] + s[3])) * b.scale;
+}
+
+// the same from the batch-major panels dY [rows][ld] (no transposed copy exists): a block owns 64 columns of one layer,
+// 8 lanes x 16 B cover them, 32 row groups stride the rows; fixed-order LDS reduction over the row groups.
+// (Db16::dyt = the panel, ld = its row stride, row_base counts 64-column blocks.)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_db16_cols(Db16Batch b) {
+  __shared__ float sred[32][65];
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.d[j + 1].row_base) ++j;
+  const Db16& d = b.d[j];
+  const int col0 = ((int)blockIdx.x - d.row_base) * 64;
+  const int c8 = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const h16* p = d.dyt + col0 + c8 * 8;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  int r = rg;
+  for (; r + 96 < d.rows; r += 128) {        // four independent 16-B loads in flight
+    const h16x8 v0 = *reinterpret_cast<const h16x8*>(p + (size_t)r * d.ld), v1 = *reinterpret_cast<const h16x8*>(p + (size_t)(r + 32) * d.ld);
+    const h16x8 v2 = *reinterpret_cast<const h16x8*>(p + (size_t)(r + 64) * d.ld), v3 = *reinterpret_cast<const h16x8*>(p + (size_t)(r + 96) * d.ld);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += ((float)v0[e] + (float)v1[e]) + ((float)v2[e] + (float)v3[e]);
+  }
+  for (; r < d.rows; r += 32) {
+    const h16x8 v = *reinterpret_cast<const h16x8*>(p + (size_t)r * d.ld);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sred[rg][c8 * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) s += sred[g][threadIdx.x];
+    d.db[col0 + threadIdx.x] = s * b.scale;
+  }
 }
 
 }  // namespace dqnhip

@@ -166,6 +166,10 @@ struct dqnhip_learner {
   h16* dZT16[2][kMaxL + 1] = {{nullptr}};    // [k16][B]
   bool w16_dirty[4] = {true, true, true, true};
   bool wt16_by_adam = false;                 // the last optimiser launch wrote wt16 itself (tiled form)
+  // default: NO transposed panel exists — the dgrad reads the weight mirror and the wgrad reads dY / X reduction-major
+  // through the transposing LDS read (hgemm.hip.h, HGemm::ta / tb).  DQNHIP_FP16_TRANSPOSED_PANELS=1 restores the
+  // round-1 form (every operand k-major, second orientation of every panel written by its producer) for A/B runs.
+  bool redmajor = true;
   std::vector<void*> allocs16;
   // host-staging for add_transitions / acting
   void* stage_dev = nullptr; size_t stage_bytes = 0;
@@ -485,7 +489,7 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   static const int kAdamCap = getenv("DQNHIP_ADAM_BLOCKS") ? atoi(getenv("DQNHIP_ADAM_BLOCKS")) : 2048;
   static const bool kTiled = !getenv("DQNHIP_ADAM_FLAT");
   const NetLayout& l = layout_of(h, net);
-  const bool tiled = h->fp16 && kTiled && begin == 0 && end == l.arena;
+  const bool tiled = h->fp16 && !h->redmajor && kTiled && begin == 0 && end == l.arena;
   ScopedTiming t(h, 3, st);
   LaunchTimer& lt = launch_timer();
   if (tiled) {
@@ -545,7 +549,7 @@ int sync_w16(H* h, hipStream_t st, int net, bool only_t = false) {
   const NetLayout& l = layout_of(h, net);
   const int kind = net & 1;
   if (only_t && net >= 2) return 0;
-  if (only_t && h->wt16_by_adam) return 0;   // k_adam_soft_tiled already wrote the transposes
+  if (only_t && (h->wt16_by_adam || h->redmajor)) return 0;   // k_adam_soft_tiled already wrote the transposes / nobody reads them
   Cvt16Batch b{};
   for (int i = 0; i < l.L; ++i) {
     cvt16_add(b, h->w[net] + l.w_off[i], l.kp[i], l.dims[i + 1], l.kp[i], only_t ? nullptr : h->w16[net][i], h->k16[kind][i],
@@ -601,20 +605,26 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
     if (need_dx) {                         // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
       HGemm& g = gd;
       g.A = dZ[i + 1]; g.lda = l.dims[i + 1];
-      g.B = h->wt16[net][i]; g.ldb = l.dims[i + 1];
+      if (h->redmajor) { g.B = h->w16[net][i]; g.ldb = h->k16[kind][i]; g.tb = 1; }     // W[n][k_in]: rows are the reduction index
+      else { g.B = h->wt16[net][i]; g.ldb = l.dims[i + 1]; }
       g.M = rows; g.N = h->k16[kind][i]; g.K = l.dims[i + 1];
       if (i > 0) {
         g.mask = h->act16[p][i]; g.ldm = h->k16[kind][i];
         g.C16 = dZ[i]; g.ldc16 = h->k16[kind][i];
-        if (want_w) { g.CT16 = dZT[i]; g.ldct16 = rows; }
+        if (want_w && !h->redmajor) { g.CT16 = dZT[i]; g.ldct16 = rows; }
       } else {
         g.C32 = dZ32_0; g.ldc32 = l.kp[0]; g.n_valid32 = l.kp[0]; g.scale32 = 1.0f / ls;
       }
     }
     if (want_w) {                          // dW_i = dZ[i+1]^T . act[i]
       HGemm& g = gw;
-      g.A = dZT[i + 1]; g.lda = rows;
-      g.B = h->actT16[p][i]; g.ldb = rows;
+      if (h->redmajor) {                   // both operands batch-major: dY[b][n_out], X[b][k_in]
+        g.A = dZ[i + 1]; g.lda = l.dims[i + 1]; g.ta = 1;
+        g.B = h->act16[p][i]; g.ldb = h->k16[kind][i]; g.tb = 1;
+      } else {
+        g.A = dZT[i + 1]; g.lda = rows;
+        g.B = h->actT16[p][i]; g.ldb = rows;
+      }
       g.M = l.dims[i + 1]; g.N = h->k16[kind][i]; g.K = rows;
       g.C32 = garena + l.w_off[i]; g.ldc32 = l.kp[i]; g.n_valid32 = l.kp[i]; g.scale32 = 1.0f / ls;
     }
@@ -628,7 +638,13 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
       if (want_w) RC(hgemm_timed(h, st, gw, 9));
     }
   }
-  if (want_w) {                            // db_i = colsum(dZ[i+1]) for all layers in one launch
+  if (want_w && h->redmajor) {             // db_i = column sums of dZ[i+1] [rows][n_out] for all layers in one launch
+    Db16Batch b{}; b.scale = 1.0f / ls;
+    int base = 0;
+    for (int i = 0; i < l.L; ++i) { b.d[b.n++] = Db16{dZ[i + 1], l.dims[i + 1], l.dims[i + 1], rows, garena + l.b_off[i], base}; base += l.dims[i + 1] / 64; }
+    hipLaunchKernelGGL(k_db16_cols<0>, dim3(base), dim3(256), 0, st, b);
+    HIPCHK(hipGetLastError());
+  } else if (want_w) {                     // db_i = row sums of the transposed panels
     Db16Batch b{}; b.scale = 1.0f / ls;
     int base = 0;
     for (int i = 0; i < l.L; ++i) { b.d[b.n++] = Db16{dZT[i + 1], rows, l.dims[i + 1], rows, garena + l.b_off[i], base}; base += l.dims[i + 1]; }
@@ -1123,6 +1139,7 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
   }
   if (cfg->precision == DQNHIP_FP16) {
     h->fp16 = true;
+    h->redmajor = getenv("DQNHIP_FP16_TRANSPOSED_PANELS") == nullptr;
     const float user = cfg->loss_scale > 0.f ? cfg->loss_scale : 1.0f;
     h->ls_c = 16.0f * (float)(B * cfg->dp_world) * user;   // dq = (q-y)/B_global: back to O(q-y)
     h->ls_q = 4096.0f * user;
@@ -1142,22 +1159,22 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
       RC(halloc(&h->w16a[net], l.arena));
       for (int i = 0; i < L; ++i) {
         h->w16[net][i] = h->w16a[net] + l.w_off[i];
-        if (net < 2) RC(halloc(&h->wt16[net][i], (size_t)h->k16[net & 1][i] * l.dims[i + 1]));
+        if (net < 2 && !h->redmajor) RC(halloc(&h->wt16[net][i], (size_t)h->k16[net & 1][i] * l.dims[i + 1]));
       }
     }
     for (int p = 0; p < 5; ++p) {
       const int kind = p >= 2;
       for (int i = 0; i <= L; ++i) {
         RC(halloc(&h->act16[p][i], (size_t)B * h->k16[kind][i]));
-        if (p == 1 || p == 3) RC(halloc(&h->actT16[p][i], (size_t)h->k16[kind][i] * B));
+        if ((p == 1 || p == 3) && !h->redmajor) RC(halloc(&h->actT16[p][i], (size_t)h->k16[kind][i] * B));
       }
     }
     for (int kind = 0; kind < 2; ++kind)
       for (int i = 0; i <= L; ++i) {
         RC(halloc(&h->dZ16[kind][i], (size_t)B * h->k16[kind][i]));
-        RC(halloc(&h->dZT16[kind][i], (size_t)h->k16[kind][i] * B));
+        if (!h->redmajor) RC(halloc(&h->dZT16[kind][i], (size_t)h->k16[kind][i] * B));
       }
-    HIPCHK((hgemm_prepare<2, 2>())); HIPCHK((hgemm_prepare<1, 1>())); HIPCHK((hgemm_prepare<4, 2>()));
+    HIPCHK(hgemm_prepare_all());
   }
   // weights: gaussian(std 0.01), zero bias (src/dqn.cpp:350-352); targets = hard copy (:660-661)
   {

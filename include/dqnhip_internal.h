@@ -35,6 +35,11 @@ int dqnhip_test_gemm(int32_t mode, int32_t variant, int32_t rows, int32_t n_out,
 int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t N, int32_t K, int32_t iters,
                       float* avg_us, float* max_abs_err, float* max_ref);
 
+/* One tower layer's backward without transposed panels (see gemm_bench.hip): dgrad with the weight operand read
+ * reduction-major, wgrad with both operands reduction-major, each alone and both in one launch; us[3] = the three
+ * timings, max_abs_err over all results against the naive reference. */
+int dqnhip_test_hgemm_backward(int32_t rows, int32_t n_out, int32_t k_in, int32_t iters, float* us, float* max_abs_err, float* max_ref);
+
 /* Times the fused clip+Adam+soft-update pass on n_params random parameters (see gemm_bench.hip).
  * variant = 10*U + NT (U in {1,2,4} float4 per array in flight per thread, NT = non-temporal
  * gradient loads); touch_mb = MB of unrelated traffic between two passes (0: back to back). */
