@@ -12,11 +12,14 @@ Three layers of evidence:
      the minibatch to ~1-2 % in the parameter gradients.  north_star's 1e-4 applies to the fp32 path.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 from helpers import make_pair
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from oracle import torch_ref
 
 pytestmark = pytest.mark.gpu
@@ -92,9 +95,62 @@ def test_hgemm_kernels(pkg, gpu):
         assert rc == 0, c
         # fp32 accumulation of K products in a different order: ~sqrt(K) * 2^-24 relative to the row norm
         assert err <= 2e-5 * max(ref, 1.0), (c, err, ref)
+    # mode 6: wgrad-shaped with BOTH operands reduction-major ([K][M], [K][N]; transposing LDS reads), both tiles
+    for c in [(6, 2, 64, 64, 128), (6, 2, 128, 192, 256), (6, 1, 128, 128, 64), (6, 1, 256, 128, 192), (6, 2, 1024, 128, 4096),
+              (6, 0, 1024, 1024, 512), (6, 12, 128, 128, 256)]:
+        rc, err, ref = run(*c)
+        assert rc == 0, c
+        assert err <= 2e-5 * max(ref, 1.0), (c, err, ref)
+    assert run(6, 3, 256, 128, 64)[0] != 0          # no 256x128 kernel for reduction-major operands: refused
     assert run(0, 2, 64, 64, 64)[0] != 0           # the split-K tile needs K % 128 == 0: refused, not wrong
     assert run(0, 1, 192, 128, 64)[0] != 0          # 128x128 tile on M = 192: refused
     assert run(0, 3, 384, 128, 64)[0] != 0          # 256x128 tile on M = 384: refused
+
+
+def test_hgemm_layer_backward_without_transposed_panels(pkg, gpu):
+    """dgrad with the weight operand reduction-major + wgrad with both operands reduction-major (what the learner
+    launches): each alone and both in ONE launch (hgemm_nt<1,1,2,3>), against the naive device reference."""
+    lib = pkg.capi.load_test()
+    fn = lib.dqnhip_test_hgemm_backward
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int32] * 4 + [C.POINTER(C.c_float)] * 3
+    for (rows, n_out, k_in) in [(128, 128, 128), (256, 384, 128), (128, 256, 512), (512, 1024, 1024), (4096, 1024, 128)]:
+        us = (C.c_float * 3)(); err, ref = C.c_float(), C.c_float()
+        assert fn(rows, n_out, k_in, 2, us, C.byref(err), C.byref(ref)) == 0, (rows, n_out, k_in)
+        assert err.value <= 2e-5 * max(ref.value, 1.0), (rows, n_out, k_in, err.value, ref.value)
+
+
+def test_fp16_learner_same_with_and_without_transposed_panels(pkg, gpu):
+    """The default learner (no transposed panel anywhere) against the round-1 form (DQNHIP_FP16_TRANSPOSED_PANELS=1, every
+    operand k-major): same rounding points, same reduction order inside the MFMA chains — parameters after three
+    updates agree to fp32 round-off (the bias-gradient and optimiser kernels sum in a different order)."""
+    import subprocess, sys, json, os
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from __graft_entry__ import load_package
+from synth import synth_replay
+pkg = load_package()
+d = pkg.DQN(58, minibatch=256, hidden=(256, 128, 128), memory=4096, seed=3, precision="fp16", use_graph=False)
+rep = synth_replay(np.random.default_rng(5), 2000, 58)
+d.add_transitions_arrays(*rep)
+rng = np.random.default_rng(7)
+out = []
+for _ in range(3):
+    out.append(list(d.UpdateActorCritic(rng.integers(0, 2000, 256).astype(np.int32))))
+print("RESULT" + json.dumps({"stats": out, "w": [d.get_params(n).astype(np.float64).tolist() for n in range(4)]}))
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    res = []
+    for env_extra in ({}, {"DQNHIP_FP16_TRANSPOSED_PANELS": "1"}):
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:]))
+    a, b = res
+    assert np.allclose(a["stats"], b["stats"], rtol=1e-4, atol=1e-6), (a["stats"], b["stats"])
+    for wa, wb in zip(a["w"], b["w"]):
+        wa, wb = np.asarray(wa), np.asarray(wb)
+        assert np.abs(wa - wb).max() <= 2e-5 * max(np.abs(wb).max(), 1e-6) + 3e-7, np.abs(wa - wb).max()
 
 
 @pytest.mark.parametrize("shape", [
