@@ -65,6 +65,10 @@ struct HGemm {
 // [0, tiles0) work on g[0], the rest on g[1].
 struct HGemmBatch { HGemm g[2]; int n; int tiles0; };
 
+// bias gradients of all tower layers of one net: db_l[n] = scale * sum_b dY_l[b][n]
+struct Db16 { const h16* dyt; int ld; int n_out; int rows; float* db; int row_base; };
+struct Db16Batch { Db16 d[8]; int n; float scale; };
+
 __device__ __forceinline__ int hg_tile_of_block(int bid, int total) {
   // XCD x (= bid % 8) gets a contiguous run of row-major tiles: they share A row panels and
   // sweep all of B, so each XCD's L2 holds its A panels + B once (bijective for any total)
@@ -410,8 +414,9 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch ba
 #define HG_FOR_EACH_KERNEL(X) \
   X(2, 2, 0, 0) X(2, 2, 2, 2) X(2, 2, 3, 3) X(1, 1, 0, 0) X(1, 1, 2, 2) X(1, 1, 3, 3) X(1, 1, 2, 3) X(4, 2, 0, 0)
 
+inline hipError_t hgemm_wgrad_db_prepare();
 inline hipError_t hgemm_prepare_all() {
-  hipError_t e = hipSuccess;
+  hipError_t e = hgemm_wgrad_db_prepare();
 #define HG_PREP(WM, WN, M0, M1)                                                                                     \
   if (e == hipSuccess)                                                                                               \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_nt<WM, WN, M0, M1>), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -522,9 +527,7 @@ inline hipError_t cvt16_launch(const Cvt16Batch& b, hipStream_t st) {
   return hipGetLastError();
 }
 
-// bias gradients of all tower layers of one net: db_l[n] = scale * sum_b dYT_l[n][b]
-struct Db16 { const h16* dyt; int ld; int n_out; int rows; float* db; int row_base; };
-struct Db16Batch { Db16 d[8]; int n; float scale; };
+// bias gradients from the TRANSPOSED panels (round-1 form): db_l[n] = scale * sum_b dYT_l[n][b]
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void k_db16(Db16Batch b) {
   int j = 0;
@@ -548,13 +551,12 @@ __global__ __launch_bounds__(256) void k_db16(Db16Batch b) {
 // the same from the batch-major panels dY [rows][ld] (no transposed copy exists): a block owns 64 columns of one layer,
 // 8 lanes x 16 B cover them, 32 row groups stride the rows; fixed-order LDS reduction over the row groups.
 // (Db16::dyt = the panel, ld = its row stride, row_base counts 64-column blocks.)
-template <int UNUSED = 0>
-__global__ __launch_bounds__(256) void k_db16_cols(Db16Batch b) {
-  __shared__ float sred[32][65];
+__device__ __forceinline__ void db16_cols_block(const Db16Batch& b, int blk, float* scratch /* 32 x 65 floats of LDS */) {
+  float (*sred)[65] = reinterpret_cast<float (*)[65]>(scratch);
   int j = 0;
-  while (j + 1 < b.n && (int)blockIdx.x >= b.d[j + 1].row_base) ++j;
+  while (j + 1 < b.n && blk >= b.d[j + 1].row_base) ++j;
   const Db16& d = b.d[j];
-  const int col0 = ((int)blockIdx.x - d.row_base) * 64;
+  const int col0 = (blk - d.row_base) * 64;
   const int c8 = threadIdx.x & 7, rg = threadIdx.x >> 3;
   const h16* p = d.dyt + col0 + c8 * 8;
   float acc[8];
@@ -581,6 +583,32 @@ __global__ __launch_bounds__(256) void k_db16_cols(Db16Batch b) {
     for (int g = 0; g < 32; ++g) s += sred[g][threadIdx.x];
     d.db[col0 + threadIdx.x] = s * b.scale;
   }
+}
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_db16_cols(Db16Batch b) {
+  __shared__ float sred[32 * 65];
+  db16_cols_block(b, (int)blockIdx.x, sred);
+}
+
+// The first layer's wgrad has few tiles (N_out x 128 inputs = 32 at 4x1024) and a long reduction (the minibatch): its
+// launch leaves most of the chip idle for ~20 us at 4096 rows.  The bias-gradient column sums of ALL layers ride in
+// it as extra workgroups (they only need the dY panels, complete by then).
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void hgemm_wgrad_db(HGemmBatch batch, Db16Batch db) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char hg_smem[];
+  if ((int)blockIdx.x < batch.tiles0) hgemm_body<1, 1, MODE>(batch.g[0], (int)blockIdx.x);
+  else db16_cols_block(db, (int)blockIdx.x - batch.tiles0, reinterpret_cast<float*>(hg_smem));
+}
+inline hipError_t hgemm_wgrad_db_prepare() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_wgrad_db<3>), hipFuncAttributeMaxDynamicSharedMemorySize, HGCfg<1, 1>::LDS_BYTES);
+}
+// g: a reduction-major wgrad that takes the 64x64 split-K tile; db_blocks = 64-column blocks of db
+inline hipError_t hgemm_wgrad_db_launch(const HGemm& g, const Db16Batch& db, int db_blocks, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+  if (hgemm_mode(g) != 3 || g.M % 64 || g.N % 64 || g.K % 128) return hipErrorInvalidValue;
+  HGemmBatch b{}; b.n = 1; b.g[0] = g; b.tiles0 = (int)hgemm_tiles(g, false);
+  if (t0) hipExtLaunchKernelGGL((hgemm_wgrad_db<3>), dim3((unsigned)(b.tiles0 + db_blocks)), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, b, db);
+  else hipLaunchKernelGGL((hgemm_wgrad_db<3>), dim3((unsigned)(b.tiles0 + db_blocks)), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, b, db);
+  return hipGetLastError();
 }
 
 }  // namespace dqnhip

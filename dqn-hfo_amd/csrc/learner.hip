@@ -599,6 +599,7 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
   const NetLayout& l = layout_of(h, net);
   const int kind = net & 1;
   h16** dZ = h->dZ16[kind]; h16** dZT = h->dZT16[kind];
+  bool db_done = false;
   for (int i = l.L - 1; i >= 0; --i) {
     HGemm gd{}, gw{};
     const bool need_dx = i > 0 || input_grad;
@@ -628,6 +629,21 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
       g.M = l.dims[i + 1]; g.N = h->k16[kind][i]; g.K = rows;
       g.C32 = garena + l.w_off[i]; g.ldc32 = l.kp[i]; g.n_valid32 = l.kp[i]; g.scale32 = 1.0f / ls;
     }
+    // the last wgrad of the pass (first layer: few tiles, long reduction) carries the bias-gradient column sums of
+    // every layer as extra workgroups — all dZ panels are complete by now
+    static const bool kDbRider = !getenv("DQNHIP_SEPARATE_DB16");
+    if (i == 0 && want_w && !need_dx && h->redmajor && kDbRider && hgemm_uses_small_tile(gw) && gw.K % 128 == 0) {
+      Db16Batch b{}; b.scale = 1.0f / ls;
+      int base = 0;
+      for (int j = 0; j < l.L; ++j) { b.d[b.n++] = Db16{dZ[j + 1], l.dims[j + 1], l.dims[j + 1], rows, garena + l.b_off[j], base}; base += l.dims[j + 1] / 64; }
+      ScopedTiming t(h, 9, st);
+      LaunchTimer& lt = launch_timer();
+      hipEvent_t e0 = lt.start, e1 = lt.stop;
+      lt.start = lt.stop = nullptr;
+      HIPCHK(hgemm_wgrad_db_launch(gw, b, base, st, e0, e1));
+      db_done = true;
+      continue;
+    }
     // both read dZ[i+1] and neither reads the other's output: at small minibatches (both on the
     // 64x64 split-K tile) they share one launch
     if (need_dx && want_w && kHgemmPairs && hgemm_uses_small_tile(gd) && hgemm_uses_small_tile(gw) && gd.K % 128 == 0 && gw.K % 128 == 0) {
@@ -638,13 +654,13 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
       if (want_w) RC(hgemm_timed(h, st, gw, 9));
     }
   }
-  if (want_w && h->redmajor) {             // db_i = column sums of dZ[i+1] [rows][n_out] for all layers in one launch
+  if (want_w && h->redmajor && !db_done) {  // db_i = column sums of dZ[i+1] [rows][n_out] for all layers in one launch
     Db16Batch b{}; b.scale = 1.0f / ls;
     int base = 0;
     for (int i = 0; i < l.L; ++i) { b.d[b.n++] = Db16{dZ[i + 1], l.dims[i + 1], l.dims[i + 1], rows, garena + l.b_off[i], base}; base += l.dims[i + 1] / 64; }
     hipLaunchKernelGGL(k_db16_cols<0>, dim3(base), dim3(256), 0, st, b);
     HIPCHK(hipGetLastError());
-  } else if (want_w) {                     // db_i = row sums of the transposed panels
+  } else if (want_w && !db_done) {         // db_i = row sums of the transposed panels
     Db16Batch b{}; b.scale = 1.0f / ls;
     int base = 0;
     for (int i = 0; i < l.L; ++i) { b.d[b.n++] = Db16{dZT[i + 1], rows, l.dims[i + 1], rows, garena + l.b_off[i], base}; base += l.dims[i + 1]; }
