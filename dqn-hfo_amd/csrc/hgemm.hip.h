@@ -52,6 +52,7 @@ struct HGemm {
   int relu;                    // leaky ReLU(0.01) on the result
   const h16* mask; int ldm;    // [M][ldm]: multiply by lrelu'(mask) = mask > 0 ? 1 : 0.01 (may be null)
   float scale32;               // the fp32 output is multiplied by this (loss-scale removal)
+  float* sumsq_partial;        // one slot per workgroup of this problem: sum of squares of the fp32 values it wrote (may be null)
   // Operand orientation in memory.  0: k-major — [rows][ld] with the reduction index contiguous (a lane's MFMA fragment
   // is one 16-B piece).  1: REDUCTION-major — [K][ld] with the M (resp. N) index contiguous; fragments then come out of
   // LDS through the transposing read ds_read_b64_tr_b16.  With it the three layer GEMMs read the SAME batch-major panels
@@ -67,7 +68,7 @@ struct HGemmBatch { HGemm g[2]; int n; int tiles0; };
 
 // bias gradients of all tower layers of one net: db_l[n] = scale * sum_b dY_l[b][n]
 struct Db16 { const h16* dyt; int ld; int n_out; int rows; float* db; int row_base; };
-struct Db16Batch { Db16 d[8]; int n; float scale; };
+struct Db16Batch { Db16 d[8]; int n; float scale; float* sumsq_partial; /* one slot per 64-column block of k_db16_cols (may be null) */ };
 
 __device__ __forceinline__ int hg_tile_of_block(int bid, int total) {
   // XCD x (= bid % 8) gets a contiguous run of row-major tiles: they share A row panels and
@@ -338,6 +339,7 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
 
   // ---- epilogue 2: m-major outputs, 8 consecutive n per thread
   constexpr int CPR = BN / 8;               // chunks per row
+  float sq = 0.f;                           // sum of squares of the fp32 values this thread writes (clip norm)
   for (int q = tid; q < BM * CPR; q += NT) {
     const int row = q / CPR, c8 = q % CPR;
     float v[8];
@@ -378,10 +380,25 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
       float* d = g.C32 + (size_t)gm * g.ldc32 + gn;
       *reinterpret_cast<hg_f32x4*>(d) = hg_f32x4{v[0] * s, v[1] * s, v[2] * s, v[3] * s};
       *reinterpret_cast<hg_f32x4*>(d + 4) = hg_f32x4{v[4] * s, v[5] * s, v[6] * s, v[7] * s};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sq = fmaf(v[e] * s, v[e] * s, sq);
     }
     if (g.CT16) {                            // keep the finished values for the transposed pass
       hg_f32x4* p = reinterpret_cast<hg_f32x4*>(Tt + row * TLD + c8 * 8);
       p[0] = hg_f32x4{v[0], v[1], v[2], v[3]}; p[1] = hg_f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+  if (g.sumsq_partial) {                    // fixed-order block reduction: lanes, then the waves in index order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    __shared__ float s_sq[NW];
+    if (lane == 0) s_sq[w] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) t += s_sq[i];
+      g.sumsq_partial[bid] = t;
     }
   }
   if (!g.CT16) return;
@@ -581,7 +598,14 @@ __device__ __forceinline__ void db16_cols_block(const Db16Batch& b, int blk, flo
     float s = 0.f;
 #pragma unroll
     for (int g = 0; g < 32; ++g) s += sred[g][threadIdx.x];
-    d.db[col0 + threadIdx.x] = s * b.scale;
+    s *= b.scale;
+    d.db[col0 + threadIdx.x] = s;
+    if (b.sumsq_partial) {                   // one wave: butterfly, lane 0 stores
+      float q = s * s;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+      if (threadIdx.x == 0) b.sumsq_partial[blk] = q;
+    }
   }
 }
 template <int UNUSED = 0>

@@ -68,6 +68,7 @@ struct NetLayout {
   size_t dense = 0;            // dense (Caffe-order) parameter count
   // sum-of-squares partial slots
   int part_off[kMaxL + 1] = {0};  // per tower layer, then head
+  int part_db = 0;                // fp16 learner: first slot of the bias-gradient workgroups
   int n_part = 0;
 };
 
@@ -90,6 +91,9 @@ void layout_init(NetLayout& l, int in_dim, const dqnhip_config& c, bool actor) {
   l.hb_off = off; off += 64;
   dense += (size_t)l.NH * H + l.NH;
   l.part_off[l.L] = part; part += (H / 64) * l.NH;    // k_head_bwd uses the first H/64, k_head_wred one per (head, 64 columns)
+  // fp16 learner: the bias gradients come from their own workgroups (k_db16_cols, one per 64 columns): their slots
+  l.part_db = part;
+  for (int i = 0; i < l.L; ++i) part += l.dims[i + 1] / 64;
   l.arena = round_up_z(off, 64);
   l.dense = dense;
   l.n_part = part;
@@ -595,7 +599,7 @@ int tower_forward16_pair(H* h, hipStream_t st, int p0, int net0, int p1, int net
 // Tower backward in fp16 from dZ16[kind][L] (already scaled by `ls`).  want_w: dW (fp32, unscaled)
 // into garena + bias gradients; input_grad: fp32 dZ32_0[rows][kp0] (unscaled).
 int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float* dZ32_0, int rows,
-                     bool want_w, bool input_grad, float ls) {
+                     bool want_w, bool input_grad, float ls, float* partial = nullptr) {
   const NetLayout& l = layout_of(h, net);
   const int kind = net & 1;
   h16** dZ = h->dZ16[kind]; h16** dZT = h->dZT16[kind];
@@ -628,12 +632,13 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
       }
       g.M = l.dims[i + 1]; g.N = h->k16[kind][i]; g.K = rows;
       g.C32 = garena + l.w_off[i]; g.ldc32 = l.kp[i]; g.n_valid32 = l.kp[i]; g.scale32 = 1.0f / ls;
+      if (partial) g.sumsq_partial = partial + l.part_off[i];      // clip-norm share of this layer's dW (unscaled)
     }
     // the last wgrad of the pass (first layer: few tiles, long reduction) carries the bias-gradient column sums of
     // every layer as extra workgroups — all dZ panels are complete by now
     static const bool kDbRider = !getenv("DQNHIP_SEPARATE_DB16");
     if (i == 0 && want_w && !need_dx && h->redmajor && kDbRider && hgemm_uses_small_tile(gw) && gw.K % 128 == 0) {
-      Db16Batch b{}; b.scale = 1.0f / ls;
+      Db16Batch b{}; b.scale = 1.0f / ls; b.sumsq_partial = partial ? partial + l.part_db : nullptr;
       int base = 0;
       for (int j = 0; j < l.L; ++j) { b.d[b.n++] = Db16{dZ[j + 1], l.dims[j + 1], l.dims[j + 1], rows, garena + l.b_off[j], base}; base += l.dims[j + 1] / 64; }
       ScopedTiming t(h, 9, st);
@@ -655,7 +660,7 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
     }
   }
   if (want_w && h->redmajor && !db_done) {  // db_i = column sums of dZ[i+1] [rows][n_out] for all layers in one launch
-    Db16Batch b{}; b.scale = 1.0f / ls;
+    Db16Batch b{}; b.scale = 1.0f / ls; b.sumsq_partial = partial ? partial + l.part_db : nullptr;
     int base = 0;
     for (int i = 0; i < l.L; ++i) { b.d[b.n++] = Db16{dZ[i + 1], l.dims[i + 1], l.dims[i + 1], rows, garena + l.b_off[i], base}; base += l.dims[i + 1] / 64; }
     hipLaunchKernelGGL(k_db16_cols<0>, dim3(base), dim3(256), 0, st, b);
@@ -694,6 +699,10 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
   const int Hh = la.dims[L], Hc = lc.dims[L];
   hipStream_t st = h->stream;
   const bool split = phase == 10;
+  // single learner, no transposed panels: the clip norm comes from the partial sums the wgrad / bias-gradient / head
+  // workgroups leave behind (as on the fp32 path); data-parallel ranks need the norm of the REDUCED gradient: k_sumsq
+  static const bool kPart16 = !getenv("DQNHIP_FP16_SUMSQ_KERNEL");
+  const bool part16 = kPart16 && !dp && h->redmajor;
   if (phase == 11) {
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
@@ -761,7 +770,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->dZT16[1][L], h->ls_c)); }
       else { a.dZ16 = h->dZ16[1][L]; a.dZT16 = h->dZT16[1][L]; a.ldT = B; a.scale16 = h->ls_c; RC(head_backward<1>(h, st, a)); }
     }
-    RC(tower_backward16(h, st, DQNHIP_CRITIC, 3, h->g[1], nullptr, B, true, false, h->ls_c));
+    RC(tower_backward16(h, st, DQNHIP_CRITIC, 3, h->g[1], nullptr, B, true, false, h->ls_c, part16 ? h->part[1] : nullptr));
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)h->loss_partial,
                          h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr);
@@ -770,8 +779,8 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     return 0;
   }
   if (phase == 1) {
-    RC(sumsq_launch(h, 1));
-    RC(adam_launch(h, st, 1, h->part_dp, h->n_part_dp, 0, lc.arena));
+    if (part16) RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
+    else { RC(sumsq_launch(h, 1)); RC(adam_launch(h, st, 1, h->part_dp, h->n_part_dp, 0, lc.arena)); }
     RC(sync_w16(h, st, DQNHIP_CRITIC, true));          // the Adam pass wrote the fp16 mirrors of critic and target
     RC(tower_forward16(h, st, 4, DQNHIP_CRITIC, B));
     static const bool kQRider16 = !getenv("DQNHIP_SEPARATE_QHEAD");
@@ -797,7 +806,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->dZT16[0][L], h->ls_a)); }
       else { a.dZ16 = h->dZ16[0][L]; a.dZT16 = h->dZT16[0][L]; a.ldT = B; a.scale16 = h->ls_a; RC(head_backward<kNO>(h, st, a)); }
     }
-    RC(tower_backward16(h, st, DQNHIP_ACTOR, 1, h->g[0], nullptr, B, true, false, h->ls_a));
+    RC(tower_backward16(h, st, DQNHIP_ACTOR, 1, h->g[0], nullptr, B, true, false, h->ls_a, part16 ? h->part[0] : nullptr));
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)nullptr, 0,
                          (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail);
@@ -808,8 +817,8 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
   if (phase == 2) {
     const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
                         dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world)};
-    RC(sumsq_launch(h, 0));
-    RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena, &tick));   // + iteration counters / statistics (k_tick's work)
+    if (part16) RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick));
+    else { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena, &tick)); }   // + iteration counters / statistics (k_tick's work)
     RC(sync_w16(h, st, DQNHIP_ACTOR, true));
     h->h_actor_iter += 1; h->h_critic_iter += 1;
     return 0;
