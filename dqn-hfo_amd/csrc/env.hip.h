@@ -154,10 +154,7 @@ __global__ void k_env_step(EnvDev e) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < kNO; ++j) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
-    }
+    for (int j = 0; j < kNO; ++j) acc[j] = wave_sum64(acc[j]);
     if (lane < kAP) {
       float v = 0.0f;
 #pragma unroll

@@ -431,7 +431,10 @@ template <int NH, int MODE>
 int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nullptr) {
   HeadArgs2 a2{}; a2.p[0] = a; if (b) a2.p[1] = *b;
   if (NH > 1 && a.rows >= 1024 && a.H <= 1024 && a.H % 4 == 0)   // (single-head: the block-per-row form measured faster, 6.6 vs 8.8 us)
-    hipLaunchKernelGGL((k_head_fwd_rows<NH, MODE>), dim3(256, b ? 2 : 1), dim3(256), 0, st, a2);
+  {
+    static const int kRowsBlocks = getenv("DQNHIP_HEAD_ROWS_BLOCKS") ? atoi(getenv("DQNHIP_HEAD_ROWS_BLOCKS")) : 256;
+    hipLaunchKernelGGL((k_head_fwd_rows<NH, MODE>), dim3(kRowsBlocks, b ? 2 : 1), dim3(256), 0, st, a2);
+  }
   else
     hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(std::min(a.rows, 1024), b ? 2 : 1), dim3(256), 0, st, a2);
   HIPCHK(hipGetLastError());

@@ -183,6 +183,20 @@ __global__ void k_gather(Ring ring, const DevState* rs, const DevState* st, cons
   }
 }
 
+// Sum over the 64 lanes of a wave with DPP moves (VALU speed) instead of six ds_bpermute butterfly steps: quad
+// xor 1, xor 2, half-row mirror, row mirror give every lane its 16-lane row total; row_bcast15 / row_bcast31 chain
+// the four row totals into lane 63, which is broadcast.  (Ten heads x six dependent LDS-crossbar shuffles were
+// ~2.5 us per row in the one-wave-per-row head kernels.)  Order: fixed, the same in every wave.
+__device__ __forceinline__ float wave_sum64(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // ---- skinny head layers ------------------------------------------------------
 // action_layer(4) + actionpara_layer(6) of the actor and q_values_layer(1) of
 // the critic (src/dqn.cpp:426-427, 450) are K=H4 dot products per row: one wave
@@ -277,14 +291,24 @@ __global__ __launch_bounds__(256) void k_head_fwd_rows(HeadArgs2 a2) {
       const int k = lane * 4 + 256 * t;
       wreg[j][t] = k < a.H ? *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+  // the next row of this wave is fetched while the current one is reduced (the loop was one exposed memory latency
+  // per row: 4 rows per wave at 4096 rows)
+  auto load_row = [&](int row, f32x4 (&v)[4]) {
     const float* x = a.X + (size_t)row * a.ldx;
-    f32x4 xv[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int k = lane * 4 + 256 * t;
-      xv[t] = k < a.H ? *reinterpret_cast<const f32x4*>(x + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[t] = k < a.H ? *reinterpret_cast<const f32x4*>(x + k) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  const int row_step = gridDim.x * 4;
+  f32x4 xn[4];
+  if ((int)(blockIdx.x * 4 + wave) < a.rows) load_row(blockIdx.x * 4 + wave, xn);
+  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += row_step) {
+    f32x4 xv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xv[t] = xn[t];
+    if (row + row_step < a.rows) load_row(row + row_step, xn);
     float acc[NH];
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
@@ -294,9 +318,7 @@ __global__ __launch_bounds__(256) void k_head_fwd_rows(HeadArgs2 a2) {
         s = fmaf(xv[t].x, wreg[j][t].x, s); s = fmaf(xv[t].y, wreg[j][t].y, s);
         s = fmaf(xv[t].z, wreg[j][t].z, s); s = fmaf(xv[t].w, wreg[j][t].w, s);
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-      acc[j] = s;
+      acc[j] = wave_sum64(s);
     }
     if (lane < kAP) {
       float v = 0.0f;
