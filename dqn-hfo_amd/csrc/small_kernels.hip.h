@@ -602,10 +602,15 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
   f32x4 wv[NH], acc[NH];
 #pragma unroll
   for (int j = 0; j < NH; ++j) { wv[j] = *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k0); acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 4
+  // all 16 rows of the wave's strip in flight before the first use (the stores below may alias as far as the
+  // compiler knows, so it would not hoist the loads itself: 4 in flight per thread made the kernel latency-bound)
+  f32x4 xr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xr[r] = *reinterpret_cast<const f32x4*>(a.X4 + (size_t)(m0 + w * 16 + r) * a.H + k0);
+#pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ml = w * 16 + r, m = m0 + ml;
-    const f32x4 x = *reinterpret_cast<const f32x4*>(a.X4 + (size_t)m * a.H + k0);
+    const f32x4 x = xr[r];
     f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
