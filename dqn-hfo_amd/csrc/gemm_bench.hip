@@ -595,6 +595,14 @@ struct ChainArgs {
   int* err;
 };
 
+// the learner's single-layer forward kernel with write-through (sc1) output stores: does a kernel boundary get cheaper
+// when the launch leaves no dirty lines behind for the end-of-kernel write-back?  (map bit 2 of dqnhip_test_chain)
+__global__ __launch_bounds__(256) void k_fwd_lds_wt(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  fwd_lds_body<2, 2, true, 2, true>(batch.prob[pi], tile_p, tile_q, smem);
+}
 __global__ __launch_bounds__(256) void k_fwd_chain(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_fail;
@@ -643,7 +651,7 @@ __global__ __launch_bounds__(256) void k_fwd_chain(ChainArgs a) {
 extern "C" int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, float* us_launches, float* us_persistent,
                                  float* max_abs_diff, int32_t* gave_up) {
   // map bit 0: tile -> XCD map (0 learner's, 1 slab per XCD); bit 1: write-through (sc1) hand-off without a release fence
-  const int wt = (map >> 1) & 1; map &= 1;
+  const int wt = (map >> 1) & 1, wt_launches = (map >> 2) & 1; map &= 1;
   if (layers < 1 || layers > 8 || iters < 1) return 1;
   const int rows = 256, width = 1024;
   hipStream_t s; CK(hipStreamCreate(&s));
@@ -663,13 +671,14 @@ extern "C" int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, flo
   CK(hipMalloc(&a.err, sizeof(int))); CK(hipMemsetAsync(a.err, 0, sizeof(int), s));
   const int lds = fwd_lds_bytes<2, 2, true>();
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_chain), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_lds_wt), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   auto run_launches = [&]() -> hipError_t {
     for (int l = 0; l < layers; ++l) {
       GemmBatch b{}; b.n = 1;
       GemmProblem& p = b.prob[0];
       p.P = a.W[l]; p.ldp = width; p.Q = ref[l]; p.ldq = width; p.C = ref[l + 1]; p.ldc = width;
       p.Pdim = width; p.Qdim = rows; p.Kred = width; p.bias = a.bias[l]; p.relu = 1;
-      hipError_t e = fwd_lds_launch<2, 2, true>(b, s);
+      hipError_t e = wt_launches ? direct_launch(k_fwd_lds_wt, b, 32, 32, (fwd_lds_bytes<2, 2, true>()), s) : fwd_lds_launch<2, 2, true>(b, s);
       if (e != hipSuccess) return e;
     }
     return hipSuccess;

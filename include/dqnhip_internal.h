@@ -48,7 +48,8 @@ int dqnhip_test_adam(int64_t n_params, int32_t variant, int32_t blocks, int32_t 
 /* Persistent-kernel probe: `layers` dependent 256 x 1024 x 1024 forward layers as `layers` launches of the
  * learner's gemm_fwd_lds<2,2> vs ONE launch of 256 co-resident workgroups with per-(layer, 32-row slab)
  * arrival counters (see gemm_bench.hip).  map bit 0: 0 the learner's tile->XCD map, 1 one slab per XCD;
- * bit 1: hand-off by write-through (sc1) tile stores without a release fence instead of plain stores + release.
+ * bit 1: hand-off by write-through (sc1) tile stores without a release fence instead of plain stores + release;
+ * bit 2: the SEPARATE launches use write-through output stores (does a boundary get cheaper with nothing dirty?).
  * max_abs_diff compares the two results (same arithmetic: expected 0); gave_up != 0 if a bounded spin expired. */
 int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, float* us_launches, float* us_persistent,
                       float* max_abs_diff, int32_t* gave_up);
