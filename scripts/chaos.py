@@ -10,10 +10,12 @@ from synth import synth_replay
 pkg = load_package()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"        # fp16: minibatch 128; parameter sharing is an fp32-only feature
+MB = 128 if prec == "fp16" else 64
 S, hid = 58, (256, 128, 128)
 tmp = tempfile.mkdtemp()
-A = pkg.DQN(S, minibatch=64, hidden=hid, memory=20000, seed=1, use_graph=True, save_path=os.path.join(tmp, "a"))
-Bl = pkg.DQN(S, minibatch=64, hidden=hid, memory=20000, seed=2, use_graph=False, save_path=os.path.join(tmp, "b"))
+A = pkg.DQN(S, minibatch=MB, hidden=hid, memory=20000, seed=1, use_graph=True, save_path=os.path.join(tmp, "a"), precision=prec)
+Bl = pkg.DQN(S, minibatch=MB, hidden=hid, memory=20000, seed=2, use_graph=False, save_path=os.path.join(tmp, "b"), precision=prec)
 envA = pkg.EnvFrontEnd(A, 48, max_steps=80, p_end=0.03, seed=3)
 envB = pkg.EnvFrontEnd(Bl, 16, max_steps=80, p_end=0.03, seed=4)
 shared_w = shared_r = False
@@ -32,7 +34,7 @@ while time.time() - t0 < budget:
     elif op == "add":
         d = A if rng.random() < 0.5 else Bl
         d.add_transitions_arrays(*synth_replay(rng, int(rng.integers(1, 3000)), S, mean_len=20))
-    elif op == "share_w":
+    elif op == "share_w" and prec == "fp32":
         shared_w = not shared_w
         A.ShareParameters(Bl, 2 if shared_w else 0, 1 if shared_w else 0)
     elif op == "share_r" and not shared_r:
@@ -40,7 +42,7 @@ while time.time() - t0 < budget:
     elif op == "snap" and A.actor_iter() > 0:
         A.Snapshot(os.path.join(tmp, "snapA"), False, False)
         a, c, m = pkg.FindLatestSnapshot(os.path.join(tmp, "snapA"))
-        R = pkg.DQN(S, minibatch=64, hidden=hid, memory=100, seed=9)
+        R = pkg.DQN(S, minibatch=MB, hidden=hid, memory=100, seed=9, precision=prec)
         R.RestoreActorSolver(a); R.RestoreCriticSolver(c)
         for net in range(2):
             np.testing.assert_array_equal(R.get_params(net), A.get_params(net))
