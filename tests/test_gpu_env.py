@@ -74,6 +74,32 @@ def test_env_graph_replay_matches_oracle(pkg, gpu):
     env.close(); oenv.close(); dqn.close(); orc.close()
 
 
+@pytest.mark.parametrize("workers,use_graph", [(48, False), (48, True), (600, False)])
+def test_env_step_sequences_match_single_steps(pkg, gpu, workers, use_graph):
+    """Inside a sequence of steps the episode flush of step t rides in step t+1's first-layer launch (<= 512 workers;
+    above that the flush keeps its own launch and the dedicated head kernel runs): sequences of 1, 2, 7 and 19 steps —
+    eager and graph-replayed — must leave the same workers and the same replay as the oracle stepping one at a time."""
+    dqn, orc, data, rng = make_pair(pkg, B=32, S=59, hidden=(128, 64, 64, 64), n_replay=100, capacity=60000, use_graph=use_graph)
+    kw = dict(max_steps=30, unum=7, p_end=0.08, p_goal=0.4, seed=5)
+    env = pkg.EnvFrontEnd(dqn, workers, **kw)
+    oenv = c_oracle.OracleEnv(orc, workers, **kw)
+    for n in (1, 2, 7, 19, 1, 16, 3):
+        env.step(0.2, n)
+        for _ in range(n):
+            oenv.step(0.2)
+        o = oenv.read()
+        np.testing.assert_array_equal(env.debug_read("action").astype(np.int32), o["action"])
+        np.testing.assert_array_equal(env.debug_read("episode_len").astype(np.int32), o["episode_len"])
+        np.testing.assert_allclose(env.debug_read("state"), o["state"], atol=1e-6)
+        assert dqn.memory_size() == orc.memory_size()
+    a, b = dqn.read_memory(0, dqn.memory_size()), orc.read_memory(0, orc.memory_size())
+    np.testing.assert_allclose(a[0], b[0], atol=1e-6); np.testing.assert_allclose(a[2], b[2], atol=2e-5)
+    np.testing.assert_allclose(a[3], b[3], atol=2e-4); np.testing.assert_allclose(a[4], b[4], atol=1e-6)
+    np.testing.assert_array_equal(a[5], b[5])
+    assert env.stats()[1] == oenv.stats()[1] > 0
+    env.close(); oenv.close(); dqn.close(); orc.close()
+
+
 def test_env_wraps_ring_and_rejects_bad_config(pkg, gpu):
     dqn = pkg.DQN(59, minibatch=32, hidden=(64,), memory=3000)
     with pytest.raises(pkg.DQNFatal):
