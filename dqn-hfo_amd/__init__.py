@@ -9,10 +9,10 @@ import by name; see load_package() in __graft_entry__.py).
 """
 from . import capi
 from ._build import build
-from .learner import (DQN, DQNFatal, EnvFrontEnd, FindLatestSnapshot, FindHiScore, RemoveFilesMatchingRegexp, FilesMatchingRegexp, RemoveSnapshots, reduce_gradients_local, Action, Transition, GetAction, GetParamOffset, PrintActorOutput,
+from .learner import (DQN, DQNFatal, EnvFrontEnd, FindLatestSnapshot, FindHiScore, RemoveFilesMatchingRegexp, FilesMatchingRegexp, RemoveSnapshots, reduce_gradients_local, dp_rendezvous_file, dp_rendezvous_cleanup, Action, Transition, GetAction, GetParamOffset, PrintActorOutput,
                       ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET, KIND_W, KIND_M, KIND_V, KIND_G,
                       DASH, TURN, TACKLE, KICK)
 
-__all__ = ["capi", "build", "DQN", "DQNFatal", "EnvFrontEnd", "FindLatestSnapshot", "FindHiScore", "RemoveFilesMatchingRegexp", "FilesMatchingRegexp", "RemoveSnapshots", "reduce_gradients_local", "Action", "Transition", "GetAction", "GetParamOffset",
+__all__ = ["capi", "build", "DQN", "DQNFatal", "EnvFrontEnd", "FindLatestSnapshot", "FindHiScore", "RemoveFilesMatchingRegexp", "FilesMatchingRegexp", "RemoveSnapshots", "reduce_gradients_local", "dp_rendezvous_file", "dp_rendezvous_cleanup", "Action", "Transition", "GetAction", "GetParamOffset",
            "PrintActorOutput", "ACTOR", "CRITIC", "ACTOR_TARGET", "CRITIC_TARGET", "KIND_W", "KIND_M",
            "KIND_V", "KIND_G", "DASH", "TURN", "TACKLE", "KICK"]

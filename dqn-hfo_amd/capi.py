@@ -6,6 +6,8 @@ from ._build import LIB, TEST_LIB, build
 
 MAX_HIDDEN = 8
 DP_ID_BYTES = 128        # DQNHIP_DP_ID_BYTES
+DP_PER_LAYER, DP_HALF_GRADS = 1, 2                  # dqnhip_dp_init flags
+TUNE_FP16_WGRAD_PER_LAYER = 1                       # dqnhip_config.tuning_flags bits
 ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET = 0, 1, 2, 3
 KIND_W, KIND_M, KIND_V, KIND_G = 0, 1, 2, 3
 
@@ -22,6 +24,7 @@ class Config(C.Structure):
         ("device", C.c_int32), ("dp_world", C.c_int32), ("dp_rank", C.c_int32), ("use_graph", C.c_int32),
         ("seed", C.c_uint64), ("stream", C.c_void_p), ("grad_arena", C.c_void_p),
         ("grad_arena_bytes", C.c_size_t), ("precision", C.c_int32), ("loss_scale", C.c_float),
+        ("tuning_flags", C.c_int32),
     ]
 
 
@@ -40,11 +43,16 @@ SIGNATURES = {
     "dqnhip_update": (C.c_int, [H, ip, fp, fp]),
     "dqnhip_update_async": (C.c_int, [H, ip]),
     "dqnhip_update_phase": (C.c_int, [H, C.c_int32, ip]),
+    "dqnhip_update_abort": (C.c_int, [H]),
+    "dqnhip_apply_update": (C.c_int, [H, C.c_int32]),
     "dqnhip_grad_buffer": (C.c_int, [H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "dqnhip_read_stats": (C.c_int, [H, fp, fp]),
     "dqnhip_dp_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
     "dqnhip_dp_init": (C.c_int, [H, C.c_void_p, C.c_size_t, C.c_int32]),
     "dqnhip_dp_init_file": (C.c_int, [H, C.c_char_p, C.c_int32, C.c_int32]),
+    "dqnhip_dp_rendezvous_file": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
+    "dqnhip_dp_rendezvous_cleanup": (C.c_int, [C.c_char_p, C.c_int32]),
+    "dqnhip_dp_graph_active": (C.c_int, [H, ip]),
     "dqnhip_dp_broadcast_params": (C.c_int, [H, C.c_int32]),
     "dqnhip_dp_update": (C.c_int, [H, ip]),
     "dqnhip_dp_destroy": (C.c_int, [H]),

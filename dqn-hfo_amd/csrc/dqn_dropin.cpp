@@ -402,6 +402,11 @@ int DQN::actor_iter() const { int32_t a = 0, c = 0; DQNHIP_CK(dqnhip_get_iters(h
 void DQN::ShareParameters(DQN& other, int num_actor_layers_to_share, int num_critic_layers_to_share) {
   DQNHIP_CK(dqnhip_share_parameters(h_, other.h_, num_actor_layers_to_share, num_critic_layers_to_share));
 }
+// src/dqn.cpp:1037-1045 shares the blobs of two caffe::Layer objects; the nets here are parameter arenas
+// in HBM without Layer objects, and the one caller (ShareParameters) is implemented on arena prefixes
+void DQN::ShareLayer(caffe::Layer<float>&, caffe::Layer<float>&) {
+  LOG(FATAL) << "DQN::ShareLayer: no caffe::Layer objects exist behind this DQN; use ShareParameters(other, n_actor, n_critic)";
+}
 void DQN::ShareReplayMemory(DQN& other) { DQNHIP_CK(dqnhip_share_replay_memory(h_, other.h_)); }
 
 }  // namespace dqn

@@ -273,6 +273,7 @@ extern "C" int dqnhip_test_gemm(int32_t mode, int32_t variant, int32_t rows, int
 
 // ======================= fp16-input family (hgemm.hip.h) ========================================
 #define HG_CLOCKPROBE 1
+#define HG_WITH_CT16 1      // test build: the transposed-output epilogue / conversion / row-sum kernels the learner no longer uses
 #include "hgemm.hip.h"
 
 namespace {
@@ -345,7 +346,7 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
     CK(hipMalloc(&src, (size_t)M * N * 4)); CK(hipMalloc(&d16, (size_t)M * ld16 * 2)); CK(hipMalloc(&dT, (size_t)ld16 * M * 2)); CK(hipMalloc(&db, ld16 * 4));
     hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, src, (size_t)M * N, 5u, -1.f, 1.f);
     CK(hipMemsetAsync(d16, 0xff, (size_t)M * ld16 * 2, s)); CK(hipMemsetAsync(dT, 0xff, (size_t)ld16 * M * 2, s));
-    Cvt16Batch b{}; cvt16_add(b, src, N, M, N - 3, d16, ld16, dT, M, 2.0f);
+    Cvt16Batch b{}; cvt16_add(b, src, N, M, N - 3, d16, ld16, 2.0f, dT, M);
     CK(cvt16_launch(b, s));
     Db16Batch q{}; q.n = 1; q.scale = 0.5f; q.d[0] = Db16{dT, M, ld16, M, db, 0};
     hipLaunchKernelGGL(k_db16<0>, dim3(ld16), dim3(256), 0, s, q);

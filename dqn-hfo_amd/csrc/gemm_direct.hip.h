@@ -890,18 +890,8 @@ __global__ __launch_bounds__(256) void gemm_bwd_seq(const GemmBatch batch) {
 struct LaunchTimer { hipEvent_t start = nullptr, stop = nullptr; };
 inline LaunchTimer& launch_timer() { static thread_local LaunchTimer t; return t; }
 
-// DQNHIP_LDS_PAD (bytes, env, tuning only): over-allocate dynamic LDS to cap workgroups per CU
-inline int lds_pad_bytes() {
-  static int pad = -1;
-  if (pad < 0) { const char* e = getenv("DQNHIP_LDS_PAD"); pad = e ? atoi(e) : 0; }
-  return pad;
-}
 template <typename K>
 inline hipError_t direct_launch(K kernel, GemmBatch& batch, int BP, int BQ, int lds_bytes, hipStream_t stream) {
-  if (lds_pad_bytes() > lds_bytes) {
-    lds_bytes = lds_pad_bytes();
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-  }
   int base = 0;
   for (int i = 0; i < batch.n; ++i) {
     GemmProblem& p = batch.prob[i];

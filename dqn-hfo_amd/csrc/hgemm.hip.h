@@ -61,10 +61,11 @@ struct HGemm {
   int ta, tb;
 };
 
-// Up to two independent problems of the same tile configuration in one launch (the two actors' /
-// the two critics' same-depth layers, or a layer's dgrad + wgrad at small minibatches): blocks
-// [0, tiles0) work on g[0], the rest on g[1].
-struct HGemmBatch { HGemm g[2]; int n; int tiles0; };
+// Up to four independent problems of the same tile configuration in one launch (the two actors' /
+// the two critics' same-depth layers; a layer's dgrad + wgrad at small minibatches; ALL wgrads of a net
+// once its dgrad chain has produced every dZ panel): blocks [tile_end[i-1], tile_end[i]) work on g[i].
+constexpr int kHGemmMax = 4;
+struct HGemmBatch { HGemm g[kHGemmMax]; int n; int tile_end[kHGemmMax]; };
 
 // bias gradients of all tower layers of one net: db_l[n] = scale * sum_b dY_l[b][n]
 struct Db16 { const h16* dyt; int ld; int n_out; int rows; float* db; int row_base; };
@@ -383,10 +384,12 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) sq = fmaf(v[e] * s, v[e] * s, sq);
     }
+#ifdef HG_WITH_CT16
     if (g.CT16) {                            // keep the finished values for the transposed pass
       hg_f32x4* p = reinterpret_cast<hg_f32x4*>(Tt + row * TLD + c8 * 8);
       p[0] = hg_f32x4{v[0], v[1], v[2], v[3]}; p[1] = hg_f32x4{v[4], v[5], v[6], v[7]};
     }
+#endif
   }
   if (g.sumsq_partial) {                    // fixed-order block reduction: lanes, then the waves in index order
 #pragma unroll
@@ -401,6 +404,8 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
       g.sumsq_partial[bid] = t;
     }
   }
+#ifdef HG_WITH_CT16
+  // (test build only: the learner keeps no transposed panel — the dgrad / wgrad operands are read reduction-major)
   if (!g.CT16) return;
   __syncthreads();
   // ---- epilogue 3: transposed output  CT16[n][m]: 4 lanes cover 32 consecutive m of one n (64 B)
@@ -413,17 +418,25 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
     for (int e = 0; e < 8; ++e) o[e] = (h16)Tt[(c8 * 8 + e) * TLD + n];
     *reinterpret_cast<h16x8*>(g.CT16 + (size_t)(n0 + n) * g.ldct16 + m0 + c8 * 8) = o;
   }
+#endif
 }
 
-// One launch carries one problem, or two of the same tile configuration; MODE0 / MODE1 = their operand orientations
-// (blocks [0, tiles0) work on g[0], the rest on g[1]).
+// One launch carries up to kHGemmMax problems of the same tile configuration; MODE0 = the operand orientation of
+// problem 0, MODE1 = that of every later problem.
+__device__ __forceinline__ int hg_select(const HGemmBatch& batch, int blk, int& bid) {
+  int sel = 0;
+#pragma unroll
+  for (int i = 1; i < kHGemmMax; ++i) if (i < batch.n && blk >= batch.tile_end[i - 1]) sel = i;      // wave-uniform
+  bid = blk - (sel ? batch.tile_end[sel - 1] : 0);
+  return sel;
+}
 template <int WM, int WN, int MODE0, int MODE1>
 __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch batch) {
-  const int sel = (batch.n > 1 && (int)blockIdx.x >= batch.tiles0) ? 1 : 0;      // wave-uniform
-  const int bid = (int)blockIdx.x - sel * batch.tiles0;
+  int bid;
+  const int sel = hg_select(batch, (int)blockIdx.x, bid);
   if constexpr (MODE0 == MODE1) hgemm_body<WM, WN, MODE0>(batch.g[sel], bid);
   else if (sel == 0) hgemm_body<WM, WN, MODE0>(batch.g[0], bid);
-  else hgemm_body<WM, WN, MODE1>(batch.g[1], bid);
+  else hgemm_body<WM, WN, MODE1>(batch.g[sel], bid);
 }
 
 // the instantiations the learner uses: forward (0), dgrad (2 = B reduction-major), wgrad (3 = both), and a small-
@@ -431,9 +444,9 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch ba
 #define HG_FOR_EACH_KERNEL(X) \
   X(2, 2, 0, 0) X(2, 2, 2, 2) X(2, 2, 3, 3) X(1, 1, 0, 0) X(1, 1, 2, 2) X(1, 1, 3, 3) X(1, 1, 2, 3) X(4, 2, 0, 0)
 
-inline hipError_t hgemm_wgrad_db_prepare();
+inline hipError_t hgemm_group_db_prepare();
 inline hipError_t hgemm_prepare_all() {
-  hipError_t e = hgemm_wgrad_db_prepare();
+  hipError_t e = hgemm_group_db_prepare();
 #define HG_PREP(WM, WN, M0, M1)                                                                                     \
   if (e == hipSuccess)                                                                                               \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_nt<WM, WN, M0, M1>), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -443,16 +456,17 @@ inline hipError_t hgemm_prepare_all() {
   return e;
 }
 
-// picks the tile: 256x128 (8 waves) when THAT fills the chip (two 4096-row problems in one launch), 128x128 when that
+// Tile choice: 256x128 (8 waves) when THAT fills the chip (two 4096-row problems in one launch), 128x128 when that
 // does, else 64x64 with in-workgroup split-K.  force: 0 auto, 1 128x128, 2 64x64, 3 256x128.
 inline bool hgemm_big_ok(const HGemm& g) { return (g.M % 128 == 0) && (g.N % 128 == 0); }
 inline bool hgemm_huge_ok(const HGemm& g) { return (g.M % 256 == 0) && (g.N % 128 == 0) && !g.ta && !g.tb; }
 inline long hgemm_tiles(const HGemm& g, bool big) { return big ? (long)(g.M / 128) * (g.N / 128) : (long)(g.M / 64) * (g.N / 64); }
-inline bool hgemm_huge_enabled() { static const bool on = getenv("DQNHIP_NO_HGEMM_256") == nullptr; return on; }
 inline int hgemm_mode(const HGemm& g) { return (g.ta ? 1 : 0) | (g.tb ? 2 : 0); }
 
-inline hipError_t hgemm_launch_batch(const HGemm* gs, int n, hipStream_t st, int force = 0, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-  if (n < 1 || n > 2) return hipErrorInvalidValue;
+// fills b (problems, tile ranges) and returns the tile configuration in wm / wn; hipErrorInvalidValue if the
+// problems do not fit one
+inline hipError_t hgemm_plan(const HGemm* gs, int n, int force, HGemmBatch& b, int& wm, int& wn, long& blocks) {
+  if (n < 1 || n > kHGemmMax) return hipErrorInvalidValue;
   bool big_ok = true, huge_ok = true; long tiles_big = 0, tiles_huge = 0;
   for (int i = 0; i < n; ++i) {
     big_ok = big_ok && hgemm_big_ok(gs[i]); huge_ok = huge_ok && hgemm_huge_ok(gs[i]);
@@ -460,22 +474,30 @@ inline hipError_t hgemm_launch_batch(const HGemm* gs, int n, hipStream_t st, int
   }
   if (big_ok) for (int i = 0; i < n; ++i) tiles_big += hgemm_tiles(gs[i], true);
   if (huge_ok) for (int i = 0; i < n; ++i) tiles_huge += (long)(gs[i].M / 256) * (gs[i].N / 128);
-  const bool huge = force == 3 || (force == 0 && huge_ok && tiles_huge >= 192 && hgemm_huge_enabled());
+  const bool huge = force == 3 || (force == 0 && huge_ok && tiles_huge >= 192);
   const bool big = !huge && (force == 1 || (force == 0 && big_ok && tiles_big >= 192));
   if (huge && !huge_ok) return hipErrorInvalidValue;
   if (big && !big_ok) return hipErrorInvalidValue;
-  HGemmBatch b{};
+  b = HGemmBatch{};
   b.n = n;
-  for (int i = 0; i < n; ++i) b.g[i] = gs[i];
-  long blocks = 0;
-  if (huge) { blocks = tiles_huge; b.tiles0 = (int)((long)(gs[0].M / 256) * (gs[0].N / 128)); }
-  else if (big) { blocks = tiles_big; b.tiles0 = (int)hgemm_tiles(gs[0], true); }
-  else {
-    for (int i = 0; i < n; ++i) { if (gs[i].M % 64 || gs[i].N % 64 || gs[i].K % 128) return hipErrorInvalidValue; blocks += hgemm_tiles(gs[i], false); }
-    b.tiles0 = (int)hgemm_tiles(gs[0], false);
+  blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    b.g[i] = gs[i];
+    if (huge) blocks += (long)(gs[i].M / 256) * (gs[i].N / 128);
+    else if (big) blocks += hgemm_tiles(gs[i], true);
+    else { if (gs[i].M % 64 || gs[i].N % 64 || gs[i].K % 128) return hipErrorInvalidValue; blocks += hgemm_tiles(gs[i], false); }
+    b.tile_end[i] = (int)blocks;
   }
-  const int wm = huge ? 4 : (big ? 2 : 1), wn = huge ? 2 : (big ? 2 : 1);
+  wm = huge ? 4 : (big ? 2 : 1); wn = huge ? 2 : (big ? 2 : 1);
+  return hipSuccess;
+}
+
+inline hipError_t hgemm_launch_batch(const HGemm* gs, int n, hipStream_t st, int force = 0, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+  HGemmBatch b; int wm, wn; long blocks;
+  hipError_t e = hgemm_plan(gs, n, force, b, wm, wn, blocks);
+  if (e != hipSuccess) return e;
   const int m0 = hgemm_mode(gs[0]), m1 = n > 1 ? hgemm_mode(gs[1]) : m0;
+  for (int i = 2; i < n; ++i) if (hgemm_mode(gs[i]) != m1) return hipErrorInvalidValue;
   bool launched = false;
 #define HG_TRY(WM, WN, M0, M1)                                                                                                          \
   if (!launched && wm == WM && wn == WN && m0 == M0 && m1 == M1) {                                                                      \
@@ -500,7 +522,7 @@ inline bool hgemm_uses_small_tile(const HGemm& g) { return !(hgemm_big_ok(g) && 
 struct Cvt16 {
   const float* src; int ld_src; int rows; int cols;   // cols = valid source columns (<= ld_src)
   h16* dst; int ld16;                                 // [rows][ld16], columns >= cols written as 0 (may be null)
-  h16* dstT; int ldT;                                 // [ld16][ldT] transposed (may be null)
+  h16* dstT; int ldT;                                 // [ld16][ldT] transposed (test build only; null in the learner)
   float scale;
   int tiles_r, tiles_c, tile_base;
 };
@@ -522,15 +544,17 @@ __global__ __launch_bounds__(256) void k_cvt16(Cvt16Batch b) {
     t[r][tx] = v;
     if (d.dst && row < d.rows) d.dst[(size_t)row * d.ld16 + col] = (h16)v;
   }
+#ifdef HG_WITH_CT16
   if (!d.dstT) return;
   __syncthreads();
   for (int c = ty; c < 64; c += 4) {
     const int row = r0 + tx;
     if (row < d.ldT) d.dstT[(size_t)(c0 + c) * d.ldT + row] = (h16)(row < d.rows ? t[tx][c] : 0.f);
   }
+#endif
 }
 
-inline void cvt16_add(Cvt16Batch& b, const float* src, int ld_src, int rows, int cols, h16* dst, int ld16, h16* dstT, int ldT, float scale) {
+inline void cvt16_add(Cvt16Batch& b, const float* src, int ld_src, int rows, int cols, h16* dst, int ld16, float scale, h16* dstT = nullptr, int ldT = 0) {
   Cvt16& d = b.d[b.n];
   d.src = src; d.ld_src = ld_src; d.rows = rows; d.cols = cols; d.dst = dst; d.ld16 = ld16; d.dstT = dstT; d.ldT = ldT; d.scale = scale;
   d.tiles_r = (rows + 63) / 64; d.tiles_c = ld16 / 64;
@@ -544,7 +568,8 @@ inline hipError_t cvt16_launch(const Cvt16Batch& b, hipStream_t st) {
   return hipGetLastError();
 }
 
-// bias gradients from the TRANSPOSED panels (round-1 form): db_l[n] = scale * sum_b dYT_l[n][b]
+#ifdef HG_WITH_CT16
+// bias gradients from TRANSPOSED panels (round-1 form, test build only): db_l[n] = scale * sum_b dYT_l[n][b]
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void k_db16(Db16Batch b) {
   int j = 0;
@@ -564,6 +589,7 @@ __global__ __launch_bounds__(256) void k_db16(Db16Batch b) {
   __syncthreads();
   if (threadIdx.x == 0) d.db[n] = ((s[0] + s[1]) + (s[2] + s[3])) * b.scale;
 }
+#endif
 
 // the same from the batch-major panels dY [rows][ld] (no transposed copy exists): a block owns 64 columns of one layer,
 // 8 lanes x 16 B cover them, 32 row groups stride the rows; fixed-order LDS reduction over the row groups.
@@ -614,24 +640,42 @@ __global__ __launch_bounds__(256) void k_db16_cols(Db16Batch b) {
   db16_cols_block(b, (int)blockIdx.x, sred);
 }
 
-// The first layer's wgrad has few tiles (N_out x 128 inputs = 32 at 4x1024) and a long reduction (the minibatch): its
-// launch leaves most of the chip idle for ~20 us at 4096 rows.  The bias-gradient column sums of ALL layers ride in
-// it as extra workgroups (they only need the dY panels, complete by then).
-template <int MODE>
-__global__ __launch_bounds__(256, 1) void hgemm_wgrad_db(HGemmBatch batch, Db16Batch db) {
+// ALL wgrads of a net in one launch, with the bias-gradient column sums of every layer as extra workgroups.
+// Alone, a layer's wgrad (N_out x K_in = 1024 x 1024, reduction = the minibatch) is 64 tiles of 128 x 128 — a quarter
+// of the chip — or 256 of 64 x 64 at four times the operand bytes per FLOP (455 TF at 4096 rows, r02 profile);
+// once the dgrad chain has produced every dZ panel the L wgrads are independent, and together they are
+// 3 x 64 + 8 = 200 tiles of 128 x 128 (+ 48 column-sum workgroups) at 4 x 1024: one round on 256 CUs.
+template <int WM, int WN>
+__global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_group_db(HGemmBatch batch, Db16Batch db) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char hg_smem[];
-  if ((int)blockIdx.x < batch.tiles0) hgemm_body<1, 1, MODE>(batch.g[0], (int)blockIdx.x);
-  else db16_cols_block(db, (int)blockIdx.x - batch.tiles0, reinterpret_cast<float*>(hg_smem));
+  const int nt = batch.tile_end[batch.n - 1];
+  if ((int)blockIdx.x < nt) {
+    int bid;
+    const int sel = hg_select(batch, (int)blockIdx.x, bid);
+    hgemm_body<WM, WN, 3>(batch.g[sel], bid);
+  } else db16_cols_block(db, (int)blockIdx.x - nt, reinterpret_cast<float*>(hg_smem));
 }
-inline hipError_t hgemm_wgrad_db_prepare() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_wgrad_db<3>), hipFuncAttributeMaxDynamicSharedMemorySize, HGCfg<1, 1>::LDS_BYTES);
+inline hipError_t hgemm_group_db_prepare() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_group_db<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, HGCfg<1, 1>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_group_db<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, HGCfg<2, 2>::LDS_BYTES);
+  return e;
 }
-// g: a reduction-major wgrad that takes the 64x64 split-K tile; db_blocks = 64-column blocks of db
-inline hipError_t hgemm_wgrad_db_launch(const HGemm& g, const Db16Batch& db, int db_blocks, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-  if (hgemm_mode(g) != 3 || g.M % 64 || g.N % 64 || g.K % 128) return hipErrorInvalidValue;
-  HGemmBatch b{}; b.n = 1; b.g[0] = g; b.tiles0 = (int)hgemm_tiles(g, false);
-  if (t0) hipExtLaunchKernelGGL((hgemm_wgrad_db<3>), dim3((unsigned)(b.tiles0 + db_blocks)), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, b, db);
-  else hipLaunchKernelGGL((hgemm_wgrad_db<3>), dim3((unsigned)(b.tiles0 + db_blocks)), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, b, db);
+// gs: n reduction-major wgrads (mode 3); db_blocks = 64-column blocks of db (0: none).  big: 128 x 128 tiles
+// (every M, N a multiple of 128), else 64 x 64 split-K tiles.
+inline hipError_t hgemm_group_db_launch(const HGemm* gs, int n, bool big, const Db16Batch& db, int db_blocks, hipStream_t st,
+                                        hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+  for (int i = 0; i < n; ++i) if (hgemm_mode(gs[i]) != 3) return hipErrorInvalidValue;
+  HGemmBatch b; int wm, wn; long blocks;
+  hipError_t e = hgemm_plan(gs, n, big ? 1 : 2, b, wm, wn, blocks);
+  if (e != hipSuccess) return e;
+  const unsigned grid = (unsigned)(blocks + db_blocks);
+  if (big) {
+    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, b, db);
+    else hipLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, b, db);
+  } else {
+    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, b, db);
+    else hipLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, b, db);
+  }
   return hipGetLastError();
 }
 

@@ -54,6 +54,10 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline size_t round_up_z(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 constexpr int kMaxL = DQNHIP_MAX_HIDDEN;
+// fp16 learner: ALL wgrads of a net in one launch of 128x128 tiles from this many minibatch rows (the reduction
+// length); below, the per-layer form (a layer's dgrad + wgrad sharing a launch of 64x64 split-K tiles) is as fast or
+// faster (measured at 256 / 512 / 1024 / 2048 / 4096 rows: +0.7 / -6 / -28 / -37 / -68 us per update)
+constexpr int kGroupMinRows = 512;
 
 // Internal parameter arena of one net: tower layer l has W_l[dims[l+1]][kp[l]] (K
 // padded to a multiple of 64 so every GEMM tile is whole) and b_l[dims[l+1]];
@@ -109,8 +113,6 @@ struct dqnhip_learner {
   NetLayout la, lc;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t aux = nullptr;                 // branch stream (nullptr: single-stream schedule)
-  std::vector<hipEvent_t> events; int ev_next = 0;
   // parameter arenas
   float* w[4] = {nullptr, nullptr, nullptr, nullptr};
   float* m[2] = {nullptr, nullptr};
@@ -137,8 +139,13 @@ struct dqnhip_learner {
   // native data parallelism (dqnhip_dp_*): one RCCL communicator per learner
   ncclComm_t comm = nullptr;
   bool dp_per_layer = false;            // bucket the gradient all-reduce per layer on comm_stream
+  bool dp_half = false;                 // gradients cross the links as bf16 (half the bytes); [loss, q, flag] tails stay fp32
+  uint16_t* g16[2] = {nullptr, nullptr};   // bf16 transfer image of each gradient arena (dp_half)
+  float* dp_tails = nullptr;            // dp_half: {critic tail[4], actor tail[4]}, one fp32 all-reduce with the actor's gradients
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ev[2] = {nullptr, nullptr};
+  hipGraphExec_t dp_graph = nullptr;    // the whole data-parallel update (collectives included), captured
+  bool dp_graph_failed = false;
   int next_phase = 0;                   // dqnhip_update_phase order check (0: an update may start)
   // minibatch panels / activations: pass 0 AT, 1 A, 2 CT, 3 C1, 4 C2
   float* Xa_s = nullptr; float* Xa_n = nullptr; float* Xc_tr = nullptr; float* Xc_pl = nullptr; float* Xc_nx = nullptr;
@@ -156,24 +163,17 @@ struct dqnhip_learner {
   int* tick_ticket = nullptr;                                // arrival counter of the update's last launch (k_adam_soft + tick)
   float* head_slab = nullptr; int* head_ticket = nullptr;   // k_head_bwd cross-block reduction
   float* head_slab2 = nullptr;                               // k_head_bwd_big row-chunk slabs (minibatch >= 1024)
-  // mixed precision (cfg.precision == DQNHIP_FP16): fp16 copies of the tower weights in both
-  // orientations, fp16 activations / gradients in both orientations (hgemm.hip.h)
+  // mixed precision (cfg.precision == DQNHIP_FP16): ONE fp16 mirror of each weight arena and batch-major fp16
+  // activation / gradient panels; the dgrad and wgrad GEMMs read them reduction-major (hgemm.hip.h), so no
+  // transposed copy of anything exists
   bool fp16 = false;
   float ls_c = 1.f, ls_q = 1.f, ls_a = 1.f;  // static loss scales: critic step, dQ/da pass, actor step
   int k16[2][kMaxL + 1] = {{0}};             // fp16 panel widths per net kind (k16[.][0] = in_dim rounded to 128)
   h16* w16a[4] = {nullptr, nullptr, nullptr, nullptr};   // fp16 mirror of each weight arena (written by the Adam pass)
   h16* w16[4][kMaxL] = {{nullptr}};          // = w16a[net] + w_off[i]: [N_out][kp]
-  h16* wt16[2][kMaxL] = {{nullptr}};         // [k16][N_out], online nets only (dgrad operand)
   h16* act16[5][kMaxL + 1] = {{nullptr}};    // [B][k16]
-  h16* actT16[5][kMaxL + 1] = {{nullptr}};   // [k16][B], passes 1 (actor) and 3 (critic train): wgrad operand
   h16* dZ16[2][kMaxL + 1] = {{nullptr}};     // [B][k16]   per net kind
-  h16* dZT16[2][kMaxL + 1] = {{nullptr}};    // [k16][B]
   bool w16_dirty[4] = {true, true, true, true};
-  bool wt16_by_adam = false;                 // the last optimiser launch wrote wt16 itself (tiled form)
-  // default: NO transposed panel exists — the dgrad reads the weight mirror and the wgrad reads dY / X reduction-major
-  // through the transposing LDS read (hgemm.hip.h, HGemm::ta / tb).  DQNHIP_FP16_TRANSPOSED_PANELS=1 restores the
-  // round-1 form (every operand k-major, second orientation of every panel written by its producer) for A/B runs.
-  bool redmajor = true;
   std::vector<void*> allocs16;
   // host-staging for add_transitions / acting
   void* stage_dev = nullptr; size_t stage_bytes = 0;
@@ -296,24 +296,6 @@ int validate(const dqnhip_config* c) {
 
 size_t grad_arena_floats(const NetLayout& la, const NetLayout& lc) { return la.arena + 64 + lc.arena + 64; }
 
-// ---- two-stream scheduling ------------------------------------------------------------
-// The update is a DAG with a few independent branches (the two forward chains of phase 0,
-// every layer's wgrad next to the dgrad chain, per-layer Adam ahead of the forward that
-// consumes it).  Branches run on an auxiliary stream; dependencies are events.  Under graph
-// capture the same calls become parallel branches of the hipGraph.  A dependent kernel
-// boundary costs ~2 us on this chip and a 256-workgroup layer leaves room for a second
-// kernel, so a concurrent branch hides both (measured: 6.5 vs 9.9 us per layer).
-hipStream_t aux_of(H* h) { return (h->aux && !h->timing) ? h->aux : h->stream; }
-
-int stream_wait(H* h, hipStream_t waiter, hipStream_t signaler) {
-  if (waiter == signaler) return 0;
-  hipEvent_t ev = h->events[h->ev_next];
-  h->ev_next = (h->ev_next + 1) % (int)h->events.size();
-  HIPCHK(hipEventRecord(ev, signaler));
-  HIPCHK(hipStreamWaitEvent(waiter, ev, 0));
-  return 0;
-}
-
 // ---- forward / backward building blocks ----------------------------------------
 
 struct FwdPass { int net; const NetLayout* l; float** act; };
@@ -337,8 +319,7 @@ int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, 
   ScopedTiming t(h, !lds_ok ? 6 : (n == 1 ? 5 : 0), st);
   // acting-time batches (<= 128 rows, e.g. 64 env workers): 16x16 tiles so that one layer still spreads
   // over 256 workgroups (64 rows x 1024 outputs = 256 tiles) instead of 64
-  static const bool kSmallTiles = !getenv("DQNHIP_NO_SMALL_TILES");
-  if (n == 1 && rows <= 128 && lds_ok && kSmallTiles) HIPCHK((fwd_lds_launch<1, 1, true>(b, st)));
+  if (n == 1 && rows <= 128 && lds_ok) HIPCHK((fwd_lds_launch<1, 1, true>(b, st)));
   else if (n == 1 && rows >= 512 && lds_ok && l.dims[i + 1] % 64 == 0) HIPCHK((fwd_lds_launch<4, 2, true>(b, st)));   // enough rows to fill the chip with 64x32 tiles (fewer bytes per FLOP)
   else if (n == 1) { if (lds_ok) HIPCHK((fwd_lds_launch<2, 2, true>(b, st))); else HIPCHK((fwd_direct_launch<2, 2>(b, st))); }
   else { if (lds_ok) HIPCHK((fwd_lds_launch<4, 2, true>(b, st))); else HIPCHK((fwd_direct_launch<4, 2>(b, st))); }
@@ -349,22 +330,16 @@ int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows) 
   return 0;
 }
 
-// Tower backward from dZ[L] (gradient wrt the last tower pre-activation) down.  The dgrad
-// chain runs on `st`; each layer's wgrad (which only needs dZ[i+1]) goes to the auxiliary
-// stream when there is one, else shares a mixed-mode launch with the dgrad.
+// Tower backward from dZ[L] (gradient wrt the last tower pre-activation) down, one launch per layer on `st`.
 // want_w: produce dW/db (+sumsq partials) into garena; input_grad: also dZ[0].
-// On return the aux stream may still be running wgrads: the caller joins before using them.
 // in_lo / in_hi: when only these input columns of dZ[0] are consumed (the critic's action columns), the
 // first layer's dgrad computes just the 16-column tiles that cover them.
 // RCCL sum all-reduce of one slice of a gradient arena on the communication stream, ordered after
 // everything enqueued on `st` so far (per-layer bucketing; defined with dqnhip_dp_*)
-int dp_reduce_slice(H* h, hipStream_t st, float* ptr, size_t count);
+int dp_reduce_slice(H* h, hipStream_t st, int net, size_t off, size_t count);
 
 int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* garena, float* partial,
                    float** act, float** dZ, int rows, bool want_w, bool input_grad, int in_lo = 0, int in_hi = -1) {
-  hipStream_t ax = aux_of(h);
-  static const bool kNarrowDgrad = !getenv("DQNHIP_NO_NARROW_DGRAD");
-  const bool split = want_w && ax != st;
   for (int i = l.L - 1; i >= 0; --i) {
     GemmBatch bd{}, bw{};
     const bool need_dx = (i > 0 || input_grad);
@@ -387,21 +362,13 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
       p.db = garena + l.b_off[i];
       p.partial = partial ? partial + l.part_off[i] : nullptr;
     }
-    if (split) {
-      RC(stream_wait(h, ax, st));          // dZ[i+1] is complete on st at this point
-      HIPCHK((wgrad_direct_launch<1, 1>(bw, ax)));
-      if (need_dx) HIPCHK((dgrad_direct_launch<1, 1>(bd, st)));
-    } else if (need_dx && want_w) {
+    // reduction width (the layer's outputs) wide enough: dY through the LDS transpose, scheduled form
+    const bool lds_ok = l.dims[i + 1] >= 512 && l.dims[i + 1] % 256 == 0;
+    if (need_dx && want_w) {               // ONE workgroup type: its wgrad tile, then its dgrad tile (gemm_bwd_seq)
       GemmBatch b{}; b.n = 2; b.prob[0] = bd.prob[0]; b.prob[1] = bw.prob[0];
       ScopedTiming t(h, 4, st);
-      // dY through the LDS transpose when the layer is wide enough (measured: pair 16.6 -> see DESIGN)
-      static const bool kPairLds = !getenv("DQNHIP_PAIR_DIRECT");
-      static const bool kSeq = !getenv("DQNHIP_PAIR_COOP");
-      const bool lds_ok = kPairLds && l.dims[i + 1] >= 512 && l.dims[i + 1] % 256 == 0;
-      if (kSeq) { if (lds_ok) HIPCHK((bwd_seq_launch<true>(b, st))); else HIPCHK((bwd_seq_launch<false>(b, st))); }
-      else if (lds_ok) HIPCHK((bwd_pair_direct_launch<1, true>(b, st)));
-      else HIPCHK(bwd_pair_direct_launch<1>(b, st));
-    } else if (need_dx && i == 0 && in_hi > in_lo && rows % 16 == 0 && kNarrowDgrad) {
+      if (lds_ok) HIPCHK((bwd_seq_launch<true>(b, st))); else HIPCHK((bwd_seq_launch<false>(b, st)));
+    } else if (need_dx && i == 0 && in_hi > in_lo && rows % 16 == 0) {
       GemmProblem& p = bd.prob[0];
       const int c0 = (in_lo / 16) * 16, c1 = std::min(l.kp[0], (in_hi + 15) / 16 * 16);
       p.P += c0; p.C += c0; p.Pdim = c1 - c0;
@@ -410,19 +377,16 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
       HIPCHK(dgrad_narrow_launch(bd, st));
     } else if (need_dx) {
       ScopedTiming t(h, 1, st);
-      // reduction width (the layer's outputs) wide enough: dY through the LDS transpose, scheduled form
-      if (l.dims[i + 1] >= 512 && l.dims[i + 1] % 256 == 0) HIPCHK((dgrad_lds_launch<1, 1>(bd, st)));
+      if (lds_ok) HIPCHK((dgrad_lds_launch<1, 1>(bd, st)));
       else HIPCHK((dgrad_direct_launch<1, 1>(bd, st)));
     } else {
-      ScopedTiming t(h, 2, st);
       // wgrad alone = the first layer (K_in = 64 / 128 columns): 16-output tiles, 4x the workgroups
-      static const bool kNarrow = !getenv("DQNHIP_NO_NARROW_WGRAD");
-      if (kNarrow) HIPCHK((wgrad_narrow_launch<1>(bw, st)));
-      else HIPCHK((wgrad_direct_launch<1, 1>(bw, st)));
+      ScopedTiming t(h, 2, st);
+      HIPCHK((wgrad_narrow_launch<1>(bw, st)));
     }
     // data parallel, bucketed: layer i's dW/db are final once this launch has run -> start their
     // all-reduce on the communication stream while the chain continues with layer i-1
-    if (want_w && h->comm && h->dp_per_layer) RC(dp_reduce_slice(h, st, garena + l.w_off[i], (i + 1 < l.L ? l.w_off[i + 1] : l.hw_off) - l.w_off[i]));
+    if (want_w && h->comm && h->dp_per_layer) RC(dp_reduce_slice(h, st, net, l.w_off[i], (i + 1 < l.L ? l.w_off[i + 1] : l.hw_off) - l.w_off[i]));
   }
   return 0;
 }
@@ -431,10 +395,7 @@ template <int NH, int MODE>
 int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nullptr) {
   HeadArgs2 a2{}; a2.p[0] = a; if (b) a2.p[1] = *b;
   if (NH > 1 && a.rows >= 1024 && a.H <= 1024 && a.H % 4 == 0)   // (single-head: the block-per-row form measured faster, 6.6 vs 8.8 us)
-  {
-    static const int kRowsBlocks = getenv("DQNHIP_HEAD_ROWS_BLOCKS") ? atoi(getenv("DQNHIP_HEAD_ROWS_BLOCKS")) : 256;
-    hipLaunchKernelGGL((k_head_fwd_rows<NH, MODE>), dim3(kRowsBlocks, b ? 2 : 1), dim3(256), 0, st, a2);
-  }
+    hipLaunchKernelGGL((k_head_fwd_rows<NH, MODE>), dim3(256, b ? 2 : 1), dim3(256), 0, st, a2);
   else
     hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(std::min(a.rows, 1024), b ? 2 : 1), dim3(256), 0, st, a2);
   HIPCHK(hipGetLastError());
@@ -443,10 +404,10 @@ int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nu
 
 // rows >= 1024: the bandwidth-tiled kernel pair; optionally emits the scaled fp16 panels itself
 template <int NH>
-int head_backward_big(H* h, hipStream_t st, HeadBwdArgs a, h16* dZ16, h16* dZT16, float scale16) {
-  HeadBwdBigArgs b{}; b.a = a; b.dZ16 = dZ16; b.dZT16 = dZT16; b.ldT = a.rows; b.scale16 = scale16; b.slab2 = h->head_slab2;
+int head_backward_big(H* h, hipStream_t st, HeadBwdArgs a, h16* dZ16, float scale16) {
+  HeadBwdBigArgs b{}; b.a = a; b.dZ16 = dZ16; b.scale16 = scale16; b.slab2 = h->head_slab2;
   const int chunks = a.rows / 64;
-  const size_t lds = (size_t)(64 * NH + 4 * NH * 256) * sizeof(float) + 256 * 72 * sizeof(h16);
+  const size_t lds = (size_t)(64 * NH + 4 * NH * 256) * sizeof(float);
   static bool prepared = false;
   if (!prepared) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_bwd_big<NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); prepared = true; }
   hipLaunchKernelGGL((k_head_bwd_big<NH>), dim3(chunks, a.H / 256), dim3(256), lds, st, b);
@@ -461,12 +422,11 @@ inline bool head_big_ok(const H* h, int rows, int Hd) { return h->head_slab2 != 
 
 template <int NH>
 int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
-  if (head_big_ok(h, a.rows, a.H)) return head_backward_big<NH>(h, st, a, nullptr, nullptr, 1.0f);
+  if (head_big_ok(h, a.rows, a.H)) return head_backward_big<NH>(h, st, a, nullptr, 1.0f);
   // row chunks: enough blocks to cover the chip a few times over, <= 64 rows per chunk
   const int RC = std::max(1, std::min(16, a.rows / 64));   // (64 chunks measured slower at B=4096: the last arriver's slab walk)
   const int rows_c = (a.rows + RC - 1) / RC;
   size_t lds = ((size_t)rows_c * NH + 16 * NH * 64 + 16) * sizeof(float);
-  if (a.dZT16 != nullptr) lds += (size_t)64 * (rows_c + 8) * sizeof(h16);
   a.slab = h->head_slab; a.ticket = h->head_ticket;
   int ry = 0;                                               // extra grid rows for the q rider (16 rows per block)
   if (a.q_out != nullptr) { a.rc_blocks = RC; ry = ((a.rows + 15) / 16 + a.H / 64 - 1) / (a.H / 64); }
@@ -491,50 +451,26 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   a.beta1 = h->cfg.momentum; a.beta2 = h->cfg.momentum2; a.eps = h->cfg.delta;
   a.clip = h->cfg.clip_gradients; a.tau = (float)h->cfg.tau;
   a.soft_update_freq = h->cfg.soft_update_freq; a.which = net; a.st = h->st;
-  static const bool kTickInAdam = !getenv("DQNHIP_SEPARATE_TICK");
-  if (tick && kTickInAdam) { a.tick_ticket = h->tick_ticket; a.tick = *tick; }
-  static const int kAdamCap = getenv("DQNHIP_ADAM_BLOCKS") ? atoi(getenv("DQNHIP_ADAM_BLOCKS")) : 2048;
-  static const bool kTiled = !getenv("DQNHIP_ADAM_FLAT");
-  const NetLayout& l = layout_of(h, net);
-  const bool tiled = h->fp16 && !h->redmajor && kTiled && begin == 0 && end == l.arena;
+  if (tick) { a.tick_ticket = h->tick_ticket; a.tick = *tick; }
   ScopedTiming t(h, 3, st);
   LaunchTimer& lt = launch_timer();
-  if (tiled) {
-    // fp16 mode: the pass writes wt16 (the transposed fp16 weights the dgrad GEMMs read) itself
-    a.n_tseg = l.L; a.n_fseg = 0; a.n_tiles = 0;
-    for (int i = 0; i < l.L; ++i) {
-      a.tseg[i] = {l.w_off[i], l.dims[i + 1], l.kp[i], h->wt16[net][i], l.dims[i + 1], a.n_tiles};
-      a.n_tiles += (l.dims[i + 1] / 64) * (l.kp[i] / 64);
-      const size_t b0 = l.b_off[i], b1 = i + 1 < l.L ? l.w_off[i + 1] : l.hw_off;
-      a.fseg[a.n_fseg++] = {b0 / 4, (b1 - b0) / 4};
-    }
-    a.fseg[a.n_fseg++] = {l.hw_off / 4, (l.arena - l.hw_off) / 4};
-    const int blocks = a.n_tiles + 8;
-    if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft_tiled, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
-    else hipLaunchKernelGGL(k_adam_soft_tiled, dim3(blocks), dim3(256), 0, st, a);
-    h->wt16_by_adam = true;
-  } else {
-    int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)kAdamCap);
-    if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
-    else hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, a);
-    h->wt16_by_adam = false;
-  }
+  // 2048 blocks: grids of 512 .. 8192 measured within +-3 % (profiles/r02_adam_probe.txt)
+  const int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)2048);
+  if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
-  if (tick && !kTickInAdam) {
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(256), 0, st, *tick);
-    HIPCHK(hipGetLastError());
-  }
   return 0;
 }
 
+// clip norm of the REDUCED gradient (data parallel); under DQNHIP_DP_HALF_GRADS the same pass widens the bf16
+// transfer image back into the fp32 arena
 int sumsq_launch(H* h, int net) {
   const NetLayout& l = layout_of(h, net);
-  hipLaunchKernelGGL(k_sumsq, dim3(h->n_part_dp), dim3(256), 0, h->stream, h->g[net], l.arena / 4, h->part_dp);
+  if (h->dp_half) hipLaunchKernelGGL(k_sumsq_bf16, dim3(h->n_part_dp), dim3(256), 0, h->stream, (const uint16_t*)h->g16[net], h->g[net], l.arena / 4, h->part_dp);
+  else hipLaunchKernelGGL(k_sumsq, dim3(h->n_part_dp), dim3(256), 0, h->stream, h->g[net], l.arena / 4, h->part_dp);
   HIPCHK(hipGetLastError());
   return 0;
 }
-
-int sumsq_launch(H* h, int net);
 
 // ---- mixed-precision building blocks (hgemm.hip.h) --------------------------------------------
 
@@ -547,37 +483,30 @@ int hgemm_timed(H* h, hipStream_t st, const HGemm* gs, int n, int fam, int force
   return 0;
 }
 int hgemm_timed(H* h, hipStream_t st, const HGemm& g, int fam) { return hgemm_timed(h, st, &g, 1, fam); }
-static const bool kHgemmPairs = !getenv("DQNHIP_NO_HGEMM_PAIRS");
 
-// fp32 master weights of `net` -> fp16 mirror [N][kp] (unless only_t) + transposed copies for the
-// online nets.  The Adam pass keeps the mirrors current by itself; after it only the transposes
-// are rebuilt (only_t).  The full form runs after host-side weight changes (w16_dirty).
-int sync_w16(H* h, hipStream_t st, int net, bool only_t = false) {
+// fp32 master weights of `net` -> fp16 mirror [N][kp].  The Adam pass keeps the mirrors current by itself; this
+// runs after host-side weight changes (w16_dirty).
+int sync_w16(H* h, hipStream_t st, int net) {
   const NetLayout& l = layout_of(h, net);
   const int kind = net & 1;
-  if (only_t && net >= 2) return 0;
-  if (only_t && (h->wt16_by_adam || h->redmajor)) return 0;   // k_adam_soft_tiled already wrote the transposes / nobody reads them
   Cvt16Batch b{};
   for (int i = 0; i < l.L; ++i) {
-    cvt16_add(b, h->w[net] + l.w_off[i], l.kp[i], l.dims[i + 1], l.kp[i], only_t ? nullptr : h->w16[net][i], h->k16[kind][i],
-              net < 2 ? h->wt16[net][i] : nullptr, l.dims[i + 1], 1.0f);
+    cvt16_add(b, h->w[net] + l.w_off[i], l.kp[i], l.dims[i + 1], l.kp[i], h->w16[net][i], h->k16[kind][i], 1.0f);
     if (b.n == 8) { HIPCHK(cvt16_launch(b, st)); b = Cvt16Batch{}; }
   }
   HIPCHK(cvt16_launch(b, st));
-  if (!only_t) h->w16_dirty[net] = false;
+  h->w16_dirty[net] = false;
   return 0;
 }
 
 HGemm fwd16_problem(H* h, int p, int net, int rows, int i) {
   const NetLayout& l = layout_of(h, net);
   const int kind = net & 1;
-  const bool needT = (p == 1 || p == 3);
   HGemm g{};
   g.A = h->act16[p][i]; g.lda = h->k16[kind][i];
   g.B = h->w16[net][i]; g.ldb = h->k16[kind][i];
   g.M = rows; g.N = l.dims[i + 1]; g.K = h->k16[kind][i];
   g.C16 = h->act16[p][i + 1]; g.ldc16 = l.dims[i + 1];
-  if (needT) { g.CT16 = h->actT16[p][i + 1]; g.ldct16 = rows; }
   if (i == l.L - 1) { g.C32 = h->act[p][l.L]; g.ldc32 = l.kp[l.L]; g.n_valid32 = l.dims[l.L]; }
   g.bias = h->w[net] + l.b_off[i]; g.relu = 1; g.scale32 = 1.0f;
   return g;
@@ -590,7 +519,6 @@ int tower_forward16(H* h, hipStream_t st, int p, int net, int rows) {
 // two independent passes of the same net kind, layer by layer in ONE launch each (the target and
 // the online net: same shapes, different weights and inputs)
 int tower_forward16_pair(H* h, hipStream_t st, int p0, int net0, int p1, int net1, int rows) {
-  if (!kHgemmPairs) { RC(tower_forward16(h, st, p0, net0, rows)); return tower_forward16(h, st, p1, net1, rows); }
   const NetLayout& l = layout_of(h, net0);
   for (int i = 0; i < l.L; ++i) {
     const HGemm gs[2] = {fwd16_problem(h, p0, net0, rows, i), fwd16_problem(h, p1, net1, rows, i)};
@@ -601,89 +529,75 @@ int tower_forward16_pair(H* h, hipStream_t st, int p0, int net0, int p1, int net
 
 // Tower backward in fp16 from dZ16[kind][L] (already scaled by `ls`).  want_w: dW (fp32, unscaled)
 // into garena + bias gradients; input_grad: fp32 dZ32_0[rows][kp0] (unscaled).
+// No transposed copy of any panel exists: the dgrad reads the weight mirror W[n][k_in] reduction-major (its rows ARE
+// the reduction index), the wgrad reads dY[b][n_out] and X[b][k_in] reduction-major (hgemm.hip.h, HGemm::ta / tb).
+// Schedule: the dgrad chain first (one launch per layer), then ALL wgrads of the net + the bias-gradient column
+// sums in ONE launch (hgemm_group_db) — at that point every dZ panel is complete and the wgrads are independent.
+// cfg.tuning_flags & DQNHIP_TUNE_FP16_WGRAD_PER_LAYER restores the per-layer form (a layer's dgrad + wgrad sharing a
+// launch when both take the 64x64 tile; the bias sums riding in the first layer's wgrad launch).
 int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float* dZ32_0, int rows,
                      bool want_w, bool input_grad, float ls, float* partial = nullptr) {
   const NetLayout& l = layout_of(h, net);
   const int kind = net & 1;
-  h16** dZ = h->dZ16[kind]; h16** dZT = h->dZT16[kind];
-  bool db_done = false;
+  h16** dZ = h->dZ16[kind];
+  const bool grouped = want_w && l.L <= kHGemmMax && rows >= kGroupMinRows && !(h->cfg.tuning_flags & DQNHIP_TUNE_FP16_WGRAD_PER_LAYER);
+  HGemm gws[kMaxL];
   for (int i = l.L - 1; i >= 0; --i) {
-    HGemm gd{}, gw{};
+    HGemm gd{};
+    HGemm& gw = gws[i]; gw = HGemm{};
     const bool need_dx = i > 0 || input_grad;
     if (need_dx) {                         // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
       HGemm& g = gd;
       g.A = dZ[i + 1]; g.lda = l.dims[i + 1];
-      if (h->redmajor) { g.B = h->w16[net][i]; g.ldb = h->k16[kind][i]; g.tb = 1; }     // W[n][k_in]: rows are the reduction index
-      else { g.B = h->wt16[net][i]; g.ldb = l.dims[i + 1]; }
+      g.B = h->w16[net][i]; g.ldb = h->k16[kind][i]; g.tb = 1;
       g.M = rows; g.N = h->k16[kind][i]; g.K = l.dims[i + 1];
       if (i > 0) {
         g.mask = h->act16[p][i]; g.ldm = h->k16[kind][i];
         g.C16 = dZ[i]; g.ldc16 = h->k16[kind][i];
-        if (want_w && !h->redmajor) { g.CT16 = dZT[i]; g.ldct16 = rows; }
       } else {
         g.C32 = dZ32_0; g.ldc32 = l.kp[0]; g.n_valid32 = l.kp[0]; g.scale32 = 1.0f / ls;
       }
     }
-    if (want_w) {                          // dW_i = dZ[i+1]^T . act[i]
+    if (want_w) {                          // dW_i = dZ[i+1]^T . act[i]: both operands batch-major, dY[b][n_out], X[b][k_in]
       HGemm& g = gw;
-      if (h->redmajor) {                   // both operands batch-major: dY[b][n_out], X[b][k_in]
-        g.A = dZ[i + 1]; g.lda = l.dims[i + 1]; g.ta = 1;
-        g.B = h->act16[p][i]; g.ldb = h->k16[kind][i]; g.tb = 1;
-      } else {
-        g.A = dZT[i + 1]; g.lda = rows;
-        g.B = h->actT16[p][i]; g.ldb = rows;
-      }
+      g.A = dZ[i + 1]; g.lda = l.dims[i + 1]; g.ta = 1;
+      g.B = h->act16[p][i]; g.ldb = h->k16[kind][i]; g.tb = 1;
       g.M = l.dims[i + 1]; g.N = h->k16[kind][i]; g.K = rows;
       g.C32 = garena + l.w_off[i]; g.ldc32 = l.kp[i]; g.n_valid32 = l.kp[i]; g.scale32 = 1.0f / ls;
       if (partial) g.sumsq_partial = partial + l.part_off[i];      // clip-norm share of this layer's dW (unscaled)
     }
-    // the last wgrad of the pass (first layer: few tiles, long reduction) carries the bias-gradient column sums of
-    // every layer as extra workgroups — all dZ panels are complete by now
-    static const bool kDbRider = !getenv("DQNHIP_SEPARATE_DB16");
-    if (i == 0 && want_w && !need_dx && h->redmajor && kDbRider && hgemm_uses_small_tile(gw) && gw.K % 128 == 0) {
-      Db16Batch b{}; b.scale = 1.0f / ls; b.sumsq_partial = partial ? partial + l.part_db : nullptr;
-      int base = 0;
-      for (int j = 0; j < l.L; ++j) { b.d[b.n++] = Db16{dZ[j + 1], l.dims[j + 1], l.dims[j + 1], rows, garena + l.b_off[j], base}; base += l.dims[j + 1] / 64; }
-      ScopedTiming t(h, 9, st);
-      LaunchTimer& lt = launch_timer();
-      hipEvent_t e0 = lt.start, e1 = lt.stop;
-      lt.start = lt.stop = nullptr;
-      HIPCHK(hgemm_wgrad_db_launch(gw, b, base, st, e0, e1));
-      db_done = true;
-      continue;
-    }
-    // both read dZ[i+1] and neither reads the other's output: at small minibatches (both on the
+    if (grouped) { if (need_dx) RC(hgemm_timed(h, st, gd, 8)); continue; }
+    // per-layer form: both read dZ[i+1] and neither reads the other's output — at small minibatches (both on the
     // 64x64 split-K tile) they share one launch
-    if (need_dx && want_w && kHgemmPairs && hgemm_uses_small_tile(gd) && hgemm_uses_small_tile(gw) && gd.K % 128 == 0 && gw.K % 128 == 0) {
+    if (need_dx && want_w && hgemm_uses_small_tile(gd) && hgemm_uses_small_tile(gw) && gd.K % 128 == 0 && gw.K % 128 == 0) {
       const HGemm gs[2] = {gd, gw};
       RC(hgemm_timed(h, st, gs, 2, 8, 2));      // both on the 64x64 tile, as each would be alone
     } else {
       if (need_dx) RC(hgemm_timed(h, st, gd, 8));
-      if (want_w) RC(hgemm_timed(h, st, gw, 9));
+      if (want_w && (i > 0 || need_dx)) RC(hgemm_timed(h, st, gw, 9));
     }
   }
-  if (want_w && h->redmajor && !db_done) {  // db_i = column sums of dZ[i+1] [rows][n_out] for all layers in one launch
-    Db16Batch b{}; b.scale = 1.0f / ls; b.sumsq_partial = partial ? partial + l.part_db : nullptr;
-    int base = 0;
-    for (int i = 0; i < l.L; ++i) { b.d[b.n++] = Db16{dZ[i + 1], l.dims[i + 1], l.dims[i + 1], rows, garena + l.b_off[i], base}; base += l.dims[i + 1] / 64; }
-    hipLaunchKernelGGL(k_db16_cols<0>, dim3(base), dim3(256), 0, st, b);
-    HIPCHK(hipGetLastError());
-  } else if (want_w && !db_done) {         // db_i = row sums of the transposed panels
-    Db16Batch b{}; b.scale = 1.0f / ls;
-    int base = 0;
-    for (int i = 0; i < l.L; ++i) { b.d[b.n++] = Db16{dZT[i + 1], rows, l.dims[i + 1], rows, garena + l.b_off[i], base}; base += l.dims[i + 1]; }
-    hipLaunchKernelGGL(k_db16<0>, dim3(base), dim3(256), 0, st, b);
+  if (!want_w) return 0;
+  // db_i = column sums of dZ[i+1] [rows][n_out], one workgroup per 64 columns
+  Db16Batch db{}; db.scale = 1.0f / ls; db.sumsq_partial = partial ? partial + l.part_db : nullptr;
+  int db_blocks = 0;
+  for (int i = 0; i < l.L; ++i) { db.d[db.n++] = Db16{dZ[i + 1], l.dims[i + 1], l.dims[i + 1], rows, garena + l.b_off[i], db_blocks}; db_blocks += l.dims[i + 1] / 64; }
+  ScopedTiming t(h, 9, st);
+  LaunchTimer& lt = launch_timer();
+  hipEvent_t e0 = lt.start, e1 = lt.stop;
+  lt.start = lt.stop = nullptr;
+  if (grouped) {
+    // 128x128 tiles: a quarter of the operand bytes per FLOP of the 64x64 split-K tile (fp16 mode guarantees
+    // hidden % 128 == 0, minibatch % 128 == 0 and a 128-wide first panel, so every wgrad tiles)
+    HIPCHK(hgemm_group_db_launch(gws, l.L, true, db, db_blocks, st, e0, e1));
+  } else if (!input_grad && hgemm_uses_small_tile(gws[0]) && gws[0].K % 128 == 0) {
+    // per-layer form: the first layer's wgrad (few tiles, long reduction) carries the column sums
+    HIPCHK(hgemm_group_db_launch(gws, 1, false, db, db_blocks, st, e0, e1));
+  } else {
+    if (!input_grad) HIPCHK(hgemm_launch(gws[0], st, 0, e0, e1));
+    hipLaunchKernelGGL(k_db16_cols<0>, dim3(db_blocks), dim3(256), 0, st, db);
     HIPCHK(hipGetLastError());
   }
-  return 0;
-}
-
-// fp32 [rows][ld] gradient wrt the last tower activation -> scaled fp16 (+ transposed)
-int head_grad16(H* h, hipStream_t st, int kind, const float* dZL, int rows, float ls, bool withT) {
-  const NetLayout& l = kind ? h->lc : h->la;
-  Cvt16Batch b{};
-  cvt16_add(b, dZL, l.kp[l.L], rows, l.dims[l.L], h->dZ16[kind][l.L], l.dims[l.L], withT ? h->dZT16[kind][l.L] : nullptr, rows, ls);
-  HIPCHK(cvt16_launch(b, st));
   return 0;
 }
 
@@ -695,17 +609,17 @@ inline uint64_t sample_key(const H* h) { return (uint64_t)h->cfg.seed + 0x9E3779
 int run_phase16(H* h, int phase, const int* idx_dev) {
   const int B = h->B, L = h->L;
   const NetLayout &la = h->la, &lc = h->lc;
-  const bool dp = h->cfg.dp_world > 1;
+  const bool dp = h->cfg.dp_world > 1 || h->dp_half;     // (a one-rank group with bf16 exchange runs the N-rank code path)
   const float inv_batch = 1.0f / (float)(B * h->cfg.dp_world);
-  float* actor_tail = h->g[0] + la.arena;
-  float* critic_tail = h->g[1] + lc.arena;
+  float* actor_tail = h->dp_half ? h->dp_tails + 4 : h->g[0] + la.arena;
+  float* critic_tail = h->dp_half ? h->dp_tails : h->g[1] + lc.arena;
   const int Hh = la.dims[L], Hc = lc.dims[L];
   hipStream_t st = h->stream;
   const bool split = phase == 10;
-  // single learner, no transposed panels: the clip norm comes from the partial sums the wgrad / bias-gradient / head
-  // workgroups leave behind (as on the fp32 path); data-parallel ranks need the norm of the REDUCED gradient: k_sumsq
-  static const bool kPart16 = !getenv("DQNHIP_FP16_SUMSQ_KERNEL");
-  const bool part16 = kPart16 && !dp && h->redmajor;
+  // single learner: the clip norm comes from the partial sums the wgrad / bias-gradient / head workgroups leave
+  // behind (as on the fp32 path); data-parallel ranks need the norm of the REDUCED gradient: k_sumsq
+  const bool part16 = !dp;
+  auto cvt = [&](Cvt16Batch& b, const float* src, int ld, h16* dst, int ld16) { cvt16_add(b, src, ld, B, ld, dst, ld16, 1.0f); };
   if (phase == 11) {
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
@@ -713,7 +627,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     RC(tower_forward16(h, st, 1, DQNHIP_ACTOR, B));
     RC((head_forward<kNO, HEAD_ACTOR>(h, st, hA)));
     Cvt16Batch b{};
-    cvt16_add(b, h->Xc_pl, lc.kp[0], B, lc.kp[0], h->act16[4][0], h->k16[1][0], nullptr, B, 1.0f);
+    cvt(b, h->Xc_pl, lc.kp[0], h->act16[4][0], h->k16[1][0]);
     HIPCHK(cvt16_launch(b, st));
     return 0;
   }
@@ -724,17 +638,17 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
                        (const DevState*)h->st, idx_dev, sample_key(h), go, B);
     HIPCHK(hipGetLastError());
     // the state parts of the two critic panels whose action columns the actor heads fill (still zero here) are
-    // converted in the same launch; the heads then write mu / mu' straight into the fp16 panels as well
-    static const bool kHeads16 = !getenv("DQNHIP_SEPARATE_CVT2");
-    const bool heads16 = kHeads16 && !split;
+    // converted in the same launch; the heads then write mu / mu' straight into the fp16 panels as well.  (The
+    // split form — phase 10 / 11, the online actor's forward deferred — converts them after the heads.)
+    const bool heads16 = !split;
     {
       Cvt16Batch b{};
-      cvt16_add(b, h->Xa_n, la.kp[0], B, la.kp[0], h->act16[0][0], h->k16[0][0], nullptr, B, 1.0f);
-      cvt16_add(b, h->Xa_s, la.kp[0], B, la.kp[0], h->act16[1][0], h->k16[0][0], h->actT16[1][0], B, 1.0f);
-      cvt16_add(b, h->Xc_tr, lc.kp[0], B, lc.kp[0], h->act16[3][0], h->k16[1][0], h->actT16[3][0], B, 1.0f);
+      cvt(b, h->Xa_n, la.kp[0], h->act16[0][0], h->k16[0][0]);
+      cvt(b, h->Xa_s, la.kp[0], h->act16[1][0], h->k16[0][0]);
+      cvt(b, h->Xc_tr, lc.kp[0], h->act16[3][0], h->k16[1][0]);
       if (heads16) {
-        cvt16_add(b, h->Xc_nx, lc.kp[0], B, lc.kp[0], h->act16[2][0], h->k16[1][0], nullptr, B, 1.0f);
-        cvt16_add(b, h->Xc_pl, lc.kp[0], B, lc.kp[0], h->act16[4][0], h->k16[1][0], nullptr, B, 1.0f);
+        cvt(b, h->Xc_nx, lc.kp[0], h->act16[2][0], h->k16[1][0]);
+        cvt(b, h->Xc_pl, lc.kp[0], h->act16[4][0], h->k16[1][0]);
       }
       HIPCHK(cvt16_launch(b, st));
     }
@@ -751,8 +665,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     else RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));
     if (!heads16) {
       Cvt16Batch b{};
-      cvt16_add(b, h->Xc_nx, lc.kp[0], B, lc.kp[0], h->act16[2][0], h->k16[1][0], nullptr, B, 1.0f);
-      if (!split) cvt16_add(b, h->Xc_pl, lc.kp[0], B, lc.kp[0], h->act16[4][0], h->k16[1][0], nullptr, B, 1.0f);
+      cvt(b, h->Xc_nx, lc.kp[0], h->act16[2][0], h->k16[1][0]);
       HIPCHK(cvt16_launch(b, st));
     }
     RC(tower_forward16_pair(h, st, 2, DQNHIP_CRITIC_TARGET, 3, DQNHIP_CRITIC, B));
@@ -770,24 +683,23 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[3][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L]; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
-      if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->dZT16[1][L], h->ls_c)); }
-      else { a.dZ16 = h->dZ16[1][L]; a.dZT16 = h->dZT16[1][L]; a.ldT = B; a.scale16 = h->ls_c; RC(head_backward<1>(h, st, a)); }
+      if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->ls_c)); }
+      else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_c; RC(head_backward<1>(h, st, a)); }
     }
     RC(tower_backward16(h, st, DQNHIP_CRITIC, 3, h->g[1], nullptr, B, true, false, h->ls_c, part16 ? h->part[1] : nullptr));
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)h->loss_partial,
-                         h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr);
+                         h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr, (const DevState*)h->st);
       HIPCHK(hipGetLastError());
     }
     return 0;
   }
   if (phase == 1) {
+    // the Adam pass writes the fp16 mirrors of the critic and its target itself
     if (part16) RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
     else { RC(sumsq_launch(h, 1)); RC(adam_launch(h, st, 1, h->part_dp, h->n_part_dp, 0, lc.arena)); }
-    RC(sync_w16(h, st, DQNHIP_CRITIC, true));          // the Adam pass wrote the fp16 mirrors of critic and target
     RC(tower_forward16(h, st, 4, DQNHIP_CRITIC, B));
-    static const bool kQRider16 = !getenv("DQNHIP_SEPARATE_QHEAD");
-    const bool q_sep16 = head_big_ok(h, B, Hc) || !kQRider16;     // small minibatches: q(s, mu(s)) rides in the dq = -1 head launch, as on the fp32 path
+    const bool q_sep16 = head_big_ok(h, B, Hc);        // small minibatches: q(s, mu(s)) rides in the dq = -1 head launch, as on the fp32 path
     if (q_sep16) {
       HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
       a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.b = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q = h->q2;
@@ -798,7 +710,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
       if (!q_sep16) { a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial; }
-      if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], nullptr, h->ls_q)); }
+      if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->ls_q)); }
       else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_q; RC(head_backward<1>(h, st, a)); }
     }
     RC(tower_backward16(h, st, DQNHIP_CRITIC, 4, nullptr, h->dZc[0], B, false, true, h->ls_q));
@@ -806,13 +718,13 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;
       a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.X4 = h->act[1][L]; a.H = Hh; a.rows = B; a.dZ = h->dZa[L];
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
-      if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->dZT16[0][L], h->ls_a)); }
-      else { a.dZ16 = h->dZ16[0][L]; a.dZT16 = h->dZT16[0][L]; a.ldT = B; a.scale16 = h->ls_a; RC(head_backward<kNO>(h, st, a)); }
+      if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->ls_a)); }
+      else { a.dZ16 = h->dZ16[0][L]; a.scale16 = h->ls_a; RC(head_backward<kNO>(h, st, a)); }
     }
     RC(tower_backward16(h, st, DQNHIP_ACTOR, 1, h->g[0], nullptr, B, true, false, h->ls_a, part16 ? h->part[0] : nullptr));
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)nullptr, 0,
-                         (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail);
+                         (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail, (const DevState*)h->st);
       HIPCHK(hipGetLastError());
     }
     return 0;
@@ -821,8 +733,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
                         dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world)};
     if (part16) RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick));
-    else { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena, &tick)); }   // + iteration counters / statistics (k_tick's work)
-    RC(sync_w16(h, st, DQNHIP_ACTOR, true));
+    else { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena, &tick)); }   // + iteration counters / statistics
     h->h_actor_iter += 1; h->h_critic_iter += 1;
     return 0;
   }
@@ -840,12 +751,12 @@ int run_phase(H* h, int phase, const int* idx_dev) {
   if (h->fp16) return run_phase16(h, phase, idx_dev);
   const int B = h->B, L = h->L;
   const NetLayout &la = h->la, &lc = h->lc;
-  const bool dp = h->cfg.dp_world > 1;
+  const bool dp = h->cfg.dp_world > 1 || h->dp_half;     // (a one-rank group with bf16 exchange runs the N-rank code path)
   const float inv_batch = 1.0f / (float)(B * h->cfg.dp_world);
-  float* actor_tail = h->g[0] + la.arena;
-  float* critic_tail = h->g[1] + lc.arena;
+  float* actor_tail = h->dp_half ? h->dp_tails + 4 : h->g[0] + la.arena;
+  float* critic_tail = h->dp_half ? h->dp_tails : h->g[1] + lc.arena;
   const int Hh = la.dims[L], Hc = lc.dims[L];
-  hipStream_t st = h->stream, ax = aux_of(h);
+  hipStream_t st = h->stream;
   const bool split = phase == 10;          // phase 10 = phase 0 without the online actor's forward, 11 = that forward
   if (phase == 11) {
     FwdPass pA{DQNHIP_ACTOR, &la, h->act[1]};
@@ -871,31 +782,20 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
     hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
+    FwdPass cp[2] = {pCT, pC1};
     if (split) {
       // data-parallel overlap form: the online actor's forward (phase 11) is left out so that it can
       // run while the critic gradients are being all-reduced
       RC(tower_forward(h, st, &pAT, 1, B));
       RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT)));
-      FwdPass cp[2] = {pCT, pC1};
-      RC(tower_forward(h, st, cp, 2, B));
-    } else if (ax != st) {
-      // branch 1 (st):  actor_target(s') -> critic_target(s', mu'(s'))   [src/dqn.cpp:889-891]
-      // branch 2 (aux): actor(s) [:910-911, pre-update weights] -> critic(s, a) train fwd [:904]
-      RC(stream_wait(h, ax, st));
-      RC(tower_forward(h, st, &pAT, 1, B));
-      RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT)));
-      RC(tower_forward(h, st, &pCT, 1, B));
-      RC(tower_forward(h, ax, &pA, 1, B));
-      RC((head_forward<kNO, HEAD_ACTOR>(h, ax, hA)));
-      RC(tower_forward(h, ax, &pC1, 1, B));
-      RC(stream_wait(h, st, ax));
     } else {
+      // actor_target(s') [src/dqn.cpp:889-891] and actor(s) [:910-911, pre-update weights] layer by layer in one
+      // launch each, then critic_target(s', mu'(s')) and the critic(s, a) train forward [:904] likewise
       FwdPass ap[2] = {pAT, pA};
       RC(tower_forward(h, st, ap, 2, B));
       RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));     // both actors' heads in one launch
-      FwdPass cp[2] = {pCT, pC1};
-      RC(tower_forward(h, st, cp, 2, B));
     }
+    RC(tower_forward(h, st, cp, 2, B));
     {
       HeadTrainArgs t{};
       t.Xt = h->act[2][L]; t.Wt = wat(h, DQNHIP_CRITIC_TARGET, lc.hw_off); t.bt = wat(h, DQNHIP_CRITIC_TARGET, lc.hb_off);
@@ -915,40 +815,25 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       RC(head_backward<1>(h, st, a));
     }
     RC(tower_backward(h, st, lc, DQNHIP_CRITIC, h->g[1], h->part[1], h->act[3], h->dZc, B, true, false));
-    RC(stream_wait(h, st, ax));            // all critic wgrads done
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)h->loss_partial,
-                         h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr);
+                         h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr, (const DevState*)h->st);
       HIPCHK(hipGetLastError());
     }
     return 0;
   }
   if (phase == 1) {
-    // ClipGradients + Adam + Net::Update of the critic, soft update of critic_target fused.
-    // Per layer, on the auxiliary stream, so that layer i of the forward below only waits for
-    // the Adam of layer i (every launch re-derives the same global clip scale from the partials).
+    // ClipGradients + Adam + Net::Update of the critic, soft update of critic_target fused (one pass)
     const float* part = h->part[1]; int n_part = lc.n_part;
     if (dp) { RC(sumsq_launch(h, 1)); part = h->part_dp; n_part = h->n_part_dp; }
     FwdPass pC2{DQNHIP_CRITIC, &lc, h->act[4]};
     h->act[4][0] = h->Xc_pl;
-    if (ax != st) {
-      RC(stream_wait(h, ax, st));
-      for (int i = 0; i < L; ++i) {
-        RC(adam_launch(h, ax, 1, part, n_part, lc.w_off[i], i + 1 < L ? lc.w_off[i + 1] : lc.hw_off));
-        RC(stream_wait(h, st, ax));
-        RC(layer_forward(h, st, &pC2, 1, B, i));       // critic(s, mu(s)), UPDATED weights [:913-916]
-      }
-      RC(adam_launch(h, ax, 1, part, n_part, lc.hw_off, lc.arena));
-      RC(stream_wait(h, st, ax));
-    } else {
-      RC(adam_launch(h, st, 1, part, n_part, 0, lc.arena));
-      RC(tower_forward(h, st, &pC2, 1, B));
-    }
+    RC(adam_launch(h, st, 1, part, n_part, 0, lc.arena));
+    RC(tower_forward(h, st, &pC2, 1, B));                // critic(s, mu(s)), UPDATED weights [:913-916]
     // q(s, mu(s)) with the updated critic [:913-916] and, in the same launch, the seed of
     // BackwardFrom(q_values_layer): q diff = -1 per row, input gradient only (the reference's
     // discarded critic dW, SURVEY a11, is never computed).  The seed does not depend on q.
-    static const bool kQRider = !getenv("DQNHIP_SEPARATE_QHEAD");
-    const bool q_sep = head_big_ok(h, B, Hc) || !kQRider;
+    const bool q_sep = head_big_ok(h, B, Hc);            // minibatches >= 1024: the bandwidth-tiled head kernels
     if (q_sep) {
       HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
       a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.b = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q = h->q2;
@@ -970,17 +855,16 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       RC(head_backward<kNO>(h, st, a));
     }
     RC(tower_backward(h, st, la, DQNHIP_ACTOR, h->g[0], h->part[0], h->act[1], h->dZa, B, true, false));
-    RC(stream_wait(h, st, ax));            // all actor wgrads done
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)nullptr, 0,
-                         (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail);
+                         (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail, (const DevState*)h->st);
       HIPCHK(hipGetLastError());
     }
     return 0;
   }
   if (phase == 2) {
     // the actor's optimiser pass is the update's last launch: its last-arriving block also publishes
-    // (critic_loss, avg_q) and advances the iteration / sampling counters (what k_tick did in its own launch)
+    // (critic_loss, avg_q) and advances the iteration / sampling counters
     const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
                         dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world)};
     if (dp) { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena, &tick)); }
@@ -1109,11 +993,6 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
   layout_init(h->lc, h->S + kNO, *cfg, false);
   if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
   else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
-  // Two-stream schedule is opt-in: every cross-stream event edge costs several us on this
-  // platform (measured: 18 edges per update -> 535 us vs 380 us single-stream).
-  if (getenv("DQNHIP_AUX")) HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
-  h->events.resize(64);
-  for (auto& e : h->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const int B = h->B, L = h->L;
   auto dalloc = [&](float** p, size_t n) -> int {
     HIPCHK(hipMalloc(p, n * sizeof(float)));
@@ -1167,7 +1046,6 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
   }
   if (cfg->precision == DQNHIP_FP16) {
     h->fp16 = true;
-    h->redmajor = getenv("DQNHIP_FP16_TRANSPOSED_PANELS") == nullptr;
     const float user = cfg->loss_scale > 0.f ? cfg->loss_scale : 1.0f;
     h->ls_c = 16.0f * (float)(B * cfg->dp_world) * user;   // dq = (q-y)/B_global: back to O(q-y)
     h->ls_q = 4096.0f * user;
@@ -1185,23 +1063,14 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
     for (int net = 0; net < 4; ++net) {
       const NetLayout& l = layout_of(h, net);
       RC(halloc(&h->w16a[net], l.arena));
-      for (int i = 0; i < L; ++i) {
-        h->w16[net][i] = h->w16a[net] + l.w_off[i];
-        if (net < 2 && !h->redmajor) RC(halloc(&h->wt16[net][i], (size_t)h->k16[net & 1][i] * l.dims[i + 1]));
-      }
+      for (int i = 0; i < L; ++i) h->w16[net][i] = h->w16a[net] + l.w_off[i];
     }
     for (int p = 0; p < 5; ++p) {
       const int kind = p >= 2;
-      for (int i = 0; i <= L; ++i) {
-        RC(halloc(&h->act16[p][i], (size_t)B * h->k16[kind][i]));
-        if ((p == 1 || p == 3) && !h->redmajor) RC(halloc(&h->actT16[p][i], (size_t)h->k16[kind][i] * B));
-      }
+      for (int i = 0; i <= L; ++i) RC(halloc(&h->act16[p][i], (size_t)B * h->k16[kind][i]));
     }
     for (int kind = 0; kind < 2; ++kind)
-      for (int i = 0; i <= L; ++i) {
-        RC(halloc(&h->dZ16[kind][i], (size_t)B * h->k16[kind][i]));
-        if (!h->redmajor) RC(halloc(&h->dZT16[kind][i], (size_t)h->k16[kind][i] * B));
-      }
+      for (int i = 0; i <= L; ++i) RC(halloc(&h->dZ16[kind][i], (size_t)B * h->k16[kind][i]));
     HIPCHK(hgemm_prepare_all());
   }
   // weights: gaussian(std 0.01), zero bias (src/dqn.cpp:350-352); targets = hard copy (:660-661)
@@ -1231,9 +1100,6 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
       HIPCHK(hipMemcpyAsync(h->w[net + 2], h->w[net], l.arena * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     }
   }
-  HIPCHK(direct_prepare(gemm_wgrad_direct<1, 1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
-  HIPCHK(direct_prepare(gemm_bwd_pair_direct<1>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
-  HIPCHK(direct_prepare(gemm_bwd_pair_direct<1, true>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_bwd_seq<true>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_bwd_seq<false>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4));
@@ -1270,8 +1136,6 @@ int dqnhip_destroy(dqnhip_handle h) {
   for (void* p : h->allocs16) hipFree(p);
   if (h->stage_dev) hipFree(h->stage_dev);
   if (h->act_buf) hipFree(h->act_buf);
-  if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
-  for (auto& e : h->events) hipEventDestroy(e);
   if (h->own_stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -1349,12 +1213,20 @@ int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host)
   if (phase != 0 && phase != 10) rc = run_phase(h, phase, idx_dev);
   else {
     RingUse ring_use(h);
-    RC(sync_dirty16(h));
-    RC(stage_indices(h, idx_host, &idx_dev));
-    rc = run_phase(h, phase, idx_dev);
+    rc = sync_dirty16(h);
+    if (!rc) rc = stage_indices(h, idx_host, &idx_dev);
+    if (!rc) rc = run_phase(h, phase, idx_dev);
   }
-  if (!rc) h->next_phase = phase == 0 ? 1 : phase == 10 ? 11 : phase == 11 ? 1 : phase == 1 ? 2 : 0;
+  // a failed phase abandons the update: the next one starts from phase 0 / 10 again (one transient error must not
+  // wedge the learner in "out of order" for good)
+  h->next_phase = rc ? 0 : (phase == 0 ? 1 : phase == 10 ? 11 : phase == 11 ? 1 : phase == 1 ? 2 : 0);
   return rc;
+}
+
+int dqnhip_update_abort(dqnhip_handle h) {
+  if (!h) return fail("null handle");
+  h->next_phase = 0;
+  return 0;
 }
 
 int dqnhip_read_stats(dqnhip_handle h, float* critic_loss, float* avg_q) {
@@ -1390,6 +1262,27 @@ int dqnhip_skipped_steps(dqnhip_handle h, int64_t* count) {
 int dqnhip_update(dqnhip_handle h, const int32_t* idx_host, float* critic_loss, float* avg_q) {
   RC(dqnhip_update_async(h, idx_host));
   return dqnhip_read_stats(h, critic_loss, avg_q);
+}
+
+// Solver::ApplyUpdate() of one net in isolation (actor_solver_->ApplyUpdate(), src/dqn.cpp:964; the tail of
+// critic_solver_->Step(1), :904) on the gradient currently in the net's arena (e.g. dqnhip_set_params(KIND_G)):
+// ClipGradients + Adam + Net::Update + the soft update of that net's target under the condition of :967, then
+// set_iter(iter + 1) of that solver (:965).  The clip norm is taken from the arena itself (k_sumsq), as after an
+// all-reduce; the same k_adam_soft pass as inside an update.
+int dqnhip_apply_update(dqnhip_handle h, int32_t net) {
+  if (!h) return fail("null handle");
+  if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return fail("net must be ACTOR or CRITIC");
+  if (h->next_phase != 0) return fail("dqnhip_apply_update: a phased update is in progress (next phase %d)", h->next_phase);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RC(sync_dirty16(h));
+  const NetLayout& l = layout_of(h, net);
+  hipLaunchKernelGGL(k_sumsq, dim3(h->n_part_dp), dim3(256), 0, h->stream, h->g[net], l.arena / 4, h->part_dp);
+  HIPCHK(hipGetLastError());
+  RC(adam_launch(h, h->stream, net, h->part_dp, h->n_part_dp, 0, l.arena));
+  hipLaunchKernelGGL(k_advance_iter, dim3(1), dim3(1), 0, h->stream, h->st, (int)net);
+  HIPCHK(hipGetLastError());
+  if (net == DQNHIP_ACTOR) h->h_actor_iter += 1; else h->h_critic_iter += 1;
+  return 0;
 }
 
 int dqnhip_grad_buffer(dqnhip_handle h, int32_t net, void** dptr, size_t* nfloats) {
@@ -1455,11 +1348,91 @@ int dp_broadcast(H* h, int root) {
   return 0;
 }
 
-int dp_reduce_slice(H* h, hipStream_t st, float* ptr, size_t count) {
+// per-layer bucket: floats [off, off + count) of net's gradient arena, on the communication stream, ordered after
+// everything enqueued on `st` so far
+int dp_reduce_slice(H* h, hipStream_t st, int net, size_t off, size_t count) {
   HIPCHK(hipEventRecord(h->comm_ev[0], st));
   HIPCHK(hipStreamWaitEvent(h->comm_stream, h->comm_ev[0], 0));
+  float* ptr = h->g[net] + off;
   NCCLCHK(ncclAllReduce(ptr, ptr, count, ncclFloat, ncclSum, h->comm, h->comm_stream));
   return 0;
+}
+
+// the exchange step after phase 0 (net = critic) / phase 1 (net = actor)
+int dp_exchange(H* h, int net) {
+  const NetLayout& l = layout_of(h, net);
+  hipStream_t st = h->stream;
+  if (h->dp_half) {
+    // bf16 image of the arena -> sum all-reduce -> (phase 1 / 2 widen it again inside k_sumsq_bf16).  The fp32
+    // tails of both nets travel once, with the actor's gradients (nothing reads them before the tick of phase 2).
+    hipLaunchKernelGGL(k_to_bf16, dim3(1024), dim3(256), 0, st, (const float*)h->g[net], l.arena / 4, h->g16[net]);
+    HIPCHK(hipGetLastError());
+    if (net == DQNHIP_ACTOR) NCCLCHK(ncclGroupStart());
+    NCCLCHK(ncclAllReduce(h->g16[net], h->g16[net], l.arena, ncclBfloat16, ncclSum, h->comm, st));
+    if (net == DQNHIP_ACTOR) {
+      NCCLCHK(ncclAllReduce(h->dp_tails, h->dp_tails, 8, ncclFloat, ncclSum, h->comm, st));
+      NCCLCHK(ncclGroupEnd());
+    }
+  } else if (h->dp_per_layer) {
+    // the tower slices are already in flight on comm_stream; what is left is the head + tail slice, then the main
+    // stream waits for the communication stream
+    RC(dp_reduce_slice(h, st, net, l.hw_off, l.arena + 4 - l.hw_off));
+    HIPCHK(hipEventRecord(h->comm_ev[1], h->comm_stream));
+    HIPCHK(hipStreamWaitEvent(st, h->comm_ev[1], 0));
+  } else {
+    NCCLCHK(ncclAllReduce(h->g[net], h->g[net], l.arena + 4, ncclFloat, ncclSum, h->comm, st));
+  }
+  return 0;
+}
+
+// phase 0, exchange, phase 1, exchange, phase 2 on the learner's stream; no host sync (capturable)
+int dp_sequence(H* h, const int* idx_dev) {
+  RC(run_phase(h, 0, idx_dev));
+  RC(dp_exchange(h, DQNHIP_CRITIC));
+  RC(run_phase(h, 1, nullptr));
+  RC(dp_exchange(h, DQNHIP_ACTOR));
+  return run_phase(h, 2, nullptr);
+}
+
+int dp_capture(H* h) {
+  hipGraph_t graph = nullptr;
+  HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  const int it_a = h->h_actor_iter, it_c = h->h_critic_iter;
+  const int rc = dp_sequence(h, nullptr);
+  h->h_actor_iter = it_a; h->h_critic_iter = it_c;   // capture does not execute
+  hipError_t e = hipStreamEndCapture(h->stream, &graph);
+  if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) return fail("hipStreamEndCapture (dp): %s", hipGetErrorString(e));
+  e = hipGraphInstantiate(&h->dp_graph, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) { h->dp_graph = nullptr; return fail("hipGraphInstantiate (dp): %s", hipGetErrorString(e)); }
+  return 0;
+}
+
+// ---- file rendezvous (one node, no launcher support) ----------------------------------------------
+// Rank r > 0 publishes a request <path>.req<r> holding a fresh random nonce and re-publishes it if it disappears;
+// rank 0 first removes whatever an earlier job left behind (<path>, <path>.req*), waits for the world-1 requests,
+// and publishes <path> = {id, nonce_1 .. nonce_{world-1}}.  A waiter accepts <path> only if it carries ITS nonce:
+// a file left by an earlier job, or written before this waiter existed, can never hand it a dead id.  After the
+// group is up (ncclCommInitRank is collective: every rank has read the file by then) rank 0 removes all of it,
+// so the same path serves the next group.
+struct RvFile { unsigned char id[DQNHIP_DP_ID_BYTES]; uint64_t nonce[64]; };
+
+bool rv_write(const std::string& path, const void* data, size_t n) {
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return false;
+  const bool ok = fwrite(data, 1, n, f) == n;
+  fclose(f);
+  if (!ok || rename(tmp.c_str(), path.c_str())) { unlink(tmp.c_str()); return false; }
+  return true;
+}
+bool rv_read(const std::string& path, void* data, size_t n) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  const size_t got = fread(data, 1, n, f);
+  fclose(f);
+  return got == n;
 }
 }  // namespace
 
@@ -1474,6 +1447,54 @@ int dqnhip_dp_unique_id(void* id_out, size_t bytes) {
   return 0;
 }
 
+int dqnhip_dp_rendezvous_file(const char* path, int32_t rank, int32_t world, int32_t timeout_s, void* id, size_t bytes) {
+  if (!path || !id) return fail("null argument");
+  if (bytes != DQNHIP_DP_ID_BYTES) return fail("dp_rendezvous_file: id must be DQNHIP_DP_ID_BYTES bytes");
+  if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail("dp_rendezvous_file: bad rank %d / world %d (<= 64)", rank, world);
+  const std::string p(path);
+  const auto t0 = std::chrono::steady_clock::now();
+  auto expired = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s; };
+  auto nap = [] { std::this_thread::sleep_for(std::chrono::milliseconds(10)); };
+  if (rank == 0) {
+    unlink(p.c_str());
+    for (int r = 1; r < world; ++r) unlink((p + ".req" + std::to_string(r)).c_str());
+    RvFile f{};
+    memcpy(f.id, id, sizeof f.id);
+    for (int r = 1; r < world; ++r) {
+      const std::string rq = p + ".req" + std::to_string(r);
+      while (!rv_read(rq, &f.nonce[r], sizeof(uint64_t)) || f.nonce[r] == 0) {
+        if (expired()) return fail("dp_rendezvous_file: rank 0 timed out after %d s waiting for rank %d (%s)", timeout_s, r, rq.c_str());
+        nap();
+      }
+    }
+    if (!rv_write(p, &f, sizeof f)) return fail("dp_rendezvous_file: cannot publish %s", path);
+    return 0;
+  }
+  std::random_device rd;
+  uint64_t nonce = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)getpid() << 17) ^
+                   (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+  if (nonce == 0) nonce = 1;
+  const std::string rq = p + ".req" + std::to_string(rank);
+  for (;;) {
+    uint64_t seen = 0;
+    if (!rv_read(rq, &seen, sizeof seen) || seen != nonce) {            // not there (yet, or rank 0 cleaned up): (re)publish
+      if (!rv_write(rq, &nonce, sizeof nonce)) return fail("dp_rendezvous_file: cannot write %s", rq.c_str());
+    }
+    RvFile f{};
+    if (rv_read(p, &f, sizeof f) && f.nonce[rank] == nonce) { memcpy(id, f.id, sizeof f.id); return 0; }
+    if (expired()) return fail("dp_rendezvous_file: rank %d timed out after %d s waiting for %s", rank, timeout_s, path);
+    nap();
+  }
+}
+
+int dqnhip_dp_rendezvous_cleanup(const char* path, int32_t world) {
+  if (!path) return fail("null argument");
+  const std::string p(path);
+  unlink(p.c_str());
+  for (int r = 1; r < world; ++r) unlink((p + ".req" + std::to_string(r)).c_str());
+  return 0;
+}
+
 int dqnhip_dp_init(dqnhip_handle h, const void* id, size_t bytes, int32_t flags) {
   if (!h || !id) return fail("null argument");
   if (bytes != sizeof(ncclUniqueId)) return fail("dp_init: id must be DQNHIP_DP_ID_BYTES = %zu bytes", sizeof(ncclUniqueId));
@@ -1483,43 +1504,33 @@ int dqnhip_dp_init(dqnhip_handle h, const void* id, size_t bytes, int32_t flags)
   HIPCHK(hipStreamSynchronize(h->stream));
   ncclUniqueId uid; memcpy(&uid, id, sizeof uid);
   NCCLCHK(ncclCommInitRank(&h->comm, h->cfg.dp_world, uid, h->cfg.dp_rank));
-  // per-layer buckets need each layer's dW AND db final when its wgrad launch has run: true for the fp32 path on
-  // one stream; the fp16 path writes all bias gradients at the end (k_db16) and keeps one collective per net
-  h->dp_per_layer = (flags & DQNHIP_DP_PER_LAYER) != 0 && !h->fp16 && h->aux == nullptr;
+  h->dp_half = (flags & DQNHIP_DP_HALF_GRADS) != 0;
+  // per-layer buckets need each layer's dW AND db final when its backward launch has run: true for the fp32 path;
+  // the fp16 path produces all wgrads of a net in one launch at the end and keeps one collective per net
+  h->dp_per_layer = (flags & DQNHIP_DP_PER_LAYER) != 0 && !h->fp16 && !h->dp_half;
   HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
   for (auto& e : h->comm_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (h->dp_half) {
+    for (int net = 0; net < 2; ++net) HIPCHK(hipMalloc(&h->g16[net], layout_of(h, net).arena * sizeof(uint16_t)));
+    HIPCHK(hipMalloc(&h->dp_tails, 8 * sizeof(float)));
+    HIPCHK(hipMemsetAsync(h->dp_tails, 0, 8 * sizeof(float), h->stream));
+  }
   drop_graphs_fwd(h);
   // replicas start from rank 0's state: weights of the four nets, Adam history, iterations
   return dp_broadcast(h, 0);
 }
 
-// Single-node rendezvous without any launcher support: rank 0 publishes the RCCL id in a file,
-// the other ranks wait for it.  (A launcher that has its own channel — MPI, torch.distributed's
-// store — passes the id to dqnhip_dp_init directly.)
+// Single-node rendezvous without any launcher support (dqnhip_dp_rendezvous_file), then dqnhip_dp_init.
+// (A launcher that has its own channel — MPI, torch.distributed's store — passes the id to dqnhip_dp_init directly.)
 int dqnhip_dp_init_file(dqnhip_handle h, const char* path, int32_t flags, int32_t timeout_s) {
   if (!h || !path) return fail("null argument");
   ncclUniqueId uid;
-  const std::string p(path), tmp = p + ".tmp";
-  if (h->cfg.dp_rank == 0) {
-    // a file left over from an earlier job would hand the other ranks a dead id (they would sit in
-    // ncclCommInitRank until its time-out): refuse to start over it
-    if (FILE* old = fopen(p.c_str(), "rb")) { fclose(old); return fail("dp_init_file: %s already exists (left over from an earlier job?): remove it or use a fresh path", path); }
-    RC(dqnhip_dp_unique_id(&uid, sizeof uid));
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(&uid, sizeof uid, 1, f) != 1) { if (f) fclose(f); return fail("dp_init_file: cannot write %s", tmp.c_str()); }
-    fclose(f);
-    if (rename(tmp.c_str(), p.c_str())) return fail("dp_init_file: cannot publish %s", path);
-  } else {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      FILE* f = fopen(p.c_str(), "rb");
-      if (f) { const size_t n = fread(&uid, 1, sizeof uid, f); fclose(f); if (n == sizeof uid) break; }
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-        return fail("dp_init_file: rank %d timed out after %d s waiting for %s", h->cfg.dp_rank, timeout_s, path);
-      std::this_thread::sleep_for(std::chrono::milliseconds(20));
-    }
-  }
-  return dqnhip_dp_init(h, &uid, sizeof uid, flags);
+  if (h->cfg.dp_rank == 0) RC(dqnhip_dp_unique_id(&uid, sizeof uid));
+  RC(dqnhip_dp_rendezvous_file(path, h->cfg.dp_rank, h->cfg.dp_world, timeout_s, &uid, sizeof uid));
+  const int rc = dqnhip_dp_init(h, &uid, sizeof uid, flags);
+  // ncclCommInitRank is collective: once it has returned on rank 0 every rank has read the file
+  if (h->cfg.dp_rank == 0) { const std::string msg = g_err; dqnhip_dp_rendezvous_cleanup(path, h->cfg.dp_world); g_err = msg; }
+  return rc;
 }
 
 int dqnhip_dp_broadcast_params(dqnhip_handle h, int32_t root) {
@@ -1534,26 +1545,30 @@ int dqnhip_dp_update(dqnhip_handle h, const int32_t* idx_host) {
   if (!h) return fail("null handle");
   if (!h->comm) return fail("dp_update: no communicator (call dqnhip_dp_init first)");
   HIPCHK(hipSetDevice(h->cfg.device));
-  const NetLayout &la = h->la, &lc = h->lc;
-  hipStream_t st = h->stream;
-  // with per-layer buckets the tower slices are already in flight on comm_stream; what is left is the
-  // head + tail slice, then the main stream waits for the communication stream
-  auto finish = [&](int net) -> int {
-    const NetLayout& l = net ? lc : la;
-    if (h->dp_per_layer) {
-      RC(dp_reduce_slice(h, st, h->g[net] + l.hw_off, l.arena + 4 - l.hw_off));
-      HIPCHK(hipEventRecord(h->comm_ev[1], h->comm_stream));
-      HIPCHK(hipStreamWaitEvent(st, h->comm_ev[1], 0));
-    } else {
-      NCCLCHK(ncclAllReduce(h->g[net], h->g[net], l.arena + 4, ncclFloat, ncclSum, h->comm, st));
+  if (h->next_phase != 0) return fail("dqnhip_dp_update: a phased update is in progress (next phase %d)", h->next_phase);
+  RingUse ring_use(h);
+  RC(sync_dirty16(h));
+  // cfg.use_graph: the whole update — 30-40 launches and both collectives — replays as ONE hipGraph (every rank
+  // captures the same sequence).  Explicit indices, kernel timing, or a capture that RCCL refuses: eager.
+  if (h->cfg.use_graph && !idx_host && !h->timing && !h->dp_graph_failed) {
+    if (RO(h)->h_size < 1) RC(refresh_ring(h));
+    if (RO(h)->h_size < 1) return fail("replay memory is empty");
+    if (!h->dp_graph && dp_capture(h)) h->dp_graph_failed = true;
+    if (h->dp_graph) {
+      HIPCHK(hipGraphLaunch(h->dp_graph, h->stream));
+      h->h_actor_iter += 1; h->h_critic_iter += 1;
+      return 0;
     }
-    return 0;
-  };
-  RC(dqnhip_update_phase(h, 0, idx_host));
-  RC(finish(1));
-  RC(dqnhip_update_phase(h, 1, nullptr));
-  RC(finish(0));
-  return dqnhip_update_phase(h, 2, nullptr);
+  }
+  const int* idx_dev = nullptr;
+  RC(stage_indices(h, idx_host, &idx_dev));
+  return dp_sequence(h, idx_dev);
+}
+
+int dqnhip_dp_graph_active(dqnhip_handle h, int32_t* active) {
+  if (!h || !active) return fail("null argument");
+  *active = h->dp_graph != nullptr;
+  return 0;
 }
 
 int dqnhip_dp_destroy(dqnhip_handle h) {
@@ -1561,9 +1576,14 @@ int dqnhip_dp_destroy(dqnhip_handle h) {
   hipSetDevice(h->cfg.device);
   hipStreamSynchronize(h->stream);
   hipStreamSynchronize(h->comm_stream);
+  if (h->dp_graph) { hipGraphExecDestroy(h->dp_graph); h->dp_graph = nullptr; }
+  h->dp_graph_failed = false;
   ncclCommDestroy(h->comm); h->comm = nullptr;
   hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr;
   for (auto& e : h->comm_ev) { if (e) hipEventDestroy(e); e = nullptr; }
+  for (int net = 0; net < 2; ++net) if (h->g16[net]) { hipFree(h->g16[net]); h->g16[net] = nullptr; }
+  if (h->dp_tails) { hipFree(h->dp_tails); h->dp_tails = nullptr; }
+  h->dp_half = false; h->dp_per_layer = false;
   return 0;
 }
 
@@ -2238,12 +2258,10 @@ static int env_one_step(dqnhip_env* e, bool more_follow) {
   FwdPass fp{DQNHIP_ACTOR, &la, e->acts};
   // 5 launches per batched step at L = 4 inside a sequence: the actor heads ride in k_env_step (one wave per worker
   // computes its own 10 outputs), the ring bookkeeping in the flush's last block, and the flush itself in the NEXT
-  // step's first-layer launch; DQNHIP_ENV_SEPARATE=1 restores the 8-launch form for A/B measurements
-  static const bool kFused = !getenv("DQNHIP_ENV_SEPARATE");
-  static const bool kRide = !getenv("DQNHIP_ENV_NO_RIDER");
+  // step's first-layer launch
   // (beyond a few hundred workers the dedicated head kernel and a separate commit win: one wave per head row is
   // slower than the tiled head kernel there, and N arrivals on one counter serialise at ~12 ns each)
-  const bool fused = kFused && la.dims[la.L] % 4 == 0 && d.N <= 512;
+  const bool fused = la.dims[la.L] % 4 == 0 && d.N <= 512;
   if (fused) {
     d.head_x = e->acts[la.L]; d.head_h = la.dims[la.L];
     d.head_w = wat(h, DQNHIP_ACTOR, la.hw_off); d.head_b = wat(h, DQNHIP_ACTOR, la.hb_off);
@@ -2277,7 +2295,7 @@ static int env_one_step(dqnhip_env* e, bool more_follow) {
   }
   hipLaunchKernelGGL(k_env_step, dim3(d.N), dim3(64), 2 * d.SP * sizeof(float), st, d);
   HIPCHK(hipGetLastError());
-  if (more_follow && kRide && fused && l0_direct && !h->timing) { e->flush_deferred = true; return 0; }
+  if (more_follow && fused && l0_direct && !h->timing) { e->flush_deferred = true; return 0; }
   hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), d.T * sizeof(float), st, d, RO(h)->ring,
                      (const DevState*)RO(h)->st, h->cfg.gamma);
   HIPCHK(hipGetLastError());

@@ -408,9 +408,9 @@ struct HeadBwdArgs {
   // two used to be separate dependent launches for no reason.
   int rc_blocks;                       // row chunks of the backward part (0: gridDim.y)
   const float* q_bias; float* q_out; double* qsum_partial;
-  // fp16 learner: also emit the tower-top gradient as the scaled fp16 panel(s) the fp16 GEMMs read —
-  // dZ16 [rows][H] and (wgrad operand) dZT16 [H][ldT] — instead of a separate conversion launch
-  _Float16* dZ16; _Float16* dZT16; int ldT; float scale16;
+  // fp16 learner: also emit the tower-top gradient as the scaled fp16 panel the fp16 GEMMs read (dZ16 [rows][H])
+  // instead of a separate conversion launch
+  _Float16* dZ16; float scale16;
 };
 // Grid = (H/64 column blocks) x (RC row chunks); block = 64 columns x 16 row groups.  Each block
 // writes its dZ rows directly and a partial dW slab; the LAST block to arrive for a column block
@@ -439,7 +439,6 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   const int r0 = rc * rows_c, r1 = min(a.rows, r0 + rows_c);
   float* s_dy = sm;                                    // [rows_c][NH]
   float* s_acc = sm + rows_c * NH;                     // [16][NH][64]
-  _Float16* s_t = reinterpret_cast<_Float16*>(s_acc + 16 * NH * 64 + 16);   // fp16 mode: [64][rows_c + 8] halves
   __shared__ int s_last;
   const int tid = threadIdx.x;
   const bool want_w = a.dW != nullptr;
@@ -486,21 +485,7 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
     if (NH == kNO) s0 += s1;
     const float dz = s0 * lrelu_mask(xv);
     a.dZ[(size_t)m * a.H + k] = dz;
-    if (a.dZ16 != nullptr) {
-      const _Float16 hz = (_Float16)(dz * a.scale16);
-      a.dZ16[(size_t)m * a.H + k] = hz;
-      if (a.dZT16 != nullptr) s_t[kc * (rows_c + 8) + (m - r0)] = hz;
-    }
-  }
-  if (a.dZT16 != nullptr) {                             // [64 columns][rows of this chunk] -> 16-B pieces of the transposed panel
-    __syncthreads();
-    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
-    const int per_row = (r1 - r0) >> 3;                 // rows_c is a multiple of 8 (minibatch % 128 == 0 in fp16 mode)
-    for (int q = tid; q < 64 * per_row; q += 1024) {
-      const int col = q / per_row, c8 = q % per_row;
-      *reinterpret_cast<h8*>(a.dZT16 + (size_t)(blockIdx.x * 64 + col) * a.ldT + r0 + c8 * 8) =
-          *reinterpret_cast<const h8*>(s_t + col * (rows_c + 8) + c8 * 8);
-    }
+    if (a.dZ16 != nullptr) a.dZ16[(size_t)m * a.H + k] = (_Float16)(dz * a.scale16);
   }
   if (!want_w) return;
 #pragma unroll
@@ -562,22 +547,20 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
 // Same arithmetic as k_head_bwd, re-tiled for bandwidth: block = 64 rows x 256 columns, wave = 16
 // rows, lane = 4 consecutive columns (16-B loads / stores of X4 and dZ).  Per-chunk partial head
 // gradients go to a slab [rows/64][NH][H]; k_head_wred adds the chunks in index order.  In fp16
-// mode the tower-top gradient is written directly as the scaled fp16 panel in both orientations
-// (the transposed one through an LDS tile), replacing the fp32 panel + conversion pass.
+// mode the tower-top gradient is written directly as the scaled fp16 panel, replacing the fp32 panel +
+// conversion pass.
 struct HeadBwdBigArgs {
   HeadBwdArgs a;
-  _Float16* dZ16; _Float16* dZT16; int ldT; float scale16;   // fp16 outputs (null: fp32 a.dZ only)
+  _Float16* dZ16; float scale16;                             // fp16 output (null: fp32 a.dZ only)
   float* slab2;                                              // [rows/64][NH][H] then [rows/64][16]
 };
 template <int NH>
 __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
   typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-  typedef __attribute__((ext_vector_type(8))) _Float16 h8;
   const HeadBwdArgs& a = b.a;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_dy = sm;                                    // [64][NH]
   float* s_red = sm + 64 * NH;                         // [4][NH][256]
-  _Float16* s_t = reinterpret_cast<_Float16*>(s_red + 4 * NH * 256);   // [256][72] halves
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int m0 = blockIdx.x * 64, kb = blockIdx.y * 256, k0 = kb + lane * 4;
   const bool want_w = a.dW != nullptr;
@@ -625,24 +608,14 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
     if (b.dZ16 != nullptr) {
       const h4 hz = h4{(_Float16)(dz.x * b.scale16), (_Float16)(dz.y * b.scale16), (_Float16)(dz.z * b.scale16), (_Float16)(dz.w * b.scale16)};
       *reinterpret_cast<h4*>(b.dZ16 + (size_t)m * a.H + k0) = hz;
-      if (b.dZT16 != nullptr) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) s_t[(lane * 4 + c) * 72 + ml] = hz[c];
-      }
     }
   }
   if (want_w) {
 #pragma unroll
     for (int j = 0; j < NH; ++j) *reinterpret_cast<f32x4*>(s_red + ((w * NH + j) * 256 + lane * 4)) = acc[j];
   }
-  __syncthreads();
-  if (b.dZT16 != nullptr) {                              // [256 columns][64 rows] -> 128-B row pieces
-    for (int q = tid; q < 256 * 8; q += 256) {
-      const int col = q >> 3, c8 = q & 7;
-      *reinterpret_cast<h8*>(b.dZT16 + (size_t)(kb + col) * b.ldT + m0 + c8 * 8) = *reinterpret_cast<const h8*>(s_t + col * 72 + c8 * 8);
-    }
-  }
   if (!want_w) return;
+  __syncthreads();
   float* slab = b.slab2 + (size_t)blockIdx.x * NH * a.H;
   for (int i = tid; i < NH * 256; i += 256) {
     const int j = i >> 8, c = i & 255;
@@ -708,6 +681,42 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, size
   if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
+// Data-parallel exchange in half the bytes (dqnhip_dp_init flag DQNHIP_DP_HALF_GRADS): the gradient arena crosses
+// the links as bf16 (fp32's exponent range: no loss scale, no overflow; 8 significant bits, round-to-nearest-even)
+// and is widened again by the pass that takes the clip norm of the reduced gradient.
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__global__ __launch_bounds__(256) void k_to_bf16(const float* __restrict__ g, size_t n4, uint16_t* __restrict__ out) {
+  typedef __attribute__((ext_vector_type(4))) uint16_t u16x4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    reinterpret_cast<u16x4*>(out)[i] = u16x4{f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
+  }
+}
+// bf16 image (after the all-reduce) -> fp32 arena + sum-of-squares partials (k_sumsq's layout and order)
+__global__ __launch_bounds__(256) void k_sumsq_bf16(const uint16_t* __restrict__ in, float* __restrict__ g, size_t n4,
+                                                    float* __restrict__ partial) {
+  typedef __attribute__((ext_vector_type(4))) uint16_t u16x4;
+  __shared__ float s[4];
+  float acc = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const u16x4 h = reinterpret_cast<const u16x4*>(in)[i];
+    const f32x4 v = f32x4{__builtin_bit_cast(float, (uint32_t)h.x << 16), __builtin_bit_cast(float, (uint32_t)h.y << 16),
+                          __builtin_bit_cast(float, (uint32_t)h.z << 16), __builtin_bit_cast(float, (uint32_t)h.w << 16)};
+    reinterpret_cast<f32x4*>(g)[i] = v;
+    acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
 // SGDSolver::ClipGradients + AdamSolver::ComputeUpdateValue + Net::Update +
 // DQN::SoftUpdateNet in ONE pass over (w, g, m, v, w_target)
 // (Caffe sgd_solver.cpp/adam_solver.cpp @2ef5847; src/dqn.cpp:
@@ -732,12 +741,6 @@ struct AdamArgs {
   // by then every block has read the iteration counters it is about to advance) runs tick_body
   int* tick_ticket;               // null: no tick duty
   TickArgs tick;
-  // fp16 mode, tiled form (k_adam_soft_tiled): the tower weight matrices are walked in 64 x 64 tiles so that the
-  // pass can also write the TRANSPOSED fp16 copy the dgrad GEMMs read (wt16[k][n]) through an LDS tile — what a
-  // separate transposing conversion launch per net did before.  Everything else (biases, heads) stays flat.
-  int n_tseg, n_fseg, n_tiles;
-  struct TileSeg { size_t off; int N, Kp; _Float16* wT; int ldT; int tile_base; } tseg[8];
-  struct FlatSeg { size_t off4, n4; } fseg[10];
 };
 // body shared by the stand-alone kernel and the mixed GEMM+Adam launch: block `blk` of
 // `nblk` 256-thread blocks strides over the arena slice
@@ -771,7 +774,7 @@ __device__ __forceinline__ void adam_scalars(const AdamArgs& a, int blk, float* 
     // g*0 = NaN in m, v, w and the targets for good.  Every block derives the same norm, so every
     // block takes the same decision: skip the whole step and raise the sticky flag.
     s[7] = isfinite(sumsq) ? 0.0f : 1.0f;
-    if (s[7] != 0.0f && blk == 0) { atomicOr(&a.st->flags, kFlagGradNorm); atomicAdd(&a.st->skipped_steps, 1); }
+    if (s[7] != 0.0f && blk == 0) { atomicOr(&a.st->flags, kFlagGradNorm); atomicAdd(&a.st->skipped_steps, 1); }   // one launch per net per update
   }
   __syncthreads();
 }
@@ -838,117 +841,6 @@ __global__ __launch_bounds__(256) void k_adam_soft_t(AdamArgs a) {
 }
 __device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot, double* sq);   // below
 
-// one float4 of every array: the same arithmetic as adam_soft_body's inner loop
-__device__ __forceinline__ void adam_elem4(const AdamArgs& a, size_t i, float scale, float step, bool soft, f32x4& w_out) {
-  const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2, tau = a.tau, omt = 1 - a.tau;
-  f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i], m = reinterpret_cast<const f32x4*>(a.m)[i], v = reinterpret_cast<const f32x4*>(a.v)[i];
-  f32x4 w = reinterpret_cast<const f32x4*>(a.w)[i], wt = reinterpret_cast<const f32x4*>(a.wt)[i];
-  float* gp = reinterpret_cast<float*>(&g); float* mp = reinterpret_cast<float*>(&m); float* vp = reinterpret_cast<float*>(&v);
-  float* wp = reinterpret_cast<float*>(&w); float* tp = reinterpret_cast<float*>(&wt);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float gi = gp[e] * scale;
-    const float mi = fmaf(omb1, gi, a.beta1 * mp[e]);
-    const float vi = fmaf(omb2, gi * gi, a.beta2 * vp[e]);
-    const float upd = step * (mi / (sqrtf(vi) + a.eps));
-    const float wi = wp[e] - upd;
-    mp[e] = mi; vp[e] = vi; wp[e] = wi;
-    if (soft) tp[e] = fmaf(tau, wi, omt * tp[e]);
-  }
-  reinterpret_cast<f32x4*>(a.m)[i] = m; reinterpret_cast<f32x4*>(a.v)[i] = v; reinterpret_cast<f32x4*>(a.w)[i] = w;
-  if (soft) reinterpret_cast<f32x4*>(a.wt)[i] = wt;
-  typedef __attribute__((ext_vector_type(4))) _Float16 h16x4_t;
-  reinterpret_cast<h16x4_t*>(a.w16)[i] = h16x4_t{(_Float16)wp[0], (_Float16)wp[1], (_Float16)wp[2], (_Float16)wp[3]};
-  if (soft) reinterpret_cast<h16x4_t*>(a.wt16)[i] = h16x4_t{(_Float16)tp[0], (_Float16)tp[1], (_Float16)tp[2], (_Float16)tp[3]};
-  w_out = w;
-}
-
-// fp16 mode: blocks [0, n_tiles) own one 64 x 64 tile of a tower weight matrix each; the blocks after them
-// stride over the flat segments (biases, heads).
-__global__ __launch_bounds__(256) void k_adam_soft_tiled(AdamArgs a) {
-  __shared__ float s[8];
-  __shared__ double sq[4];
-  __shared__ int s_last;
-  __shared__ _Float16 sT[64][72];                         // [k][n] halves, 144-B rows (16-B aligned chunks)
-  adam_scalars(a, blockIdx.x, s);
-  if (s[7] == 0.0f) {
-    const float scale = s[4], step = s[5];
-    const bool soft = s[6] != 0.0f;
-    const int b = blockIdx.x;
-    if (b < a.n_tiles) {
-      int j = 0;
-      while (j + 1 < a.n_tseg && b >= a.tseg[j + 1].tile_base) ++j;
-      const AdamArgs::TileSeg& t = a.tseg[j];
-      const int tl = b - t.tile_base, tk_n = t.Kp >> 6;
-      const int n0 = (tl / tk_n) << 6, k0 = (tl % tk_n) << 6;
-      // 16 lanes cover one 256-B row segment, a wave 4 rows per instruction (whole lines); all 20 float4 loads
-      // of the thread's four rows are issued before the first use
-      const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
-      const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2, tau = a.tau, omt = 1 - a.tau;
-      f32x4 g[4], m[4], v[4], w[4], wt[4];
-      size_t idx[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        idx[q] = (t.off + (size_t)(n0 + r0 + 16 * q) * t.Kp + k0) / 4 + c4;
-        g[q] = reinterpret_cast<const f32x4*>(a.g)[idx[q]]; m[q] = reinterpret_cast<const f32x4*>(a.m)[idx[q]];
-        v[q] = reinterpret_cast<const f32x4*>(a.v)[idx[q]]; w[q] = reinterpret_cast<const f32x4*>(a.w)[idx[q]];
-        wt[q] = reinterpret_cast<const f32x4*>(a.wt)[idx[q]];
-      }
-      typedef __attribute__((ext_vector_type(4))) _Float16 h16x4_t;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float* gp = reinterpret_cast<float*>(&g[q]); float* mp = reinterpret_cast<float*>(&m[q]); float* vp = reinterpret_cast<float*>(&v[q]);
-        float* wp = reinterpret_cast<float*>(&w[q]); float* tp = reinterpret_cast<float*>(&wt[q]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float gi = gp[e] * scale;
-          const float mi = fmaf(omb1, gi, a.beta1 * mp[e]);
-          const float vi = fmaf(omb2, gi * gi, a.beta2 * vp[e]);
-          const float upd = step * (mi / (sqrtf(vi) + a.eps));
-          const float wi = wp[e] - upd;
-          mp[e] = mi; vp[e] = vi; wp[e] = wi;
-          if (soft) tp[e] = fmaf(tau, wi, omt * tp[e]);
-          sT[c4 * 4 + e][r0 + 16 * q] = (_Float16)wi;
-        }
-        reinterpret_cast<f32x4*>(a.m)[idx[q]] = m[q]; reinterpret_cast<f32x4*>(a.v)[idx[q]] = v[q]; reinterpret_cast<f32x4*>(a.w)[idx[q]] = w[q];
-        if (soft) reinterpret_cast<f32x4*>(a.wt)[idx[q]] = wt[q];
-        reinterpret_cast<h16x4_t*>(a.w16)[idx[q]] = h16x4_t{(_Float16)wp[0], (_Float16)wp[1], (_Float16)wp[2], (_Float16)wp[3]};
-        if (soft) reinterpret_cast<h16x4_t*>(a.wt16)[idx[q]] = h16x4_t{(_Float16)tp[0], (_Float16)tp[1], (_Float16)tp[2], (_Float16)tp[3]};
-      }
-      __syncthreads();
-      typedef __attribute__((ext_vector_type(8))) _Float16 h8;
-      const int kk = threadIdx.x >> 2, part = threadIdx.x & 3;   // one transposed row = 64 halves = 4 x 32 B
-      h8* dst = reinterpret_cast<h8*>(t.wT + (size_t)(k0 + kk) * t.ldT + n0 + part * 16);
-      dst[0] = *reinterpret_cast<const h8*>(&sT[kk][part * 16]);
-      dst[1] = *reinterpret_cast<const h8*>(&sT[kk][part * 16 + 8]);
-    } else {
-      const int fb = b - a.n_tiles, nfb = (int)gridDim.x - a.n_tiles;
-      for (int f = 0; f < a.n_fseg; ++f)
-        for (size_t i = (size_t)fb * 256 + threadIdx.x; i < a.fseg[f].n4; i += (size_t)nfb * 256) {
-          f32x4 w;
-          adam_elem4(a, a.fseg[f].off4 + i, scale, step, soft, w);
-        }
-    }
-  }
-  if (a.tick_ticket == nullptr) return;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    constexpr int kSub = 16;
-    const int G = (int)gridDim.x, sub = (int)blockIdx.x % kSub;
-    const int expect = (G + kSub - 1 - sub) / kSub;
-    int* c = a.tick_ticket + sub * 32;
-    int last = 0;
-    if (__hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1) {
-      *c = 0;
-      int* top = a.tick_ticket + kSub * 32;
-      const int groups = G < kSub ? G : kSub;
-      if (__hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) { *top = 0; last = 1; }
-    }
-    s_last = last;
-  }
-  __syncthreads();
-  if (s_last) tick_body(a.tick, s, sq);
-}
 __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   __shared__ float s[8];
   __shared__ double sq[4];
@@ -988,8 +880,10 @@ __global__ __launch_bounds__(256) void k_local_reduce(LocalReduce a) {
 
 // Reduce the per-block loss / q partials into the gradient-arena tails
 // ([loss_sum, q_sum, 0, 0]) so they ride in the gradient all-reduce.
+// tail[2] carries this rank's non-finite-target flag (0 / 1): the flag is raised from the rank's OWN replay shard,
+// so without it one rank would stop with "Target not finite!" while the others walk into the next collective.
 __global__ __launch_bounds__(256) void k_tails(const float* loss_partial, int n_loss, const double* q_partial, int n_q,
-                                               float inv_batch, float* critic_tail, float* actor_tail) {
+                                               float inv_batch, float* critic_tail, float* actor_tail, const DevState* st) {
   // one block, same reduction tree as k_tick (strided partials, butterfly, fixed cross-wave order)
   __shared__ float sdot[4];
   __shared__ double sq[4];
@@ -1005,7 +899,7 @@ __global__ __launch_bounds__(256) void k_tails(const float* loss_partial, int n_
   if (critic_tail != nullptr) {
     dot = (sdot[0] + sdot[1]) + (sdot[2] + sdot[3]);
     critic_tail[0] = dot * inv_batch / 2.0f;   // EuclideanLoss: dot / num / 2
-    critic_tail[1] = 0.f; critic_tail[2] = 0.f; critic_tail[3] = 0.f;
+    critic_tail[1] = 0.f; critic_tail[2] = (st->flags & kFlagTarget) ? 1.0f : 0.f; critic_tail[3] = 0.f;
   }
   if (actor_tail != nullptr) {
     qs = (sq[0] + sq[1]) + (sq[2] + sq[3]);
@@ -1037,14 +931,14 @@ __device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot /*[4]*/
     }
   } else qs = (double)a.actor_tail[1];   // data parallel: tails were all-reduced
   if (t != 0) return;
+  if (a.q_partial == nullptr && a.critic_tail[2] != 0.0f) atomicOr(&a.st->flags, kFlagTarget);   // some rank's target was not finite
   a.st->critic_loss = a.critic_tail[0];
   a.st->avg_q = (float)(qs / (double)a.batch);
   a.st->actor_iter += 1; a.st->critic_iter += 1; a.st->update_counter += 1;
 }
-__global__ __launch_bounds__(256) void k_tick(TickArgs a) {
-  __shared__ float sdot[4];
-  __shared__ double sq[4];
-  tick_body(a, sdot, sq);
+// ++iter of one solver (dqnhip_apply_update: set_iter(iter() + 1), src/dqn.cpp:965)
+__global__ void k_advance_iter(DevState* st, int which) {
+  if (which == 0) st->actor_iter += 1; else st->critic_iter += 1;
 }
 
 // ---- acting-time helpers ---------------------------------------------------------

@@ -84,7 +84,7 @@ class DQN:
                  gamma=0.99, beta=0.5, tau=0.001, soft_update_freq=1, actor_lr=1e-5, critic_lr=1e-3,
                  momentum=0.95, momentum2=0.999, clip_grad=10.0, memory_threshold=1000, seed=1,
                  device=0, dp_world=1, dp_rank=0, use_graph=False, stream=None, grad_arena=None,
-                 grad_arena_bytes=0, tid=0, save_path="state/dqn", precision="fp32", loss_scale=0.0):
+                 grad_arena_bytes=0, tid=0, save_path="state/dqn", precision="fp32", loss_scale=0.0, tuning=0):
         self.lib = capi.load()
         cfg = capi.Config()
         self.lib.dqnhip_default_config(C.byref(cfg), state_size)
@@ -104,6 +104,7 @@ class DQN:
         cfg.grad_arena_bytes = grad_arena_bytes
         cfg.precision = {"fp32": 0, "fp16": 1}[precision]
         cfg.loss_scale = loss_scale
+        cfg.tuning_flags = int(tuning)                  # capi.TUNE_* bits: alternative schedules of the same arithmetic
         self.cfg = cfg
         self.h = capi.H()
         self._ck(self.lib.dqnhip_create(C.byref(cfg), C.byref(self.h)))
@@ -372,6 +373,14 @@ class DQN:
         keep, ip = self._idx(idx)
         self._ck(self.lib.dqnhip_update_phase(self.h, phase, ip))
 
+    def update_abort(self):
+        """Abandon a phased update whose exchange step failed (the next update starts afresh)."""
+        self._ck(self.lib.dqnhip_update_abort(self.h))
+
+    def apply_update(self, net):
+        """Solver::ApplyUpdate of one net on the gradient in its arena (src/dqn.cpp:904 tail, :964-965)."""
+        self._ck(self.lib.dqnhip_apply_update(self.h, net))
+
     # -- native data parallelism (RCCL inside the library, include/dqnhip.h dqnhip_dp_*) -------
     @staticmethod
     def dp_unique_id():
@@ -381,13 +390,25 @@ class DQN:
             raise DQNFatal(lib.dqnhip_last_error().decode())
         return buf.raw
 
-    def dp_init(self, unique_id, per_layer=False):
+    @staticmethod
+    def _dp_flags(per_layer, half_grads):
+        return (capi.DP_PER_LAYER if per_layer else 0) | (capi.DP_HALF_GRADS if half_grads else 0)
+
+    def dp_init(self, unique_id, per_layer=False, half_grads=False):
         assert len(unique_id) == capi.DP_ID_BYTES
         buf = C.create_string_buffer(bytes(unique_id), capi.DP_ID_BYTES)
-        self._ck(self.lib.dqnhip_dp_init(self.h, buf, capi.DP_ID_BYTES, 1 if per_layer else 0))
+        self._ck(self.lib.dqnhip_dp_init(self.h, buf, capi.DP_ID_BYTES, self._dp_flags(per_layer, half_grads)))
 
-    def dp_init_file(self, path, per_layer=False, timeout_s=120):
-        self._ck(self.lib.dqnhip_dp_init_file(self.h, os.fsencode(path), 1 if per_layer else 0, int(timeout_s)))
+    def dp_init_file(self, path, per_layer=False, timeout_s=120, half_grads=False):
+        self._ck(self.lib.dqnhip_dp_init_file(self.h, os.fsencode(path), self._dp_flags(per_layer, half_grads), int(timeout_s)))
+
+    def dp_graph_active(self):
+        v = C.c_int32()
+        self._ck(self.lib.dqnhip_dp_graph_active(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def dp_destroy(self):
+        self._ck(self.lib.dqnhip_dp_destroy(self.h))
 
     def dp_broadcast_params(self, root=0):
         self._ck(self.lib.dqnhip_dp_broadcast_params(self.h, int(root)))
@@ -535,6 +556,19 @@ def RemoveSnapshots(regexp, min_iter):
     lib = capi.load()
     if lib.dqnhip_remove_snapshots(os.fsencode(regexp), int(min_iter)) != 0:
         raise DQNFatal(lib.dqnhip_last_error().decode())
+
+
+def dp_rendezvous_file(path, rank, world, unique_id=None, timeout_s=120):
+    """File rendezvous of a data-parallel group (needs no GPU): rank 0 passes the id, the others receive it."""
+    lib = capi.load()
+    buf = C.create_string_buffer(bytes(unique_id) if unique_id is not None else b"", capi.DP_ID_BYTES)
+    if lib.dqnhip_dp_rendezvous_file(os.fsencode(path), int(rank), int(world), int(timeout_s), buf, capi.DP_ID_BYTES) != 0:
+        raise DQNFatal(lib.dqnhip_last_error().decode())
+    return buf.raw
+
+
+def dp_rendezvous_cleanup(path, world):
+    capi.load().dqnhip_dp_rendezvous_cleanup(os.fsencode(path), int(world))
 
 
 def reduce_gradients_local(learners, net):

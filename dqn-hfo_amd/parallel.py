@@ -28,8 +28,6 @@ import os
 import torch
 import torch.distributed as dist
 
-_SYNC_PROBE = bool(os.environ.get("DQNHIP_DP_SYNC_PROBE"))   # measurement aid: split phases, blocking collective
-
 
 class DataParallelUpdate:
     def __init__(self, backend, critic_grad, actor_grad, group=None, overlap=False):
@@ -48,13 +46,9 @@ class DataParallelUpdate:
         b = self.backend
         if self.overlap:
             b.update_phase(10, idx)
-            if _SYNC_PROBE:
-                dist.all_reduce(self.critic_grad, op=dist.ReduceOp.SUM, group=self.group)
-                b.update_phase(11, None)
-            else:
-                work = dist.all_reduce(self.critic_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                b.update_phase(11, None)
-                work.wait()                 # stream dependency, not a host sync
+            work = dist.all_reduce(self.critic_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b.update_phase(11, None)
+            work.wait()                     # stream dependency, not a host sync
         else:
             b.update_phase(0, idx)
             dist.all_reduce(self.critic_grad, op=dist.ReduceOp.SUM, group=self.group)
@@ -115,12 +109,14 @@ class NativeDataParallel:
         self.backend.dp_update(idx)
 
 
-def make_native_data_parallel(pkg, state_size, rank, world, device, group=None, per_layer=False, **dqn_kwargs):
+def make_native_data_parallel(pkg, state_size, rank, world, device, group=None, per_layer=False, half_grads=False,
+                              **dqn_kwargs):
     """One learner per rank with an RCCL communicator inside the library.  Needs an initialised
-    torch.distributed group only to ship the id when world > 1."""
+    torch.distributed group only to ship the id when world > 1.  use_graph=True (a DQN keyword) makes
+    dqnhip_dp_update replay the whole update, collectives included, as one captured hipGraph."""
     dqn = pkg.DQN(state_size, device=device, dp_world=world, dp_rank=rank, **dqn_kwargs)
     box = [pkg.DQN.dp_unique_id() if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(box, src=0, group=group)
-    dqn.dp_init(box[0], per_layer=per_layer)
+    dqn.dp_init(box[0], per_layer=per_layer, half_grads=half_grads)
     return dqn, NativeDataParallel(dqn)

@@ -8,8 +8,11 @@
 // device-resident ring), same error convention (glog CHECK / LOG(FATAL) -> abort).  What differs is
 // behind the surface: no caffe::Net / caffe::Solver members — one dqnhip_handle (include/dqnhip.h).
 // The reference's protected helpers that took caffe::Net& arguments (SelectActionGreedily,
-// CriticForward, InputDataIntoLayers, CloneNet, SoftUpdateNet, ShareLayer: src/dqn.hpp:116-117,
-// 149-184) have no caller outside src/dqn.cpp and are not declared.
+// CriticForward, InputDataIntoLayers, CloneNet, SoftUpdateNet: src/dqn.hpp:149-184) have no caller
+// outside src/dqn.cpp and are not declared.  The PUBLIC ShareLayer(caffe::Layer&, caffe::Layer&)
+// (src/dqn.hpp:115-116) is declared for source compatibility; no caffe::Layer object exists behind
+// this surface (its only caller is ShareParameters, src/dqn.cpp:1064-1075), so calling it is a
+// LOG(FATAL) that points at ShareParameters.
 #ifndef DQNHIP_DQN_HPP_
 #define DQNHIP_DQN_HPP_
 
@@ -104,6 +107,7 @@ class DQN {
   void SnapshotReplayMemory(const std::string& filename);
   int memory_size() const;
 
+  void ShareLayer(caffe::Layer<float>& param_owner, caffe::Layer<float>& param_slave);     // src/dqn.hpp:115-116
   void ShareParameters(DQN& other, int num_actor_layers_to_share, int num_critic_layers_to_share);
   void ShareReplayMemory(DQN& other);
 

@@ -104,7 +104,15 @@ typedef struct dqnhip_config {
                                 minibatch % 128 == 0 and hidden[i] % 128 == 0.       */
   float loss_scale;          /* FP16 only: multiplies the built-in static scales of the
                                 back-propagated gradients (0 or 1: defaults)           */
+  int32_t tuning_flags;      /* DQNHIP_TUNE_* bits: A/B switches that select an alternative
+                                SCHEDULE of the same arithmetic (0 = the measured winners).
+                                The library reads no environment variable; every bit has a
+                                parity test (tests/test_gpu_tuning_flags.py).          */
 } dqnhip_config;
+
+/* fp16 learner: one wgrad launch per layer (a layer's dgrad + wgrad sharing a launch at small
+ * minibatches) instead of ALL wgrads of a net + the bias-gradient sums in one launch. */
+#define DQNHIP_TUNE_FP16_WGRAD_PER_LAYER 1
 
 typedef struct dqnhip_learner* dqnhip_handle;
 
@@ -157,6 +165,19 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host);
  * arena, so 10, [start all-reduce of the critic gradients], 11, [wait], 1, .. hides
  * it behind the collective.  10 + 11 compute exactly what 0 computes. */
 int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host);
+/* Abandons a phased update that will not be completed (the caller's exchange step failed): the
+ * next dqnhip_update_phase / dqnhip_update* starts a fresh update.  A phase that itself returns
+ * non-zero abandons the update on its own.  Weights already stepped by phase 1 stay stepped. */
+int dqnhip_update_abort(dqnhip_handle h);
+
+/* Replaces one solver's ApplyUpdate() in isolation (actor_solver_->ApplyUpdate(), src/dqn.cpp:964; the
+ * tail of critic_solver_->Step(1), :904): ClipGradients + Adam + Net::Update on the gradient currently in
+ * the net's arena (e.g. written with dqnhip_set_params(.., DQNHIP_KIND_G, ..)), the soft update of that
+ * net's target under the reference's condition (:967: max_iter() after both solvers' increments of a full
+ * update), then set_iter(iter() + 1) of that solver (:965).  net = DQNHIP_ACTOR or DQNHIP_CRITIC.
+ * The optimiser pass of dqnhip_update is this same kernel: tests pin it here on identical (w, g, m, v,
+ * w', iter) to a few ulp. */
+int dqnhip_apply_update(dqnhip_handle h, int32_t net);
 
 /* Device pointer + length (floats) of one net's gradient arena, including a
  * 4-float tail [loss_sum, q_sum, 0, 0] so the two reported scalars ride in the
@@ -171,16 +192,29 @@ int dqnhip_grad_buffer(dqnhip_handle h, int32_t net, void** dptr, size_t* nfloat
  *   dqnhip_dp_unique_id   rank 0 creates the RCCL id (DQNHIP_DP_ID_BYTES); the launcher ships it
  *   dqnhip_dp_init        every rank: ncclCommInitRank, then rank 0's weights (4 nets), Adam
  *                         history and iterations are broadcast so the replicas start identical
- *   dqnhip_dp_init_file   the same with a file as the rendezvous (one node, no launcher support); the path must
- *                         not exist beforehand (rank 0 refuses a leftover file) and is the caller's to remove
+ *   dqnhip_dp_init_file   the same with files as the rendezvous (one node, no launcher support):
+ *                         dqnhip_dp_rendezvous_file + dqnhip_dp_init; rank 0 removes the files once the group is up
+ *   dqnhip_dp_rendezvous_file   the rendezvous alone (needs no GPU): rank 0 passes the id in, ranks 1..world-1
+ *                         receive it.  Every waiter publishes <path>.req<rank> with a fresh nonce and accepts <path>
+ *                         only if it carries that nonce, rank 0 clears leftovers first: a file from an earlier or a
+ *                         crashed job can never hand out a dead id, and the same path can be reused.
  * flags: DQNHIP_DP_PER_LAYER buckets each all-reduce per tower layer on a communication stream,
- * started as soon as that layer's wgrad has run (backward order), head + tail last (fp32 learner only; the
- * fp16 learner keeps one collective per net). */
+ * started as soon as that layer's backward launch has run (backward order), head + tail last (fp32 learner only; the
+ * fp16 learner produces all wgrads of a net in one launch and keeps one collective per net).
+ * DQNHIP_DP_HALF_GRADS: the gradient arenas cross the links as bf16 — half the bytes (6.4 instead of 12.9 MB per
+ * net at 4x1024); the [loss, q, flag] tails stay fp32 and travel once, with the actor's gradients.  The reduced
+ * gradient then carries 8 significant bits (tests/test_gpu_dp_hip.py bounds the effect); meant for the fp16 learner.
+ * cfg.use_graph: dqnhip_dp_update captures phase 0 / all-reduce / phase 1 / all-reduce / phase 2 ONCE and replays
+ * it as a hipGraph (eager if RCCL refuses the capture: dqnhip_dp_graph_active tells). */
 #define DQNHIP_DP_ID_BYTES 128
 #define DQNHIP_DP_PER_LAYER 1
+#define DQNHIP_DP_HALF_GRADS 2
 int dqnhip_dp_unique_id(void* id_out, size_t bytes);
 int dqnhip_dp_init(dqnhip_handle h, const void* id, size_t bytes, int32_t flags);
 int dqnhip_dp_init_file(dqnhip_handle h, const char* path, int32_t flags, int32_t timeout_s);
+int dqnhip_dp_rendezvous_file(const char* path, int32_t rank, int32_t world, int32_t timeout_s, void* id, size_t bytes);
+int dqnhip_dp_rendezvous_cleanup(const char* path, int32_t world);
+int dqnhip_dp_graph_active(dqnhip_handle h, int32_t* active);
 int dqnhip_dp_broadcast_params(dqnhip_handle h, int32_t root);
 int dqnhip_dp_update(dqnhip_handle h, const int32_t* idx_host);
 int dqnhip_dp_destroy(dqnhip_handle h);
@@ -192,7 +226,12 @@ int dqnhip_dp_destroy(dqnhip_handle h);
  * sticky until reported here) produced a non-finite TD target or loss, or if a clip+Adam step was
  * skipped because the gradient norm was not finite (fp16 overflow; weights are left untouched). */
 int dqnhip_read_stats(dqnhip_handle h, float* critic_loss, float* avg_q);
-/* Optimiser steps skipped so far because of a non-finite gradient norm. */
+/* Optimiser steps skipped so far because of a non-finite gradient norm (one count per net per update).
+ * A skipped step still ends the update normally: the iteration counters, the soft-update schedule and
+ * the sampling counter advance (as they would after Caffe's Step with a zero update); only w, m, v and
+ * the targets are left untouched.  Under native data parallelism every rank takes the same decision (the
+ * norm is that of the REDUCED gradient) and a rank-local "Target not finite!" is shared through the
+ * all-reduced tail, so all ranks report the same error at the same update. */
 int dqnhip_skipped_steps(dqnhip_handle h, int64_t* count);
 
 /* Sum-reduce the gradient arenas (tails included) of n learners of one data-parallel group that

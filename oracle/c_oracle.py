@@ -89,6 +89,7 @@ def lib():
         L.orc_get_action.argtypes = [fp, C.c_int, ip, fp, fp]
         L.orc_update_phase.argtypes = [C.c_void_p, C.c_int, ip]
         L.orc_update.argtypes = [C.c_void_p, ip, fp, fp]
+        L.orc_apply_update.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_stats_from_tails.argtypes = [C.c_void_p]
         L.orc_last_stats.argtypes = [C.c_void_p, fp, fp]
         L.orc_debug_read.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_size_t]
@@ -240,6 +241,11 @@ class Oracle:
     def update_phase(self, phase, idx):
         i = np.ascontiguousarray(idx, dtype=np.int32)
         rc = self.L.orc_update_phase(self.h, phase, i.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert rc == 0, rc
+
+    def apply_update(self, net):
+        """One solver's ApplyUpdate on the gradient in grad_view(net) (+ that net's soft update, ++iter)."""
+        rc = self.L.orc_apply_update(self.h, net)
         assert rc == 0, rc
 
     def set_stats_from_tails(self):

@@ -636,6 +636,22 @@ int orc_update_phase(orc *o, int phase, const int32_t *idx) {
   return 1;
 }
 
+/* One solver's ApplyUpdate() in isolation, on the gradient currently in g[net]: ClipGradients +
+ * Adam + Net::Update (actor_solver_->ApplyUpdate(), src/dqn.cpp:964; the tail of
+ * critic_solver_->Step(1), :904), the soft update of THAT net's target if max_iter() after both
+ * increments of a full update would be a multiple of soft_update_freq (:967-970), then ++iter of
+ * that net (:965).  Lets the optimiser pass be compared on identical (w, g, m, v, w', iter). */
+int orc_apply_update(orc *o, int net) {
+  const orc_config *c = &o->cfg;
+  if (net != 0 && net != 1) return 1;
+  const orc_layout *l = net ? &o->lc : &o->la;
+  const int mx = (o->iter[0] + 1) > (o->iter[1] + 1) ? (o->iter[0] + 1) : (o->iter[1] + 1);
+  solver_apply(l, o->w[net], o->g[net], o->m[net], o->v[net], o->iter[net], net ? c->lr_critic : c->lr_actor, c);
+  if (mx % c->soft_update_freq == 0) soft_update(l->count, o->w[net], o->w[net + 2], c->tau);
+  o->iter[net] += 1;
+  return 0;
+}
+
 int orc_update(orc *o, const int32_t *idx, float *loss, float *avgq) {
   for (int p = 0; p < 3; ++p) { int rc = orc_update_phase(o, p, idx); if (rc) return rc; }
   if (loss) *loss = o->last_loss;

@@ -244,14 +244,127 @@ def test_native_rccl_one_rank(pkg, gpu, per_layer):
 
 
 def test_native_rccl_file_rendezvous(pkg, gpu, tmp_path):
-    d = pkg.DQN(59, minibatch=32, hidden=(64,), memory=2048, dp_world=1, dp_rank=0)
+    """dqnhip_dp_init_file: a stale file of an earlier job is no obstacle (rank 0 clears it and waiters would only
+    accept a file that carries their own nonce), the files are gone once the group is up, and the same path serves
+    the next group."""
+    path = tmp_path / "rccl_id"
+    path.write_bytes(b"\x07" * 128)                       # left over from a crashed job
+    (tmp_path / "rccl_id.req1").write_bytes(b"\x01" * 8)
+    for _ in range(2):
+        d = pkg.DQN(59, minibatch=32, hidden=(64,), memory=2048, dp_world=1, dp_rank=0)
+        d.add_transitions_arrays(*synth_replay(np.random.default_rng(1), 512, 59, mean_len=10))
+        d.dp_init_file(str(path), timeout_s=10)
+        assert not path.exists()
+        d.dp_update(np.arange(32))
+        assert all(np.isfinite(d.read_stats()))
+        d.close()
+
+
+def test_abandoned_phased_update_does_not_wedge_the_learner(pkg, gpu):
+    """A caller whose exchange step failed abandons the update with dqnhip_update_abort; a phase that fails abandons
+    it by itself.  Either way the next update starts normally (next_phase used to stay stuck)."""
+    d = pkg.DQN(59, minibatch=32, hidden=(64, 64), memory=2048, dp_world=2, dp_rank=0)
     d.add_transitions_arrays(*synth_replay(np.random.default_rng(1), 512, 59, mean_len=10))
-    d.dp_init_file(str(tmp_path / "rccl_id"), timeout_s=10)
-    assert (tmp_path / "rccl_id").stat().st_size == 128
-    d.dp_update(np.arange(32))
-    assert all(np.isfinite(d.read_stats()))
+    d.update_phase(0, np.arange(32)); d.update_phase(1)
+    with pytest.raises(pkg.DQNFatal, match="out of order"):
+        d.update_phase(0, np.arange(32))
+    d.update_abort()
+    d.update_phase(0, np.arange(32)); d.update_phase(1); d.update_phase(2)
+    with pytest.raises(pkg.DQNFatal, match="out of range"):
+        d.update_phase(0, np.arange(32) + 5000)          # fails inside phase 0
+    d.update_phase(0, np.arange(32)); d.update_phase(1); d.update_phase(2)
+    assert d.actor_iter() == 2 and all(np.isfinite(d.read_stats()))
     d.close()
-    d2 = pkg.DQN(59, minibatch=32, hidden=(64,), memory=2048, dp_world=1, dp_rank=0)
-    with pytest.raises(pkg.DQNFatal, match="already exists"):
-        d2.dp_init_file(str(tmp_path / "rccl_id"), timeout_s=5)       # a leftover file is refused, not reused
-    d2.close()
+
+
+def test_non_finite_target_on_one_rank_is_reported_by_all(pkg, gpu):
+    """The TD-target flag is raised from a rank's OWN replay shard; it rides in the all-reduced critic tail so that
+    every rank reports 'Target not finite!' for the same update (otherwise one rank stops and the others walk
+    into the next collective)."""
+    ranks = [pkg.DQN(59, minibatch=32, hidden=(64, 64), memory=2048, seed=4, dp_world=2, dp_rank=r) for r in (0, 1)]
+    for r, d in enumerate(ranks):
+        s, a, rew, mc, nx, term = synth_replay(np.random.default_rng(1 + r), 512, 59, mean_len=10)
+        if r == 1:
+            rew[:] = np.inf
+        d.add_transitions_arrays(s, a, rew, mc, nx, term)
+    _dp_step(pkg, ranks, [np.arange(32), np.arange(32)])
+    for d in ranks:
+        with pytest.raises(pkg.DQNFatal, match="Target not finite"):
+            d.read_stats()
+    for d in ranks:
+        d.close()
+
+
+def _bf16(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("precision,B,hid", [("fp32", 64, (256, 128, 64, 64)), ("fp16", 128, (256, 128))])
+def test_native_rccl_half_grads_one_rank(pkg, gpu, precision, B, hid):
+    """DQNHIP_DP_HALF_GRADS: the gradient arena crosses the (here: one-rank) all-reduce as bf16 and is widened again
+    by the clip-norm pass; the [loss, q, flag] tails travel as fp32.  After the first update the critic's arena holds
+    exactly bf16(plain gradient) (round-to-nearest-even), the reported scalars are those of the plain update, and
+    three updates stay within the 8-bit gradient precision of the plain learner."""
+    S = 59
+    rng = np.random.default_rng(5)
+    w = [torch_ref.init_params_np(rng, S, hid, a) * 5 for a in (True, False)]
+    data = synth_replay(rng, 1024, S, mean_len=10)
+    idx = rng.integers(0, 1024, size=(3, B))
+    dp = pkg.DQN(S, minibatch=B, hidden=hid, memory=4096, seed=2, dp_world=1, dp_rank=0, precision=precision)
+    ref = pkg.DQN(S, minibatch=B, hidden=hid, memory=4096, seed=2, precision=precision)
+    for d in (dp, ref):
+        for net in (0, 1):
+            d.set_params(net, w[net]); d.CloneNet(net)
+        d.add_transitions_arrays(*data)
+    dp.dp_init(pkg.DQN.dp_unique_id(), half_grads=True)
+    ref.update_phase(0, idx[0]); g_c = ref.get_params(1, pkg.KIND_G)
+    ref.update_phase(1); g_a = ref.get_params(0, pkg.KIND_G); ref.update_phase(2)
+    dp.dp_update(idx[0])
+    np.testing.assert_array_equal(dp.get_params(1, pkg.KIND_G), _bf16(g_c))
+    ga_dp = dp.get_params(0, pkg.KIND_G)
+    np.testing.assert_array_equal(ga_dp, _bf16(ga_dp))                       # bf16 values ...
+    assert _fro(ga_dp, g_a) <= 2e-2                                          # ... of (nearly) the plain actor gradient
+    s_dp, s_ref = dp.read_stats(), ref.read_stats()
+    assert abs(s_dp[0] - s_ref[0]) <= 1e-6 * max(1, abs(s_ref[0]))           # loss: same forward, fp32 tail
+    assert abs(s_dp[1] - s_ref[1]) <= 2e-3 * max(1, abs(s_ref[1]))           # avg Q: after the (bf16-gradient) critic step
+    for u in (1, 2):
+        dp.dp_update(idx[u]); ref.UpdateActorCritic(idx[u])
+    lr = {0: 1e-5, 1: 1e-3, 2: 1e-5 * 1e-3, 3: 1e-3 * 1e-3}
+    for net in range(4):
+        dd = np.abs(dp.get_params(net) - ref.get_params(net))
+        assert dd.max() <= 3 * lr[net] + 1e-6 and dd.mean() <= 0.05 * lr[net] + 1e-8, (net, dd.max(), dd.mean())
+    assert dp.skipped_steps() == 0
+    dp.close(); ref.close()
+
+
+@pytest.mark.parametrize("precision,per_layer,half", [("fp32", False, False), ("fp32", True, False), ("fp16", False, True)])
+def test_native_rccl_update_replays_as_one_graph(pkg, gpu, precision, per_layer, half):
+    """cfg.use_graph under native data parallelism: phase 0 / all-reduce / phase 1 / all-reduce / phase 2 — RCCL's
+    kernels and the communication-stream fork/join included — are captured once and replayed.  A graph-replaying
+    group member and an eager one hold the same bits after every update."""
+    B, S, hid = 128, 59, (256, 128, 128)
+    rng = np.random.default_rng(6)
+    w = [torch_ref.init_params_np(rng, S, hid, a) * 5 for a in (True, False)]
+    data = synth_replay(rng, 1024, S, mean_len=10)
+    ds = [pkg.DQN(S, minibatch=B, hidden=hid, memory=4096, seed=2, dp_world=1, dp_rank=0, precision=precision, use_graph=g)
+          for g in (True, False)]
+    for d in ds:
+        for net in (0, 1):
+            d.set_params(net, w[net]); d.CloneNet(net)
+        d.add_transitions_arrays(*data)
+        d.dp_init(pkg.DQN.dp_unique_id(), per_layer=per_layer, half_grads=half)
+    for u in range(5):
+        for d in ds:
+            d.dp_update(None)                           # on-device sampling: same seed, same counter
+        assert ds[0].read_stats() == ds[1].read_stats()
+    assert ds[0].dp_graph_active(), "RCCL refused the capture: the data-parallel update runs eagerly"
+    assert not ds[1].dp_graph_active()
+    for net in range(4):
+        np.testing.assert_array_equal(ds[0].get_params(net), ds[1].get_params(net))
+    assert ds[0].actor_iter() == ds[1].actor_iter() == 5
+    ds[0].dp_update(rng.integers(0, 1024, B))           # explicit indices: eager path beside the captured graph
+    assert all(np.isfinite(ds[0].read_stats()))
+    for d in ds:
+        d.close()

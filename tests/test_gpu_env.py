@@ -46,6 +46,36 @@ def test_env_front_end_matches_oracle(pkg, gpu, workers, eps, S, hidden, wscale)
     env.close(); oenv.close(); dqn.close(); orc.close()
 
 
+@pytest.mark.parametrize("workers,use_graph", [(1024, False), (2048, False), (2048, True)])
+def test_env_many_workers_match_oracle(pkg, gpu, workers, use_graph):
+    """BASELINE.json configs[4]'s worker count (2048; 1024 beside it): above 512 workers the step takes the tiled head
+    kernel, the flush in its own launch and a separate commit.  Transition by transition against the oracle for a
+    few batched steps with a small tower (episodes of <= 10 steps, so every worker finishes several)."""
+    dqn, orc, data, rng = make_pair(pkg, B=32, S=58, hidden=(128, 64, 64, 64), n_replay=100, capacity=120000, wscale=10.0,
+                                    use_graph=use_graph)
+    kw = dict(max_steps=10, unum=7, p_end=0.1, p_goal=0.4, seed=13)
+    env = pkg.EnvFrontEnd(dqn, workers, **kw)
+    oenv = c_oracle.OracleEnv(orc, workers, **kw)
+    total = 0
+    for eps, n in ((0.2, 1), (0.2, 5), (0.0, 17), (1.0, 2)):
+        env.step(eps, n); oenv.step(eps, n); total += n
+        o = oenv.read()
+        np.testing.assert_array_equal(env.debug_read("action").astype(np.int32), o["action"])       # indices exact
+        np.testing.assert_allclose(env.debug_read("arg1"), o["arg1"], atol=1e-4, rtol=1e-5)      # parameters reach +-180: fp32 round-off of a different summation order
+        np.testing.assert_allclose(env.debug_read("reward"), o["reward"], atol=5e-5)      # differences of distances ~100: the max over 2048 workers is a few 1e-5
+        np.testing.assert_array_equal(env.debug_read("episode_len").astype(np.int32), o["episode_len"])
+        np.testing.assert_allclose(env.debug_read("state"), o["state"], atol=1e-6)
+        assert dqn.memory_size() == orc.memory_size()
+    s1, s2 = env.stats(), oenv.stats()
+    assert s1[0] == s2[0] == total * workers and s1[1] == s2[1] > 2 * workers and s1[3] == s2[3]
+    n = dqn.memory_size()
+    a, b = dqn.read_memory(0, n), orc.read_memory(0, n)
+    np.testing.assert_allclose(a[0], b[0], atol=1e-6); np.testing.assert_allclose(a[1], b[1], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(a[2], b[2], atol=5e-5); np.testing.assert_allclose(a[3], b[3], atol=4e-4)
+    np.testing.assert_allclose(a[4], b[4], atol=1e-6); np.testing.assert_array_equal(a[5], b[5])
+    env.close(); oenv.close(); dqn.close(); orc.close()
+
+
 def test_env_graph_replay_matches_oracle(pkg, gpu):
     """use_graph: the batched step is replayed as captured hipGraphs (16-step and 1-step), epsilon is
     a device scalar; 37 = 2 x 16 + 5 exercises both graphs, a changed epsilon the scalar."""

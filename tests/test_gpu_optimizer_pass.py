@@ -1,0 +1,156 @@
+"""The optimiser pass in isolation: identical (w, g, m, v, w', iter) loaded into the HIP learner and the C oracle,
+ONE Solver::ApplyUpdate each (dqnhip_apply_update / orc_apply_update: ClipGradients + Adam + Net::Update + soft
+target update, src/dqn.cpp:904 tail, :964-970), results compared to a few ulp.  This replaces "within one Adam
+step" of the whole-update tests as the pin for the optimiser: there the two sides already start from gradients
+that differ by summation order; here the gradient is the same bits.
+
+What may legitimately differ: the clip norm (oracle: one double sum per blob, added in float; HIP: fp32 partials
+per block, tree-added) -> the clip scale agrees to ~1e-7 relative, so a clipped g, hence m, moves by <= 1-2 ulp
+and v by <= 2-3 ulp; everything after that is the same sequence of fp32 operations (fma forms included)."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle, torch_ref
+
+pytestmark = pytest.mark.gpu
+
+ULP = np.finfo(np.float32).eps      # 2^-23
+
+
+def _pair(pkg, S, hidden, precision="fp32", **kw):
+    B = 128 if precision == "fp16" else 32
+    d = pkg.DQN(S, minibatch=B, hidden=hidden, memory=64, seed=1, precision=precision, **kw)
+    okw = {}
+    if "clip_grad" in kw: okw["clip"] = kw["clip_grad"]
+    if "soft_update_freq" in kw: okw["soft_update_freq"] = kw["soft_update_freq"]
+    if "tau" in kw: okw["tau"] = kw["tau"]
+    o = c_oracle.Oracle(B=B, S=S, hidden=hidden, capacity=64, **okw)
+    return d, o
+
+
+def _load(pkg, d, o, rng, S, hidden, net, gnorm, it_a, it_c):
+    actor = net == 0
+    n = d.param_count(net)
+    w = (torch_ref.init_params_np(rng, S, hidden, actor) * 3 + rng.normal(0, 1e-3, n)).astype(np.float32)
+    wt = (w + rng.normal(0, 1e-2, n)).astype(np.float32)
+    g = rng.normal(0, 1, n).astype(np.float32)
+    g *= np.float32(gnorm / np.linalg.norm(g.astype(np.float64)))
+    g[rng.integers(0, n, n // 50)] = 0.0                          # exact zeros (pad-like entries) stay exact
+    m = rng.normal(0, 1e-3, n).astype(np.float32)
+    v = (rng.uniform(0, 1, n) ** 4 * 1e-4).astype(np.float32)    # down to ~0: sqrt(v) + eps matters
+    for x in (d, o):
+        x.set_params(net, w); x.set_params(net + 2, wt)
+        x.set_params(net, m, pkg.KIND_M); x.set_params(net, v, pkg.KIND_V)
+        x.set_iters(it_a, it_c)
+    d.set_params(net, g, pkg.KIND_G)
+    o.grad_view(net)[:] = g
+    return w, wt, g, m, v
+
+
+def _check(pkg, d, o, net, before, exact_scale, t, clip=10.0):
+    """exact_scale: the clip does not rescale the gradient (norm below the threshold, or clipping disabled) — the two
+    sides then run the same fp32 operations on the same bits: m and v must be IDENTICAL, w within one rounding.
+    Otherwise "a few ulp" is measured against the magnitude of the TERMS of each sum (m = (1-b1) g + b1 m0 can
+    cancel, and an ulp of the result is then not the scale of the round-off)."""
+    w0, wt0, g, m0, v0 = before
+    b1, b2, eps = 0.95, 0.999, 1e-8
+    lr = 1e-5 if net == 0 else 1e-3
+    corr = np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+    nrm = np.linalg.norm(g.astype(np.float64))
+    gs = np.abs(g.astype(np.float64)) * (clip / nrm if (clip >= 0 and nrm > clip) else 1.0)
+    m_terms = (1 - b1) * gs + b1 * np.abs(m0)
+    ma, mb = d.get_params(net, pkg.KIND_M).astype(np.float64), o.get_params(net, pkg.KIND_M).astype(np.float64)
+    va, vb = d.get_params(net, pkg.KIND_V).astype(np.float64), o.get_params(net, pkg.KIND_V).astype(np.float64)
+    if exact_scale:
+        np.testing.assert_array_equal(ma, mb); np.testing.assert_array_equal(va, vb)
+    assert (np.abs(ma - mb) <= 3 * ULP * m_terms).all(), (np.abs(ma - mb) / np.maximum(m_terms, 1e-300)).max() / ULP
+    assert (np.abs(va - vb) <= 6 * ULP * vb).all(), (np.abs(va - vb) / np.maximum(vb, 1e-300)).max() / ULP
+    wa, wb = d.get_params(net), o.get_params(net)
+    # the step itself (w0 - w1) against the scale of ITS terms, plus one rounding of w
+    step_a, step_b = w0.astype(np.float64) - wa, w0.astype(np.float64) - wb
+    step_scale = lr * corr * m_terms / (np.sqrt(vb) + eps)
+    tol = (2 if exact_scale else 10) * ULP * step_scale + 1.0 * ULP * np.abs(wb)
+    assert (np.abs(step_a - step_b) <= tol).all(), (np.abs(step_a - step_b) / np.maximum(tol, 1e-300)).max()
+    assert np.abs(step_b).max() > 0
+    ta, tb = d.get_params(net + 2), o.get_params(net + 2)
+    assert (np.abs(ta.astype(np.float64) - tb) <= 1.0 * ULP * np.abs(tb) + np.abs(step_a - step_b)).all()
+    return wa, wb
+
+
+@pytest.mark.parametrize("net", [0, 1])
+@pytest.mark.parametrize("t", [1, 2, 1000])
+@pytest.mark.parametrize("gnorm,clip", [(3.0, 10.0), (250.0, 10.0), (250.0, -1.0)])     # clip inactive / active / disabled
+def test_apply_update_matches_oracle_to_a_few_ulp(pkg, gpu, net, t, gnorm, clip):
+    S, hidden = 59, (256, 128, 64, 64)
+    d, o = _pair(pkg, S, hidden, clip_grad=clip)
+    rng = np.random.default_rng(100 * net + t + int(gnorm))
+    it = t - 1
+    before = _load(pkg, d, o, rng, S, hidden, net, gnorm, it if net == 0 else it + 3, it if net == 1 else it + 5)
+    d.apply_update(net); o.apply_update(net)
+    _check(pkg, d, o, net, before, exact_scale=(clip < 0 or gnorm <= clip), t=t, clip=clip)
+    assert (d.actor_iter(), d.critic_iter()) == tuple(o.get_iters())
+    d.close(); o.close()
+
+
+def test_apply_update_soft_update_schedule_and_zero_gradient(pkg, gpu):
+    """soft_update_freq = 3: the target moves only when max_iter() (after both increments of a full update) is a
+    multiple of 3 (src/dqn.cpp:967); a zero gradient with zero history leaves the weights bit-identical."""
+    S, hidden = 59, (128, 64)
+    d, o = _pair(pkg, S, hidden, soft_update_freq=3, tau=0.25)
+    rng = np.random.default_rng(1)
+    for it, moves in ((0, False), (1, False), (2, True), (5, True), (6, False)):
+        before = _load(pkg, d, o, rng, S, hidden, 1, 5.0, it, it)
+        d.apply_update(1); o.apply_update(1)
+        _check(pkg, d, o, 1, before, exact_scale=True, t=it + 1)
+        moved = not np.array_equal(d.get_params(3), before[1])
+        assert moved == moves, (it, moved)
+    n = d.param_count(0)
+    w = torch_ref.init_params_np(rng, S, hidden, True)
+    d.set_params(0, w); d.set_params(0, np.zeros(n, np.float32), pkg.KIND_G)
+    d.set_params(0, np.zeros(n, np.float32), pkg.KIND_M); d.set_params(0, np.zeros(n, np.float32), pkg.KIND_V)
+    d.apply_update(0)
+    np.testing.assert_array_equal(d.get_params(0), w)
+    assert d.skipped_steps() == 0
+    d.close(); o.close()
+
+
+def test_apply_update_is_the_pass_inside_an_update(pkg, gpu):
+    """Phases 0 + 1 of an update leave the actor's gradient in its arena; finishing with phase 2 and finishing a twin
+    learner with dqnhip_apply_update(ACTOR) give the same weights bit for bit (same kernel, norm taken by k_sumsq
+    instead of the epilogue partials: the clip is inactive here, so the scale is exactly 1 either way)."""
+    from synth import synth_replay
+    S, hidden, B = 59, (128, 64, 64), 32
+    rng = np.random.default_rng(2)
+    w = [torch_ref.init_params_np(rng, S, hidden, a) for a in (True, False)]
+    data = synth_replay(rng, 512, S, mean_len=10)
+    idx = rng.integers(0, 512, B)
+    ds = [pkg.DQN(S, minibatch=B, hidden=hidden, memory=1024, seed=1, clip_grad=1e9) for _ in range(2)]
+    for d in ds:
+        for net in (0, 1):
+            d.set_params(net, w[net]); d.CloneNet(net)
+        d.add_transitions_arrays(*data)
+        d.update_phase(0, idx); d.update_phase(1)
+    ds[0].update_phase(2)
+    ds[1].update_abort()                       # the phased update is abandoned after phase 1 ...
+    ds[1].apply_update(pkg.ACTOR)              # ... and the actor step applied on its own
+    for net in (0, 2):
+        np.testing.assert_array_equal(ds[0].get_params(net), ds[1].get_params(net))
+    np.testing.assert_array_equal(ds[0].get_params(0, pkg.KIND_M), ds[1].get_params(0, pkg.KIND_M))
+    np.testing.assert_array_equal(ds[0].get_params(0, pkg.KIND_V), ds[1].get_params(0, pkg.KIND_V))
+    for d in ds:
+        d.close()
+
+
+def test_apply_update_fp16_learner_keeps_its_mirrors(pkg, gpu):
+    """fp16 learner: the pass also writes the fp16 weight mirrors the GEMMs read — an update after an isolated
+    ApplyUpdate must see the stepped weights (checked through the greedy action of the stepped actor)."""
+    S, hidden = 58, (128, 128)
+    d, o = _pair(pkg, S, hidden, precision="fp16")
+    rng = np.random.default_rng(3)
+    before = _load(pkg, d, o, rng, S, hidden, 0, 50.0, 0, 0)
+    d.apply_update(0); o.apply_update(0)
+    _check(pkg, d, o, 0, before, exact_scale=False, t=1)
+    st = rng.uniform(-1, 1, (8, S)).astype(np.float32)
+    a = d.SelectActionGreedily(st)             # fp32 acting path on the stepped master weights
+    np.testing.assert_allclose(a, o.actor_forward(st), atol=1e-3, rtol=1e-3)
+    d.close(); o.close()
