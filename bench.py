@@ -89,7 +89,30 @@ KERNEL_NAMES = {"hgemm_fwd": "hgemm_nt<2,2>/<1,1> (forward epilogue)", "hgemm_dg
                 "gemm_dgrad": "gemm_dgrad_lds<1,1>", "gemm_wgrad": "gemm_wgrad_direct<1,1>"}
 
 
-PMC_SUMMARY = "profiles/r02_pmc_summary.json"
+PMC_SUMMARY = "profiles/r03_pmc_summary.json"
+
+# xGMI (MI355X, 8 GPUs fully connected): 7 links per GPU, 153.6 GB/s per link counting both directions = 76.8 GB/s
+# each way.  Two bounds for a sum all-reduce of S bytes over N ranks: ONE ring = every byte crosses one
+# link per step, 2 (N-1)/N S / b; ALL links busy (N-1 edge-disjoint rings, or direct reduce-scatter + all-gather) =
+# that divided by N-1.  Per-collective latency floor on top (launch + 2 (N-1) hops).
+XGMI_LINK_GBS_ONE_WAY = 76.8
+COLLECTIVE_LATENCY_US = 20.0
+
+
+def allreduce_projection_us(nbytes, world):
+    if world < 2:
+        return {"one_ring_us": 0.0, "all_links_us": 0.0}
+    vol = 2.0 * (world - 1) / world * nbytes
+    one = vol / (XGMI_LINK_GBS_ONE_WAY * 1e9) * 1e6
+    return {"one_ring_us": round(one + COLLECTIVE_LATENCY_US, 1), "all_links_us": round(one / (world - 1) + COLLECTIVE_LATENCY_US, 1)}
+
+
+def grad_bytes(S_, hidden, half):
+    """bytes per update that cross the links: both gradient arenas (critic, then actor) + the fp32 tails"""
+    na = sum(tower_weights(S_, hidden)) + sum(hidden) + 10 * hidden[-1] + 10
+    nc = sum(tower_weights(S_ + 10, hidden)) + sum(hidden) + hidden[-1] + 1
+    per = 2 if half else 4
+    return [nc * per + 16, na * per + 16]
 
 
 def pmc_traffic(kernel):
@@ -179,6 +202,14 @@ def timed(step, sync, n, warm):
     return (time.perf_counter() - t0) / n
 
 
+def env_roofline(S_, workers, us_per_step):
+    """a batched env step is one actor forward per worker = 2 * Wa FLOP (tower + heads), fp32 MFMA"""
+    wa = sum(tower_weights(S_, HIDDEN)) + 10 * HIDDEN[-1]
+    ach = 2.0 * wa * workers / (us_per_step * 1e-6) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
+            "flops_per_env_step": 2 * wa}
+
+
 def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
     """Per-config records next to the headline (BASELINE.json configs[2] and [4]; strong scaling when N > 1).
     Small replay memories: these time kernels, not prefill."""
@@ -215,8 +246,44 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
         env = pkg.EnvFrontEnd(d, 64, max_steps=500, p_end=0.01, seed=5)
         env.step(0.1, 20); env.stats()
         t1 = time.perf_counter(); env.step(0.1, 200); env.stats(); dt = (time.perf_counter() - t1) / 200
-        out["configs2_64workers_s68"] = {"env_steps_per_s": round(64 / dt, 1), "us_per_batched_step": round(dt * 1e6, 2)}
+        out["configs2_64workers_s68"] = {"env_steps_per_s": round(64 / dt, 1), "us_per_batched_step": round(dt * 1e6, 2),
+                                         "roofline": env_roofline(68, 64, dt * 1e6)}
         env.close(); d.close()
+        # what ONE rank of configs[4] on 8 GPUs runs (4096 / 8 = 512 rows), with the communicator in place (one rank:
+        # the all-reduce moves nothing): the captured data-parallel update against the eager one and against the plain
+        # captured update -> what the collectives' launches and the bf16 conversion cost beside the kernels
+        rec = {}
+        for prec, half in (("fp16", True), ("fp32", False)):
+            r = {}
+            for name, kw, dp_kw in (("plain_graph", dict(use_graph=True), None), ("dp_eager", dict(use_graph=False), dict(half_grads=half, per_layer=not half)),
+                                    ("dp_graph", dict(use_graph=True), dict(half_grads=half, per_layer=not half))):
+                d = pkg.DQN(S, minibatch=512, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, precision=prec, **kw)
+                prefill(d, 150000, seed=7)
+                if dp_kw is not None:
+                    d.dp_init(pkg.DQN.dp_unique_id(), **dp_kw)
+                    step = lambda d=d: d.dp_update(None)
+                else:
+                    step = lambda d=d: d.update_async(None)
+                r[name + "_ms"] = round(timed(step, torch.cuda.synchronize, 300, 30) * 1e3, 4)
+                if dp_kw is not None and kw["use_graph"]:
+                    r["dp_graph_captured"] = d.dp_graph_active()
+                d.read_stats(); d.close()
+            gb = grad_bytes(S, HIDDEN, half)
+            pr = [allreduce_projection_us(b, 8) for b in gb]
+            one = out["configs4_1gpu_b4096_%s" % prec]["ms_per_update"]
+            r["exchange"] = "bf16 gradients + fp32 tails, one collective per net" if half else "fp32, per-layer buckets on a communication stream"
+            r["projection_8gpu"] = {"allreduce_bytes": gb, "allreduce_us_one_ring": [p["one_ring_us"] for p in pr],
+                                    "allreduce_us_all_links": [p["all_links_us"] for p in pr],
+                                    "ms_per_update_one_ring": round(r["dp_graph_ms"] + sum(p["one_ring_us"] for p in pr) * 1e-3, 4),
+                                    "ms_per_update_all_links": round(r["dp_graph_ms"] + sum(p["all_links_us"] for p in pr) * 1e-3, 4),
+                                    "ms_per_update_1gpu_b4096": one,
+                                    "speedup_one_ring": round(one / (r["dp_graph_ms"] + sum(p["one_ring_us"] for p in pr) * 1e-3), 2),
+                                    "speedup_all_links": round(one / (r["dp_graph_ms"] + sum(p["all_links_us"] for p in pr) * 1e-3), 2),
+                                    "speedup_without_collectives": round(one / r["dp_graph_ms"], 2),
+                                    "note": "PROJECTION (no overlap assumed; link rate %.1f GB/s one way, %.0f us latency per collective): the first real 8-GPU "
+                                            "run checks it" % (XGMI_LINK_GBS_ONE_WAY, COLLECTIVE_LATENCY_US)}
+            rec[prec] = r
+        out["configs4_rank_shape_b512"] = rec
         return out
     if not native:
         return None
@@ -225,8 +292,10 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
         rows = GB // world
         if rows % (128 if prec == "fp16" else 32):
             continue
+        half = prec == "fp16" and not args.dp_fp32_grads
         d, dp = par.make_native_data_parallel(pkg, S, rank, world, local_rank, minibatch=rows, hidden=HIDDEN, memory=200000,
-                                              seed=1, precision=prec, per_layer=args.dp_per_layer)
+                                              seed=1, precision=prec, per_layer=not args.dp_single_bucket, half_grads=half,
+                                              use_graph=not args.no_graph)
         prefill(d, 150000, seed=7 + rank)
         t_dp = timed(lambda: dp.update(None), barrier, n_it, 20)
 
@@ -242,10 +311,17 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
             one.close()
         barrier()
         if rank == 0:
+            gb = grad_bytes(S, HIDDEN, half)
+            pr = [allreduce_projection_us(b, world) for b in gb]
             out["strong_b4096_%s" % prec] = {"n_gpus": world, "rows_per_gpu": rows, "ms_per_update": round(t_dp * 1e3, 4),
                                              "ms_per_update_without_collectives": round(t_loc * 1e3, 4),
                                              "allreduce_us_per_update": round((t_dp - t_loc) * 1e6, 1),
-                                             "ms_per_update_1gpu": round(t_one * 1e3, 4), "speedup_vs_1gpu": round(t_one / t_dp, 3)}
+                                             "ms_per_update_1gpu": round(t_one * 1e3, 4), "speedup_vs_1gpu": round(t_one / t_dp, 3),
+                                             "exchange": "bf16 gradients + fp32 tails" if half else "fp32",
+                                             "projection": {"allreduce_bytes": gb, "allreduce_us_one_ring": sum(p["one_ring_us"] for p in pr),
+                                                            "allreduce_us_all_links": sum(p["all_links_us"] for p in pr),
+                                                            "speedup_one_ring": round(t_one / (t_loc + sum(p["one_ring_us"] for p in pr) * 1e-6), 3),
+                                                            "speedup_all_links": round(t_one / (t_loc + sum(p["all_links_us"] for p in pr) * 1e-6), 3)}}
     return out if rank == 0 else None
 
 
@@ -271,7 +347,9 @@ def main():
                     help="torch.distributed backend (nccl = RCCL; gloo only for the 2-ranks-on-one-GPU flow test)")
     ap.add_argument("--share-device0", action="store_true",
                     help="testing: every rank uses GPU 0 (needs --backend gloo; RCCL refuses duplicate devices)")
-    ap.add_argument("--dp-per-layer", action="store_true", help="native DP: bucket each all-reduce per tower layer on a communication stream")
+    ap.add_argument("--dp-single-bucket", action="store_true", help="native DP, fp32 learner: ONE all-reduce per net instead of per-layer buckets on a communication stream")
+    ap.add_argument("--dp-fp32-grads", action="store_true", help="native DP, fp16 learner: all-reduce fp32 gradients instead of bf16 (DQNHIP_DP_HALF_GRADS)")
+    ap.add_argument("--tuning", type=int, default=0, help="dqnhip_config.tuning_flags (A/B switches, include/dqnhip.h DQNHIP_TUNE_*)")
     ap.add_argument("--no-subrecords", action="store_true", help="skip the per-config sub-records (configs #3, #5; strong scaling under N > 1)")
     ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],
                     help="N>1: dp = gradient all-reduce (weak scaling), replicas = independent learners")
@@ -312,14 +390,16 @@ def main():
         par = import_module("dqn_hfo_amd.parallel")
         # ONE seed for the whole group: identical initialisation (rank 0's state is broadcast anyway), the
         # per-shard sample streams are decorrelated by dp_rank inside the library
-        common = dict(minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1, precision=args.precision)
+        common = dict(minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1, precision=args.precision, tuning=args.tuning)
+        half = args.precision == "fp16" and not args.dp_fp32_grads
         if native:
             # the communicator inside libdqnhip.so has never met more than one real GPU in this repo's own runs
             # (one-GPU boxes only): if ANY rank fails to bring it up, every rank falls back — by agreement over
             # torch.distributed — to the other transport of the same algorithm (torch's RCCL all-reduce between the
             # update phases), and the JSON line says so.  Same kernels, same numbers, a few host round trips more.
             try:
-                dqn, dp = par.make_native_data_parallel(pkg, S, rank, world, local_rank, per_layer=args.dp_per_layer, **common)
+                dqn, dp = par.make_native_data_parallel(pkg, S, rank, world, local_rank, per_layer=not args.dp_single_bucket and not half,
+                                                        half_grads=half, use_graph=not args.no_graph, **common)
             except Exception as e:                                  # noqa: BLE001 — reported, not swallowed
                 native_error = repr(e)[:300]
                 dqn = dp = None
@@ -346,7 +426,7 @@ def main():
         step = lambda: dp.update(None)
     else:
         dqn = pkg.DQN(S, minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1 + rank, device=local_rank,
-                      use_graph=not args.no_graph, precision=args.precision)
+                      use_graph=not args.no_graph, precision=args.precision, tuning=args.tuning)
         step = lambda: dqn.update_async(None)
     prefill(dqn, args.replay - 1, seed=100 + rank)     # AddTransitions keeps <= capacity-1 (src/dqn.cpp:776)
 
@@ -417,6 +497,23 @@ def main():
                 "families_us": {f: [round(stats[f][0] * 1e3, 2), stats[f][1] / n_t] for f in stats}}
     torch.cuda.synchronize()
 
+    # What the reference's UNCHANGED driver gets through the drop-in (src/dqn_main.cpp:361 -> DQN::Update ->
+    # UpdateActorCritic; DQN::Benchmark, src/dqn.cpp:487-498): indices drawn on the host (std::mt19937), staged H2D,
+    # and a blocking (loss, avg_q) read-back per update — against the async headline above.  Measured inside the
+    # library (dqnhip_benchmark_blocking), so no Python is in the loop; and the one-deep pipelined read-back.
+    dropin = None
+    if rank == 0 and not dist_on and not args.no_subrecords:
+        ms_b = dqn.BenchmarkBlocking(1000, 100, seed=1, pipelined=False)
+        ms_p = dqn.BenchmarkBlocking(1000, 100, seed=1, pipelined=True)
+        ms_a = elapsed / args.steps * 1e3
+        dropin = {"blocking_ms_per_update": round(ms_b, 5), "blocking_updates_per_s": round(1e3 / ms_b, 1),
+                  "pipelined_ms_per_update": round(ms_p, 5), "pipelined_updates_per_s": round(1e3 / ms_p, 1),
+                  "async_headline_ms_per_update": round(ms_a, 5),
+                  "blocking_vs_async": round(ms_b / ms_a, 4), "pipelined_vs_async": round(ms_p / ms_a, 4),
+                  "what": "dqnhip_update(h, idx_host, &loss, &avg_q) x 1000 with host-drawn indices = DQN::UpdateActorCritic() of the "
+                          "drop-in (dqn_dropin.cpp), i.e. DQN::Benchmark / dqn_main.cpp:361; pipelined = dqnhip_update_pipelined "
+                          "(-pipelined_stats: returns the previous update's scalars)"}
+
     # env-steps/sec (the other half of BASELINE.json's metric): N synthetic workers -> batched
     # SelectActions + GetAction + HFOGameState reward + LabelTransitions/AddTransitions, all on device
     env_res = None
@@ -437,7 +534,8 @@ def main():
             dt = time.perf_counter() - t1
             env_res["workers_%d" % workers] = {"env_steps_per_s": round(workers * n_env / dt, 1),
                                                "us_per_batched_step": round(dt / n_env * 1e6, 2),
-                                               "episodes": st[1], "max_episode_steps": T}
+                                               "episodes": st[1], "max_episode_steps": T,
+                                               "roofline": env_roofline(S, workers, dt / n_env * 1e6)}
             env.close()
         if not args.no_cpu_baseline and world == 1:
             from oracle import c_oracle, torch_ref
@@ -471,7 +569,8 @@ def main():
                                        % (world, "RCCL inside libdqnhip.so (dqnhip_dp_update)" if native else args.backend + " via torch.distributed",
                                           "global-minibatch updates" if args.strong else "minibatch-%d updates" % B)) if use_dp else
                                       ("replicas x%d" % world if world > 1 else "single"),
-                       "hip_graph": (not args.no_graph) and not use_dp, "prewarm_updates": prewarm,
+                       "hip_graph": (not args.no_graph) and (not use_dp or (native and dqn.dp_graph_active())), "prewarm_updates": prewarm,
+                       "tuning_flags": args.tuning,
                        **({"native_dp_error": native_error} if native_error else {}),
                        "sampling": "on-device Philox, uniform with replacement"},
             "update_gflop": round(fl / 1e9, 3),
@@ -514,6 +613,8 @@ def main():
             sub = {"error": "%s: %s" % (type(ex).__name__, ex)}
         dog.cancel()
         if rank == 0:
+            if isinstance(sub, dict) and dropin is not None:
+                sub["dropin_blocking_b%d" % B] = dropin
             out["sub_records"] = sub
     if rank == 0:
         final_line = json.dumps(out)

@@ -40,6 +40,8 @@ DEFINE_int32(hip_device, 0, "HIP device ordinal of this process's learners.");
 DEFINE_bool(hip_graph, true, "Replay each update as one captured hipGraph.");
 DEFINE_string(precision, "fp32", "fp32 (exact-fp32 MFMA, the parity path) or fp16 (fp16 MFMA operands, fp32 accumulate).");
 DEFINE_bool(device_sampling, false, "Sample minibatch indices on the device (counter-based) instead of the host std::mt19937.");
+DEFINE_bool(pipelined_stats, false, "UpdateActorCritic() returns the (loss, avg_q) of the PREVIOUS update (dqnhip_update_pipelined): "
+                                    "the device does not idle on the per-update read-back; the logged / smoothed values lag by one update.");
 
 #define DQNHIP_CK(call) CHECK((call) == 0) << dqnhip_last_error()
 
@@ -226,11 +228,14 @@ DQN::DQN(caffe::SolverParameter& actor_solver_param, caffe::SolverParameter& cri
 
 DQN::~DQN() { DQNHIP_CK(dqnhip_destroy(h_)); }
 
+// src/dqn.cpp:487-498: a wall-clock timer around `iterations` calls of UpdateActorCritic() — host-drawn
+// indices and a blocking (loss, avg_q) per call, unless -device_sampling / -pipelined_stats say otherwise
 void DQN::Benchmark(int iterations) {
   LOG(INFO) << "*** Benchmark begins ***";
-  float ms = 0;
-  DQNHIP_CK(dqnhip_benchmark(h_, 0, iterations, &ms));
-  LOG(INFO) << "Average Update: " << ms << " ms.";
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iterations; ++i) UpdateActorCritic();
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  LOG(INFO) << "Average Update: " << ms / iterations << " ms.";
   LOG(INFO) << "*** Benchmark ends ***";
 }
 
@@ -390,7 +395,8 @@ std::pair<float, float> DQN::UpdateActorCritic(const std::vector<int>& transitio
   CHECK_EQ((int)transitions.size(), minibatch_);
   float loss = 0, avgq = 0;
   static_assert(sizeof(int) == sizeof(int32_t), "indices travel as int32");
-  DQNHIP_CK(dqnhip_update(h_, reinterpret_cast<const int32_t*>(transitions.data()), &loss, &avgq));
+  if (FLAGS_pipelined_stats) DQNHIP_CK(dqnhip_update_pipelined(h_, reinterpret_cast<const int32_t*>(transitions.data()), &loss, &avgq));
+  else DQNHIP_CK(dqnhip_update(h_, reinterpret_cast<const int32_t*>(transitions.data()), &loss, &avgq));
   return std::make_pair(loss, avgq);
 }
 

@@ -183,8 +183,13 @@ struct dqnhip_learner {
   bool timing = false;
   std::vector<TimingRec> recs;
   // graph
-  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // [0]: device-sampled, [1]: explicit idx
+  hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};  // [0]: device-sampled, [1]: explicit idx (pinned buffer -> memcpy node), [2], [3]: explicit idx in the pipelined slots
   bool graph_failed = false;
+  // dqnhip_update_pipelined
+  hipEvent_t pipe_ev[2] = {nullptr, nullptr};
+  int* pipe_idx_dev[2] = {nullptr, nullptr}; int* pipe_idx_pinned[2] = {nullptr, nullptr};
+  float* pipe_stats[2] = {nullptr, nullptr};
+  unsigned long long pipe_count = 0;
 };
 
 namespace {
@@ -965,7 +970,7 @@ size_t dqnhip_grad_arena_bytes(const dqnhip_config* cfg) {
 }
 
 static int create_impl(H* h, const dqnhip_config* cfg);
-static void drop_graphs_fwd(H* h) { for (int i = 0; i < 2; ++i) if (h->graph_exec[i]) { hipGraphExecDestroy(h->graph_exec[i]); h->graph_exec[i] = nullptr; } }
+static void drop_graphs_fwd(H* h) { for (auto& g : h->graph_exec) if (g) { hipGraphExecDestroy(g); g = nullptr; } }
 
 int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   if (!out) return fail("out is null");
@@ -1119,7 +1124,13 @@ int dqnhip_destroy(dqnhip_handle h) {
   dqnhip_dp_destroy(h);
   hipStreamSynchronize(h->stream);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-  for (int i = 0; i < 2; ++i) if (h->graph_exec[i]) hipGraphExecDestroy(h->graph_exec[i]);
+  for (auto& g : h->graph_exec) if (g) hipGraphExecDestroy(g);
+  for (int i = 0; i < 2; ++i) {
+    if (h->pipe_ev[i]) hipEventDestroy(h->pipe_ev[i]);
+    if (h->pipe_idx_dev[i]) hipFree(h->pipe_idx_dev[i]);
+    if (h->pipe_idx_pinned[i]) hipHostFree(h->pipe_idx_pinned[i]);
+    if (h->pipe_stats[i]) hipHostFree(h->pipe_stats[i]);
+  }
   for (int i = 0; i < 4; ++i) hipFree(h->w[i]);
   for (int i = 0; i < 2; ++i) { hipFree(h->m[i]); hipFree(h->v[i]); hipFree(h->part[i]); }
   if (h->own_grad) hipFree(h->grad_base);
@@ -1143,13 +1154,14 @@ int dqnhip_destroy(dqnhip_handle h) {
 
 // ---- update -----------------------------------------------------------------------
 
-static int capture_graph(H* h, int which) {
+static int capture_graph(H* h, int which, const int* idx_fixed = nullptr) {
   // Capture phases 0,1,2 once; replays re-read every changing scalar from DevState
-  // and (which == 1) the indices from the fixed pinned buffer through a memcpy node.
+  // and (which == 1) the indices from the fixed pinned buffer through a memcpy node; which == 2, 3: the indices
+  // are already in the given device buffer (dqnhip_update_pipelined's two slots).
   hipGraph_t graph = nullptr;
   HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
-  const int* idx_dev = nullptr;
+  const int* idx_dev = idx_fixed;
   if (which == 1) {
     hipError_t e = hipMemcpyAsync(h->idx_dev, h->idx_pinned, h->B * sizeof(int), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) rc = fail("capture memcpy: %s", hipGetErrorString(e));
@@ -1264,6 +1276,72 @@ int dqnhip_update(dqnhip_handle h, const int32_t* idx_host, float* critic_loss, 
   return dqnhip_read_stats(h, critic_loss, avg_q);
 }
 
+// One-deep pipelined form of dqnhip_update: enqueues update t and returns the scalars of update t-1 (zeros on the
+// first call).  The host then waits for update t-1 only, while update t is already queued behind it — the device
+// never idles on the host's index draw, the H2D of the indices or the read-back, which dqnhip_update pays on
+// every call.  Indices and scalars use two pinned slots each (nothing in flight is overwritten).
+int dqnhip_update_pipelined(dqnhip_handle h, const int32_t* idx_host, float* critic_loss, float* avg_q) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->cfg.dp_world > 1) return fail("dqnhip_update_pipelined: dp_world > 1 requires dqnhip_update_phase / dqnhip_dp_update");
+  if (h->next_phase != 0) return fail("dqnhip_update_pipelined: a phased update is in progress (next phase %d)", h->next_phase);
+  if (!h->pipe_ev[0]) {
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(hipEventCreateWithFlags(&h->pipe_ev[i], hipEventDisableTiming));
+      HIPCHK(hipMalloc(&h->pipe_idx_dev[i], h->B * sizeof(int)));
+      HIPCHK(hipHostMalloc((void**)&h->pipe_idx_pinned[i], h->B * sizeof(int), hipHostMallocDefault));
+      HIPCHK(hipHostMalloc((void**)&h->pipe_stats[i], 64, hipHostMallocDefault));
+      memset(h->pipe_stats[i], 0, 64);
+    }
+  }
+  const int slot = (int)(h->pipe_count & 1);
+  {
+    RingUse ring_use(h);
+    RC(sync_dirty16(h));
+    const int* idx_dev = nullptr;
+    if (idx_host) {
+      RC(refresh_ring(h));
+      for (int i = 0; i < h->B; ++i)
+        if (idx_host[i] < 0 || idx_host[i] >= RO(h)->h_size) return fail("sampled index %d = %d out of range [0,%lld)", i, idx_host[i], RO(h)->h_size);
+      // slot's previous user was update t-2, whose completion the previous call already waited for
+      memcpy(h->pipe_idx_pinned[slot], idx_host, h->B * sizeof(int));
+      HIPCHK(hipMemcpyAsync(h->pipe_idx_dev[slot], h->pipe_idx_pinned[slot], h->B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      idx_dev = h->pipe_idx_dev[slot];
+    } else if (RO(h)->h_size < 1) {
+      RC(refresh_ring(h));
+      if (RO(h)->h_size < 1) return fail("replay memory is empty");
+    }
+    const int which = idx_host ? 2 + slot : 0;
+    if (h->cfg.use_graph && !h->timing && !h->graph_failed) {
+      if (!h->graph_exec[which] && capture_graph(h, which, idx_dev)) h->graph_failed = true;
+    }
+    if (h->cfg.use_graph && !h->timing && !h->graph_failed && h->graph_exec[which]) {
+      HIPCHK(hipGraphLaunch(h->graph_exec[which], h->stream));
+      h->h_actor_iter += 1; h->h_critic_iter += 1;
+    } else {
+      for (int p = 0; p < 3; ++p) RC(run_phase(h, p, idx_dev));
+    }
+  }
+  HIPCHK(hipMemcpyAsync(h->pipe_stats[slot], &h->st->critic_loss, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipEventRecord(h->pipe_ev[slot], h->stream));
+  const int prev = slot ^ 1;
+  float loss = 0.f, q = 0.f; int flags = 0;
+  if (h->pipe_count > 0) {
+    HIPCHK(hipEventSynchronize(h->pipe_ev[prev]));
+    loss = h->pipe_stats[prev][0]; q = h->pipe_stats[prev][1];
+    memcpy(&flags, &h->pipe_stats[prev][2], sizeof flags);
+  }
+  h->pipe_count += 1;
+  if (critic_loss) *critic_loss = loss;
+  if (avg_q) *avg_q = q;
+  if (flags) {     // sticky on the device: report through the blocking path, which clears them
+    float l2, q2;
+    return dqnhip_read_stats(h, &l2, &q2) ? 1 : fail("update flags raised");
+  }
+  if (!std::isfinite(loss)) return fail("Critic loss not finite!");
+  return 0;
+}
+
 // Solver::ApplyUpdate() of one net in isolation (actor_solver_->ApplyUpdate(), src/dqn.cpp:964; the tail of
 // critic_solver_->Step(1), :904) on the gradient currently in the net's arena (e.g. dqnhip_set_params(KIND_G)):
 // ClipGradients + Adam + Net::Update + the soft update of that net's target under the condition of :967, then
@@ -1312,6 +1390,35 @@ int dqnhip_benchmark(dqnhip_handle h, int32_t warmup, int32_t iterations, float*
   return 0;
 }
 
+
+// What the reference's driver gets from this library (src/dqn_main.cpp:361 -> DQN::Update -> UpdateActorCritic, and
+// DQN::Benchmark, src/dqn.cpp:487-498, which loops over it): host-drawn indices (std::mt19937 +
+// uniform_int_distribution, SampleTransitionsFromMemory :501-509), staged to the device, and a BLOCKING read of
+// (critic_loss, avg_q) after every update.  pipelined != 0: dqnhip_update_pipelined instead.
+int dqnhip_benchmark_blocking(dqnhip_handle h, int32_t warmup, int32_t iterations, uint64_t seed, int32_t pipelined, float* avg_ms) {
+  if (!h) return fail("null handle");
+  if (iterations < 1) return fail("iterations must be >= 1");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  int32_t size = 0;
+  RC(dqnhip_memory_size(h, &size));
+  if (size < 1) return fail("replay memory is empty");
+  std::mt19937 rng((uint32_t)seed);
+  std::vector<int32_t> idx(h->B);
+  float loss = 0, avgq = 0;
+  auto one = [&]() -> int {
+    for (int32_t& i : idx) i = std::uniform_int_distribution<int>(0, size - 1)(rng);
+    return pipelined ? dqnhip_update_pipelined(h, idx.data(), &loss, &avgq) : dqnhip_update(h, idx.data(), &loss, &avgq);
+  };
+  for (int i = 0; i < warmup; ++i) RC(one());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iterations; ++i) RC(one());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (pipelined) RC(dqnhip_read_stats(h, &loss, &avgq));      // drains the one outstanding read-back
+  if (avg_ms) *avg_ms = (float)(ms / iterations);
+  return 0;
+}
 
 // ---- native data parallelism: RCCL over xGMI inside the library --------------------
 // The reference has no collective (threads + one mutex, src/dqn_main.cpp:62-63, 359-363).  Here a
@@ -2005,9 +2112,7 @@ int dqnhip_clone_to_target(dqnhip_handle h, int32_t net) {
 
 // ---- multi-agent sharing (src/dqn.cpp:1036-1083, src/dqn_main.cpp:305-323) ------------------
 
-static void drop_graphs(H* h) {
-  for (int i = 0; i < 2; ++i) if (h->graph_exec[i]) { hipGraphExecDestroy(h->graph_exec[i]); h->graph_exec[i] = nullptr; }
-}
+static void drop_graphs(H* h) { drop_graphs_fwd(h); }
 
 static bool same_nets(const H* a, const H* b) {
   if (a->S != b->S || a->L != b->L) return false;

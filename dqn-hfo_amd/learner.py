@@ -365,6 +365,13 @@ class DQN:
             raise DQNFatal("need %d indices, got %d" % (self.kMinibatchSize, i.size))
         return i, i.ctypes.data_as(capi.ip)
 
+    def UpdateActorCriticPipelined(self, idx=None):
+        """dqnhip_update_pipelined: enqueue this update, return (critic_loss, avg_q) of the PREVIOUS one."""
+        loss, avgq = C.c_float(), C.c_float()
+        keep, ip = self._idx(idx)
+        self._ck(self.lib.dqnhip_update_pipelined(self.h, ip, C.byref(loss), C.byref(avgq)))
+        return loss.value, avgq.value
+
     def update_async(self, idx=None):
         keep, ip = self._idx(idx)
         self._ck(self.lib.dqnhip_update_async(self.h, ip))
@@ -453,6 +460,13 @@ class DQN:
         """src/dqn.cpp:487-498; returns the average update time in ms."""
         ms = C.c_float()
         self._ck(self.lib.dqnhip_benchmark(self.h, warmup, iterations, C.byref(ms)))
+        return ms.value
+
+    def BenchmarkBlocking(self, iterations=1000, warmup=50, seed=1, pipelined=False):
+        """DQN::Benchmark as the drop-in's caller sees it: host-drawn indices + a (loss, avg_q) read-back per
+        update (blocking, or one-deep pipelined); average wall-clock ms per update."""
+        ms = C.c_float()
+        self._ck(self.lib.dqnhip_benchmark_blocking(self.h, warmup, iterations, seed, int(pipelined), C.byref(ms)))
         return ms.value
 
     # -- parameters ------------------------------------------------------------------------------------

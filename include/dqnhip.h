@@ -147,6 +147,15 @@ int dqnhip_destroy(dqnhip_handle h);
 int dqnhip_update(dqnhip_handle h, const int32_t* idx_host,
                   float* critic_loss, float* avg_q);
 
+/* One-deep pipelined dqnhip_update: enqueues update t and returns (critic_loss, avg_q) of update t-1
+ * ((0, 0) on the first call).  What dqnhip_update costs beside the kernels — the host's index draw, the
+ * H2D copy of the indices and a blocking read-back per update — then overlaps the previous update
+ * instead of idling the device; the indices and scalars use two pinned slots each.  Semantic
+ * difference to the reference's UpdateActorCritic: the returned pair (and a "Target not finite!" /
+ * "Critic loss not finite!" failure) lags by one update; dqnhip_read_stats drains the last one. */
+int dqnhip_update_pipelined(dqnhip_handle h, const int32_t* idx_host,
+                            float* critic_loss, float* avg_q);
+
 /* Same update, enqueued on the stream without a host sync (the scalars stay
  * on the device; read them with dqnhip_read_stats). */
 int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host);
@@ -245,6 +254,13 @@ int dqnhip_reduce_gradients_local(dqnhip_handle* learners, int32_t n, int32_t ne
  * returns the average in milliseconds ("Average Update: X ms"). */
 int dqnhip_benchmark(dqnhip_handle h, int32_t warmup, int32_t iterations,
                      float* avg_ms);
+
+/* DQN::Benchmark as the reference's driver experiences it through the drop-in (src/dqn.cpp:487-498 loops over
+ * UpdateActorCritic(): indices drawn on the host with std::mt19937 + uniform_int_distribution, :501-509, and a
+ * blocking (critic_loss, avg_q) per update): wall-clock average over `iterations` calls of dqnhip_update
+ * (pipelined = 0) or dqnhip_update_pipelined (pipelined = 1) after `warmup` untimed ones. */
+int dqnhip_benchmark_blocking(dqnhip_handle h, int32_t warmup, int32_t iterations, uint64_t seed,
+                              int32_t pipelined, float* avg_ms);
 
 /* Replaces the greedy branch of DQN::SelectActions -> SelectActionGreedily
  * (src/dqn.cpp:695-711, 734-766): actor forward on n states [n, S] (host),

@@ -105,3 +105,36 @@ def test_non_finite_gradient_norm_skips_the_step(pkg, gpu):
     assert np.isfinite(dqn.get_params(1)).all()               # the critic step (finite gradients) did run
     assert not np.array_equal(dqn.get_params(1), wc0)
     dqn.close(); orc.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pipelined_update_returns_the_previous_updates_scalars(pkg, gpu, use_graph):
+    """dqnhip_update_pipelined = dqnhip_update with the (loss, avg_q) read-back one update late: the same indices give
+    the same weights bit for bit, call t returns what the blocking form returned at call t-1 ((0, 0) first), and
+    dqnhip_read_stats drains the last one.  A non-finite target surfaces one call later."""
+    B = 32
+    kw = dict(B=B, S=59, hidden=(128, 64, 64, 64), n_replay=1024, use_graph=use_graph)
+    d1, o1, data, rng = make_pair(pkg, **kw)
+    d2, o2, _, _ = make_pair(pkg, **kw)
+    idx = rng.integers(0, 1024, size=(6, B))
+    blocking = [d1.UpdateActorCritic(i) for i in idx]
+    piped = [d2.UpdateActorCriticPipelined(i) for i in idx]
+    assert piped[0] == (0.0, 0.0)
+    assert piped[1:] == blocking[:-1]
+    assert d2.read_stats() == blocking[-1]
+    for net in range(4):
+        np.testing.assert_array_equal(d1.get_params(net), d2.get_params(net))
+    assert d2.actor_iter() == 6
+    # device-side sampling through the pipelined form, and the blocking benchmark of both forms
+    d2.UpdateActorCriticPipelined(None)
+    assert d2.BenchmarkBlocking(20, 2, seed=3, pipelined=False) > 0 and d2.BenchmarkBlocking(20, 2, seed=3, pipelined=True) > 0
+    assert all(np.isfinite(d2.read_stats()))
+    # CHECK(isfinite(target)) one call late
+    s, a, r, mc, nx, term = data
+    r = r.copy(); r[:] = np.inf
+    d2.ClearReplayMemory(); d2.add_transitions_arrays(s, a, r, mc, nx, term)
+    d2.UpdateActorCriticPipelined(idx[0])              # enqueued; reports the (finite) previous update
+    with pytest.raises(pkg.DQNFatal, match="Target not finite"):
+        d2.UpdateActorCriticPipelined(idx[1])
+    for x in (d1, d2, o1, o2):
+        x.close()

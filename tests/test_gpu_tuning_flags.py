@@ -38,11 +38,13 @@ def test_fp16_grouped_wgrad_equals_per_layer(pkg, gpu, B, hidden):
     a = _run(pkg, 0, B, hidden)
     b = _run(pkg, pkg.capi.TUNE_FP16_WGRAD_PER_LAYER, B, hidden)
     assert np.allclose(a[0], b[0], rtol=1e-4, atol=1e-6), (a[0], b[0])
-    for (ga, gc), (gb_a, gb_c) in zip(a[1], b[1]):
+    for it, ((ga, gc), (gb_a, gb_c)) in enumerate(zip(a[1], b[1])):
         for x, y in ((ga, gb_a), (gc, gb_c)):
-            # one rows-long fp32 chain per element against four rows/4-long ones, on heavily cancelling sums: a few 1e-5
-            # of the gradient's norm (the fp16 rounding of the operands, common to both, is ~1e-3)
-            assert np.linalg.norm(x.astype(np.float64) - y) <= 2e-4 * max(np.linalg.norm(y), 1e-30), np.linalg.norm(x.astype(np.float64) - y) / np.linalg.norm(y)
+            # first update (identical weights): one rows-long fp32 chain per element against four rows/4-long ones, on
+            # heavily cancelling sums -> a few 1e-5 of the gradient's norm (the fp16 rounding of the operands, common to
+            # both, is ~1e-3).  Later updates start from weights that already differ by Adam steps of magnitude lr.
+            rel = np.linalg.norm(x.astype(np.float64) - y) / max(np.linalg.norm(y), 1e-30)
+            assert rel <= (2e-4 if it == 0 else 5e-3), (it, rel)
     # parameters: Adam's first steps have magnitude lr whatever |g| is, so an element whose gradient is ~0 may step the
     # other way: bounded by the steps taken, tiny on average
     lr = {0: 1e-5, 1: 1e-3, 2: 1e-5 * 1e-3, 3: 1e-3 * 1e-3}
