@@ -56,17 +56,22 @@ __device__ __forceinline__ float env_feature(const EnvDev& e, unsigned long long
   return fmaf(2.0f, u, -1.0f);
 }
 
-// HFOGameState::update (src/hfo_game.cpp:122-173) minus hfo.step(): status / player_on_ball given
-__device__ __forceinline__ void game_update(GameState& g, const float* st, int status, int pob) {
+// the angle of a (sin, cos) feature pair as HFOGameState::update forms it (src/hfo_game.cpp:137-144):
+// acos of the cosine in double, negated when the sine is negative
+__device__ __forceinline__ float game_angle(float sin_v, float cos_v) {
+  float a = (float)acos((double)cos_v);
+  if (sin_v < 0) a = (float)((double)a * -1.);
+  return a;
+}
+// HFOGameState::update (src/hfo_game.cpp:122-173) minus hfo.step(): status / player_on_ball given.  The two angles
+// (ball: features 51/52, goal: 13/14) come in precomputed: two software double acos are the longest dependent
+// chain of a worker's step, and two lanes of the wave evaluate them side by side.
+__device__ __forceinline__ void game_update(GameState& g, const float* st, int status, int pob, float ball_ang_rad, float goal_ang_rad) {
   g.status = status;
   if (status != 0) g.episode_over = 1;
   const float ball_proximity = st[53], goal_proximity = st[15];
   const float ball_dist = (float)(1.0 - (double)ball_proximity), goal_dist = (float)(1.0 - (double)goal_proximity);
   const float kickable = st[12];
-  float ball_ang_rad = (float)acos((double)st[52]);
-  if (st[51] < 0) ball_ang_rad = (float)((double)ball_ang_rad * -1.);
-  float goal_ang_rad = (float)acos((double)st[14]);
-  if (st[13] < 0) goal_ang_rad = (float)((double)goal_ang_rad * -1.);
   const float alpha = fmaxf(ball_ang_rad, goal_ang_rad) - fminf(ball_ang_rad, goal_ang_rad);
   const float ball_dist_goal = (float)sqrt((double)(ball_dist * ball_dist + goal_dist * goal_dist) -
                                            2. * (double)ball_dist * (double)goal_dist * cos((double)alpha));
@@ -116,7 +121,7 @@ __device__ __forceinline__ void env_reset_worker(const EnvDev& e, int w, int lan
   __syncthreads();
   if (lane == 0) {
     GameState gs; game_reset(gs);
-    game_update(gs, s_state, 0, 0);
+    game_update(gs, s_state, 0, 0, game_angle(s_state[51], s_state[52]), game_angle(s_state[13], s_state[14]));
     e.game[w] = gs; e.len[w] = 0; e.g[w] = g + 1;
   }
 }
@@ -126,26 +131,33 @@ __global__ void k_env_init(EnvDev e) {
   env_reset_worker(e, blockIdx.x, threadIdx.x, s_state);
 }
 
-// one environment step of every worker (block = one wave = one worker)
-__global__ void k_env_step(EnvDev e) {
+// one environment step of every worker: block = one worker, 4 waves.  What used to be one wave's serial chain
+// (heads -> store -> reload -> features -> game update, 10 us at 64 workers) runs side by side: the four waves split
+// the head dot products' k range, threads [0, SP) draw the next state while threads [SP, 2 SP) draw the first state of
+// the next episode, and two lanes evaluate the two double-precision acos of HFOGameState::update: 8.4 us.
+// (Also computing the first tower layer of the NEXT step here, from the state row the block has just produced — one
+// launch fewer per step — was built and measured: 77 instead of 29 us per step at 64 workers.  64 blocks on 64 CUs
+// each pull all of W0 (512 KB) through one CU's load path, where the separate launch spreads it over 256.)
+__global__ __launch_bounds__(256) void k_env_step(EnvDev e) {
   const float epsilon = e.eps[0];
-  extern __shared__ float s_next[];
+  extern __shared__ float s_next[];                  // [2 SP]: next state | first state of the next episode
   __shared__ float s_ao[16];
-  const int w = blockIdx.x, lane = threadIdx.x;
+  __shared__ float s_part[4][16];
+  const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = e.len[w];
   const unsigned long long g = e.g[w];
   GameState gs;                                      // fetched now, used at the end: its latency hides behind the heads
-  if (lane == 0) gs = e.game[w];
+  if (tid == 0) gs = e.game[w];
   // SelectAction(state, epsilon): ONE epsilon draw per call (src/dqn.cpp:700)
   const bool rnd = env_u01(e.seed, g, w, 0) < epsilon;
   if (e.head_x != nullptr) {
-    // SelectActionGreedily's last step for this worker: the 10 head outputs of its tower-top row (one wave:
-    // float4 k-strips, butterfly) — the separate head launch of the batched step folded in
+    // SelectActionGreedily's last step for this worker: the 10 head outputs of its tower-top row — the separate head
+    // launch of the batched step folded in.  Thread t owns the float4 k-strip t (+ 256 strips per round).
     const float* x = e.head_x + (size_t)w * e.head_h;
     float acc[kNO];
 #pragma unroll
     for (int j = 0; j < kNO; ++j) acc[j] = 0.0f;
-    for (int k = lane * 4; k < e.head_h; k += 256) {
+    for (int k = tid * 4; k < e.head_h; k += 1024) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
 #pragma unroll
       for (int j = 0; j < kNO; ++j) {
@@ -154,74 +166,80 @@ __global__ void k_env_step(EnvDev e) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < kNO; ++j) acc[j] = wave_sum64(acc[j]);
-    if (lane < kAP) {
-      float v = 0.0f;
-#pragma unroll
-      for (int j = 0; j < kNO; ++j) if (lane == j) v = acc[j] + e.head_b[j];
-      e.out16[(size_t)w * kAP + lane] = v;
-    }
-    __syncthreads();               // one wave: orders the out16 stores before the loads below
-  }
-  if (lane < kAP) {
-    float v = 0.0f;
-    if (lane < kNO) {
-      if (rnd) {                                   // GetRandomActorOutput (src/dqn.cpp:664-682)
-        const float u = env_u01(e.seed, g, w, 1 + lane);
-        if (lane < kNA) v = fmaf(2.0f, u, -1.0f);
-        else if (lane == kNA + 0) v = fmaf(200.0f, u, -100.0f);
-        else if (lane == kNA + 4) v = 100.0f * u;
-        else v = fmaf(360.0f, u, -180.0f);
-      } else v = e.out16[(size_t)w * kAP + lane];
-    }
-    s_ao[lane] = v;
-    e.ep_a[((size_t)w * e.T + len) * kAP + lane] = v;
+    for (int j = 0; j < kNO; ++j) { acc[j] = wave_sum64(acc[j]); if (lane == 0) s_part[wave][j] = acc[j]; }
   }
   float* eps_row = e.ep_s + ((size_t)w * e.T + len) * e.SP;
   float* cur = e.cur + (size_t)w * e.SP;
-  // synthetic server: does the episode end on this step, and how (every lane evaluates the same two draws: the
-  // wave needs the answer to know which state the worker shows the actor next)
+  // synthetic server: does the episode end on this step, and how (every thread evaluates the same two draws: the
+  // block needs the answer to know which state the worker shows the actor next)
   int status = 0;
   if (env_u01(e.seed, g, w, 11) < e.p_end) status = env_u01(e.seed, g, w, 12) < e.p_goal ? 1 : 2;   // GOAL / CAPTURED_BY_DEFENSE
   if (status == 0 && len + 1 >= e.T) status = 4;                                                   // OUT_OF_TIME
   float* s_first = s_next + e.SP;                    // first state of the next episode (only if this one ends)
-  for (int f = lane; f < e.SP; f += 64) {
-    eps_row[f] = cur[f];
-    const float v = f < e.S ? env_feature(e, g, w, f) : 0.0f;
-    s_next[f] = v;
-    if (status != 0) s_first[f] = f < e.S ? env_feature(e, g + 1, w, f) : 0.0f;
+  for (int i = tid; i < 2 * e.SP; i += 256) {
+    const bool first = i >= e.SP;
+    const int f = first ? i - e.SP : i;
+    if (!first) { eps_row[f] = cur[f]; s_next[f] = f < e.S ? env_feature(e, g, w, f) : 0.0f; }
+    else if (status != 0) s_first[f] = f < e.S ? env_feature(e, g + 1, w, f) : 0.0f;
   }
   __syncthreads();
+  if (tid < kAP) {
+    float v = 0.0f;
+    if (tid < kNO) {
+      if (e.head_x != nullptr) v = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + e.head_b[tid];
+      else v = e.out16[(size_t)w * kAP + tid];       // written by the separate head launch
+    }
+    if (e.head_x != nullptr) e.out16[(size_t)w * kAP + tid] = v;
+    if (tid < kNO && rnd) {                          // GetRandomActorOutput (src/dqn.cpp:664-682)
+      const float u = env_u01(e.seed, g, w, 1 + tid);
+      if (tid < kNA) v = fmaf(2.0f, u, -1.0f);
+      else if (tid == kNA + 0) v = fmaf(200.0f, u, -100.0f);
+      else if (tid == kNA + 4) v = 100.0f * u;
+      else v = fmaf(360.0f, u, -180.0f);
+    }
+    s_ao[tid] = v;
+    e.ep_a[((size_t)w * e.T + len) * kAP + tid] = v;
+  }
   // the actor's next input row: the next state, or — the episode is over — the first state of the new one
   // (src/dqn_main.cpp:97-105; the finished episode's transitions are labelled and added by k_env_flush, which
-  // no longer has to run before the next forward pass)
-  for (int f = lane; f < e.SP; f += 64) cur[f] = status != 0 ? s_first[f] : s_next[f];
-  if (lane == 0) {
-    // GetAction (src/dqn.cpp:196-208)
-    float c0 = s_ao[0], c1 = s_ao[1], c3 = s_ao[3];
-    const float c2 = -99999.0f;
-    int best = 0; float bv = c0;
-    if (c1 > bv) { best = 1; bv = c1; }
-    if (c2 > bv) { best = 2; bv = c2; }
-    if (c3 > bv) { best = 3; bv = c3; }
-    const int o1 = best == 0 ? 0 : best == 1 ? 2 : best == 2 ? 3 : 4;
-    const int o2 = best == 0 ? 1 : best == 3 ? 5 : -1;
-    e.act[w] = best; e.arg1[w] = s_ao[kNA + o1]; e.arg2[w] = o2 < 0 ? 0.0f : s_ao[kNA + o2];
-    const int pob = env_u01(e.seed, g, w, 13) < 0.5f ? e.unum : -1;
-    game_update(gs, s_next, status, pob);
-    int goal = 0;
-    const float r = game_reward(gs, e.unum, &goal);
-    e.ep_r[(size_t)w * e.T + len] = r; e.rew[w] = r;
-    if (status != 0) {
-      // new episode: HFOGameState() and the initial update after the forced DASH(0,0) (src/dqn_main.cpp:103-105)
-      GameState g0; game_reset(g0);
-      game_update(g0, s_first, 0, 0);
-      e.game[w] = g0; e.len[w] = 0; e.g[w] = g + 2;
-    } else {
-      e.game[w] = gs; e.len[w] = len + 1; e.g[w] = g + 1;
+  // does not have to run before the next forward pass)
+  const float* s_sel = status != 0 ? s_first : s_next;
+  for (int f = tid; f < e.SP; f += 256) cur[f] = s_sel[f];     // (thread f also made the ep_s copy of cur[f] above)
+  if (wave == 0) {
+    // the four angles of this step's (at most) two HFOGameState::update calls, one per lane: lanes 0 / 1 the ball and
+    // goal angles of the next state, lanes 2 / 3 those of the new episode's first state
+    const float* src = (lane & 2) ? s_first : s_next;
+    const bool ball = (lane & 1) == 0;
+    float ang = 0.0f;
+    if (lane < 2 || (lane < 4 && status != 0)) ang = game_angle(src[ball ? 51 : 13], src[ball ? 52 : 14]);
+    const float goal_next = __shfl(ang, 1, 64), ball_first = __shfl(ang, 2, 64), goal_first = __shfl(ang, 3, 64);
+    if (lane == 0) {
+      // GetAction (src/dqn.cpp:196-208)
+      float c0 = s_ao[0], c1 = s_ao[1], c3 = s_ao[3];
+      const float c2 = -99999.0f;
+      int best = 0; float bv = c0;
+      if (c1 > bv) { best = 1; bv = c1; }
+      if (c2 > bv) { best = 2; bv = c2; }
+      if (c3 > bv) { best = 3; bv = c3; }
+      const int o1 = best == 0 ? 0 : best == 1 ? 2 : best == 2 ? 3 : 4;
+      const int o2 = best == 0 ? 1 : best == 3 ? 5 : -1;
+      e.act[w] = best; e.arg1[w] = s_ao[kNA + o1]; e.arg2[w] = o2 < 0 ? 0.0f : s_ao[kNA + o2];
+      const int pob = env_u01(e.seed, g, w, 13) < 0.5f ? e.unum : -1;
+      game_update(gs, s_next, status, pob, ang, goal_next);
+      int goal = 0;
+      const float r = game_reward(gs, e.unum, &goal);
+      e.ep_r[(size_t)w * e.T + len] = r; e.rew[w] = r;
+      if (status != 0) {
+        // new episode: HFOGameState() and the initial update after the forced DASH(0,0) (src/dqn_main.cpp:103-105)
+        GameState g0; game_reset(g0);
+        game_update(g0, s_first, 0, 0, ball_first, goal_first);
+        e.game[w] = g0; e.len[w] = 0; e.g[w] = g + 2;
+      } else {
+        e.game[w] = gs; e.len[w] = len + 1; e.g[w] = g + 1;
+      }
+      e.done[w] = status != 0 ? len + 1 : 0;           // length of the finished episode (0: still open)
+      e.n_steps[w] += 1; e.reward_sum[w] += (double)r; e.n_goals[w] += goal;
     }
-    e.done[w] = status != 0 ? len + 1 : 0;           // length of the finished episode (0: still open)
-    e.n_steps[w] += 1; e.reward_sum[w] += (double)r; e.n_goals[w] += goal;
   }
 }
 

@@ -2352,7 +2352,6 @@ __global__ __launch_bounds__(256) void k_env_l0_flush(const GemmBatch batch, Env
   }
   env_flush_block(e, ring, st, gamma, (int)blockIdx.x - batch.total_tiles, (int)gridDim.x - batch.total_tiles, smem);
 }
-
 // one batched env step on the learner's stream: SelectActionGreedily for all workers, then the
 // per-worker epsilon draw / GetAction / reward / episode bookkeeping / AddTransitions
 static int env_one_step(dqnhip_env* e, bool more_follow) {
@@ -2361,10 +2360,10 @@ static int env_one_step(dqnhip_env* e, bool more_follow) {
   hipStream_t st = h->stream;
   const NetLayout& la = h->la;
   FwdPass fp{DQNHIP_ACTOR, &la, e->acts};
-  // 5 launches per batched step at L = 4 inside a sequence: the actor heads ride in k_env_step (one wave per worker
-  // computes its own 10 outputs), the ring bookkeeping in the flush's last block, and the flush itself in the NEXT
-  // step's first-layer launch
-  // (beyond a few hundred workers the dedicated head kernel and a separate commit win: one wave per head row is
+  // 5 launches per batched step at L = 4 inside a sequence: the actor heads ride in k_env_step (the four waves of a
+  // worker's block compute its own 10 outputs), the ring bookkeeping in the flush's last block, and the flush itself
+  // in the NEXT step's first-layer launch.
+  // (beyond a few hundred workers the dedicated head kernel and a separate commit win: one block per head row is
   // slower than the tiled head kernel there, and N arrivals on one counter serialise at ~12 ns each)
   const bool fused = la.dims[la.L] % 4 == 0 && d.N <= 512;
   if (fused) {
@@ -2398,7 +2397,7 @@ static int env_one_step(dqnhip_env* e, bool more_follow) {
     a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.b = wat(h, DQNHIP_ACTOR, la.hb_off); a.out16 = d.out16;
     RC((head_forward<kNO, HEAD_ACTOR>(h, st, a)));
   }
-  hipLaunchKernelGGL(k_env_step, dim3(d.N), dim3(64), 2 * d.SP * sizeof(float), st, d);
+  hipLaunchKernelGGL(k_env_step, dim3(d.N), dim3(256), 2 * d.SP * sizeof(float), st, d);
   HIPCHK(hipGetLastError());
   if (more_follow && fused && l0_direct && !h->timing) { e->flush_deferred = true; return 0; }
   hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), d.T * sizeof(float), st, d, RO(h)->ring,

@@ -104,12 +104,17 @@ def test_env_graph_replay_matches_oracle(pkg, gpu):
     env.close(); oenv.close(); dqn.close(); orc.close()
 
 
-@pytest.mark.parametrize("workers,use_graph", [(48, False), (48, True), (600, False)])
-def test_env_step_sequences_match_single_steps(pkg, gpu, workers, use_graph):
-    """Inside a sequence of steps the episode flush of step t rides in step t+1's first-layer launch (<= 512 workers;
+@pytest.mark.parametrize("workers,use_graph,S,hidden", [
+    (48, False, 59, (128, 64, 64, 64)), (48, True, 59, (128, 64, 64, 64)), (600, False, 59, (128, 64, 64, 64)),
+    # wide towers: k_env_step(t) computes the first layer of step t+1 itself and the flush rides on the SECOND layer's
+    # launch (S = 59: one 64-wide k chunk; S = 68: two)
+    (48, False, 59, (256, 512, 128)), (64, True, 68, (512, 512, 512, 64)), (33, True, 59, (64, 512)),
+])
+def test_env_step_sequences_match_single_steps(pkg, gpu, workers, use_graph, S, hidden):
+    """Inside a sequence of steps the episode flush of step t rides in a tower-layer launch of step t+1 (<= 512 workers;
     above that the flush keeps its own launch and the dedicated head kernel runs): sequences of 1, 2, 7 and 19 steps —
     eager and graph-replayed — must leave the same workers and the same replay as the oracle stepping one at a time."""
-    dqn, orc, data, rng = make_pair(pkg, B=32, S=59, hidden=(128, 64, 64, 64), n_replay=100, capacity=60000, use_graph=use_graph)
+    dqn, orc, data, rng = make_pair(pkg, B=32, S=S, hidden=hidden, n_replay=100, capacity=60000, use_graph=use_graph)
     kw = dict(max_steps=30, unum=7, p_end=0.08, p_goal=0.4, seed=5)
     env = pkg.EnvFrontEnd(dqn, workers, **kw)
     oenv = c_oracle.OracleEnv(orc, workers, **kw)
