@@ -412,10 +412,12 @@ template <int NH>
 int head_backward_big(H* h, hipStream_t st, HeadBwdArgs a, h16* dZ16, float scale16) {
   HeadBwdBigArgs b{}; b.a = a; b.dZ16 = dZ16; b.scale16 = scale16; b.slab2 = h->head_slab2;
   const int chunks = a.rows / 64;
+  const int riders = (NH == 1 && a.q_out != nullptr) ? chunks : 0;     // as many rider blocks again: 4 rows per block and round
+  b.chunks = riders ? chunks : 0;
   const size_t lds = (size_t)(64 * NH + 4 * NH * 256) * sizeof(float);
   static bool prepared = false;
   if (!prepared) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_bwd_big<NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); prepared = true; }
-  hipLaunchKernelGGL((k_head_bwd_big<NH>), dim3(chunks, a.H / 256), dim3(256), lds, st, b);
+  hipLaunchKernelGGL((k_head_bwd_big<NH>), dim3(chunks + riders, a.H / 256), dim3(256), lds, st, b);
   HIPCHK(hipGetLastError());
   if (a.dW != nullptr) {
     hipLaunchKernelGGL((k_head_wred<NH>), dim3(a.H / 64, NH), dim3(256), 0, st, b, chunks);
@@ -624,39 +626,25 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
   // single learner: the clip norm comes from the partial sums the wgrad / bias-gradient / head workgroups leave
   // behind (as on the fp32 path); data-parallel ranks need the norm of the REDUCED gradient: k_sumsq
   const bool part16 = !dp;
-  auto cvt = [&](Cvt16Batch& b, const float* src, int ld, h16* dst, int ld16) { cvt16_add(b, src, ld, B, ld, dst, ld16, 1.0f); };
   if (phase == 11) {
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
     hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
+    hA.xc16 = h->act16[4][0]; hA.ldxc16 = h->k16[1][0];
     RC(tower_forward16(h, st, 1, DQNHIP_ACTOR, B));
     RC((head_forward<kNO, HEAD_ACTOR>(h, st, hA)));
-    Cvt16Batch b{};
-    cvt(b, h->Xc_pl, lc.kp[0], h->act16[4][0], h->k16[1][0]);
-    HIPCHK(cvt16_launch(b, st));
     return 0;
   }
   if (phase == 0 || phase == 10) {
+    // the gather writes the five minibatch panels in fp16 as well (what the GEMMs read: no conversion launch); the
+    // action columns of the two critic panels the actor heads fill are still zero here — the heads write mu / mu'
+    // straight into the fp32 AND the fp16 panels
     GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
-                 h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
+                 h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx,
+                 h->act16[1][0], h->act16[0][0], h->act16[3][0], h->act16[4][0], h->act16[2][0]};
     hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
                        (const DevState*)h->st, idx_dev, sample_key(h), go, B);
     HIPCHK(hipGetLastError());
-    // the state parts of the two critic panels whose action columns the actor heads fill (still zero here) are
-    // converted in the same launch; the heads then write mu / mu' straight into the fp16 panels as well.  (The
-    // split form — phase 10 / 11, the online actor's forward deferred — converts them after the heads.)
-    const bool heads16 = !split;
-    {
-      Cvt16Batch b{};
-      cvt(b, h->Xa_n, la.kp[0], h->act16[0][0], h->k16[0][0]);
-      cvt(b, h->Xa_s, la.kp[0], h->act16[1][0], h->k16[0][0]);
-      cvt(b, h->Xc_tr, lc.kp[0], h->act16[3][0], h->k16[1][0]);
-      if (heads16) {
-        cvt(b, h->Xc_nx, lc.kp[0], h->act16[2][0], h->k16[1][0]);
-        cvt(b, h->Xc_pl, lc.kp[0], h->act16[4][0], h->k16[1][0]);
-      }
-      HIPCHK(cvt16_launch(b, st));
-    }
     if (split) RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B));
     else RC(tower_forward16_pair(h, st, 0, DQNHIP_ACTOR_TARGET, 1, DQNHIP_ACTOR, B));
     HeadArgs hAT{}; hAT.X = h->act[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
@@ -665,14 +653,9 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
     hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
-    if (heads16) { hAT.xc16 = h->act16[2][0]; hAT.ldxc16 = h->k16[1][0]; hA.xc16 = h->act16[4][0]; hA.ldxc16 = h->k16[1][0]; }
+    hAT.xc16 = h->act16[2][0]; hAT.ldxc16 = h->k16[1][0]; hA.xc16 = h->act16[4][0]; hA.ldxc16 = h->k16[1][0];
     if (split) RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT)));
     else RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));
-    if (!heads16) {
-      Cvt16Batch b{};
-      cvt(b, h->Xc_nx, lc.kp[0], h->act16[2][0], h->k16[1][0]);
-      HIPCHK(cvt16_launch(b, st));
-    }
     RC(tower_forward16_pair(h, st, 2, DQNHIP_CRITIC_TARGET, 3, DQNHIP_CRITIC, B));
     {
       HeadTrainArgs t{};
@@ -704,17 +687,11 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     if (part16) RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
     else { RC(sumsq_launch(h, 1)); RC(adam_launch(h, st, 1, h->part_dp, h->n_part_dp, 0, lc.arena)); }
     RC(tower_forward16(h, st, 4, DQNHIP_CRITIC, B));
-    const bool q_sep16 = head_big_ok(h, B, Hc);        // small minibatches: q(s, mu(s)) rides in the dq = -1 head launch, as on the fp32 path
-    if (q_sep16) {
-      HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
-      a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.b = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q = h->q2;
-      a.qsum_partial = h->q_partial;
-      RC((head_forward<1, HEAD_Q_POLICY>(h, st, a)));
-    }
     {
+      // q(s, mu(s)) rides in the dq = -1 head launch (rider blocks), as on the fp32 path
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
-      if (!q_sep16) { a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial; }
+      a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial;
       if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->ls_q)); }
       else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_q; RC(head_backward<1>(h, st, a)); }
     }
@@ -838,17 +815,10 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // q(s, mu(s)) with the updated critic [:913-916] and, in the same launch, the seed of
     // BackwardFrom(q_values_layer): q diff = -1 per row, input gradient only (the reference's
     // discarded critic dW, SURVEY a11, is never computed).  The seed does not depend on q.
-    const bool q_sep = head_big_ok(h, B, Hc);            // minibatches >= 1024: the bandwidth-tiled head kernels
-    if (q_sep) {
-      HeadArgs a{}; a.X = h->act[4][L]; a.ldx = Hc; a.H = Hc; a.rows = B;
-      a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.b = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q = h->q2;
-      a.qsum_partial = h->q_partial;
-      RC((head_forward<1, HEAD_Q_POLICY>(h, st, a)));
-    }
     {
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
-      if (!q_sep) { a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial; }
+      a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial;
       RC(head_backward<1>(h, st, a));
     }
     RC(tower_backward(h, st, lc, DQNHIP_CRITIC, nullptr, nullptr, h->act[4], h->dZc, B, false, true, h->S, h->S + kNO));

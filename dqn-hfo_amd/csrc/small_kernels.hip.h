@@ -145,6 +145,9 @@ struct GatherOut {
   float* Xa_s; float* Xa_n; int KaP;
   float* Xc_tr; float* Xc_pl; float* Xc_nx; int KcP;
   float* reward; float* mc; float* term; int* idx;
+  // fp16 learner: the same five panels as fp16 (what its GEMMs read), written here instead of by a conversion launch
+  // (null: fp32 learner).  Row strides = KaP / KcP (the fp16 learner pads both to 128).
+  _Float16* Ha_s; _Float16* Ha_n; _Float16* Hc_tr; _Float16* Hc_pl; _Float16* Hc_nx;
 };
 // rs: the DevState that holds the ring's (head,size) — another learner's under
 // ShareReplayMemory; st: this learner's (sampling counter)
@@ -176,6 +179,12 @@ __global__ void k_gather(Ring ring, const DevState* rs, const DevState* st, cons
     o.Xc_tr[(size_t)row * o.KcP + c] = c < S ? sv : av;
     o.Xc_pl[(size_t)row * o.KcP + c] = sv;
     o.Xc_nx[(size_t)row * o.KcP + c] = nv;
+    if (o.Ha_s != nullptr) {
+      if (c < o.KaP) { o.Ha_s[(size_t)row * o.KaP + c] = (_Float16)sv; o.Ha_n[(size_t)row * o.KaP + c] = (_Float16)nv; }
+      o.Hc_tr[(size_t)row * o.KcP + c] = (_Float16)(c < S ? sv : av);
+      o.Hc_pl[(size_t)row * o.KcP + c] = (_Float16)sv;
+      o.Hc_nx[(size_t)row * o.KcP + c] = (_Float16)nv;
+    }
   }
   if (lane == 0) {
     o.reward[row] = ring.reward[slot]; o.mc[row] = ring.mc[slot];
@@ -553,6 +562,9 @@ struct HeadBwdBigArgs {
   HeadBwdArgs a;
   _Float16* dZ16; float scale16;                             // fp16 output (null: fp32 a.dZ only)
   float* slab2;                                              // [rows/64][NH][H] then [rows/64][16]
+  // rider (NH == 1, dq = -1 pass; a.q_out != null): blocks with blockIdx.x >= chunks compute q = head(X4) + the avg-Q
+  // partials (critic(s, mu(s)) head forward, src/dqn.cpp:913-916), one wave per row — as in k_head_bwd
+  int chunks;
 };
 template <int NH>
 __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
@@ -562,6 +574,53 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
   float* s_dy = sm;                                    // [64][NH]
   float* s_red = sm + 64 * NH;                         // [4][NH][256]
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  if (NH == 1 && b.chunks > 0 && (int)blockIdx.x >= b.chunks) {
+    // one wave per row, four rows of the wave in flight at once (16 x 16-B loads per lane before the first use:
+    // with one row at a time the rider was a chain of exposed memory latencies, 9 us at 4096 rows)
+    const int nwave = ((int)gridDim.x - b.chunks) * (int)gridDim.y * 4;
+    const int wv = (((int)blockIdx.x - b.chunks) * (int)gridDim.y + (int)blockIdx.y) * 4 + w;
+    const bool hoist = a.H <= 1024;
+    f32x4 wreg[4];
+    if (hoist) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const int k = lane * 4 + 256 * t; wreg[t] = k < a.H ? *reinterpret_cast<const f32x4*>(a.W + k) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    for (int r0 = wv * 4; r0 < a.rows; r0 += nwave * 4) {
+      if (hoist) {
+        f32x4 xr[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int k = lane * 4 + 256 * t;
+            xr[j][t] = (r0 + j < a.rows && k < a.H) ? *reinterpret_cast<const f32x4*>(a.X4 + (size_t)(r0 + j) * a.H + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc = fmaf(xr[j][t].x, wreg[t].x, acc); acc = fmaf(xr[j][t].y, wreg[t].y, acc);
+            acc = fmaf(xr[j][t].z, wreg[t].z, acc); acc = fmaf(xr[j][t].w, wreg[t].w, acc);
+          }
+          acc = wave_sum64(acc);
+          if (lane == 0 && r0 + j < a.rows) { const float v = acc + a.q_bias[0]; a.q_out[r0 + j] = v; a.qsum_partial[r0 + j] = (double)v; }
+        }
+      } else {
+        for (int j = 0; j < 4 && r0 + j < a.rows; ++j) {
+          const float* x = a.X4 + (size_t)(r0 + j) * a.H;
+          float acc = 0.0f;
+          for (int k = lane * 4; k < a.H; k += 256) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k), wv4 = *reinterpret_cast<const f32x4*>(a.W + k);
+            acc = fmaf(xv.x, wv4.x, acc); acc = fmaf(xv.y, wv4.y, acc); acc = fmaf(xv.z, wv4.z, acc); acc = fmaf(xv.w, wv4.w, acc);
+          }
+          acc = wave_sum64(acc);
+          if (lane == 0) { const float v = acc + a.q_bias[0]; a.q_out[r0 + j] = v; a.qsum_partial[r0 + j] = (double)v; }
+        }
+      }
+    }
+    return;
+  }
   const int m0 = blockIdx.x * 64, kb = blockIdx.y * 256, k0 = kb + lane * 4;
   const bool want_w = a.dW != nullptr;
   for (int i = tid; i < 64 * NH; i += 256) {
