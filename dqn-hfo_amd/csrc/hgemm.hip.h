@@ -83,12 +83,14 @@ __device__ __forceinline__ int hg_tile_of_block(int bid, int total) {
 __device__ unsigned long long hg_clk[2];   // shader cycles / 100 MHz ticks of block 17's main loop (test build only)
 #endif
 
-template <int WM, int WN>
+// TM: 32-row MFMA block PAIRS a wave stacks in M — wave tile (64 TM) x 64.  TM = 2 (<2,2,2>: four waves of 128 x 64 on a
+// 256 x 128 workgroup tile): 6 fragment reads per 8 MFMAs instead of 4 per 4, and 48 KiB of operands per 4.2 MFLOP.
+template <int WM, int WN, int TM = 1>
 struct HGCfg {
   static constexpr int NW = (WM * WN >= 4) ? WM * WN : 4;                   // waves per workgroup (4, or 8 for <4,2>)
   static constexpr int NT = NW * 64;
   static constexpr int WK = (WM * WN >= 4) ? 1 : 4 / (WM * WN);
-  static constexpr int BM = WM * 64, BN = WN * 64;
+  static constexpr int BM = WM * 64 * TM, BN = WN * 64;
   // <2,2>: a stage is 256 row slots of 128 B (32 KiB): slots 0-127 = A rows, 128-255 = B rows of one 64-deep K tile.
   // <4,2>: 384 row slots (48 KiB): 256 A rows + 128 B rows.  <1,1>: two 64-deep sub-tiles, each 64 A rows + 64 B rows
   // (K step 128).
@@ -114,12 +116,14 @@ typedef __attribute__((__vector_size__(4 * sizeof(short)))) short hg_s16x4;
 typedef __attribute__((address_space(3))) hg_s16x4* hg_lds_s16x4_ptr;
 
 // MODE = ta | tb << 1 of the problem (compile time: the fragment loads of the main loop differ)
-template <int WM, int WN, int MODE>
+template <int WM, int WN, int MODE, int TM = 1>
 __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
-  using Cfg = HGCfg<WM, WN>;
+  using Cfg = HGCfg<WM, WN, TM>;
   constexpr int NW = Cfg::NW, NT = Cfg::NT;
+  constexpr int MI = 2 * TM;                 // 32-row MFMA blocks per wave in M
   constexpr bool TA = (MODE & 1) != 0, TB = (MODE & 2) != 0;
-  static_assert(MODE == 0 || NW == 4, "reduction-major operands: 128x128 and 64x64 tiles only");
+  static_assert(MODE == 0 || (NW == 4 && TM == 1), "reduction-major operands: 128x128 and 64x64 tiles only");
+  static_assert(TM == 1 || Cfg::WK == 1, "tall wave tiles: no in-workgroup split-K");
 #ifdef HG_CLOCKPROBE
   const unsigned long long hg_c0 = clock64(), hg_r0 = wall_clock64();
 #endif
@@ -144,7 +148,8 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
   const h16* wbase = nullptr; const h16* wbase_b = nullptr;
   size_t dma_step = KSTEP;                   // elements between two stages of this wave's source (KSTEP columns, or KSTEP rows)
   uint32_t voff[LOADS];
-  if constexpr (NW == 4) {
+  constexpr int APW = BM / 8 / NW, BPW = BN / 8 / NW;      // per-wave A / B pieces of a stage in the rows-split-over-all-waves scheme
+  if constexpr (NW == 4 && TM == 1) {
     const bool from_a = (WK == 1) ? (wu < 2) : ((wu & 1) == 0);
     const bool red = from_a ? TA : TB;                          // wave-uniform (a constant when TA == TB)
     const int ld = __builtin_amdgcn_readfirstlane(from_a ? g.lda : g.ldb);
@@ -174,13 +179,15 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
       }
     }
   } else {
-    wbase = g.A + (size_t)(m0 + wu * 32) * g.lda;
-    wbase_b = g.B + (size_t)(n0 + wu * 16) * g.ldb;
+    // every wave owns a run of A rows and a run of B rows: <4,2> (8 waves) 32 + 16 rows, <2,2,2> (4 waves) 64 + 32
+    static_assert(APW + BPW == LOADS, "stage pieces");
+    wbase = g.A + (size_t)(m0 + wu * APW * 8) * g.lda;
+    wbase_b = g.B + (size_t)(n0 + wu * BPW * 8) * g.ldb;
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
-      const bool pa = i < 4;
-      const int rl = pa ? i * 8 : (i - 4) * 8;                  // row inside this wave's run of the matrix
-      const int R = (pa ? wu * 32 : BM + wu * 16) + rl + r8;    // stage slot
+      const bool pa = i < APW;
+      const int rl = pa ? i * 8 : (i - APW) * 8;                // row inside this wave's run of the matrix
+      const int R = (pa ? wu * APW * 8 : BM + wu * BPW * 8) + rl + r8;    // stage slot
       const int c = pc ^ ((R >> 1) & 7);
       voff[i] = (uint32_t)(((rl + r8) * (pa ? g.lda : g.ldb) + c * 8) * 2);
     }
@@ -190,12 +197,12 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
   // serialises the fragment prefetch; all ordering of the DMA is done by hand (counted vmcnt + barrier).
   auto issue1 = [&](int kt, int i) {
     const h16* base; uint32_t dst;
-    if constexpr (NW == 4) {
+    if constexpr (NW == 4 && TM == 1) {
       base = wbase + (size_t)kt * dma_step;
       dst = lds0 + (uint32_t)((kt % STAGES) * Cfg::STAGE + (wu * LOADS + i) * 1024);
     } else {
-      base = (i < 4 ? wbase : wbase_b) + (size_t)kt * KSTEP;
-      dst = lds0 + (uint32_t)((kt % STAGES) * Cfg::STAGE + (i < 4 ? (wu * 4 + i) : (BM / 8 + wu * 2 + (i - 4))) * 1024);
+      base = (i < APW ? wbase : wbase_b) + (size_t)kt * KSTEP;
+      dst = lds0 + (uint32_t)((kt % STAGES) * Cfg::STAGE + (i < APW ? (wu * APW + i) : (BM / 8 + wu * BPW + (i - APW))) * 1024);
     }
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :: "v"(voff[i]), "s"(base), "s"(dst) : "memory");
@@ -208,16 +215,16 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
   for (int s = 0; s < NSUB; ++s) {
     if constexpr (WK == 1) {
       const int o = (((2 * s + hi) ^ sw) << 4) + l31 * 128;
-      offa[s] = wm * 64 * 128 + o; offb[s] = (BM + wn * 64) * 128 + o;
+      offa[s] = wm * 64 * TM * 128 + o; offb[s] = (BM + wn * 64) * 128 + o;
     } else {
       const int o = (((2 * w + hi) ^ sw) << 4) + l31 * 128;     // this wave's k16 slice of each sub-tile
       offa[s] = s * 16384 + o; offb[s] = s * 16384 + 8192 + o;
     }
   }
 
-  hg_f32x16 acc[2][2];
+  hg_f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -241,7 +248,7 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
       tro[r][1] = ((WK == 1) ? (BM + wn * 64) * 128 : 8192) + o;
     }
   }
-  h16x8 fa[2][2], fb[2][2];                 // [register buffer][32-row half]
+  h16x8 fa[2][MI], fb[2][2];                // [register buffer][32-row block]
   auto load_frags = [&](int buf, int kt, int s) {
     const unsigned char* st = hg_smem + (kt % STAGES) * Cfg::STAGE;
     // reduction-major operand: block i (32 columns) = +64 B along the row, i.e. chunk bit 2: XOR 64 on the swizzled offset
@@ -253,9 +260,12 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
       return u.v;
     };
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
       if constexpr (TA) fa[buf][i] = tr_frag(0, i);
       else fa[buf][i] = *reinterpret_cast<const h16x8*>(st + offa[s] + i * 32 * 128);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
       if constexpr (TB) fb[buf][i] = tr_frag(1, i);
       else fb[buf][i] = *reinterpret_cast<const h16x8*>(st + offb[s] + i * 32 * 128);
     }
@@ -311,6 +321,11 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
       HG_PIN();
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 2; i < MI; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[cur][0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[cur][1], acc[i][1], 0, 0, 0);
+      }
     }
   };
   int kt = 0;
@@ -326,12 +341,12 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
   {
     float* Tw = Tt + (WK == 1 ? 0 : w * BM * TLD);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int m = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+          const int m = wm * 64 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
           const int n = wn * 64 + j * 32 + l31;
           Tw[m * TLD + n] = acc[i][j][e];
         }
@@ -439,6 +454,18 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch ba
   else hgemm_body<WM, WN, MODE1>(batch.g[sel], bid);
 }
 
+#ifdef HG_WITH_CT16
+// Probe (test build only): k-major problems on 256 x 128 tiles of FOUR waves, 128 x 64 per wave — 25 %
+// fewer LDS fragment bytes and DMA bytes per FLOP than the 64 x 64 wave tile.  Measured (profiles/r03_fp16_gemm_tiles.txt):
+// 607 TF against 668 TF for the eight-wave 256 x 128 tile on two 4096 x 1024 x 1024 problems, 784 against 805 TF at K = 4096
+// (128 x 128 tiles: 833 TF): the plateau is not set by LDS read traffic.  The learner does not launch it.
+__global__ __launch_bounds__(256, 1) void hgemm_nt_tall(HGemmBatch batch) {
+  int bid;
+  const int sel = hg_select(batch, (int)blockIdx.x, bid);
+  hgemm_body<2, 2, 0, 2>(batch.g[sel], bid);
+}
+#endif
+
 // the instantiations the learner uses: forward (0), dgrad (2 = B reduction-major), wgrad (3 = both), and a small-
 // minibatch layer's dgrad + wgrad in one launch (2, 3)
 #define HG_FOR_EACH_KERNEL(X) \
@@ -447,6 +474,9 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch ba
 inline hipError_t hgemm_group_db_prepare();
 inline hipError_t hgemm_prepare_all() {
   hipError_t e = hgemm_group_db_prepare();
+#ifdef HG_WITH_CT16
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_nt_tall), hipFuncAttributeMaxDynamicSharedMemorySize, HGCfg<2, 2, 2>::LDS_BYTES);
+#endif
 #define HG_PREP(WM, WN, M0, M1)                                                                                     \
   if (e == hipSuccess)                                                                                               \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_nt<WM, WN, M0, M1>), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -457,7 +487,8 @@ inline hipError_t hgemm_prepare_all() {
 }
 
 // Tile choice: 256x128 (8 waves) when THAT fills the chip (two 4096-row problems in one launch), 128x128 when that
-// does, else 64x64 with in-workgroup split-K.  force: 0 auto, 1 128x128, 2 64x64, 3 256x128.
+// does, else 64x64 with in-workgroup split-K.  force: 0 auto, 1 128x128, 2 64x64, 3 256x128 on eight waves,
+// 4 256x128 on four waves (128x64 per wave).
 inline bool hgemm_big_ok(const HGemm& g) { return (g.M % 128 == 0) && (g.N % 128 == 0); }
 inline bool hgemm_huge_ok(const HGemm& g) { return (g.M % 256 == 0) && (g.N % 128 == 0) && !g.ta && !g.tb; }
 inline long hgemm_tiles(const HGemm& g, bool big) { return big ? (long)(g.M / 128) * (g.N / 128) : (long)(g.M / 64) * (g.N / 64); }
@@ -474,7 +505,7 @@ inline hipError_t hgemm_plan(const HGemm* gs, int n, int force, HGemmBatch& b, i
   }
   if (big_ok) for (int i = 0; i < n; ++i) tiles_big += hgemm_tiles(gs[i], true);
   if (huge_ok) for (int i = 0; i < n; ++i) tiles_huge += (long)(gs[i].M / 256) * (gs[i].N / 128);
-  const bool huge = force == 3 || (force == 0 && huge_ok && tiles_huge >= 192);
+  const bool huge = force == 3 || force == 4 || (force == 0 && huge_ok && tiles_huge >= 192);
   const bool big = !huge && (force == 1 || (force == 0 && big_ok && tiles_big >= 192));
   if (huge && !huge_ok) return hipErrorInvalidValue;
   if (big && !big_ok) return hipErrorInvalidValue;
@@ -498,6 +529,16 @@ inline hipError_t hgemm_launch_batch(const HGemm* gs, int n, hipStream_t st, int
   if (e != hipSuccess) return e;
   const int m0 = hgemm_mode(gs[0]), m1 = n > 1 ? hgemm_mode(gs[1]) : m0;
   for (int i = 2; i < n; ++i) if (hgemm_mode(gs[i]) != m1) return hipErrorInvalidValue;
+  if (force == 4) {
+#ifdef HG_WITH_CT16
+    if (m0 != 0 || m1 != 0) return hipErrorInvalidValue;
+    if (t0) hipExtLaunchKernelGGL(hgemm_nt_tall, dim3((unsigned)blocks), dim3(256), (HGCfg<2, 2, 2>::LDS_BYTES), st, t0, t1, 0, b);
+    else hipLaunchKernelGGL(hgemm_nt_tall, dim3((unsigned)blocks), dim3(256), (HGCfg<2, 2, 2>::LDS_BYTES), st, b);
+    return hipGetLastError();
+#else
+    return hipErrorInvalidValue;
+#endif
+  }
   bool launched = false;
 #define HG_TRY(WM, WN, M0, M1)                                                                                                          \
   if (!launched && wm == WM && wn == WN && m0 == M0 && m1 == M1) {                                                                      \

@@ -89,7 +89,10 @@ def test_hgemm_kernels(pkg, gpu):
              # K = 64 / 128 / 192 exercise the 3-stage ring's prologue and tail; pairs also of the other shapes
              (0, 3, 256, 128, 64), (0, 3, 512, 256, 128), (1, 3, 256, 256, 192), (5, 3, 1024, 384, 1024), (2, 3, 512, 128, 512),
              (0, 13, 256, 128, 64), (1, 13, 512, 256, 320), (5, 13, 4096, 1024, 1024), (4, 10, 4096, 1024, 1024),
-             (5, 11, 512, 256, 256), (1, 12, 128, 128, 256)]
+             (5, 11, 512, 256, 256), (1, 12, 128, 128, 256),
+             # 256x128 tile on FOUR waves, 128x64 per wave (tile 4; pairs +10): prologue / tail of its 3-stage ring, all epilogues
+             (0, 4, 256, 128, 64), (0, 4, 512, 256, 128), (1, 4, 256, 256, 192), (4, 4, 1024, 384, 1024), (2, 4, 512, 128, 512),
+             (0, 14, 256, 128, 64), (1, 14, 512, 256, 320), (4, 14, 4096, 1024, 1024)]
     for c in cases:
         rc, err, ref = run(*c)
         assert rc == 0, c
