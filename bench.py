@@ -349,6 +349,7 @@ def main():
                     help="testing: every rank uses GPU 0 (needs --backend gloo; RCCL refuses duplicate devices)")
     ap.add_argument("--dp-single-bucket", action="store_true", help="native DP, fp32 learner: ONE all-reduce per net instead of per-layer buckets on a communication stream")
     ap.add_argument("--dp-fp32-grads", action="store_true", help="native DP, fp16 learner: all-reduce fp32 gradients instead of bf16 (DQNHIP_DP_HALF_GRADS)")
+    ap.add_argument("--dp-timeout", type=int, default=600, help="N > 1: seconds the headline measurement may take before every rank gives up")
     ap.add_argument("--tuning", type=int, default=0, help="dqnhip_config.tuning_flags (A/B switches, include/dqnhip.h DQNHIP_TUNE_*)")
     ap.add_argument("--no-subrecords", action="store_true", help="skip the per-config sub-records (configs #3, #5; strong scaling under N > 1)")
     ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],
@@ -436,6 +437,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1: the captured data-parallel update (RCCL inside a hipGraph, per-layer buckets on a communication stream) has
+    # only ever met ONE rank on this repo's build boxes.  A rank stuck in a collective cannot be interrupted from Python, so a
+    # watchdog bounds the damage: if the headline has not been measured within --dp-timeout seconds every rank leaves, and rank 0
+    # prints a line that says so (value null) instead of hanging the driver.  Re-run with --no-graph / --dp-single-bucket.
+    hang_dog = None
+    if dist_on and world > 1:
+        import threading
+
+        def _hung():
+            if rank == 0:
+                print(json.dumps({"metric": "DQN updates/sec, 1v0 HFO, 4x1024 MLP, minibatch %d" % B, "value": None, "unit": "updates/s",
+                                  "n_gpus": world, "error": "data-parallel headline did not finish within %d s (graph=%s, per_layer=%s): "
+                                  "rerun with --no-graph or --dp-single-bucket" % (args.dp_timeout, not args.no_graph, not args.dp_single_bucket)}), flush=True)
+            os._exit(3)
+        hang_dog = threading.Timer(float(args.dp_timeout), _hung)
+        hang_dog.daemon = True
+        hang_dog.start()
+
     # Untimed preparation that is not one of the W warm-up steps: the first update captures the hipGraph, and
     # the GPU needs a few tens of milliseconds of load before its clocks settle.  With a short --warmup / --steps
     # pair (the driver has used 5 / 20 = 9 ms in total) the timed region would otherwise sit on that ramp.
@@ -457,6 +476,8 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if hang_dog is not None:
+        hang_dog.cancel()
     if dist_on:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

@@ -79,6 +79,19 @@ __device__ __forceinline__ int hg_tile_of_block(int bid, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+// 2-D form for problems whose operand panels are LONG (wgrad: a panel is 128 columns x the whole minibatch, 1 MiB at
+// 4096 rows): an XCD's 8 concurrent tiles form a 2 x 4 block of the tile grid, so its L2 pulls 2 A panels + 4 B panels
+// instead of 1 + 8 (PMC, round 3: the grouped wgrad launch fetched 263 MB for ~50 MB of unique operands — 5.8 TB/s of
+// fabric traffic over its 45 us, i.e. it ran AT the fabric rate).  Needs (tiles_m / 2) * (tiles_n / 4) % 8 == 0.
+__device__ __forceinline__ bool hg_tile_2d(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  if ((tiles_m & 1) || (tiles_n & 3) || (((tiles_m >> 1) * (tiles_n >> 2)) & 7)) return false;
+  const int xcd = bid & 7, j = bid >> 3;
+  const int q = ((j >> 3) << 3) + xcd, jj = j & 7, bn = tiles_n >> 2;
+  tm = ((q / bn) << 1) + (jj >> 2);
+  tn = ((q % bn) << 2) + (jj & 3);
+  return true;
+}
+
 #ifdef HG_CLOCKPROBE
 __device__ unsigned long long hg_clk[2];   // shader cycles / 100 MHz ticks of block 17's main loop (test build only)
 #endif
@@ -133,8 +146,12 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (WK == 1) ? (w >> 1) : 0, wn = (WK == 1) ? (w & 1) : 0;
   const int tiles_n = g.N / BN, tiles_m = g.M / BM;
-  const int T = hg_tile_of_block(bid, tiles_m * tiles_n);
-  const int m0 = (T / tiles_n) * BM, n0 = (T % tiles_n) * BN;
+  int tm, tn;
+  if (!(TA && TB && hg_tile_2d(bid, tiles_m, tiles_n, tm, tn))) {
+    const int T = hg_tile_of_block(bid, tiles_m * tiles_n);
+    tm = T / tiles_n; tn = T % tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
   const int nk = g.K / KSTEP;
 
   // ---- LDS-DMA source addresses.  A piece is 8 row slots (1 KiB); lane -> (slot R, physical chunk pc) fetches logical

@@ -113,17 +113,92 @@ int blob_table(dqnhip_handle h, int net, std::vector<ParamBlob>& out, size_t& to
   return 0;
 }
 
-std::string net_proto(const std::vector<ParamBlob>& tbl, const std::vector<float>& w, bool actor) {
+// Net::ToProto (what Solver::Snapshot writes, src/dqn.cpp:589-590): the net's name, then EVERY layer of the
+// initialised net with its LayerParameter as Net::Init left it — the layers CreateActorNet / CreateCriticNet build
+// (src/dqn.cpp:399-455: MemoryData inputs, Silence, Concat, the Tower() of InnerProduct + in-place ReLU(0.01) pairs,
+// the heads, EuclideanLoss), the Split layer InsertSplits adds where two layers consume one top (the actor's tower
+// top feeds action_layer and actionpara_layer: "ip<L>_ip<L>_relu_layer_0_split"), `phase: TRAIN` on every layer
+// (Net::Init sets it where absent) — and the learnable blobs on the InnerProduct layers.  Fields are emitted in
+// field-number order, as the C++ protobuf serialiser does.  caffe.proto @2ef5847 numbers: LayerParameter name 1, type 2,
+// bottom 3, top 4, blobs 7, phase 10, concat_param 104 {axis 2}, inner_product_param 117 {num_output 1, weight_filler 3
+// {type 1, std 6}}, memory_data_param 119 {batch_size 1, channels 2, height 3, width 4}, relu_param 123 {negative_slope 1}
+// (not re-verifiable offline; CopyTrainedLayersFrom only needs name + blobs, which the tests pin).
+void put_float(std::string& o, int field, float v) { put_tag(o, field, 5); o.append(reinterpret_cast<const char*>(&v), 4); }
+
+struct LayerSpec {
+  std::string name, type;
+  std::vector<std::string> bottom, top;
+  std::string params;                       // the layer-type parameter message, already tagged (field >= 100)
+  int blob0 = -1;                           // index into the ParamBlob table of this layer's weight blob (-1: no blobs)
+};
+
+std::string layer_proto(const LayerSpec& l, const std::vector<ParamBlob>& tbl, const std::vector<float>& w) {
+  std::string o;
+  put_bytes(o, 1, l.name);
+  put_bytes(o, 2, l.type);
+  for (auto& b : l.bottom) put_bytes(o, 3, b);
+  for (auto& t : l.top) put_bytes(o, 4, t);
+  if (l.blob0 >= 0)
+    for (int k = 0; k < 2; ++k) put_bytes(o, 7, blob_proto(tbl[l.blob0 + k].shape, w.data() + tbl[l.blob0 + k].offset, tbl[l.blob0 + k].count));
+  put_int(o, 10, 0);                        // phase: TRAIN
+  o += l.params;
+  return o;
+}
+
+std::string net_proto(const std::vector<ParamBlob>& tbl, const std::vector<float>& w, bool actor, const dqnhip_config& c) {
+  auto memory_data = [&](const std::string& name, const std::string& top, const std::string& dummy, int batch, int channels, int height) {
+    LayerSpec l; l.name = name; l.type = "MemoryData"; l.top = {top, dummy};
+    std::string p; put_int(p, 1, batch); put_int(p, 2, channels); put_int(p, 3, height); put_int(p, 4, 1);
+    put_bytes(l.params, 119, p);
+    return l;
+  };
+  auto inner_product = [&](const std::string& name, const std::string& bottom, const std::string& top, int num_output, int blob0) {
+    LayerSpec l; l.name = name; l.type = "InnerProduct"; l.bottom = {bottom}; l.top = {top}; l.blob0 = blob0;
+    std::string filler; put_bytes(filler, 1, "gaussian"); put_float(filler, 6, 0.01f);
+    std::string p; put_int(p, 1, num_output); put_bytes(p, 3, filler);
+    put_bytes(l.params, 117, p);
+    return l;
+  };
+  std::vector<LayerSpec> layers;
+  const int B = c.minibatch, S = c.state_size;
+  layers.push_back(memory_data("state_input_layer", "states", "dummy1", B, 1, S));                        // :421-422, :434-435
+  std::string input = "states";
+  if (actor) {
+    LayerSpec sl; sl.name = "silence"; sl.type = "Silence"; sl.bottom = {"dummy1"}; layers.push_back(sl);  // :423
+  } else {
+    layers.push_back(memory_data("action_input_layer", "actions", "dummy2", B, 1, DQNHIP_ACTION_SIZE));    // :436-438
+    layers.push_back(memory_data("action_params_input_layer", "action_params", "dummy3", B, 1, DQNHIP_ACTION_PARAM_SIZE));
+    layers.push_back(memory_data("target_input_layer", "target", "dummy4", B, 1, 1));                       // :442-443 {B,1,1,1}
+    LayerSpec sl; sl.name = "silence"; sl.type = "Silence"; sl.bottom = {"dummy1", "dummy2", "dummy3", "dummy4"}; layers.push_back(sl);
+    LayerSpec cc; cc.name = "concat"; cc.type = "Concat"; cc.bottom = {"states", "actions", "action_params"}; cc.top = {"state_actions"};
+    std::string p; put_int(p, 2, 2); put_bytes(cc.params, 104, p);                                           // axis 2, :445-447
+    layers.push_back(cc);
+    input = "state_actions";
+  }
+  int blob = 0;
+  for (int i = 1; i <= c.num_hidden; ++i) {                                                                  // Tower(), :399-415
+    const std::string top = "ip" + std::to_string(i);
+    layers.push_back(inner_product(top + "_layer", input, top, c.hidden[i - 1], blob)); blob += 2;
+    LayerSpec r; r.name = top + "_relu_layer"; r.type = "ReLU"; r.bottom = {top}; r.top = {top};
+    std::string p; put_float(p, 1, 0.01f); put_bytes(r.params, 123, p);
+    layers.push_back(r);
+    input = top;
+  }
+  if (actor) {
+    // InsertSplits: the tower top (last written by the in-place ReLU) has two consumers
+    const std::string sp = input + "_" + input + "_relu_layer_0_split";
+    LayerSpec s; s.name = sp; s.type = "Split"; s.bottom = {input}; s.top = {sp + "_0", sp + "_1"};
+    layers.push_back(s);
+    layers.push_back(inner_product("action_layer", sp + "_0", "actions", DQNHIP_ACTION_SIZE, blob)); blob += 2;           // :426
+    layers.push_back(inner_product("actionpara_layer", sp + "_1", "action_params", DQNHIP_ACTION_PARAM_SIZE, blob));      // :427
+  } else {
+    layers.push_back(inner_product("q_values_layer", input, "q_values", 1, blob));                                         // :450
+    LayerSpec l; l.name = "loss"; l.type = "EuclideanLoss"; l.bottom = {"q_values", "target"}; l.top = {"loss"};           // :451-452
+    layers.push_back(l);
+  }
   std::string o;
   put_bytes(o, 1, actor ? "Actor" : "Critic");           // np.set_name, src/dqn.cpp:420,433
-  for (size_t i = 0; i < tbl.size(); i += 2) {
-    std::string l;
-    put_bytes(l, 1, tbl[i].layer);
-    put_bytes(l, 2, "InnerProduct");
-    put_bytes(l, 7, blob_proto(tbl[i].shape, w.data() + tbl[i].offset, tbl[i].count));
-    put_bytes(l, 7, blob_proto(tbl[i + 1].shape, w.data() + tbl[i + 1].offset, tbl[i + 1].count));
-    put_bytes(o, 100, l);
-  }
+  for (auto& l : layers) put_bytes(o, 100, layer_proto(l, tbl, w));
   return o;
 }
 
@@ -182,7 +257,9 @@ int dqnhip_save_caffemodel(dqnhip_handle h, int32_t net, const char* filename) {
   if (blob_table(h, net, tbl, total)) return 1;
   std::vector<float> w(total);
   if (dqnhip_get_params(h, net, DQNHIP_KIND_W, w.data(), total)) return 1;
-  if (!write_file(filename, net_proto(tbl, w, net == DQNHIP_ACTOR))) return fail(std::string("cannot write ") + filename);
+  dqnhip_config cfg;
+  if (dqnhip_get_config(h, &cfg)) return 1;
+  if (!write_file(filename, net_proto(tbl, w, net == DQNHIP_ACTOR, cfg))) return fail(std::string("cannot write ") + filename);
   return 0;
 }
 

@@ -26,9 +26,9 @@ stats r03_env_s68_w64 0 "rocprofv3 --kernel-trace --stats — round 3, batched e
 stats r03_env_s58_w2048 0 "rocprofv3 --kernel-trace --stats — round 3, batched env front-end, S=58, 2048 workers (BASELINE configs[4]); per batched env step" python scripts/env_probe.py 58 2048
 fi
 if [ "$what" != stats ]; then
-scripts/pmc_fetch.sh > $O/pmc_fetch.log 2>&1; cp gpurun_out/pmc_fetch.json $O/ 2>/dev/null
-scripts/pmc_summary.sh > $O/pmc_summary.log 2>&1; cp gpurun_out/pmc_summary.json $O/ 2>/dev/null
-[ -s $O/pmc_summary.json ] || { echo "EMPTY pmc_summary.json"; rc=1; }
+scripts/r03_pmc.sh > $O/pmc.log 2>&1
+[ -s $O/r03_pmc_summary.json ] || { echo "EMPTY r03_pmc_summary.json"; rc=1; }
+python -c "import json,sys; j=json.load(open('$O/r03_pmc_summary.json')); sys.exit(0 if len(j['kernels'])>5 and len(j['kernels_fp16_b4096'])>5 else 1)" || { echo "PMC summary has too few kernels"; rc=1; }
 fi
 ls -la $O
 exit $rc

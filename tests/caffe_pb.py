@@ -27,10 +27,27 @@ def _build():
     _field(m, "diff", 6, _F.TYPE_FLOAT, _F.LABEL_REPEATED, packed=True)
     for i, n in enumerate(("num", "channels", "height", "width")):
         _field(m, n, i + 1, _F.TYPE_INT32)
+    m = fd.message_type.add(); m.name = "FillerParameter"
+    _field(m, "type", 1, _F.TYPE_STRING); _field(m, "value", 2, _F.TYPE_FLOAT); _field(m, "std", 6, _F.TYPE_FLOAT)
+    m = fd.message_type.add(); m.name = "InnerProductParameter"
+    _field(m, "num_output", 1, _F.TYPE_UINT32); _field(m, "bias_term", 2, _F.TYPE_BOOL)
+    _field(m, "weight_filler", 3, _F.TYPE_MESSAGE, type_name=".caffe.FillerParameter")
+    m = fd.message_type.add(); m.name = "MemoryDataParameter"
+    for i, n in enumerate(("batch_size", "channels", "height", "width")):
+        _field(m, n, i + 1, _F.TYPE_UINT32)
+    m = fd.message_type.add(); m.name = "ReLUParameter"
+    _field(m, "negative_slope", 1, _F.TYPE_FLOAT)
+    m = fd.message_type.add(); m.name = "ConcatParameter"
+    _field(m, "concat_dim", 1, _F.TYPE_UINT32); _field(m, "axis", 2, _F.TYPE_INT32)
     m = fd.message_type.add(); m.name = "LayerParameter"
     _field(m, "name", 1, _F.TYPE_STRING); _field(m, "type", 2, _F.TYPE_STRING)
     _field(m, "bottom", 3, _F.TYPE_STRING, _F.LABEL_REPEATED); _field(m, "top", 4, _F.TYPE_STRING, _F.LABEL_REPEATED)
     _field(m, "blobs", 7, _F.TYPE_MESSAGE, _F.LABEL_REPEATED, type_name=".caffe.BlobProto")
+    _field(m, "phase", 10, _F.TYPE_INT32)               # enum Phase { TRAIN = 0; TEST = 1; }
+    _field(m, "concat_param", 104, _F.TYPE_MESSAGE, type_name=".caffe.ConcatParameter")
+    _field(m, "inner_product_param", 117, _F.TYPE_MESSAGE, type_name=".caffe.InnerProductParameter")
+    _field(m, "memory_data_param", 119, _F.TYPE_MESSAGE, type_name=".caffe.MemoryDataParameter")
+    _field(m, "relu_param", 123, _F.TYPE_MESSAGE, type_name=".caffe.ReLUParameter")
     m = fd.message_type.add(); m.name = "NetParameter"
     _field(m, "name", 1, _F.TYPE_STRING); _field(m, "force_backward", 5, _F.TYPE_BOOL)
     _field(m, "layer", 100, _F.TYPE_MESSAGE, _F.LABEL_REPEATED, type_name=".caffe.LayerParameter")

@@ -31,6 +31,44 @@ def dense_from_net(np_msg, actor):
     return np.concatenate(parts)
 
 
+def check_full_layer_list(m, actor):
+    """Net::ToProto writes EVERY layer of the initialised net (src/dqn.cpp:589-590), not only those with blobs: the
+    layers of CreateActorNet / CreateCriticNet (:399-455) in order, the Split that Net::Init inserts under the actor's
+    two heads, phase TRAIN everywhere, and each layer's own parameter message."""
+    L = len(HID)
+    tower = []
+    for i in range(1, L + 1):
+        tower += [("ip%d_layer" % i, "InnerProduct"), ("ip%d_relu_layer" % i, "ReLU")]
+    if actor:
+        sp = "ip%d_ip%d_relu_layer_0_split" % (L, L)
+        want = [("state_input_layer", "MemoryData"), ("silence", "Silence")] + tower + \
+               [(sp, "Split"), ("action_layer", "InnerProduct"), ("actionpara_layer", "InnerProduct")]
+    else:
+        want = [("state_input_layer", "MemoryData"), ("action_input_layer", "MemoryData"), ("action_params_input_layer", "MemoryData"),
+                ("target_input_layer", "MemoryData"), ("silence", "Silence"), ("concat", "Concat")] + tower + \
+               [("q_values_layer", "InnerProduct"), ("loss", "EuclideanLoss")]
+    assert [(l.name, l.type) for l in m.layer] == want
+    by = {l.name: l for l in m.layer}
+    assert all(l.HasField("phase") and l.phase == 0 for l in m.layer)
+    md = by["state_input_layer"].memory_data_param
+    assert (md.batch_size, md.channels, md.height, md.width) == (32, 1, S, 1) and list(by["state_input_layer"].top) == ["states", "dummy1"]
+    ip1 = by["ip1_layer"]
+    assert ip1.inner_product_param.num_output == HID[0] and ip1.inner_product_param.weight_filler.type == "gaussian"
+    assert abs(ip1.inner_product_param.weight_filler.std - 0.01) < 1e-9
+    assert list(ip1.bottom) == ["states" if actor else "state_actions"] and list(ip1.top) == ["ip1"]
+    r = by["ip2_relu_layer"]
+    assert abs(r.relu_param.negative_slope - 0.01) < 1e-9 and list(r.bottom) == list(r.top) == ["ip2"]       # in place
+    if actor:
+        assert list(by[sp].bottom) == ["ip%d" % L] and list(by[sp].top) == [sp + "_0", sp + "_1"]
+        assert list(by["action_layer"].bottom) == [sp + "_0"] and list(by["actionpara_layer"].bottom) == [sp + "_1"]
+        assert by["actionpara_layer"].inner_product_param.num_output == 6
+    else:
+        assert by["concat"].concat_param.axis == 2 and list(by["concat"].bottom) == ["states", "actions", "action_params"]
+        t = by["target_input_layer"].memory_data_param
+        assert (t.batch_size, t.channels, t.height, t.width) == (32, 1, 1, 1)
+        assert list(by["loss"].bottom) == ["q_values", "target"] and list(by["silence"].bottom) == ["dummy1", "dummy2", "dummy3", "dummy4"]
+
+
 def test_caffemodel_and_solverstate_layout(pkg, gpu, tmp_path):
     dqn, orc, data, rng = make_pair(pkg, B=32, S=S, hidden=HID, save_path=str(tmp_path / "run_agent0"))
     for _ in range(3):
@@ -41,7 +79,9 @@ def test_caffemodel_and_solverstate_layout(pkg, gpu, tmp_path):
         cm, ss = pre + "_%s_iter_3.caffemodel" % tag, pre + "_%s_iter_3.solverstate" % tag
         assert os.path.isfile(cm) and os.path.isfile(ss)
         m = NetParameter(); m.ParseFromString(open(cm, "rb").read())
-        assert m.name == ("Actor" if actor else "Critic") and [l.name for l in m.layer] == names(actor)
+        assert m.name == ("Actor" if actor else "Critic")
+        assert [l.name for l in m.layer if l.blobs] == names(actor)
+        check_full_layer_list(m, actor)
         np.testing.assert_array_equal(dense_from_net(m, actor), dqn.get_params(net))
         st = SolverState(); st.ParseFromString(open(ss, "rb").read())
         assert st.iter == 3 and st.current_step == 0 and st.learned_net.endswith("_%s_iter_3.caffemodel" % tag)
