@@ -143,3 +143,7 @@ def test_unchanged_driver_trains_on_the_gpu(pkg, gpu, tmp_path):
     r5 = subprocess.run(cmd + ["-benchmark", "-minibatch", "256"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
     log5 = r5.stderr + "".join(open(f).read() for f in glob.glob(save + "_INFO_*"))
     assert r5.returncode == 0 and "*** Benchmark begins ***" in log5 and "Average Update: " in log5, log5[-2000:]
+    # the same benchmark with the two host-side options of the drop-in: one-deep pipelined read-back, device-side sampling
+    for extra in (["-pipelined_stats"], ["-device_sampling"]):
+        r6 = subprocess.run(cmd + ["-benchmark", "-minibatch", "256"] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+        assert r6.returncode == 0 and "Average Update: " in r6.stderr + "".join(open(f).read() for f in glob.glob(save + "_INFO_*")), r6.stderr[-2000:]
