@@ -85,8 +85,8 @@ MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: fp16/bf16 dense MFMA peak
 
 KERNEL_NAMES = {"hgemm_fwd": "hgemm_nt<2,2>/<1,1> (forward epilogue)", "hgemm_dgrad": "hgemm_nt (dgrad epilogue)",
                 "hgemm_wgrad": "hgemm_nt (wgrad epilogue)","gemm_fwd_lds_4x2": "gemm_fwd_lds<4,2,true,2>", "gemm_fwd_lds_2x2": "gemm_fwd_lds<2,2,true,2>",
-                "gemm_fwd_direct": "gemm_fwd_direct<4,2,0>", "gemm_bwd_pair": "gemm_bwd_seq<true>",
-                "gemm_dgrad": "gemm_dgrad_lds<1,1>", "gemm_wgrad": "gemm_wgrad_direct<1,1>"}
+                "gemm_fwd_direct": "gemm_fwd_direct<4,2>", "gemm_bwd_pair": "gemm_bwd_seq<true>",
+                "gemm_dgrad": "gemm_dgrad_lds<1,1>", "gemm_wgrad": "gemm_wgrad_narrow<1>"}
 
 
 PMC_SUMMARY = "profiles/r03_pmc_summary.json"
@@ -127,6 +127,46 @@ def pmc_traffic(kernel):
         return int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024), "%s (%s)" % (PMC_SUMMARY, j.get("kernels_version", "kernel version not recorded"))
     except Exception:
         return None, None
+
+
+def live_pmc_traffic(kernel, extra_args):
+    """HBM-side bytes per launch of `kernel`, measured NOW on this box: two child runs of this script under
+    `rocprofv3 --kernel-trace --pmc <one counter>` (FETCH_SIZE, then WRITE_SIZE: separate passes, no other trace domain, as
+    MI355X_MICROARCH.md prescribes), eager launches, a small replay.  2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950
+    correction for wide coalesced reads).  Returns (bytes, source) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    want = kernel.replace(" ", "")
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="dqnhip_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--prewarm-ms", "0", "--no-graph", "--no-cpu-baseline",
+               "--no-env", "--no-subrecords", "--no-live-pmc", "--replay", "100000"] + list(extra_args)
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        except Exception as e:          # noqa: BLE001
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "rocprofv3 pass %s failed: %r" % (counter, e)
+        acc = []
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                n = row["Kernel_Name"].replace("void ", "").replace("dqnhip::", "")
+                n = (n[:n.index("(")] if "(" in n else n).replace(" ", "")
+                if n == want and row["Counter_Name"] == counter:
+                    acc.append(float(row["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
+        if not acc:
+            return None, "rocprofv3 pass %s: no rows for %s (rc %d)" % (counter, want, r.returncode)
+        vals[counter] = sum(acc) / len(acc)
+    return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
+        "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes of this bench.py, eager, "
+        "%d + %d launches averaged); 2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md" % (len(acc), len(acc)))
 
 
 def prefill(dqn, n, seed, chunk=131072):
@@ -351,6 +391,7 @@ def main():
     ap.add_argument("--dp-fp32-grads", action="store_true", help="native DP, fp16 learner: all-reduce fp32 gradients instead of bf16 (DQNHIP_DP_HALF_GRADS)")
     ap.add_argument("--dp-timeout", type=int, default=600, help="N > 1: seconds the headline measurement may take before every rank gives up")
     ap.add_argument("--tuning", type=int, default=0, help="dqnhip_config.tuning_flags (A/B switches, include/dqnhip.h DQNHIP_TUNE_*)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC summary instead of two live rocprofv3 --pmc child passes")
     ap.add_argument("--no-subrecords", action="store_true", help="skip the per-config sub-records (configs #3, #5; strong scaling under N > 1)")
     ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],
                     help="N>1: dp = gradient all-reduce (weak scaling), replicas = independent learners")
@@ -510,9 +551,18 @@ def main():
         per_update_launches = cnt / n_t
         flops_per_launch = fam_flops[dom] / per_update_launches
         ach = flops_per_launch / (ms * 1e-3) / 1e12
+        traffic, traffic_src = (None, None)
+        if world == 1 and not args.no_live_pmc:
+            extra = ["--minibatch", str(B), "--precision", args.precision, "--tuning", str(args.tuning)]
+            traffic, traffic_src = live_pmc_traffic(KERNEL_NAMES[dom], extra)
+        if traffic is None:
+            why = traffic_src
+            traffic, traffic_src = pmc_traffic(KERNEL_NAMES[dom])
+            if traffic_src and why:
+                traffic_src += " [live PMC pass unavailable: %s]" % why
         roof = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(KERNEL_NAMES[dom])[0],
-                "traffic_source": pmc_traffic(KERNEL_NAMES[dom])[1],
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "avg_launch_us": round(ms * 1e3, 2), "launches_per_update": per_update_launches,
                 "flops_per_launch": flops_per_launch,
                 "families_us": {f: [round(stats[f][0] * 1e3, 2), stats[f][1] / n_t] for f in stats}}
