@@ -1153,6 +1153,7 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   if (h->cfg.dp_world > 1) return fail("dqnhip_update_async: dp_world > 1 requires dqnhip_update_phase + all-reduce (or dqnhip_dp_update)");
+  if (h->dp_half) return fail("dqnhip_update_async: this learner exchanges bf16 gradients (DQNHIP_DP_HALF_GRADS): use dqnhip_dp_update");
   if (h->next_phase != 0) return fail("dqnhip_update_async: a phased update is in progress (next phase %d)", h->next_phase);
   RingUse ring_use(h);
   RC(sync_dirty16(h));
@@ -1184,6 +1185,9 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
 int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
+  // (with DQNHIP_DP_HALF_GRADS the exchange — bf16 image, all-reduce, widening by the clip-norm pass — lives inside
+  // dqnhip_dp_update: a caller-driven exchange between phases would leave phase 1 / 2 reading a stale bf16 image)
+  if (h->dp_half) return fail("dqnhip_update_phase: this learner exchanges bf16 gradients (DQNHIP_DP_HALF_GRADS): use dqnhip_dp_update");
   // 0 -> 1 -> 2 or 10 -> 11 -> 1 -> 2: a phase run out of order would apply stale gradients
   // and advance the iteration counters
   const int expect = h->next_phase;
@@ -1253,7 +1257,7 @@ int dqnhip_update(dqnhip_handle h, const int32_t* idx_host, float* critic_loss, 
 int dqnhip_update_pipelined(dqnhip_handle h, const int32_t* idx_host, float* critic_loss, float* avg_q) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
-  if (h->cfg.dp_world > 1) return fail("dqnhip_update_pipelined: dp_world > 1 requires dqnhip_update_phase / dqnhip_dp_update");
+  if (h->cfg.dp_world > 1 || h->dp_half) return fail("dqnhip_update_pipelined: data-parallel learners use dqnhip_update_phase / dqnhip_dp_update");
   if (h->next_phase != 0) return fail("dqnhip_update_pipelined: a phased update is in progress (next phase %d)", h->next_phase);
   if (!h->pipe_ev[0]) {
     for (int i = 0; i < 2; ++i) {

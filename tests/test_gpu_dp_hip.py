@@ -336,6 +336,12 @@ def test_native_rccl_half_grads_one_rank(pkg, gpu, precision, B, hid):
         dd = np.abs(dp.get_params(net) - ref.get_params(net))
         assert dd.max() <= 3 * lr[net] + 1e-6 and dd.mean() <= 0.05 * lr[net] + 1e-8, (net, dd.max(), dd.mean())
     assert dp.skipped_steps() == 0
+    # the bf16 exchange lives inside dqnhip_dp_update: the other update entry points refuse instead of reading a stale image
+    for call in (lambda: dp.update_async(idx[0]), lambda: dp.update_phase(0, idx[0]), lambda: dp.UpdateActorCriticPipelined(idx[0])):
+        with pytest.raises(pkg.DQNFatal, match="dqnhip_dp_update"):
+            call()
+    dp.dp_destroy()                                          # without the communicator it is a plain learner again
+    dp.UpdateActorCritic(idx[0])
     dp.close(); ref.close()
 
 
