@@ -16,12 +16,16 @@ S, hid = 58, (256, 128, 128)
 tmp = tempfile.mkdtemp()
 A = pkg.DQN(S, minibatch=MB, hidden=hid, memory=20000, seed=1, use_graph=True, save_path=os.path.join(tmp, "a"), precision=prec)
 Bl = pkg.DQN(S, minibatch=MB, hidden=hid, memory=20000, seed=2, use_graph=False, save_path=os.path.join(tmp, "b"), precision=prec)
+DP = pkg.DQN(S, minibatch=MB, hidden=hid, memory=20000, seed=5, use_graph=True, precision=prec, dp_world=1, dp_rank=0)
+DP.dp_init(pkg.DQN.dp_unique_id(), per_layer=(prec == "fp32"), half_grads=(prec == "fp16"))
+DP.add_transitions_arrays(*synth_replay(rng, 3000, S, mean_len=20))
 envA = pkg.EnvFrontEnd(A, 48, max_steps=80, p_end=0.03, seed=3)
 envB = pkg.EnvFrontEnd(Bl, 16, max_steps=80, p_end=0.03, seed=4)
 shared_w = shared_r = False
 t0 = time.time(); ops = 0; counts = {}
 while time.time() - t0 < budget:
-    op = rng.choice(["envA", "envB", "updA", "updB", "add", "share_w", "share_r", "snap", "file", "act"], p=[.2, .15, .2, .15, .08, .05, .02, .05, .05, .05])
+    op = rng.choice(["envA", "envB", "updA", "updB", "add", "share_w", "share_r", "snap", "file", "act", "pipe", "dp", "apply"],
+                    p=[.18, .13, .17, .12, .08, .05, .02, .05, .05, .05, .04, .04, .02])
     counts[op] = counts.get(op, 0) + 1; ops += 1
     if op == "envA": envA.step(float(rng.random()), int(rng.integers(1, 40)))
     elif op == "envB": envB.step(float(rng.random()), int(rng.integers(1, 40)))
@@ -31,6 +35,18 @@ while time.time() - t0 < budget:
             for _ in range(int(rng.integers(1, 8))):
                 l, q = d.UpdateActorCritic()
                 assert np.isfinite(l) and np.isfinite(q), (op, l, q)
+    elif op == "pipe" and A.memory_size() >= 200:         # one-deep pipelined read-back (dqnhip_update_pipelined), then drained
+        for _ in range(int(rng.integers(2, 9))):
+            l, q = A.UpdateActorCriticPipelined(rng.integers(0, A.memory_size(), MB) if rng.random() < 0.5 else None)
+            assert np.isfinite(l) and np.isfinite(q)
+        assert all(np.isfinite(A.read_stats()))
+    elif op == "dp" and DP.memory_size() >= 200:          # captured data-parallel update on a one-rank communicator (bf16 exchange for fp16)
+        for _ in range(int(rng.integers(1, 6))):
+            DP.dp_update(None)
+        assert all(np.isfinite(DP.read_stats()))
+    elif op == "apply" and A.actor_iter() > 0 and not shared_w:   # an isolated ApplyUpdate on the gradient left in the arena
+        A.apply_update(int(rng.integers(0, 2)))
+        assert np.isfinite(A.get_params(0)).all()
     elif op == "add":
         d = A if rng.random() < 0.5 else Bl
         d.add_transitions_arrays(*synth_replay(rng, int(rng.integers(1, 3000)), S, mean_len=20))
@@ -70,4 +86,5 @@ for d in (A, Bl):
 print("chaos OK: %d ops in %.0fs" % (ops, time.time() - t0), counts, "iters", A.actor_iter(), Bl.actor_iter(), "memory", A.memory_size(), Bl.memory_size())
 envB.close(); envA.close()
 if shared_w: A.ShareParameters(Bl, 0, 0)
-Bl.close(); A.close()
+assert DP.dp_graph_active() or DP.actor_iter() == 0
+Bl.close(); A.close(); DP.close()
