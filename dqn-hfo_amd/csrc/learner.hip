@@ -629,7 +629,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
   if (phase == 11) {
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
-    hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
+    hA.out16 = h->aout16; hA.xc = nullptr; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
     hA.xc16 = h->act16[4][0]; hA.ldxc16 = h->k16[1][0];
     RC(tower_forward16(h, st, 1, DQNHIP_ACTOR, B));
     RC((head_forward<kNO, HEAD_ACTOR>(h, st, hA)));
@@ -639,7 +639,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     // the gather writes the five minibatch panels in fp16 as well (what the GEMMs read: no conversion launch); the
     // action columns of the two critic panels the actor heads fill are still zero here — the heads write mu / mu'
     // straight into the fp32 AND the fp16 panels
-    GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
+    GatherOut go{nullptr, nullptr, la.kp[0], nullptr, nullptr, nullptr, lc.kp[0],
                  h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx,
                  h->act16[1][0], h->act16[0][0], h->act16[3][0], h->act16[4][0], h->act16[2][0]};
     hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
@@ -649,10 +649,10 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     else RC(tower_forward16_pair(h, st, 0, DQNHIP_ACTOR_TARGET, 1, DQNHIP_ACTOR, B));
     HeadArgs hAT{}; hAT.X = h->act[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
     hAT.W = wat(h, DQNHIP_ACTOR_TARGET, la.hw_off); hAT.b = wat(h, DQNHIP_ACTOR_TARGET, la.hb_off);
-    hAT.out16 = h->aout_t16; hAT.xc = h->Xc_nx; hAT.ldxc = lc.kp[0]; hAT.xc_col = h->S;
+    hAT.out16 = h->aout_t16; hAT.xc = nullptr; hAT.ldxc = lc.kp[0]; hAT.xc_col = h->S;     // (fp32 panels: unused in fp16 mode)
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
-    hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
+    hA.out16 = h->aout16; hA.xc = nullptr; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
     hAT.xc16 = h->act16[2][0]; hAT.ldxc16 = h->k16[1][0]; hA.xc16 = h->act16[4][0]; hA.ldxc16 = h->k16[1][0];
     if (split) RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT)));
     else RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));

@@ -174,11 +174,13 @@ __global__ void k_gather(Ring ring, const DevState* rs, const DevState* st, cons
   for (int c = lane; c < o.KcP; c += 64) {
     const float sv = c < S ? sp[c] : 0.0f;
     const float nv = c < S ? np[c] : 0.0f;
-    if (c < o.KaP) { o.Xa_s[(size_t)row * o.KaP + c] = sv; o.Xa_n[(size_t)row * o.KaP + c] = nv; }
     const float av = (c >= S && c < S + kNO) ? ap[c - S] : 0.0f;
-    o.Xc_tr[(size_t)row * o.KcP + c] = c < S ? sv : av;
-    o.Xc_pl[(size_t)row * o.KcP + c] = sv;
-    o.Xc_nx[(size_t)row * o.KcP + c] = nv;
+    if (o.Xa_s != nullptr) {                   // (fp16 learner: nothing reads the fp32 panels — not written)
+      if (c < o.KaP) { o.Xa_s[(size_t)row * o.KaP + c] = sv; o.Xa_n[(size_t)row * o.KaP + c] = nv; }
+      o.Xc_tr[(size_t)row * o.KcP + c] = c < S ? sv : av;
+      o.Xc_pl[(size_t)row * o.KcP + c] = sv;
+      o.Xc_nx[(size_t)row * o.KcP + c] = nv;
+    }
     if (o.Ha_s != nullptr) {
       if (c < o.KaP) { o.Ha_s[(size_t)row * o.KaP + c] = (_Float16)sv; o.Ha_n[(size_t)row * o.KaP + c] = (_Float16)nv; }
       o.Hc_tr[(size_t)row * o.KcP + c] = (_Float16)(c < S ? sv : av);
