@@ -154,7 +154,9 @@ struct dqnhip_learner {
   float* dZc[kMaxL + 1] = {nullptr};
   float *mb_reward = nullptr, *mb_mc = nullptr, *mb_term = nullptr;
   int* mb_idx = nullptr;
-  int* idx_dev = nullptr; int* idx_pinned = nullptr;
+  int* idx_pinned = nullptr;
+  const int* idx_pinned_dev = nullptr;  // device alias of idx_pinned: the gather reads explicit indices straight from host memory (no H2D copy)
+  float* stats_dev = nullptr;           // device alias of pinned_stats: the update's last block writes {loss, avg_q, flags} there
   float *aout_t16 = nullptr, *aout16 = nullptr, *dA16 = nullptr;
   float *q_t = nullptr, *q1 = nullptr, *q2 = nullptr, *y = nullptr, *dq = nullptr;
   float* loss_partial = nullptr; double* q_partial = nullptr; int n_head_blocks = 0;
@@ -713,7 +715,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
   }
   if (phase == 2) {
     const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
-                        dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world)};
+                        dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world), h->stats_dev};
     if (part16) RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick));
     else { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena, &tick)); }   // + iteration counters / statistics
     h->h_actor_iter += 1; h->h_critic_iter += 1;
@@ -841,7 +843,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // the actor's optimiser pass is the update's last launch: its last-arriving block also publishes
     // (critic_loss, avg_q) and advances the iteration / sampling counters
     const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
-                        dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world)};
+                        dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world), h->stats_dev};
     if (dp) { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena, &tick)); }
     else RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick));
     h->h_actor_iter += 1; h->h_critic_iter += 1;
@@ -871,8 +873,7 @@ int stage_indices(H* h, const int32_t* idx_host, const int** idx_dev) {
     // the pinned staging buffer may still be in flight from the previous update
     HIPCHK(hipStreamSynchronize(h->stream));
     memcpy(h->idx_pinned, idx_host, h->B * sizeof(int));
-    HIPCHK(hipMemcpyAsync(h->idx_dev, h->idx_pinned, h->B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    *idx_dev = h->idx_dev;
+    *idx_dev = h->idx_pinned_dev;           // the gather reads them from the pinned host buffer itself
   }
   return 0;
 }
@@ -1000,9 +1001,12 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
     for (int i = 1; i <= L; ++i) RC(dalloc(&h->act[p][i], (size_t)B * layout_of(h, p >= 2).kp[i]));
   for (int i = 0; i <= L; ++i) { RC(dalloc(&h->dZa[i], (size_t)B * h->la.kp[i])); RC(dalloc(&h->dZc[i], (size_t)B * h->lc.kp[i])); }
   RC(dalloc(&h->mb_reward, B)); RC(dalloc(&h->mb_mc, B)); RC(dalloc(&h->mb_term, B));
-  HIPCHK(hipMalloc(&h->mb_idx, B * sizeof(int))); HIPCHK(hipMalloc(&h->idx_dev, B * sizeof(int)));
-  HIPCHK(hipHostMalloc((void**)&h->idx_pinned, B * sizeof(int), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&h->pinned_stats, 64, hipHostMallocDefault));
+  HIPCHK(hipMalloc(&h->mb_idx, B * sizeof(int)));
+  HIPCHK(hipHostMalloc((void**)&h->idx_pinned, B * sizeof(int), hipHostMallocMapped));
+  HIPCHK(hipHostMalloc((void**)&h->pinned_stats, 64, hipHostMallocMapped));
+  memset(h->pinned_stats, 0, 64);
+  { void* d = nullptr; HIPCHK(hipHostGetDevicePointer(&d, h->idx_pinned, 0)); h->idx_pinned_dev = (const int*)d;
+    HIPCHK(hipHostGetDevicePointer(&d, h->pinned_stats, 0)); h->stats_dev = (float*)d; }
   RC(dalloc(&h->aout_t16, (size_t)B * kAP)); RC(dalloc(&h->aout16, (size_t)B * kAP)); RC(dalloc(&h->dA16, (size_t)B * kAP));
   RC(dalloc(&h->q_t, B)); RC(dalloc(&h->q1, B)); RC(dalloc(&h->q2, B)); RC(dalloc(&h->y, B)); RC(dalloc(&h->dq, B));
   h->n_head_blocks = (B + 3) / 4;
@@ -1097,7 +1101,6 @@ int dqnhip_destroy(dqnhip_handle h) {
   for (auto& g : h->graph_exec) if (g) hipGraphExecDestroy(g);
   for (int i = 0; i < 2; ++i) {
     if (h->pipe_ev[i]) hipEventDestroy(h->pipe_ev[i]);
-    if (h->pipe_idx_dev[i]) hipFree(h->pipe_idx_dev[i]);
     if (h->pipe_idx_pinned[i]) hipHostFree(h->pipe_idx_pinned[i]);
     if (h->pipe_stats[i]) hipHostFree(h->pipe_stats[i]);
   }
@@ -1109,7 +1112,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   hipFree(h->Xa_s); hipFree(h->Xa_n); hipFree(h->Xc_tr); hipFree(h->Xc_pl); hipFree(h->Xc_nx);
   for (int p = 0; p < 5; ++p) for (int i = 1; i <= h->L; ++i) hipFree(h->act[p][i]);
   for (int i = 0; i <= h->L; ++i) { hipFree(h->dZa[i]); hipFree(h->dZc[i]); }
-  hipFree(h->mb_reward); hipFree(h->mb_mc); hipFree(h->mb_term); hipFree(h->mb_idx); hipFree(h->idx_dev);
+  hipFree(h->mb_reward); hipFree(h->mb_mc); hipFree(h->mb_term); hipFree(h->mb_idx);
   hipHostFree(h->idx_pinned); hipHostFree(h->pinned_stats);
   hipFree(h->aout_t16); hipFree(h->aout16); hipFree(h->dA16);
   hipFree(h->q_t); hipFree(h->q1); hipFree(h->q2); hipFree(h->y); hipFree(h->dq);
@@ -1132,11 +1135,7 @@ static int capture_graph(H* h, int which, const int* idx_fixed = nullptr) {
   HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
   const int* idx_dev = idx_fixed;
-  if (which == 1) {
-    hipError_t e = hipMemcpyAsync(h->idx_dev, h->idx_pinned, h->B * sizeof(int), hipMemcpyHostToDevice, h->stream);
-    if (e != hipSuccess) rc = fail("capture memcpy: %s", hipGetErrorString(e));
-    idx_dev = h->idx_dev;
-  }
+  if (which == 1) idx_dev = h->idx_pinned_dev;
   const int it_a = h->h_actor_iter, it_c = h->h_critic_iter;
   for (int p = 0; p < 3 && !rc; ++p) rc = run_phase(h, p, idx_dev);
   h->h_actor_iter = it_a; h->h_critic_iter = it_c;   // capture does not execute
@@ -1218,13 +1217,13 @@ int dqnhip_update_abort(dqnhip_handle h) {
 int dqnhip_read_stats(dqnhip_handle h, float* critic_loss, float* avg_q) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
-  // {critic_loss, avg_q, flags, skipped_steps} are contiguous in DevState
-  HIPCHK(hipMemcpyAsync(h->pinned_stats, &h->st->critic_loss, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  // {critic_loss, avg_q, flags}: the last block of every update writes them into this pinned, host-mapped buffer itself
+  // (tick_body): no device-to-host copy, the stream sync is the only wait
   HIPCHK(hipStreamSynchronize(h->stream));
   if (critic_loss) *critic_loss = h->pinned_stats[0];
   if (avg_q) *avg_q = h->pinned_stats[1];
   int flags = 0; memcpy(&flags, &h->pinned_stats[2], sizeof flags);
-  if (flags) HIPCHK(hipMemsetAsync(&h->st->flags, 0, sizeof(int), h->stream));   // sticky until reported
+  if (flags) { HIPCHK(hipMemsetAsync(&h->st->flags, 0, sizeof(int), h->stream)); h->pinned_stats[2] = 0.0f; }   // sticky until reported
   // CHECK(std::isfinite(target)) (src/dqn.cpp:898) and CHECK(std::isfinite(critic_loss)) (:906) — the
   // reference aborts; here: an error code from the first read after the offending update, whichever
   // entry point (blocking, async, phased, hipGraph) ran it
@@ -1262,8 +1261,8 @@ int dqnhip_update_pipelined(dqnhip_handle h, const int32_t* idx_host, float* cri
   if (!h->pipe_ev[0]) {
     for (int i = 0; i < 2; ++i) {
       HIPCHK(hipEventCreateWithFlags(&h->pipe_ev[i], hipEventDisableTiming));
-      HIPCHK(hipMalloc(&h->pipe_idx_dev[i], h->B * sizeof(int)));
-      HIPCHK(hipHostMalloc((void**)&h->pipe_idx_pinned[i], h->B * sizeof(int), hipHostMallocDefault));
+      HIPCHK(hipHostMalloc((void**)&h->pipe_idx_pinned[i], h->B * sizeof(int), hipHostMallocMapped));
+      { void* d = nullptr; HIPCHK(hipHostGetDevicePointer(&d, h->pipe_idx_pinned[i], 0)); h->pipe_idx_dev[i] = (int*)d; }
       HIPCHK(hipHostMalloc((void**)&h->pipe_stats[i], 64, hipHostMallocDefault));
       memset(h->pipe_stats[i], 0, 64);
     }
@@ -1279,8 +1278,7 @@ int dqnhip_update_pipelined(dqnhip_handle h, const int32_t* idx_host, float* cri
         if (idx_host[i] < 0 || idx_host[i] >= RO(h)->h_size) return fail("sampled index %d = %d out of range [0,%lld)", i, idx_host[i], RO(h)->h_size);
       // slot's previous user was update t-2, whose completion the previous call already waited for
       memcpy(h->pipe_idx_pinned[slot], idx_host, h->B * sizeof(int));
-      HIPCHK(hipMemcpyAsync(h->pipe_idx_dev[slot], h->pipe_idx_pinned[slot], h->B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-      idx_dev = h->pipe_idx_dev[slot];
+      idx_dev = h->pipe_idx_dev[slot];      // device alias of the pinned slot (no H2D copy)
     } else if (RO(h)->h_size < 1) {
       RC(refresh_ring(h));
       if (RO(h)->h_size < 1) return fail("replay memory is empty");

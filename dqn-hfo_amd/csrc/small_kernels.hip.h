@@ -786,6 +786,9 @@ __global__ __launch_bounds__(256) void k_sumsq_bf16(const uint16_t* __restrict__
 struct TickArgs {
   DevState* st; float* critic_tail; float* actor_tail;
   const float* loss_partial; int n_loss; const double* q_partial; int n_q; float batch;
+  // host-mapped (pinned) copy of {critic_loss, avg_q, flags}: written by the update's last block, so
+  // that dqnhip_read_stats needs a stream sync but no device-to-host copy (null: none)
+  float* host_stats;
 };
 struct AdamArgs {
   float* w; float* g; float* m; float* v; float* wt;
@@ -900,7 +903,7 @@ __global__ __launch_bounds__(256) void k_adam_soft_t(AdamArgs a) {
   __shared__ float s[8];
   adam_soft_body<U, NT>(a, blockIdx.x, gridDim.x, s);
 }
-__device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot, double* sq);   // below
+__device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot, double* sq, bool skipped_now);   // below
 
 __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   __shared__ float s[8];
@@ -926,7 +929,7 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
     s_last = last;
   }
   __syncthreads();
-  if (s_last) tick_body(a.tick, s, sq);
+  if (s_last) tick_body(a.tick, s, sq, s[7] != 0.0f);
 }
 
 // Sum of up to 8 co-located gradient arenas in rank order, written back to all (dqnhip_reduce_gradients_local)
@@ -974,7 +977,7 @@ __global__ __launch_bounds__(256) void k_tails(const float* loss_partial, int n_
 // is taken from the per-block double partials when they are local (single GPU),
 // from the all-reduced float tail under data parallelism.
 // One block of 256 threads: strided partial sums, fixed butterfly + fixed cross-wave order.
-__device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot /*[4]*/, double* sq /*[4]*/) {
+__device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot /*[4]*/, double* sq /*[4]*/, bool skipped_now) {
   const int t = threadIdx.x;
   double qs = 0.0;
   if (a.q_partial != nullptr) {          // single GPU: reduce the per-block partials here
@@ -996,6 +999,14 @@ __device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot /*[4]*/
   a.st->critic_loss = a.critic_tail[0];
   a.st->avg_q = (float)(qs / (double)a.batch);
   a.st->actor_iter += 1; a.st->critic_iter += 1; a.st->update_counter += 1;
+  if (a.host_stats != nullptr) {
+    // the flags were raised with device-scope atomics (by earlier kernels of this update, or by block 0 of THIS launch —
+    // whose atomic may still be in flight: this block derived the same skip decision itself); read them the same way
+    int fl = __hip_atomic_load(&a.st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (skipped_now) fl |= kFlagGradNorm;
+    a.host_stats[0] = a.critic_tail[0]; a.host_stats[1] = (float)(qs / (double)a.batch);
+    a.host_stats[2] = __builtin_bit_cast(float, fl);
+  }
 }
 // ++iter of one solver (dqnhip_apply_update: set_iter(iter() + 1), src/dqn.cpp:965)
 __global__ void k_advance_iter(DevState* st, int which) {
