@@ -324,7 +324,8 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
                                             "run checks it" % (XGMI_LINK_GBS_ONE_WAY, COLLECTIVE_LATENCY_US)}
             rec[prec] = r
         out["configs4_rank_shape_b512"] = rec
-        return out
+        if not (args.test_strong_record and native):
+            return out
     if not native:
         return None
     # N > 1: STRONG scaling of a global minibatch of 4096 (where the batch warrants DP)
@@ -339,10 +340,17 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
         prefill(d, 150000, seed=7 + rank)
         t_dp = timed(lambda: dp.update(None), barrier, n_it, 20)
 
-        def local_only():                 # the same kernels without the two collectives (timing only)
-            d.update_phase(0); d.update_phase(1); d.update_phase(2)
-        t_loc = timed(local_only, barrier, n_it, 10)
         d.close()
+        # the same rows without the two collectives (timing only): a learner of this rank's shape with no communicator,
+        # driven phase by phase (the bf16-exchange learner itself refuses the phase API: its exchange lives in dp_update)
+        loc = pkg.DQN(S, minibatch=rows, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, dp_world=max(world, 2), dp_rank=rank % max(world, 2),
+                      precision=prec, use_graph=False)
+        prefill(loc, 150000, seed=7 + rank)
+
+        def local_only():
+            loc.update_phase(0); loc.update_phase(1); loc.update_phase(2)
+        t_loc = timed(local_only, barrier, n_it, 10)
+        loc.close()
         t_one = None
         if rank == 0:                     # the single-GPU reference for the speed-up: whole global minibatch on rank 0
             one = pkg.DQN(S, minibatch=GB, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, use_graph=True, precision=prec)
@@ -391,6 +399,7 @@ def main():
     ap.add_argument("--dp-fp32-grads", action="store_true", help="native DP, fp16 learner: all-reduce fp32 gradients instead of bf16 (DQNHIP_DP_HALF_GRADS)")
     ap.add_argument("--dp-timeout", type=int, default=600, help="N > 1: seconds the headline measurement may take before every rank gives up")
     ap.add_argument("--tuning", type=int, default=0, help="dqnhip_config.tuning_flags (A/B switches, include/dqnhip.h DQNHIP_TUNE_*)")
+    ap.add_argument("--test-strong-record", action="store_true", help="testing: also run the N > 1 strong-scaling record with the ranks there are")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC summary instead of two live rocprofv3 --pmc child passes")
     ap.add_argument("--no-subrecords", action="store_true", help="skip the per-config sub-records (configs #3, #5; strong scaling under N > 1)")
     ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],

@@ -96,6 +96,28 @@ def test_bench_runs_under_torchrun_one_rank(pkg, gpu):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 100 and d["config"]["parallelism"].startswith("dp1")
+    assert d["config"]["hip_graph"] is True                     # the data-parallel update (RCCL included) replayed as a graph
+
+
+def test_bench_strong_scaling_record_with_the_ranks_there_are(pkg, gpu):
+    """The N > 1 side record (a global minibatch of 4096 split over the ranks: captured native RCCL update, fp32 with per-layer
+    buckets and fp16 with the bf16 exchange, the no-collective twin, the single-GPU reference, the projection) has only ever
+    been reachable on a multi-GPU node; --test-strong-record runs the same code with one rank."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29647", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "20", "--warmup", "5", "--replay", "20000", "--no-cpu-baseline", "--no-env", "--force-dp",
+           "--test-strong-record", "--no-live-pmc"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    import json
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    sub = d["sub_records"]
+    assert "error" not in sub, sub
+    for prec, exch in (("fp32", "fp32"), ("fp16", "bf16 gradients + fp32 tails")):
+        rec = sub["strong_b4096_%s" % prec]
+        assert rec["rows_per_gpu"] == 4096 and rec["exchange"] == exch
+        assert 0 < rec["ms_per_update_without_collectives"] and 0 < rec["ms_per_update"] < 2 * rec["ms_per_update_1gpu"] + 1
+        assert rec["projection"]["allreduce_us_one_ring"] == 0.0           # one rank: nothing crosses a link
 
 
 def test_bench_two_ranks_flow_on_one_gpu(pkg, gpu):
