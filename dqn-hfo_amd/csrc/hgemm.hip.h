@@ -4,29 +4,34 @@
 // One kernel shape serves the three uses of a tower layer (reference: Caffe InnerProduct
 // forward / backward, called from src/dqn.cpp:904, 923, 963):
 //
-//     C[m][n] = sum_k A[m][k] * B[n][k]          A: [M][lda], B: [N][ldb], both k-contiguous
+//     C[m][n] = sum_k A[m][k] * B[n][k]
 //
-//   FWD    m = batch row, n = out unit, k = in unit   A = X16,   B = W16  [N_out][K_in]
-//   DGRAD  m = batch row, n = in unit,  k = out unit  A = dY16,  B = WT16 [K_in][N_out]
-//   WGRAD  m = out unit,  n = in unit,  k = batch row A = dYT16, B = XT16
+// Every operand lives in HBM in ONE orientation — the batch-major fp16 panels X16 [rows][k_in], dY16 [rows][n_out] and
+// the fp16 weight mirror W16 [n_out][k_in] — and is either k-major for a GEMM (the reduction index contiguous: a lane's
+// v_mfma_f32_32x32x16_f16 fragment = 8 consecutive k of one row = one 16-B ds_read_b128) or REDUCTION-major (the
+// rows ARE the reduction index: the fragment then comes out of LDS through two transposing reads ds_read_b64_tr_b16):
 //
-// i.e. every operand is kept in HBM in BOTH orientations (fp16, written by the producing
-// epilogue) so that the reduction index is always the contiguous one: a v_mfma_f32_32x32x16_f16
-// lane consumes 8 consecutive k of one row = one 16-B piece.
+//   FWD    m = batch row, n = out unit, k = in unit    A = X16 (k-major)            B = W16 (k-major)
+//   DGRAD  m = batch row, n = in unit,  k = out unit   A = dY16 (k-major)           B = W16 (reduction-major)
+//   WGRAD  m = out unit,  n = in unit,  k = batch row  A = dY16 (reduction-major)   B = X16 (reduction-major)
+//
+// (HGemm::ta / tb; rounds 1-2a kept every panel in both orientations instead.)
 //
 // Data path: global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no
 // VGPR staging), 3-4 stage ring, one s_barrier per 64-deep K tile, counted vmcnt so the next
 // tiles stay in flight across the barrier.  The LDS image is [rows][64 halves] = 128-B rows
-// whose 16-B chunks are XOR-swizzled with (row>>1)&7: the DMA writes lane-linearly, so the
-// swizzle is applied to the per-lane SOURCE address; the ds_read_b128 lane groups of a 32-row
+// whose 16-B chunks are XOR-swizzled with (row>>1)&7 (reduction-major images: ((row>>1)&1)<<2): the DMA writes
+// lane-linearly, so the swizzle is applied to the per-lane SOURCE address; the ds_read_b128 lane groups of a 32-row
 // fragment ({0-3,12-15,20-27}, ...) then hit 16 distinct 16-B slots of the 256-B bank row.
 // Wave tile 64x64 (2x2 MFMA 32x32x16): 4 ds_read_b128 per 4 MFMA = 50 % of the LDS read rate.
 //   <2,2>: 128x128 workgroup tile, waves 2x2.
+//   <4,2>: 256x128 on eight waves (two per SIMD): two k-major problems of 4096 rows in one launch.
 //   <1,1>:  64x64  workgroup tile, the 4 waves split each K tile (k16 slice w) and the four
-//           partial tiles are added in the fixed order (w0+w1)+(w2+w3) — for problems with
-//           fewer than ~200 128x128 tiles (wgrad: N_out x K_in is only 8x8 tiles).
+//           partial tiles are added in the fixed order (w0+w1)+(w2+w3) — small minibatches.
+// One launch carries up to four problems of one tile configuration (hgemm_nt), or all wgrads of a net plus the
+// bias-gradient column sums (hgemm_group_db).
 // Epilogue through LDS (fp32 tile): bias + leaky-ReLU / ReLU' mask / scale, then coalesced
-// stores of the m-major fp16 panel, the fp32 panel and the transposed fp16 panel.
+// stores of the m-major fp16 panel and / or the fp32 panel (+ a per-workgroup sum of squares for the clip norm).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
