@@ -1446,11 +1446,16 @@ int dp_exchange(H* h, int net) {
     // tails of both nets travel once, with the actor's gradients (nothing reads them before the tick of phase 2).
     hipLaunchKernelGGL(k_to_bf16, dim3(1024), dim3(256), 0, st, (const float*)h->g[net], l.arena / 4, h->g16[net]);
     HIPCHK(hipGetLastError());
-    if (net == DQNHIP_ACTOR) NCCLCHK(ncclGroupStart());
-    NCCLCHK(ncclAllReduce(h->g16[net], h->g16[net], l.arena, ncclBfloat16, ncclSum, h->comm, st));
-    if (net == DQNHIP_ACTOR) {
-      NCCLCHK(ncclAllReduce(h->dp_tails, h->dp_tails, 8, ncclFloat, ncclSum, h->comm, st));
-      NCCLCHK(ncclGroupEnd());
+    if (net == DQNHIP_CRITIC) {
+      NCCLCHK(ncclAllReduce(h->g16[net], h->g16[net], l.arena, ncclBfloat16, ncclSum, h->comm, st));
+    } else {
+      // one grouped call: the actor's bf16 image and the 8 fp32 tail floats (a failure inside the group still closes it)
+      NCCLCHK(ncclGroupStart());
+      ncclResult_t r1 = ncclAllReduce(h->g16[net], h->g16[net], l.arena, ncclBfloat16, ncclSum, h->comm, st);
+      ncclResult_t r2 = r1 == ncclSuccess ? ncclAllReduce(h->dp_tails, h->dp_tails, 8, ncclFloat, ncclSum, h->comm, st) : r1;
+      ncclResult_t r3 = ncclGroupEnd();
+      if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess)
+        return fail("grouped ncclAllReduce (actor gradients + tails) failed: %s", ncclGetErrorString(r1 != ncclSuccess ? r1 : r2 != ncclSuccess ? r2 : r3));
     }
   } else if (h->dp_per_layer) {
     // the tower slices are already in flight on comm_stream; what is left is the head + tail slice, then the main
