@@ -6,7 +6,7 @@
  * reference's src/dqn.hpp:56-134.  The reference has no FFI of its own (it is
  * a C++ class linked statically into bin/dqn, CMakeLists.txt:32-33); the
  * entry points below are what a `dqn::DQN` adaptor class binds to (see
- * INTEGRATION.md and dqn-hfo_amd/csrc/dqn_adaptor.hpp).  Every function cites
+ * INTEGRATION.md, include/dqn.hpp and dqn-hfo_amd/csrc/dqn_dropin.cpp).  Every function cites
  * the reference method it replaces.
  *
  * Conventions
