@@ -516,7 +516,7 @@ HGemm fwd16_problem(H* h, int p, int net, int rows, int i) {
   g.B = h->w16[net][i]; g.ldb = h->k16[kind][i];
   g.M = rows; g.N = l.dims[i + 1]; g.K = h->k16[kind][i];
   g.C16 = h->act16[p][i + 1]; g.ldc16 = l.dims[i + 1];
-  if (i == l.L - 1) { g.C32 = h->act[p][l.L]; g.ldc32 = l.kp[l.L]; g.n_valid32 = l.dims[l.L]; }
+  // (no fp32 copy of the tower top: the head kernels read the fp16 panel, as every tower layer reads its input)
   g.bias = h->w[net] + l.b_off[i]; g.relu = 1; g.scale32 = 1.0f;
   return g;
 }
@@ -629,7 +629,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
   // behind (as on the fp32 path); data-parallel ranks need the norm of the REDUCED gradient: k_sumsq
   const bool part16 = !dp;
   if (phase == 11) {
-    HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
+    HeadArgs hA{}; hA.X16 = h->act16[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
     hA.out16 = h->aout16; hA.xc = nullptr; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
     hA.xc16 = h->act16[4][0]; hA.ldxc16 = h->k16[1][0];
@@ -649,10 +649,10 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     HIPCHK(hipGetLastError());
     if (split) RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B));
     else RC(tower_forward16_pair(h, st, 0, DQNHIP_ACTOR_TARGET, 1, DQNHIP_ACTOR, B));
-    HeadArgs hAT{}; hAT.X = h->act[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
+    HeadArgs hAT{}; hAT.X16 = h->act16[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
     hAT.W = wat(h, DQNHIP_ACTOR_TARGET, la.hw_off); hAT.b = wat(h, DQNHIP_ACTOR_TARGET, la.hb_off);
     hAT.out16 = h->aout_t16; hAT.xc = nullptr; hAT.ldxc = lc.kp[0]; hAT.xc_col = h->S;     // (fp32 panels: unused in fp16 mode)
-    HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
+    HeadArgs hA{}; hA.X16 = h->act16[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
     hA.out16 = h->aout16; hA.xc = nullptr; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
     hAT.xc16 = h->act16[2][0]; hAT.ldxc16 = h->k16[1][0]; hA.xc16 = h->act16[4][0]; hA.ldxc16 = h->k16[1][0];
@@ -661,8 +661,8 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     RC(tower_forward16_pair(h, st, 2, DQNHIP_CRITIC_TARGET, 3, DQNHIP_CRITIC, B));
     {
       HeadTrainArgs t{};
-      t.Xt = h->act[2][L]; t.Wt = wat(h, DQNHIP_CRITIC_TARGET, lc.hw_off); t.bt = wat(h, DQNHIP_CRITIC_TARGET, lc.hb_off);
-      t.X = h->act[3][L]; t.W = wat(h, DQNHIP_CRITIC, lc.hw_off); t.b = wat(h, DQNHIP_CRITIC, lc.hb_off);
+      t.Xt16 = h->act16[2][L]; t.Wt = wat(h, DQNHIP_CRITIC_TARGET, lc.hw_off); t.bt = wat(h, DQNHIP_CRITIC_TARGET, lc.hb_off);
+      t.X16 = h->act16[3][L]; t.W = wat(h, DQNHIP_CRITIC, lc.hw_off); t.b = wat(h, DQNHIP_CRITIC, lc.hb_off);
       t.H = Hc; t.rows = B; t.reward = h->mb_reward; t.mc = h->mb_mc; t.term = h->mb_term;
       t.q_target = h->q_t; t.q = h->q1; t.y = h->y; t.dq = h->dq; t.loss_partial = h->loss_partial;
       t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch; t.st = h->st;
@@ -670,8 +670,8 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       HIPCHK(hipGetLastError());
     }
     {
-      HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[3][L];
-      a.H = Hc; a.rows = B; a.dZ = h->dZc[L]; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
+      HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X416 = h->act16[3][L];
+      a.H = Hc; a.rows = B; a.dZ = nullptr; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
       if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->ls_c)); }
       else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_c; RC(head_backward<1>(h, st, a)); }
@@ -691,8 +691,8 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     RC(tower_forward16(h, st, 4, DQNHIP_CRITIC, B));
     {
       // q(s, mu(s)) rides in the dq = -1 head launch (rider blocks), as on the fp32 path
-      HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
-      a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
+      HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X416 = h->act16[4][L];
+      a.H = Hc; a.rows = B; a.dZ = nullptr;
       a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial;
       if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->ls_q)); }
       else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_q; RC(head_backward<1>(h, st, a)); }
@@ -700,7 +700,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     RC(tower_backward16(h, st, DQNHIP_CRITIC, 4, nullptr, h->dZc[0], B, false, true, h->ls_q));
     {
       HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;
-      a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.X4 = h->act[1][L]; a.H = Hh; a.rows = B; a.dZ = h->dZa[L];
+      a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.X416 = h->act16[1][L]; a.H = Hh; a.rows = B; a.dZ = nullptr;
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
       if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->ls_a)); }
       else { a.dZ16 = h->dZ16[0][L]; a.scale16 = h->ls_a; RC(head_backward<kNO>(h, st, a)); }

@@ -213,8 +213,24 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // the critic (src/dqn.cpp:426-427, 450) are K=H4 dot products per row: one wave
 // per row, float4 strips over k, butterfly reduce.
 enum HeadMode { HEAD_ACTOR = 0, HEAD_Q = 1, HEAD_Q_TRAIN = 2, HEAD_Q_POLICY = 3 };
+// Tower-top reads of the head kernels.  fp32 learner: the fp32 activation panel.  fp16 learner: the fp16 panel the last
+// tower layer's GEMM wrote for the next consumer anyway (x16 != null) — every other layer's input is the fp16-rounded
+// activation already, and a separate fp32 copy of the tower top cost 16 MB of writes per forward pass + twice the bytes
+// in every head kernel at 4096 rows.  The head arithmetic itself stays fp32.
+typedef __attribute__((ext_vector_type(4))) _Float16 head_h4;
+__device__ __forceinline__ f32x4 head_ld4(const float* x32, const _Float16* x16, size_t idx) {
+  if (x16 != nullptr) {
+    const head_h4 v = *reinterpret_cast<const head_h4*>(x16 + idx);
+    return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w};
+  }
+  return *reinterpret_cast<const f32x4*>(x32 + idx);
+}
+__device__ __forceinline__ float head_ld1(const float* x32, const _Float16* x16, size_t idx) {
+  return x16 != nullptr ? (float)x16[idx] : x32[idx];
+}
 struct HeadArgs {
   const float* X; int ldx; int H;      // [rows][H] tower top
+  const _Float16* X16;                 // fp16 learner: the same panel in fp16 (then X is null)
   const float* W; const float* b;      // [NH][H], [NH]
   int rows;
   // HEAD_ACTOR
@@ -252,9 +268,9 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
     float acc[NH];
 #pragma unroll
     for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
-    const float* x = a.X + (size_t)row * a.ldx;
+    const size_t x0 = (size_t)row * a.ldx;
     for (int k = threadIdx.x * 4; k < a.H; k += 1024) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
+      const f32x4 xv = head_ld4(a.X, a.X16, x0 + k);
 #pragma unroll
       for (int j = 0; j < NH; ++j) {
         const f32x4 wv = hoist ? wreg[j] : *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k);
@@ -294,22 +310,42 @@ template <int NH, int MODE>
 __global__ __launch_bounds__(256) void k_head_fwd_rows(HeadArgs2 a2) {
   const HeadArgs& a = a2.p[blockIdx.y];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // a lane's four float4 strips of a row: fp32 panel k = 4 lane + 256 t (16-B loads); fp16 panel k = 8 lane + 512 (t / 2)
+  // + 4 (t % 2), i.e. two 16-B loads of eight halves each (8-B loads run at about half the rate per byte)
+  const bool in16 = a.X16 != nullptr;
+  auto kof = [&](int t) { return in16 ? lane * 8 + 512 * (t >> 1) + 4 * (t & 1) : lane * 4 + 256 * t; };
   f32x4 wreg[NH][4];
 #pragma unroll
   for (int j = 0; j < NH; ++j)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int k = lane * 4 + 256 * t;
+      const int k = kof(t);
       wreg[j][t] = k < a.H ? *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   // the next row of this wave is fetched while the current one is reduced (the loop was one exposed memory latency
   // per row: 4 rows per wave at 4096 rows)
   auto load_row = [&](int row, f32x4 (&v)[4]) {
-    const float* x = a.X + (size_t)row * a.ldx;
+    const size_t x0 = (size_t)row * a.ldx;
+    if (in16) {
+      typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+      h8 u[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int k = lane * 4 + 256 * t;
-      v[t] = k < a.H ? *reinterpret_cast<const f32x4*>(x + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 2; ++q) {
+        const int k = lane * 8 + 512 * q;
+        if (k < a.H) u[q] = *reinterpret_cast<const h8*>(a.X16 + x0 + k);
+        else { for (int e = 0; e < 8; ++e) u[q][e] = (_Float16)0.f; }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        v[2 * q] = f32x4{(float)u[q][0], (float)u[q][1], (float)u[q][2], (float)u[q][3]};
+        v[2 * q + 1] = f32x4{(float)u[q][4], (float)u[q][5], (float)u[q][6], (float)u[q][7]};
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int k = lane * 4 + 256 * t;
+        v[t] = k < a.H ? *reinterpret_cast<const f32x4*>(a.X + x0 + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
   const int row_step = gridDim.x * 4;
@@ -355,6 +391,7 @@ __global__ __launch_bounds__(256) void k_head_fwd_rows(HeadArgs2 a2) {
 struct HeadTrainArgs {
   const float* Xt; const float* Wt; const float* bt;   // target critic top / head
   const float* X; const float* W; const float* b;      // online critic top / head
+  const _Float16* Xt16; const _Float16* X16;           // fp16 learner: the tower tops in fp16 (then Xt / X are null)
   int H, rows;
   const float* reward; const float* mc; const float* term;
   float* q_target; float* q; float* y; float* dq; float* loss_partial;
@@ -367,11 +404,10 @@ __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
   __shared__ float s_part[4];
   float at = 0.0f, ao = 0.0f;
   if (row < a.rows) {
-    const float* xt = a.Xt + (size_t)row * a.H;
-    const float* x = a.X + (size_t)row * a.H;
+    const size_t x0 = (size_t)row * a.H;
     for (int k = lane * 4; k < a.H; k += 256) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(xt + k), w0 = *reinterpret_cast<const f32x4*>(a.Wt + k);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + k), w1 = *reinterpret_cast<const f32x4*>(a.W + k);
+      const f32x4 v0 = head_ld4(a.Xt, a.Xt16, x0 + k), w0 = *reinterpret_cast<const f32x4*>(a.Wt + k);
+      const f32x4 v1 = head_ld4(a.X, a.X16, x0 + k), w1 = *reinterpret_cast<const f32x4*>(a.W + k);
       at = fmaf(v0.x, w0.x, at); at = fmaf(v0.y, w0.y, at); at = fmaf(v0.z, w0.z, at); at = fmaf(v0.w, w0.w, at);
       ao = fmaf(v1.x, w1.x, ao); ao = fmaf(v1.y, w1.y, ao); ao = fmaf(v1.z, w1.z, ao); ao = fmaf(v1.w, w1.w, ao);
     }
@@ -411,6 +447,7 @@ struct HeadBwdArgs {
   const float* aout16;                 // actor: mu(s) for the inverting bounds
   float* dA16;                         // actor: post-invert head diffs (debug / parity)
   const float* W; const float* X4; int H; int rows;
+  const _Float16* X416;                // fp16 learner: the tower top in fp16 (then X4 is null)
   float* dZ; float* dW; float* db; float* partial;
   float* slab;                         // [RC][H/64][NH][64] per-row-chunk partial dW
   int* ticket;                         // [H/64] arrival counters, zero before and after every launch
@@ -435,10 +472,10 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = (((int)blockIdx.y - RC) * (int)gridDim.x + (int)blockIdx.x) * 16 + wave;
     if (row >= a.rows) return;
-    const float* x = a.X4 + (size_t)row * a.H;
+    const size_t x0 = (size_t)row * a.H;
     float acc = 0.0f;
     for (int k = lane * 4; k < a.H; k += 256) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k), wv = *reinterpret_cast<const f32x4*>(a.W + k);
+      const f32x4 xv = head_ld4(a.X4, a.X416, x0 + k), wv = *reinterpret_cast<const f32x4*>(a.W + k);
       acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
     }
 #pragma unroll
@@ -483,7 +520,7 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   const int per = (r1 - r0 + 15) / 16;
   const int m0 = r0 + rg * per, m1 = min(r1, m0 + per);
   for (int m = m0; m < m1; ++m) {
-    const float xv = a.X4[(size_t)m * a.H + k];
+    const float xv = head_ld1(a.X4, a.X416, (size_t)m * a.H + k);
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
@@ -495,7 +532,7 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
     }
     if (NH == kNO) s0 += s1;
     const float dz = s0 * lrelu_mask(xv);
-    a.dZ[(size_t)m * a.H + k] = dz;
+    if (a.dZ != nullptr) a.dZ[(size_t)m * a.H + k] = dz;
     if (a.dZ16 != nullptr) a.dZ16[(size_t)m * a.H + k] = (_Float16)(dz * a.scale16);
   }
   if (!want_w) return;
@@ -590,13 +627,28 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
     for (int r0 = wv * 4; r0 < a.rows; r0 += nwave * 4) {
       if (hoist) {
         f32x4 xr[4][4];
+        if (a.X416 != nullptr) {
+          head_h4 hr[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int k = lane * 4 + 256 * t;
-            xr[j][t] = (r0 + j < a.rows && k < a.H) ? *reinterpret_cast<const f32x4*>(a.X4 + (size_t)(r0 + j) * a.H + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-          }
+            for (int t = 0; t < 4; ++t) {
+              const int k = lane * 4 + 256 * t;
+              hr[j][t] = (r0 + j < a.rows && k < a.H) ? *reinterpret_cast<const head_h4*>(a.X416 + (size_t)(r0 + j) * a.H + k) : head_h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xr[j][t] = f32x4{(float)hr[j][t].x, (float)hr[j][t].y, (float)hr[j][t].z, (float)hr[j][t].w};
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int k = lane * 4 + 256 * t;
+              xr[j][t] = (r0 + j < a.rows && k < a.H) ? *reinterpret_cast<const f32x4*>(a.X4 + (size_t)(r0 + j) * a.H + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float acc = 0.0f;
@@ -610,10 +662,10 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
         }
       } else {
         for (int j = 0; j < 4 && r0 + j < a.rows; ++j) {
-          const float* x = a.X4 + (size_t)(r0 + j) * a.H;
+          const size_t x0 = (size_t)(r0 + j) * a.H;
           float acc = 0.0f;
           for (int k = lane * 4; k < a.H; k += 256) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k), wv4 = *reinterpret_cast<const f32x4*>(a.W + k);
+            const f32x4 xv = head_ld4(a.X4, a.X416, x0 + k), wv4 = *reinterpret_cast<const f32x4*>(a.W + k);
             acc = fmaf(xv.x, wv4.x, acc); acc = fmaf(xv.y, wv4.y, acc); acc = fmaf(xv.z, wv4.z, acc); acc = fmaf(xv.w, wv4.w, acc);
           }
           acc = wave_sum64(acc);
@@ -649,8 +701,16 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
   // all 16 rows of the wave's strip in flight before the first use (the stores below may alias as far as the
   // compiler knows, so it would not hoist the loads itself: 4 in flight per thread made the kernel latency-bound)
   f32x4 xr[16];
+  if (a.X416 != nullptr) {
+    head_h4 hr[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) xr[r] = *reinterpret_cast<const f32x4*>(a.X4 + (size_t)(m0 + w * 16 + r) * a.H + k0);
+    for (int r = 0; r < 16; ++r) hr[r] = *reinterpret_cast<const head_h4*>(a.X416 + (size_t)(m0 + w * 16 + r) * a.H + k0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xr[r] = f32x4{(float)hr[r].x, (float)hr[r].y, (float)hr[r].z, (float)hr[r].w};
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xr[r] = *reinterpret_cast<const f32x4*>(a.X4 + (size_t)(m0 + w * 16 + r) * a.H + k0);
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ml = w * 16 + r, m = m0 + ml;

@@ -4,8 +4,8 @@ Three layers of evidence:
   1. the fp16 GEMM family itself (csrc/hgemm.hip.h) against a naive device reference on the same
      fp16 inputs — all epilogues, both tile configurations, ragged K, first-layer shapes;
   2. the learner's fp16 pipeline against a numpy emulation that rounds to fp16 at exactly the points
-     the kernels do (weights, panels, every stored activation / gradient) and accumulates in
-     fp32 — tight (the only differences are fp32 summation order);
+     the kernels do (weights, panels, every stored activation / gradient — the tower top the fp32 heads read included)
+     and accumulates in fp32 — tight (the only differences are fp32 summation order);
   3. the learner against the full-precision C oracle — loose: an fp16 forward moves pre-activations
      by ~1e-3 relative, which flips ReLU' for the units nearest zero; per row that is a several-%
      change of dQ/da (measured 7-12 % Frobenius per column at width 128-256), averaging out over
@@ -46,14 +46,15 @@ def unpack(vec, in_dim, hidden, heads):
 
 
 def tower16(x, params, L):
-    """fp16 tower as the kernels run it: returns (list of stored fp16 activations, fp32 last layer)."""
+    """fp16 tower as the kernels run it: returns (list of stored fp16 activations, the tower top AS THE HEADS READ IT).
+    Round 3: the heads read the stored fp16 panel of the last layer like every tower layer reads its input (no separate
+    fp32 copy of the tower top is written any more), so the second value is the fp16-rounded activation."""
     acts = [r16(x)]
-    y = None
     for i in range(L):
         W, b = params[i]
         y = lrelu(acts[-1] @ r16(W).T + b)
         acts.append(r16(y))
-    return acts, y
+    return acts, acts[-1]
 
 
 def heads32(y, params, L):
@@ -68,7 +69,8 @@ def close16(got, want, name=""):
     scale = max(np.abs(want).max(), 1e-30)
     err = np.abs(got - want)
     # (wide layers: each output sums ~1000 units, a few of which rounded the other way: ~1e-3/sqrt(1000))
-    assert np.quantile(err, 0.9) <= 1e-4 * scale, (name, np.quantile(err, 0.9), scale)
+    # (and since the heads read the fp16 panel of the tower top, a q value sums ~1000 freshly rounded units itself)
+    assert np.quantile(err, 0.9) <= 3e-4 * scale, (name, np.quantile(err, 0.9), scale)
     assert err.max() <= 5e-3 * scale, (name, err.max(), scale)
 
 
