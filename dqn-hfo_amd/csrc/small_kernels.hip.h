@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "gemm_direct.hip.h"
 #include "gemm_common.hip.h"
@@ -228,6 +229,17 @@ __device__ __forceinline__ f32x4 head_ld4(const float* x32, const _Float16* x16,
 __device__ __forceinline__ float head_ld1(const float* x32, const _Float16* x16, size_t idx) {
   return x16 != nullptr ? (float)x16[idx] : x32[idx];
 }
+// The same with the panel type fixed at compile time: the hot loops are instantiated once per type and entered through ONE
+// branch (HEAD_DISPATCH), so that a per-load pointer test does not sit between the loads of a batch (measured on the fp32
+// headline: k_head_q_train 4.9 -> 6.1 us with the test inside the loop).
+template <bool IN16> __device__ __forceinline__ f32x4 head_ld4t(const float* x32, const _Float16* x16, size_t idx) {
+  if constexpr (IN16) { const head_h4 v = *reinterpret_cast<const head_h4*>(x16 + idx); return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w}; }
+  else return *reinterpret_cast<const f32x4*>(x32 + idx);
+}
+template <bool IN16> __device__ __forceinline__ float head_ld1t(const float* x32, const _Float16* x16, size_t idx) {
+  if constexpr (IN16) return (float)x16[idx]; else return x32[idx];
+}
+#define HEAD_DISPATCH(is16, body) do { if (is16) body(std::true_type{}); else body(std::false_type{}); } while (0)
 struct HeadArgs {
   const float* X; int ldx; int H;      // [rows][H] tower top
   const _Float16* X16;                 // fp16 learner: the same panel in fp16 (then X is null)
@@ -269,15 +281,18 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
 #pragma unroll
     for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
     const size_t x0 = (size_t)row * a.ldx;
-    for (int k = threadIdx.x * 4; k < a.H; k += 1024) {
-      const f32x4 xv = head_ld4(a.X, a.X16, x0 + k);
+    auto dots = [&](auto tag) {
+      for (int k = threadIdx.x * 4; k < a.H; k += 1024) {
+        const f32x4 xv = head_ld4t<decltype(tag)::value>(a.X, a.X16, x0 + k);
 #pragma unroll
-      for (int j = 0; j < NH; ++j) {
-        const f32x4 wv = hoist ? wreg[j] : *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k);
-        acc[j] = fmaf(xv.x, wv.x, acc[j]); acc[j] = fmaf(xv.y, wv.y, acc[j]);
-        acc[j] = fmaf(xv.z, wv.z, acc[j]); acc[j] = fmaf(xv.w, wv.w, acc[j]);
+        for (int j = 0; j < NH; ++j) {
+          const f32x4 wv = hoist ? wreg[j] : *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k);
+          acc[j] = fmaf(xv.x, wv.x, acc[j]); acc[j] = fmaf(xv.y, wv.y, acc[j]);
+          acc[j] = fmaf(xv.z, wv.z, acc[j]); acc[j] = fmaf(xv.w, wv.w, acc[j]);
+        }
       }
-    }
+    };
+    HEAD_DISPATCH(a.X16 != nullptr, dots);
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
 #pragma unroll
@@ -405,12 +420,15 @@ __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
   float at = 0.0f, ao = 0.0f;
   if (row < a.rows) {
     const size_t x0 = (size_t)row * a.H;
-    for (int k = lane * 4; k < a.H; k += 256) {
-      const f32x4 v0 = head_ld4(a.Xt, a.Xt16, x0 + k), w0 = *reinterpret_cast<const f32x4*>(a.Wt + k);
-      const f32x4 v1 = head_ld4(a.X, a.X16, x0 + k), w1 = *reinterpret_cast<const f32x4*>(a.W + k);
-      at = fmaf(v0.x, w0.x, at); at = fmaf(v0.y, w0.y, at); at = fmaf(v0.z, w0.z, at); at = fmaf(v0.w, w0.w, at);
-      ao = fmaf(v1.x, w1.x, ao); ao = fmaf(v1.y, w1.y, ao); ao = fmaf(v1.z, w1.z, ao); ao = fmaf(v1.w, w1.w, ao);
-    }
+    auto dots = [&](auto tag) {
+      for (int k = lane * 4; k < a.H; k += 256) {
+        const f32x4 v0 = head_ld4t<decltype(tag)::value>(a.Xt, a.Xt16, x0 + k), w0 = *reinterpret_cast<const f32x4*>(a.Wt + k);
+        const f32x4 v1 = head_ld4t<decltype(tag)::value>(a.X, a.X16, x0 + k), w1 = *reinterpret_cast<const f32x4*>(a.W + k);
+        at = fmaf(v0.x, w0.x, at); at = fmaf(v0.y, w0.y, at); at = fmaf(v0.z, w0.z, at); at = fmaf(v0.w, w0.w, at);
+        ao = fmaf(v1.x, w1.x, ao); ao = fmaf(v1.y, w1.y, ao); ao = fmaf(v1.z, w1.z, ao); ao = fmaf(v1.w, w1.w, ao);
+      }
+    };
+    HEAD_DISPATCH(a.X16 != nullptr, dots);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { at += __shfl_xor(at, off, 64); ao += __shfl_xor(ao, off, 64); }
@@ -474,10 +492,13 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
     if (row >= a.rows) return;
     const size_t x0 = (size_t)row * a.H;
     float acc = 0.0f;
-    for (int k = lane * 4; k < a.H; k += 256) {
-      const f32x4 xv = head_ld4(a.X4, a.X416, x0 + k), wv = *reinterpret_cast<const f32x4*>(a.W + k);
-      acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
-    }
+    auto dots = [&](auto tag) {
+      for (int k = lane * 4; k < a.H; k += 256) {
+        const f32x4 xv = head_ld4t<decltype(tag)::value>(a.X4, a.X416, x0 + k), wv = *reinterpret_cast<const f32x4*>(a.W + k);
+        acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+      }
+    };
+    HEAD_DISPATCH(a.X416 != nullptr, dots);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (lane == 0) { const float v = acc + a.q_bias[0]; a.q_out[row] = v; a.qsum_partial[row] = (double)v; }
@@ -519,8 +540,9 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
   const int per = (r1 - r0 + 15) / 16;
   const int m0 = r0 + rg * per, m1 = min(r1, m0 + per);
+  auto rows_loop = [&](auto tag) {
   for (int m = m0; m < m1; ++m) {
-    const float xv = head_ld1(a.X4, a.X416, (size_t)m * a.H + k);
+    const float xv = head_ld1t<decltype(tag)::value>(a.X4, a.X416, (size_t)m * a.H + k);
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
@@ -535,6 +557,8 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
     if (a.dZ != nullptr) a.dZ[(size_t)m * a.H + k] = dz;
     if (a.dZ16 != nullptr) a.dZ16[(size_t)m * a.H + k] = (_Float16)(dz * a.scale16);
   }
+  };
+  HEAD_DISPATCH(a.X416 != nullptr, rows_loop);
   if (!want_w) return;
 #pragma unroll
   for (int j = 0; j < NH; ++j) s_acc[(rg * NH + j) * 64 + kc] = acc[j];
