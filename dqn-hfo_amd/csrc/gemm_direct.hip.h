@@ -210,6 +210,20 @@ __device__ __forceinline__ void dgrad_direct_body(const GemmProblem& pr, int til
 #undef DG_LOAD
 #undef DG_COMPUTE
 
+  // this wave's ReLU' mask pieces, requested ahead of the cross-wave reduction
+  constexpr int NMK = (TQ * TPB + 3) / 4;
+  f32x4 mk[NMK][4];
+  if (pr.mask != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NMK; ++j) {
+      const int ab = j * 4 + wave;
+      if (ab < TQ * TPB) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          mk[j][r] = *reinterpret_cast<const f32x4*>(pr.mask + (size_t)(q0 + (ab / TPB) * 16 + li) * pr.ldm + p0 + (ab % TPB) * 64 + (lg << 4) + (r << 2));
+      }
+    }
+  }
   park_accumulators<NACC>(smem, acc, wave, lane);
   __syncthreads();
   // accumulators (a,b,pc=0..3) form float4s over pc: reduce them as a group of 4
@@ -227,7 +241,7 @@ __device__ __forceinline__ void dgrad_direct_body(const GemmProblem& pr, int til
         const int p = p0 + b * 64 + (lg << 4) + (r << 2);
         f32x4 v = f32x4{r0[r], r1[r], r2[r], r3[r]};
         if (pr.mask != nullptr) {
-          const f32x4 mv = *reinterpret_cast<const f32x4*>(pr.mask + (size_t)q * pr.ldm + p);
+          const f32x4 mv = mk[ab >> 2][r];
           v.x *= lrelu_mask(mv.x); v.y *= lrelu_mask(mv.y); v.z *= lrelu_mask(mv.z); v.w *= lrelu_mask(mv.w);
         }
         *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
@@ -278,6 +292,8 @@ __device__ __forceinline__ void dgrad_narrow_body(const GemmProblem& pr, int til
   for (int kb = nkb4; kb < nkb; ++kb) { DN_LOAD(0, kb) DN_COMPUTE(0) }
 #undef DN_LOAD
 #undef DN_COMPUTE
+  f32x4 mv = f32x4{0.f, 0.f, 0.f, 0.f};          // requested ahead of the cross-wave reduction
+  if (wave == 0 && pr.mask != nullptr) mv = *reinterpret_cast<const f32x4*>(pr.mask + (size_t)(q0 + li) * pr.ldm + p0 + (lg << 2));
   park_accumulators<NACC>(smem, acc, wave, lane);
   __syncthreads();
   if (wave == 0) {
@@ -285,7 +301,6 @@ __device__ __forceinline__ void dgrad_narrow_body(const GemmProblem& pr, int til
     f32x4 v = reduce_accumulator<NACC>(smem, 0, lane);
     const int q = q0 + li, p = p0 + (lg << 2);
     if (pr.mask != nullptr) {
-      const f32x4 mv = *reinterpret_cast<const f32x4*>(pr.mask + (size_t)q * pr.ldm + p);
       v.x *= lrelu_mask(mv.x); v.y *= lrelu_mask(mv.y); v.z *= lrelu_mask(mv.z); v.w *= lrelu_mask(mv.w);
     }
     *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
@@ -628,6 +643,16 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
 #undef L_SCHED
 #undef L_SCHED_
 
+  // this wave's bias pieces, requested ahead of the cross-wave reduction
+  constexpr int NBV = (NACC + 3) / 4;
+  f32x4 bvp[NBV];
+  if (pr.bias != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) {
+      const int e = j * 4 + wave;
+      if (e < NACC) bvp[j] = *reinterpret_cast<const f32x4*>(pr.bias + p0 + (e % TP) * 16 + (lg << 2));
+    }
+  }
   // park into this wave's own (now idle) staging region, reduce across waves in fixed order
   f32x4* park = reinterpret_cast<f32x4*>(wsm);
 #pragma unroll
@@ -646,7 +671,7 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
       v.z = (a0.z + a1.z) + (a2.z + a3.z); v.w = (a0.w + a1.w) + (a2.w + a3.w);
       const int q = q0 + a * 16 + li, p = p0 + c * 16 + (lg << 2);
       if (pr.bias != nullptr) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(pr.bias + p);
+        const f32x4 bv = bvp[e >> 2];
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
       }
       if (pr.relu) { v.x = lrelu_fwd(v.x); v.y = lrelu_fwd(v.y); v.z = lrelu_fwd(v.z); v.w = lrelu_fwd(v.w); }
@@ -688,6 +713,16 @@ __device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) roff[kb] = li * 32 + ((((kb << 2) + lg) ^ (li & 7)) << 2);
 
+  // this lane's pieces of the ReLU' mask (one per (a,b): the r this wave owns in the epilogue),
+  // requested before the reduction loop so that their latency is not exposed after it
+  f32x4 mk[TQ * TPB];
+  if (pr.mask != nullptr) {
+#pragma unroll
+    for (int ab = 0; ab < TQ * TPB; ++ab) {
+      const int r = (wave - ab) & 3;
+      mk[ab] = *reinterpret_cast<const f32x4*>(pr.mask + (size_t)(q0 + (ab / TPB) * 16 + li) * pr.ldm + p0 + (ab % TPB) * 64 + (lg << 4) + (r << 2));
+    }
+  }
   f32x4 acc[NACC];
 #pragma unroll
   for (int e = 0; e < NACC; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -784,7 +819,7 @@ __device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p
         const int p = p0 + b * 64 + (lg << 4) + (r << 2);
         f32x4 v = f32x4{r0[r], r1[r], r2[r], r3[r]};
         if (pr.mask != nullptr) {
-          const f32x4 mv = *reinterpret_cast<const f32x4*>(pr.mask + (size_t)q * pr.ldm + p);
+          const f32x4 mv = mk[ab];
           v.x *= lrelu_mask(mv.x); v.y *= lrelu_mask(mv.y); v.z *= lrelu_mask(mv.z); v.w *= lrelu_mask(mv.w);
         }
         *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
