@@ -328,6 +328,27 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
             return out
     if not native:
         return None
+    # N > 1: env-steps/sec of the WHOLE job (the other half of BASELINE.json's metric): every rank steps its own workers
+    # into its own replay shard — no collective — so the aggregate is ranks x workers x steps over the slowest rank's time
+    # (barriers on both sides).  64 workers per GPU (configs[2]'s count) and 2048 / 8 = 256 (configs[4] on a full node).
+    agg = {}
+    d = pkg.DQN(S, minibatch=256, hidden=HIDDEN, memory=200000, seed=1 + rank, device=local_rank, use_graph=True)
+    for workers in (64, 256):
+        env = pkg.EnvFrontEnd(d, workers, max_steps=500, p_end=0.01, seed=5 + rank)
+        env.step(0.1, 20); env.stats()
+        n_env = 200
+
+        def run():
+            env.step(0.1, n_env); env.stats()
+        t_env = timed(run, barrier, 1, 0)
+        if rank == 0:
+            agg["workers_%d_per_gpu" % workers] = {"n_gpus": world, "env_steps_per_s": round(world * workers * n_env / t_env, 1),
+                                                   "us_per_batched_step": round(t_env / n_env * 1e6, 2),
+                                                   "roofline_per_gpu": env_roofline(S, workers, t_env / n_env * 1e6)}
+        env.close()
+    d.close()
+    if rank == 0:
+        out["env_steps_all_ranks"] = agg
     # N > 1: STRONG scaling of a global minibatch of 4096 (where the batch warrants DP)
     for prec in ("fp32", "fp16"):
         rows = GB // world
@@ -599,7 +620,7 @@ def main():
     env_res = None
     if rank == 0 and not args.no_env:
         env_res = {}
-        for workers in (64, 1024, 2048):          # BASELINE configs #3 (64 workers) and #5 (2048 workers)
+        for workers in (64, 256, 1024, 2048):     # BASELINE configs #3 (64 workers) and #5 (2048 workers; 256 = its share per GPU on 8)
             # episode buffers must fit the replay ring: cap the episode length for the widest runs
             T = min(args.frames_per_trial, (args.replay - 1) // workers)
             if T < 100:

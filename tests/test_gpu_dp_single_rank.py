@@ -118,6 +118,10 @@ def test_bench_strong_scaling_record_with_the_ranks_there_are(pkg, gpu):
         assert rec["rows_per_gpu"] == 4096 and rec["exchange"] == exch
         assert 0 < rec["ms_per_update_without_collectives"] and 0 < rec["ms_per_update"] < 2 * rec["ms_per_update_1gpu"] + 1
         assert rec["projection"]["allreduce_us_one_ring"] == 0.0           # one rank: nothing crosses a link
+    # whole-job env-steps/sec (every rank steps its own workers into its own replay shard)
+    for workers in (64, 256):
+        e = sub["env_steps_all_ranks"]["workers_%d_per_gpu" % workers]
+        assert e["n_gpus"] == 1 and e["env_steps_per_s"] > 1e5 and 0 < e["roofline_per_gpu"]["frac"] < 1
 
 
 def test_bench_two_ranks_flow_on_one_gpu(pkg, gpu):
