@@ -281,6 +281,17 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
                                                "note": "independent streams overlap each other's launch floors"}
         for d in agents:
             d.read_stats(); d.close()
+        # configs[0]'s workload (the reference's compile-time defaults: minibatch 32, S = 59, tower 1024-512-256-128,
+        # src/dqn.hpp:19, src/dqn.cpp:425) — on the GPU, since there is no CPU backend here; async and the drop-in's blocking form
+        d = pkg.DQN(59, minibatch=32, hidden=(1024, 512, 256, 128), memory=100000, seed=1, device=local_rank, use_graph=True)
+        from synth import synth_replay
+        d.add_transitions_arrays(*synth_replay(np.random.default_rng(3), 50000, 59))
+        dt = timed(lambda: d.update_async(None), torch.cuda.synchronize, 1000, 100)
+        ms_b = d.BenchmarkBlocking(1000, 100, seed=1, pipelined=False)
+        out["configs0_ref_defaults_b32"] = {"ms_per_update": round(dt * 1e3, 4), "updates_per_s": round(1 / dt, 1),
+                                            "blocking_ms_per_update": round(ms_b, 4), "blocking_updates_per_s": round(1e3 / ms_b, 1),
+                                            "note": "launch-bound: 32 launches per update"}
+        d.read_stats(); d.close()
         # configs[2]: 1v1 (S = 68), 64 parallel workers feeding one replay buffer
         d = pkg.DQN(68, minibatch=B, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, use_graph=True)
         env = pkg.EnvFrontEnd(d, 64, max_steps=500, p_end=0.01, seed=5)
