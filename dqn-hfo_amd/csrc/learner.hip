@@ -329,7 +329,21 @@ int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, 
   if (n == 1 && rows <= 128 && lds_ok) HIPCHK((fwd_lds_launch<1, 1, true>(b, st)));
   else if (n == 1 && rows >= 512 && lds_ok && l.dims[i + 1] % 64 == 0) HIPCHK((fwd_lds_launch<4, 2, true>(b, st)));   // enough rows to fill the chip with 64x32 tiles (fewer bytes per FLOP)
   else if (n == 1) { if (lds_ok) HIPCHK((fwd_lds_launch<2, 2, true>(b, st))); else HIPCHK((fwd_direct_launch<2, 2>(b, st))); }
-  else { if (lds_ok) HIPCHK((fwd_lds_launch<4, 2, true>(b, st))); else HIPCHK((fwd_direct_launch<4, 2>(b, st))); }
+  else {
+    // grouped launches: 64x32 tiles when they still give the chip something to do; small minibatches / narrow layers
+    // (the reference's defaults: 32 rows into 512 outputs = 16 such tiles for two problems, one long chain each) take
+    // 32x32 or 16x16 tiles — same K split over the four waves, same reduction order, more workgroups
+    const long P = l.dims[i + 1];
+    const long t42 = (long)n * (P / 64) * (rows / 32), t22 = (long)n * (P / 32) * (rows / 32);
+    if (lds_ok) {
+      if (t42 >= 128) HIPCHK((fwd_lds_launch<4, 2, true>(b, st)));
+      else if (t22 >= 128 || rows > 128 || rows % 16) HIPCHK((fwd_lds_launch<2, 2, true>(b, st)));
+      else HIPCHK((fwd_lds_launch<1, 1, true>(b, st)));
+    } else {
+      if (t42 >= 64) HIPCHK((fwd_direct_launch<4, 2>(b, st)));
+      else HIPCHK((fwd_direct_launch<2, 2>(b, st)));
+    }
+  }
   return 0;
 }
 int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows) {
