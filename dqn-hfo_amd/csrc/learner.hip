@@ -388,7 +388,13 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
     if (need_dx && want_w) {               // ONE workgroup type: its wgrad tile, then its dgrad tile (gemm_bwd_seq)
       GemmBatch b{}; b.n = 2; b.prob[0] = bd.prob[0]; b.prob[1] = bw.prob[0];
       ScopedTiming t(h, 4, st);
-      if (lds_ok) HIPCHK((bwd_seq_launch<true>(b, st))); else HIPCHK((bwd_seq_launch<false>(b, st)));
+      // small minibatches / narrow layers: when the dgrad's 64x16 tiles and the wgrad's 64x64 tiles together still fit
+      // the chip in one round, they run side by side on their own workgroups (one tile's chain per launch, not two)
+      const long tiles = (long)(l.kp[i] / 64) * (rows / 16) + (long)(l.kp[i] / 64) * (l.dims[i + 1] / 64);
+      if (tiles <= 256 && rows % 16 == 0 && l.kp[i] % 64 == 0 && l.dims[i + 1] % 64 == 0) {
+        if (lds_ok) HIPCHK((bwd_pair_direct_launch<1, true>(b, st))); else HIPCHK((bwd_pair_direct_launch<1, false>(b, st)));
+      } else if (lds_ok) HIPCHK((bwd_seq_launch<true>(b, st)));
+      else HIPCHK((bwd_seq_launch<false>(b, st)));
     } else if (need_dx && i == 0 && in_hi > in_lo && rows % 16 == 0) {
       GemmProblem& p = bd.prob[0];
       const int c0 = (in_lo / 16) * 16, c1 = std::min(l.kp[0], (in_hi + 15) / 16 * 16);
@@ -1095,6 +1101,8 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
   }
   HIPCHK(direct_prepare(gemm_bwd_seq<true>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_bwd_seq<false>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
+  HIPCHK(direct_prepare((gemm_bwd_pair_direct<1, true>), 4 * 16 * 64 * 16 + 4 * 16 * 16));
+  HIPCHK(direct_prepare((gemm_bwd_pair_direct<1, false>), 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4));
   HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, true>, 4 * 2 * 6 * 512 * 4));
   RC(sync_dirty16(h));
