@@ -465,8 +465,11 @@ int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
 }
 
 // clip + Adam + Net::Update + soft target update over arena floats [begin, end)
-int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick = nullptr) {
+// corr_pre: the update's first launch (k_gather) has left this step's bias correction in DevState::adam_corr
+int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick = nullptr,
+                bool corr_pre = true) {
   AdamArgs a{};
+  a.corr_pre = corr_pre ? &h->st->adam_corr[net] : nullptr;
   a.w = h->w[net] + begin; a.g = h->g[net] + begin; a.m = h->m[net] + begin; a.v = h->v[net] + begin;
   a.wt = h->w[net + 2] + begin;
   if (h->fp16) { a.w16 = h->w16a[net] + begin; a.wt16 = h->w16a[net + 2] + begin; }
@@ -664,8 +667,8 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     GatherOut go{nullptr, nullptr, la.kp[0], nullptr, nullptr, nullptr, lc.kp[0],
                  h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx,
                  h->act16[1][0], h->act16[0][0], h->act16[3][0], h->act16[4][0], h->act16[2][0]};
-    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
-                       (const DevState*)h->st, idx_dev, sample_key(h), go, B);
+    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4 + 1), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
+                       (const DevState*)h->st, idx_dev, sample_key(h), go, B, h->st->adam_corr, h->cfg.momentum, h->cfg.momentum2);
     HIPCHK(hipGetLastError());
     if (split) RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B));
     else RC(tower_forward16_pair(h, st, 0, DQNHIP_ACTOR_TARGET, 1, DQNHIP_ACTOR, B));
@@ -775,8 +778,8 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // 1-2: sample + gather (src/dqn.cpp:846-887)
     GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
                  h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
-    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
-                       (const DevState*)h->st, idx_dev, sample_key(h), go, B);
+    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4 + 1), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
+                       (const DevState*)h->st, idx_dev, sample_key(h), go, B, h->st->adam_corr, h->cfg.momentum, h->cfg.momentum2);
     HIPCHK(hipGetLastError());
     FwdPass pAT{DQNHIP_ACTOR_TARGET, &la, h->act[0]}, pA{DQNHIP_ACTOR, &la, h->act[1]};
     FwdPass pCT{DQNHIP_CRITIC_TARGET, &lc, h->act[2]}, pC1{DQNHIP_CRITIC, &lc, h->act[3]};
@@ -1350,7 +1353,7 @@ int dqnhip_apply_update(dqnhip_handle h, int32_t net) {
   const NetLayout& l = layout_of(h, net);
   hipLaunchKernelGGL(k_sumsq, dim3(h->n_part_dp), dim3(256), 0, h->stream, h->g[net], l.arena / 4, h->part_dp);
   HIPCHK(hipGetLastError());
-  RC(adam_launch(h, h->stream, net, h->part_dp, h->n_part_dp, 0, l.arena));
+  RC(adam_launch(h, h->stream, net, h->part_dp, h->n_part_dp, 0, l.arena, nullptr, false));   // no gather ran: the pass evaluates its own correction
   hipLaunchKernelGGL(k_advance_iter, dim3(1), dim3(1), 0, h->stream, h->st, (int)net);
   HIPCHK(hipGetLastError());
   if (net == DQNHIP_ACTOR) h->h_actor_iter += 1; else h->h_critic_iter += 1;
