@@ -942,18 +942,11 @@ __device__ __forceinline__ void adam_scalars(const AdamArgs& a, int blk, float* 
 }
 template <int U = 1, int NT = 0>
 __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int nblk, float* s /*>= 8 floats*/) {
-  adam_scalars(a, blk, s);
-  if (s[7] != 0.0f) return;
-  const float scale = s[4];
-  const float step = s[5];
-  const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
-  const bool soft = s[6] != 0.0f;
-  const float tau = a.tau, omt = 1 - a.tau;
   // U float4 per array in flight per thread (U * 5 x 16-B loads before the first use); NT: the gradient is
   // read exactly once per update and never again -> non-temporal
-  for (size_t i0 = (size_t)blk * (256 * U) + threadIdx.x; i0 < a.n4; i0 += (size_t)nblk * (256 * U)) {
-    f32x4 g[U], m[U], v[U], w[U], wt[U];
-    f32x4* wq[U]; f32x4* tq[U];
+  f32x4 g[U], m[U], v[U], w[U], wt[U];
+  f32x4* wq[U]; f32x4* tq[U];
+  auto load = [&](size_t i0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t i = i0 + (size_t)u * 256;
@@ -967,6 +960,22 @@ __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int n
         wt[u] = *tq[u];
       }
     }
+  };
+  // The first (for most threads: the only, or one of two) batch of loads goes out BEFORE the per-launch scalars are
+  // derived: none of them depends on the clip scale, and the scalars' own chain (partials from the L2 of other XCDs ->
+  // wave sums -> barrier -> sqrt / divide in one lane -> barrier) is ~1.5 us that every block would otherwise spend
+  // with nothing in flight.
+  size_t i0 = (size_t)blk * (256 * U) + threadIdx.x;
+  if (i0 < a.n4) load(i0);
+  adam_scalars(a, blk, s);
+  if (s[7] != 0.0f) return;
+  const float scale = s[4];
+  const float step = s[5];
+  const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
+  const bool soft = s[6] != 0.0f;
+  const float tau = a.tau, omt = 1 - a.tau;
+  for (bool first = true; i0 < a.n4; i0 += (size_t)nblk * (256 * U), first = false) {
+    if (!first) load(i0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t i = i0 + (size_t)u * 256;
