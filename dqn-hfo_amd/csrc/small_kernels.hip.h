@@ -165,7 +165,15 @@ __device__ __forceinline__ float adam_correction(float beta1, float beta2, int t
 __global__ void k_gather(Ring ring, const DevState* rs, const DevState* st, const int* __restrict__ idx_in,
                          uint64_t seed, GatherOut o, int B, float* corr, float beta1, float beta2) {
   if (corr != nullptr && blockIdx.x == gridDim.x - 1) {
-    if (threadIdx.x < 2) corr[threadIdx.x] = adam_correction(beta1, beta2, (threadIdx.x == 0 ? st->actor_iter : st->critic_iter) + 1);
+    // four lanes, one pow() each (the two powers of a correction side by side: half the dependent chain), same
+    // expression as adam_correction() from there on
+    if (threadIdx.x < 64) {
+      const int which = (threadIdx.x >> 1) & 1, isb1 = threadIdx.x & 1;
+      const int t = (which == 0 ? st->actor_iter : st->critic_iter) + 1;
+      const double pw = pow((double)(isb1 ? beta1 : beta2), (double)t);
+      const double p1 = __shfl_down(pw, 1, 64);          // lane 2*which: pw = beta2^t, p1 = beta1^t
+      if (threadIdx.x < 4 && !isb1) corr[which] = (float)(sqrt(1.0 - pw) / (1.0 - p1));
+    }
     return;
   }
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -284,6 +292,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ float s_acc[4][NH];
   const bool hoist = a.H <= 1024;
+  const float bias_j = threadIdx.x < NH ? a.b[threadIdx.x] : 0.0f;      // requested now, used after the reduction
   f32x4 wreg[NH];
   if (hoist) {
 #pragma unroll
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
     if (threadIdx.x < kAP) {
       const int j = threadIdx.x;
       float v = 0.0f;
-      if (j < NH) v = ((s_acc[0][j] + s_acc[1][j]) + (s_acc[2][j] + s_acc[3][j])) + a.b[j];
+      if (j < NH) v = ((s_acc[0][j] + s_acc[1][j]) + (s_acc[2][j] + s_acc[3][j])) + bias_j;
       if constexpr (MODE == HEAD_ACTOR) {
         a.out16[(size_t)row * kAP + j] = v;
         if (a.xc != nullptr && j < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + j] = v;
@@ -432,6 +441,9 @@ __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
   const int row = blockIdx.x * 4 + wave;
   __shared__ float s_part[4];
   float at = 0.0f, ao = 0.0f;
+  // the row's scalars and the two biases: requested before the dot products, used after the reduction
+  float bt0 = 0.0f, b0 = 0.0f, r = 0.0f, mcv = 0.0f, tm = 0.0f;
+  if (row < a.rows && lane == 0) { bt0 = a.bt[0]; b0 = a.b[0]; r = a.reward[row]; mcv = a.mc[row]; tm = a.term[row]; }
   if (row < a.rows) {
     const size_t x0 = (size_t)row * a.H;
     auto dots = [&](auto tag) {
@@ -448,11 +460,10 @@ __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
   for (int off = 32; off > 0; off >>= 1) { at += __shfl_xor(at, off, 64); ao += __shfl_xor(ao, off, 64); }
   float d2 = 0.0f;
   if (row < a.rows && lane == 0) {
-    const float qt = at + a.bt[0], q = ao + a.b[0];
+    const float qt = at + bt0, q = ao + b0;
     a.q_target[row] = qt; a.q[row] = q;
-    const float r = a.reward[row];
-    const float off_policy = a.term[row] != 0.0f ? r : (float)((double)r + a.gamma * (double)qt);
-    const float target = (float)(a.beta * (double)a.mc[row] + (1 - a.beta) * (double)off_policy);
+    const float off_policy = tm != 0.0f ? r : (float)((double)r + a.gamma * (double)qt);
+    const float target = (float)(a.beta * (double)mcv + (1 - a.beta) * (double)off_policy);
     a.y[row] = target;
     if (!isfinite(target)) atomicOr(&a.st->flags, kFlagTarget);   // CHECK(std::isfinite(target)), src/dqn.cpp:898
     const float d = q - target;
@@ -525,6 +536,21 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   __shared__ int s_last;
   const int tid = threadIdx.x;
   const bool want_w = a.dW != nullptr;
+  const int kc = tid & 63, rg = tid >> 6;              // 16 row groups
+  const int k = blockIdx.x * 64 + kc;
+  const int per = (r1 - r0 + 15) / 16;
+  const int m0 = r0 + rg * per, m1 = min(r1, m0 + per);
+  // this thread's head weights and its first four tower-top values go out BEFORE the head diffs are staged: neither
+  // depends on them, and the staging (two dependent loads + the inverting-gradients arithmetic + a barrier) is a chain
+  // of its own.  Rows are then taken four at a time, four independent loads in flight, instead of one load per iteration.
+  constexpr int RB = 4;
+  float w[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) w[j] = a.W[(size_t)j * a.H + k];
+  float xpre[RB];
+  auto ldx = [&](int m) -> float { return a.X416 != nullptr ? (float)a.X416[(size_t)m * a.H + k] : a.X4[(size_t)m * a.H + k]; };
+#pragma unroll
+  for (int u = 0; u < RB; ++u) xpre[u] = (m0 + u < m1) ? ldx(m0 + u) : 0.0f;
   // ---- head diffs of this chunk's rows into LDS
   for (int i = tid; i < (r1 - r0) * NH; i += 1024) {
     const int m = r0 + i / NH, j = i % NH;
@@ -544,32 +570,34 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
     s_dy[i] = d;
   }
   __syncthreads();
-  const int kc = tid & 63, rg = tid >> 6;              // 16 row groups
-  const int k = blockIdx.x * 64 + kc;
-  float w[NH];
-#pragma unroll
-  for (int j = 0; j < NH; ++j) w[j] = a.W[(size_t)j * a.H + k];
   float acc[NH];
 #pragma unroll
   for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
-  const int per = (r1 - r0 + 15) / 16;
-  const int m0 = r0 + rg * per, m1 = min(r1, m0 + per);
   auto rows_loop = [&](auto tag) {
-  for (int m = m0; m < m1; ++m) {
-    const float xv = head_ld1t<decltype(tag)::value>(a.X4, a.X416, (size_t)m * a.H + k);
-    float s0 = 0.0f, s1 = 0.0f;
+  for (int mb = m0; mb < m1; mb += RB) {
+    float xb[RB];
 #pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      const float d = s_dy[(m - r0) * NH + j];
-      // Split layer: action_layer's and actionpara_layer's bottom diffs are
-      // formed separately and added
-      if (NH == kNO && j >= kNA) s1 = fmaf(d, w[j], s1); else s0 = fmaf(d, w[j], s0);
-      acc[j] = fmaf(d, xv, acc[j]);
+    for (int u = 0; u < RB; ++u)
+      xb[u] = (mb == m0) ? xpre[u] : ((mb + u < m1) ? head_ld1t<decltype(tag)::value>(a.X4, a.X416, (size_t)(mb + u) * a.H + k) : 0.0f);
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int m = mb + u;
+      if (m >= m1) break;
+      const float xv = xb[u];
+      float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NH; ++j) {
+        const float d = s_dy[(m - r0) * NH + j];
+        // Split layer: action_layer's and actionpara_layer's bottom diffs are
+        // formed separately and added
+        if (NH == kNO && j >= kNA) s1 = fmaf(d, w[j], s1); else s0 = fmaf(d, w[j], s0);
+        acc[j] = fmaf(d, xv, acc[j]);
+      }
+      if (NH == kNO) s0 += s1;
+      const float dz = s0 * lrelu_mask(xv);
+      if (a.dZ != nullptr) a.dZ[(size_t)m * a.H + k] = dz;
+      if (a.dZ16 != nullptr) a.dZ16[(size_t)m * a.H + k] = (_Float16)(dz * a.scale16);
     }
-    if (NH == kNO) s0 += s1;
-    const float dz = s0 * lrelu_mask(xv);
-    if (a.dZ != nullptr) a.dZ[(size_t)m * a.H + k] = dz;
-    if (a.dZ16 != nullptr) a.dZ16[(size_t)m * a.H + k] = (_Float16)(dz * a.scale16);
   }
   };
   HEAD_DISPATCH(a.X416 != nullptr, rows_loop);
