@@ -162,7 +162,6 @@ struct dqnhip_learner {
   float* loss_partial = nullptr; double* q_partial = nullptr; int n_head_blocks = 0;
   float* part[2] = {nullptr, nullptr};  // GEMM-epilogue sumsq partials per net
   float* part_dp = nullptr; int n_part_dp = 0;
-  int* tick_ticket = nullptr;                                // arrival counter of the update's last launch (k_adam_soft + tick)
   float* head_slab = nullptr; int* head_ticket = nullptr;   // k_head_bwd cross-block reduction
   float* head_slab2 = nullptr;                               // k_head_bwd_big row-chunk slabs (minibatch >= 1024)
   // mixed precision (cfg.precision == DQNHIP_FP16): ONE fp16 mirror of each weight arena and batch-major fp16
@@ -469,7 +468,7 @@ int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
 int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick = nullptr,
                 bool corr_pre = true) {
   AdamArgs a{};
-  a.corr_pre = corr_pre ? &h->st->adam_corr[net] : nullptr;
+  a.corr_pre = corr_pre ? &h->st->adam_corr[net] : nullptr; a.soft_pre = corr_pre ? &h->st->soft_now : nullptr;
   a.w = h->w[net] + begin; a.g = h->g[net] + begin; a.m = h->m[net] + begin; a.v = h->v[net] + begin;
   a.wt = h->w[net + 2] + begin;
   if (h->fp16) { a.w16 = h->w16a[net] + begin; a.wt16 = h->w16a[net + 2] + begin; }
@@ -483,7 +482,10 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   a.beta1 = h->cfg.momentum; a.beta2 = h->cfg.momentum2; a.eps = h->cfg.delta;
   a.clip = h->cfg.clip_gradients; a.tau = (float)h->cfg.tau;
   a.soft_update_freq = h->cfg.soft_update_freq; a.which = net; a.st = h->st;
-  if (tick) { a.tick_ticket = h->tick_ticket; a.tick = *tick; }
+  if (tick) {
+    if (!corr_pre) return fail("adam_launch: the update's bookkeeping needs the scalars k_gather leaves in DevState");
+    a.tick_on = 1; a.tick = *tick;
+  }
   ScopedTiming t(h, 3, st);
   LaunchTimer& lt = launch_timer();
   // 2048 blocks: grids of 512 .. 8192 measured within +-3 % (profiles/r02_adam_probe.txt)
@@ -668,7 +670,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
                  h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx,
                  h->act16[1][0], h->act16[0][0], h->act16[3][0], h->act16[4][0], h->act16[2][0]};
     hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4 + 1), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
-                       (const DevState*)h->st, idx_dev, sample_key(h), go, B, h->st->adam_corr, h->cfg.momentum, h->cfg.momentum2);
+                       (const DevState*)h->st, idx_dev, sample_key(h), go, B, h->st->adam_corr, h->cfg.momentum, h->cfg.momentum2, &h->st->soft_now, h->cfg.soft_update_freq);
     HIPCHK(hipGetLastError());
     if (split) RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B));
     else RC(tower_forward16_pair(h, st, 0, DQNHIP_ACTOR_TARGET, 1, DQNHIP_ACTOR, B));
@@ -779,7 +781,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
                  h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
     hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4 + 1), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
-                       (const DevState*)h->st, idx_dev, sample_key(h), go, B, h->st->adam_corr, h->cfg.momentum, h->cfg.momentum2);
+                       (const DevState*)h->st, idx_dev, sample_key(h), go, B, h->st->adam_corr, h->cfg.momentum, h->cfg.momentum2, &h->st->soft_now, h->cfg.soft_update_freq);
     HIPCHK(hipGetLastError());
     FwdPass pAT{DQNHIP_ACTOR_TARGET, &la, h->act[0]}, pA{DQNHIP_ACTOR, &la, h->act[1]};
     FwdPass pCT{DQNHIP_CRITIC_TARGET, &lc, h->act[2]}, pC1{DQNHIP_CRITIC, &lc, h->act[3]};
@@ -1042,7 +1044,6 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
     const int Hmax = std::max(h->la.dims[L], h->lc.dims[L]);
     RC(dalloc(&h->head_slab, (size_t)64 * (Hmax / 64) * kNO * 64 + 64 * 16));
     if (B >= 1024 && B % 64 == 0) RC(dalloc(&h->head_slab2, (size_t)(B / 64) * kNO * Hmax + (size_t)(B / 64) * 16));
-    HIPCHK(hipMalloc(&h->tick_ticket, 17 * 32 * sizeof(int))); HIPCHK(hipMemsetAsync(h->tick_ticket, 0, 17 * 32 * sizeof(int), h->stream));
     HIPCHK(hipMalloc(&h->head_ticket, (Hmax / 64) * sizeof(int)));
     HIPCHK(hipMemsetAsync(h->head_ticket, 0, (Hmax / 64) * sizeof(int), h->stream));
   }
@@ -1141,7 +1142,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   hipHostFree(h->idx_pinned); hipHostFree(h->pinned_stats);
   hipFree(h->aout_t16); hipFree(h->aout16); hipFree(h->dA16);
   hipFree(h->q_t); hipFree(h->q1); hipFree(h->q2); hipFree(h->y); hipFree(h->dq);
-  hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp); hipFree(h->head_slab); hipFree(h->head_ticket); hipFree(h->tick_ticket); if (h->head_slab2) hipFree(h->head_slab2);
+  hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp); hipFree(h->head_slab); hipFree(h->head_ticket); if (h->head_slab2) hipFree(h->head_slab2);
   for (void* p : h->allocs16) hipFree(p);
   if (h->stage_dev) hipFree(h->stage_dev);
   if (h->act_buf) hipFree(h->act_buf);

@@ -35,6 +35,10 @@ struct DevState {
   // block of the update's first launch (k_gather): two double pow() are a ~2 us dependent chain, which every block of
   // k_adam_soft otherwise sits through before its first load (measured: 23.2 -> 21.3 us per launch without it)
   float adam_corr[2];
+  // ... and the soft-update switch of this update (max_iter() % soft_update_freq == 0 AFTER both increments,
+  // src/dqn.cpp:967), from the same block: with both in DevState no block of k_adam_soft reads an iteration counter,
+  // so the update's bookkeeping (tick_body) no longer has to wait for the last block of the last launch
+  int soft_now;
 };
 constexpr int kFlagTarget = 1;     // a TD target of the last update(s) was not finite
 constexpr int kFlagGradNorm = 2;   // a gradient L2 norm was not finite: that clip+Adam step was skipped
@@ -163,8 +167,12 @@ __device__ __forceinline__ float adam_correction(float beta1, float beta2, int t
 // corr: when not null the launch has ONE extra block (the last) whose first two lanes evaluate this update's Adam
 // corrections (t = iter + 1 of the actor / the critic: the counters only move in the update's last block)
 __global__ void k_gather(Ring ring, const DevState* rs, const DevState* st, const int* __restrict__ idx_in,
-                         uint64_t seed, GatherOut o, int B, float* corr, float beta1, float beta2) {
+                         uint64_t seed, GatherOut o, int B, float* corr, float beta1, float beta2, int* soft_now, int soft_update_freq) {
   if (corr != nullptr && blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x == 64) {
+      const int it_a = st->actor_iter + 1, it_c = st->critic_iter + 1;
+      *soft_now = ((it_a > it_c ? it_a : it_c) % soft_update_freq) == 0;
+    }
     // four lanes, one pow() each (the two powers of a correction side by side: half the dependent chain), same
     // expression as adam_correction() from there on
     if (threadIdx.x < 64) {
@@ -923,6 +931,7 @@ struct AdamArgs {
   size_t n4;                      // arena length / 4
   const float* partial; int n_partial;
   const float* corr_pre;          // this step's bias correction, evaluated earlier in the update (DevState::adam_corr); null: here
+  const int* soft_pre;            // with corr_pre: this update's soft-update switch (DevState::soft_now)
   float lr, beta1, beta2, eps, clip, tau;
   int soft_update_freq;
   int which;                      // 0 actor, 1 critic (selects the iter counter)
@@ -930,7 +939,7 @@ struct AdamArgs {
   // the update's last launch also does k_tick's work: the block that finishes last (arrival
   // ticket; no fence needed — it consumes nothing the other blocks of THIS launch produced, and
   // by then every block has read the iteration counters it is about to advance) runs tick_body
-  int* tick_ticket;               // null: no tick duty
+  int tick_on;                    // 1: block 0 also runs tick_body (requires corr_pre / soft_pre)
   TickArgs tick;
 };
 // body shared by the stand-alone kernel and the mixed GEMM+Adam launch: block `blk` of
@@ -952,14 +961,17 @@ __device__ __forceinline__ void adam_scalars(const AdamArgs& a, int blk, float* 
     const float sumsq = (s[0] + s[1]) + (s[2] + s[3]);
     const float l2 = sqrtf(sumsq);
     s[4] = (a.clip >= 0.0f && l2 > a.clip) ? a.clip / l2 : 1.0f;
-    const int it_a = a.st->actor_iter, it_c = a.st->critic_iter;
-    const int t = (a.which == 0 ? it_a : it_c) + 1;      // t = iter_ + 1 (before increment)
-    // correction = sqrt(1 - beta2^t) / (1 - beta1^t), evaluated in double, rounded once
-    const float correction = a.corr_pre != nullptr ? *a.corr_pre : adam_correction(a.beta1, a.beta2, t);
-    s[5] = a.lr * correction;
-    // soft update condition uses max_iter() AFTER both increments (src/dqn.cpp:967)
-    const int mx = (it_a + 1) > (it_c + 1) ? (it_a + 1) : (it_c + 1);
-    s[6] = ((mx % a.soft_update_freq) == 0) ? 1.0f : 0.0f;
+    if (a.corr_pre != nullptr) {                         // inside an update: both were left in DevState by its first launch
+      s[5] = a.lr * *a.corr_pre;
+      s[6] = *a.soft_pre ? 1.0f : 0.0f;
+    } else {
+      const int it_a = a.st->actor_iter, it_c = a.st->critic_iter;
+      const int t = (a.which == 0 ? it_a : it_c) + 1;    // t = iter_ + 1 (before increment)
+      s[5] = a.lr * adam_correction(a.beta1, a.beta2, t);
+      // soft update condition uses max_iter() AFTER both increments (src/dqn.cpp:967)
+      const int mx = (it_a + 1) > (it_c + 1) ? (it_a + 1) : (it_c + 1);
+      s[6] = ((mx % a.soft_update_freq) == 0) ? 1.0f : 0.0f;
+    }
     // A non-finite norm (fp16 mode: an overflowed dZ panel) would give scale = clip/inf = 0 and
     // g*0 = NaN in m, v, w and the targets for good.  Every block derives the same norm, so every
     // block takes the same decision: skip the whole step and raise the sticky flag.
@@ -1043,28 +1055,18 @@ __device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot, double
 __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   __shared__ float s[8];
   __shared__ double sq[4];
-  __shared__ int s_last;
   adam_soft_body<1, 0>(a, blockIdx.x, gridDim.x, s);
-  if (a.tick_ticket == nullptr) return;
-  __syncthreads();                                       // this block's last reads of DevState are done
-  // Two-level arrival count: atomics on ONE word serialise at ~12 ns each (2048 blocks = 25 us,
-  // measured); 16 sub-counters on separate 128-B lines, then one top counter: <= 128 + 16 in a row.
-  if (threadIdx.x == 0) {
-    constexpr int kSub = 16;
-    const int G = (int)gridDim.x, sub = (int)blockIdx.x % kSub;
-    const int expect = (G + kSub - 1 - sub) / kSub;      // blocks with blockIdx % kSub == sub
-    int* c = a.tick_ticket + sub * 32;
-    int last = 0;
-    if (__hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1) {
-      *c = 0;                                            // re-arm for the next launch
-      int* top = a.tick_ticket + kSub * 32;
-      const int groups = G < kSub ? G : kSub;
-      if (__hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) { *top = 0; last = 1; }
-    }
-    s_last = last;
+  // The update's bookkeeping (statistics, ++iter of both solvers, the sampling counter) rides in block 0 of the update's
+  // last launch.  It used to wait for the LAST block to arrive (two levels of arrival counters: every block read the
+  // iteration counters in its prologue) — a tail of 2.5-5 us behind the last stores (same-box A/B: 3 108-3 132 against
+  // 3 138-3 157 updates/s without it).  With the bias correction and the soft-update switch left in DevState by the
+  // update's first launch, no block of this launch reads anything tick_body writes, so block 0 runs it as soon as its
+  // own slice is done, beside the other 2047 blocks.
+  if (a.tick_on && blockIdx.x == 0) {
+    const bool skipped = s[7] != 0.0f;
+    __syncthreads();
+    tick_body(a.tick, s, sq, skipped);
   }
-  __syncthreads();
-  if (s_last) tick_body(a.tick, s, sq, s[7] != 0.0f);
 }
 
 // Sum of up to 8 co-located gradient arenas in rank order, written back to all (dqnhip_reduce_gradients_local)
