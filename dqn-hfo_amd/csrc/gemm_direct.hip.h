@@ -131,10 +131,30 @@ __device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_
     }
     FWD_COMPUTE(0) FWD_COMPUTE(1) FWD_COMPUTE(2) FWD_COMPUTE(3)
   }
-  for (int kb = nkb4; kb < nkb; ++kb) { FWD_LOAD(0, kb) FWD_COMPUTE(0) }
+  // the (up to three) remaining steps: every load first, then the MFMAs (the first tower layer has K_in = 64 / 128,
+  // i.e. ONLY these steps: one load round trip instead of one per step)
+  {
+    const int rem = nkb - nkb4;
+    if (rem > 0) FWD_LOAD(0, nkb4)
+    if (rem > 1) FWD_LOAD(1, nkb4 + 1)
+    if (rem > 2) FWD_LOAD(2, nkb4 + 2)
+    if (rem > 0) FWD_COMPUTE(0)
+    if (rem > 1) FWD_COMPUTE(1)
+    if (rem > 2) FWD_COMPUTE(2)
+  }
 #undef FWD_LOAD
 #undef FWD_COMPUTE
 
+  // this wave's bias pieces, requested ahead of the cross-wave reduction
+  constexpr int NBV = (NACC + 3) / 4;
+  f32x4 bvp[NBV];
+  if (pr.bias != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) {
+      const int e = j * 4 + wave;
+      if (e < NACC) bvp[j] = *reinterpret_cast<const f32x4*>(pr.bias + p0 + (e % TP) * 16 + (lg << 2));
+    }
+  }
   park_accumulators<NACC>(smem, acc, wave, lane);
   __syncthreads();
 #pragma unroll
@@ -144,7 +164,7 @@ __device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_
       f32x4 v = reduce_accumulator<NACC>(smem, e, lane);
       const int q = q0 + a * 16 + li, p = p0 + c * 16 + (lg << 2);
       if (pr.bias != nullptr) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(pr.bias + p);
+        const f32x4 bv = bvp[e >> 2];
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
       }
       if (pr.relu) { v.x = lrelu_fwd(v.x); v.y = lrelu_fwd(v.y); v.z = lrelu_fwd(v.z); v.w = lrelu_fwd(v.w); }
@@ -366,7 +386,15 @@ __device__ __forceinline__ void wgrad_direct_body(const GemmProblem& pr, int til
 #pragma unroll
     for (int i = 0; i < NS; ++i) { WG_COMPUTE(i) }
   }
-  for (int st = nstN; st < nst; ++st) { WG_LOAD(0, st) WG_COMPUTE(0) }
+  {   // the (up to NS - 1) remaining steps: every load first (minibatch 32: these two steps are the whole reduction)
+    const int rem = nst - nstN;
+    if (rem > 0) WG_LOAD(0, nstN)
+    if (rem > 1) WG_LOAD(1, nstN + 1)
+    if (rem > 2) WG_LOAD(2, nstN + 2)
+    if (rem > 0) WG_COMPUTE(0)
+    if (rem > 1) WG_COMPUTE(1)
+    if (rem > 2) WG_COMPUTE(2)
+  }
 #undef WG_LOAD
 #undef WG_COMPUTE
 
