@@ -53,4 +53,18 @@ __device__ __forceinline__ float lrelu_mask(float y) {
   return (y > 0.0f ? 1.0f : 0.0f) + kLeakySlope * (y <= 0.0f ? 1.0f : 0.0f);
 }
 
+// Sum over the 64 lanes of a wave with DPP moves (VALU speed) instead of six ds_bpermute butterfly steps: quad
+// xor 1, xor 2, half-row mirror, row mirror give every lane its 16-lane row total; row_bcast15 / row_bcast31 chain
+// the four row totals into lane 63, which is broadcast.  (Ten heads x six dependent LDS-crossbar shuffles were
+// ~2.5 us per row in the one-wave-per-row head kernels.)  Order: fixed, the same in every wave.
+__device__ __forceinline__ float wave_sum64(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 }  // namespace dqnhip

@@ -443,8 +443,7 @@ __device__ __forceinline__ void wgrad_direct_body(const GemmProblem& pr, int til
     ssq = fmaf(v.x, v.x, ssq); ssq = fmaf(v.y, v.y, ssq); ssq = fmaf(v.z, v.z, ssq); ssq = fmaf(v.w, v.w, ssq);
   }
   if (pr.partial != nullptr) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
+    ssq = wave_sum64(ssq);
     __syncthreads();                       // every wave is done reading the parked tiles
     if (lane == 0) smem[wave] = ssq;
     __syncthreads();
@@ -535,8 +534,7 @@ __device__ __forceinline__ void wgrad_narrow_body(const GemmProblem& pr, int til
     ssq = fmaf(v, v, ssq);
   }
   if (pr.partial != nullptr) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
+    ssq = wave_sum64(ssq);
     __syncthreads();
     if (lane == 0) smem[wave] = ssq;
     __syncthreads();

@@ -455,8 +455,7 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
 #endif
   }
   if (g.sumsq_partial) {                    // fixed-order block reduction: lanes, then the waves in index order
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    sq = wave_sum64(sq);
     __shared__ float s_sq[NW];
     if (lane == 0) s_sq[w] = sq;
     __syncthreads();
@@ -671,8 +670,7 @@ __global__ __launch_bounds__(256) void k_db16(Db16Batch b) {
     const h16x8 v = *reinterpret_cast<const h16x8*>(p + i);
     acc += (((float)v[0] + (float)v[1]) + ((float)v[2] + (float)v[3])) + (((float)v[4] + (float)v[5]) + ((float)v[6] + (float)v[7]));
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  acc = wave_sum64(acc);
   __shared__ float s[4];
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -717,8 +715,7 @@ __device__ __forceinline__ void db16_cols_block(const Db16Batch& b, int blk, flo
     d.db[col0 + threadIdx.x] = s;
     if (b.sumsq_partial) {                   // one wave: butterfly, lane 0 stores
       float q = s * s;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+      q = wave_sum64(q);
       if (threadIdx.x == 0) b.sumsq_partial[blk] = q;
     }
   }

@@ -225,19 +225,6 @@ __global__ void k_gather(Ring ring, const DevState* rs, const DevState* st, cons
   }
 }
 
-// Sum over the 64 lanes of a wave with DPP moves (VALU speed) instead of six ds_bpermute butterfly steps: quad
-// xor 1, xor 2, half-row mirror, row mirror give every lane its 16-lane row total; row_bcast15 / row_bcast31 chain
-// the four row totals into lane 63, which is broadcast.  (Ten heads x six dependent LDS-crossbar shuffles were
-// ~2.5 us per row in the one-wave-per-row head kernels.)  Order: fixed, the same in every wave.
-__device__ __forceinline__ float wave_sum64(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
 
 // ---- skinny head layers ------------------------------------------------------
 // action_layer(4) + actionpara_layer(6) of the actor and q_values_layer(1) of
@@ -326,8 +313,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
     HEAD_DISPATCH(a.X16 != nullptr, dots);
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
+      acc[j] = wave_sum64(acc[j]);
       if (lane == 0) s_acc[wave][j] = acc[j];
     }
     __syncthreads();
@@ -464,8 +450,7 @@ __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
     };
     HEAD_DISPATCH(a.X16 != nullptr, dots);
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { at += __shfl_xor(at, off, 64); ao += __shfl_xor(ao, off, 64); }
+  at = wave_sum64(at); ao = wave_sum64(ao);
   float d2 = 0.0f;
   if (row < a.rows && lane == 0) {
     const float qt = at + bt0, q = ao + b0;
@@ -532,8 +517,7 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
       }
     };
     HEAD_DISPATCH(a.X416 != nullptr, dots);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    acc = wave_sum64(acc);
     if (lane == 0) { const float v = acc + a.q_bias[0]; a.q_out[row] = v; a.qsum_partial[row] = (double)v; }
     return;
   }
@@ -652,8 +636,7 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
     a.db[kc] = v;
     ssq = v * v;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
+  ssq = wave_sum64(ssq);
   if (kc == 0) s_acc[rg] = ssq;                        // s_acc is free again
   __syncthreads();
   if (tid == 0) {
@@ -841,8 +824,7 @@ __global__ __launch_bounds__(256) void k_head_wred(HeadBwdBigArgs b, int chunks)
     float t = 0.0f;
     if (blockIdx.x == 0) {
       for (int c = lane; c < chunks; c += 64) t += b.slab2[(size_t)chunks * NH * a.H + c * 16 + j];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+      t = wave_sum64(t);
       if (lane == 0) a.db[j] = t;
     }
     if (lane == 0) s_bias = t * t;
@@ -852,8 +834,7 @@ __global__ __launch_bounds__(256) void k_head_wred(HeadBwdBigArgs b, int chunks)
   v = (s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]);
   a.dW[(size_t)j * a.H + k] = v;
   float ssq = v * v;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
+  ssq = wave_sum64(ssq);
   if (lane == 0 && a.partial != nullptr) a.partial[j * gridDim.x + blockIdx.x] = ssq + s_bias;
 }
 
@@ -869,8 +850,7 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, size
     const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
     acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  acc = wave_sum64(acc);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
@@ -905,8 +885,7 @@ __global__ __launch_bounds__(256) void k_sumsq_bf16(const uint16_t* __restrict__
     reinterpret_cast<f32x4*>(g)[i] = v;
     acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  acc = wave_sum64(acc);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
@@ -951,8 +930,7 @@ __device__ __forceinline__ void adam_scalars(const AdamArgs& a, int blk, float* 
   // same order -> bit-identical scale everywhere, no extra launch
   float acc = 0.0f;
   for (int i = threadIdx.x; i < a.n_partial; i += 256) acc += a.partial[i];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  acc = wave_sum64(acc);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
   __syncthreads();
   // one lane per block evaluates the per-launch scalars (two double pow() are ~500 instructions: run by
