@@ -500,6 +500,9 @@ struct HeadBwdArgs {
 // writes its dZ rows directly and a partial dW slab; the LAST block to arrive for a column block
 // (agent-scope release -> ticket -> acquire, guide G16) adds the RC slabs in fixed order, so the
 // result does not depend on which block that is.
+// cross-block hand-off words: coherent at agent scope without a fence on either side
+__device__ __forceinline__ void slab_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float slab_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int NH>
 __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -604,22 +607,23 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
     float v = 0.0f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) v += s_acc[(g * NH + j) * 64 + kc];
-    my_slab[j * 64 + kc] = v;
+    slab_st(&my_slab[j * 64 + kc], v);
   }
   if (rg == NH && blockIdx.x == 0 && kc < NH) {       // partial bias gradient of this chunk (a spare wave)
     float v = 0.0f;
     for (int m = 0; m < r1 - r0; ++m) v += s_dy[m * NH + kc];
-    a.slab[(size_t)RC * nkb * NH * 64 + rc * 16 + kc] = v;
+    slab_st(&a.slab[(size_t)RC * nkb * NH * 64 + rc * 16 + kc], v);
   }
-  // publish the slab, take a ticket; the last arriver reduces (placement independent)
+  // publish the slab, take a ticket; the last arriver reduces (placement independent).  The slab travels as
+  // agent-scope (sc1: write-through / L2-bypassing) stores and loads, drained before the ticket — not plain stores +
+  // a release fence (the fence writes back the whole L2, this launch's dZ rows included, once per block, and the
+  // last arriver's acquire invalidates it again).  Measured alternatives at 256 rows, same-box A/B: one row chunk on
+  // 32-column blocks (no counter): no gain; the gradients from an extra grid row of blocks that walk all rows: -0.8 %.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int t = __hip_atomic_fetch_add(a.ticket + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == RC - 1);
-    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   if (!s_last) return;
@@ -627,12 +631,12 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   if (rg < NH) {
     const int j = rg;
     float v = 0.0f;
-    for (int c = 0; c < RC; ++c) v += a.slab[((size_t)c * nkb + blockIdx.x) * NH * 64 + j * 64 + kc];
+    for (int c = 0; c < RC; ++c) v += slab_ld(&a.slab[((size_t)c * nkb + blockIdx.x) * NH * 64 + j * 64 + kc]);
     a.dW[(size_t)j * a.H + k] = v;
     ssq = v * v;
   } else if (rg == NH && blockIdx.x == 0 && kc < NH) {
     float v = 0.0f;
-    for (int c = 0; c < RC; ++c) v += a.slab[(size_t)RC * nkb * NH * 64 + c * 16 + kc];
+    for (int c = 0; c < RC; ++c) v += slab_ld(&a.slab[(size_t)RC * nkb * NH * 64 + c * 16 + kc]);
     a.db[kc] = v;
     ssq = v * v;
   }
