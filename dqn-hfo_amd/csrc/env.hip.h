@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void k_env_step(EnvDev e) {
   const unsigned long long g = e.g[w];
   GameState gs;                                      // fetched now, used at the end: its latency hides behind the heads
   if (tid == 0) gs = e.game[w];
+  const float head_bias = (e.head_x != nullptr && tid < kNO) ? e.head_b[tid] : 0.0f;   // likewise
   // SelectAction(state, epsilon): ONE epsilon draw per call (src/dqn.cpp:700)
   const bool rnd = env_u01(e.seed, g, w, 0) < epsilon;
   if (e.head_x != nullptr) {
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void k_env_step(EnvDev e) {
   if (tid < kAP) {
     float v = 0.0f;
     if (tid < kNO) {
-      if (e.head_x != nullptr) v = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + e.head_b[tid];
+      if (e.head_x != nullptr) v = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + head_bias;
       else v = e.out16[(size_t)w * kAP + tid];       // written by the separate head launch
     }
     if (e.head_x != nullptr) e.out16[(size_t)w * kAP + tid] = v;
