@@ -488,8 +488,10 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   }
   ScopedTiming t(h, 3, st);
   LaunchTimer& lt = launch_timer();
-  // 2048 blocks: grids of 512 .. 8192 measured within +-3 % (profiles/r02_adam_probe.txt)
-  const int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)2048);
+  // 1536 blocks = 6 per CU, all resident at once (68 VGPRs: 7 waves per SIMD): with the loads hoisted above the prologue
+  // same-box A/B gives 18.4 us per launch against 19.3 at 2048 (a second, short round of blocks), 19.4 at 1792, 18.7 at
+  // 1280, 21.5 at 4096 (round 2, before the hoist: 512 .. 8192 within +-3 %, profiles/r02_adam_probe.txt)
+  const int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)1536);
   if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
   else hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
