@@ -335,7 +335,7 @@ int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, 
     const long P = l.dims[i + 1];
     const long t42 = (long)n * (P / 64) * (rows / 32), t22 = (long)n * (P / 32) * (rows / 32);
     if (lds_ok) {
-      if (t42 >= 192) HIPCHK((fwd_lds_launch<4, 2, true>(b, st)));
+      if (t42 >= 192) HIPCHK((fwd_lds_launch<4, 2, true, 1>(b, st)));   // one LDS image per wave (48 KiB): both tiles of a CU resident at once — same-box A/B +0.6 %
       else if (t22 >= 128 || rows > 128 || rows % 16) HIPCHK((fwd_lds_launch<2, 2, true>(b, st)));
       else HIPCHK((fwd_lds_launch<1, 1, true>(b, st)));
     } else {
