@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256) void k_head_fwd_rows(HeadArgs2 a2) {
     }
   };
   const int row_step = gridDim.x * 4;
+  const float bias_l = lane < NH ? a.b[lane] : 0.0f;   // once: inside the row loop the stores keep it from being hoisted
   f32x4 xn[4];
   if ((int)(blockIdx.x * 4 + wave) < a.rows) load_row(blockIdx.x * 4 + wave, xn);
   for (int row = blockIdx.x * 4 + wave; row < a.rows; row += row_step) {
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void k_head_fwd_rows(HeadArgs2 a2) {
     if (lane < kAP) {
       float v = 0.0f;
 #pragma unroll
-      for (int j = 0; j < NH; ++j) if (lane == j) v = acc[j] + a.b[j];
+      for (int j = 0; j < NH; ++j) if (lane == j) v = acc[j] + bias_l;
       if constexpr (MODE == HEAD_ACTOR) {
         a.out16[(size_t)row * kAP + lane] = v;
         if (a.xc != nullptr && lane < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + lane] = v;
