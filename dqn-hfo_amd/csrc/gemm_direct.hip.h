@@ -923,9 +923,7 @@ __global__ __launch_bounds__(256) void gemm_bwd_pair_direct(const GemmBatch batc
 // per CU measured ~ the SUM of their stand-alone times (the pair kernel above: 15.5 us for 2 x 4.2 us
 // of MFMA); one workgroup doing both pays the per-launch fixed cost once and keeps one wave per SIMD.
 template <bool DLDS>
-__global__ __launch_bounds__(256) void gemm_bwd_seq(const GemmBatch batch) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.x;
+__device__ __forceinline__ void bwd_seq_block(const GemmBatch& batch, const int b, float* smem) {
   int tile_p, tile_q;
   // wgrad first (measured 14.9 us; dgrad first 15.3, also with the wgrad ring pre-issued under the
   // dgrad epilogue)
@@ -941,6 +939,92 @@ __global__ __launch_bounds__(256) void gemm_bwd_seq(const GemmBatch batch) {
     if constexpr (DLDS) dgrad_lds_body<1, 1, true>(pd, tile_p, tile_q, smem);
     else dgrad_direct_body<1, 1>(pd, tile_p, tile_q, smem);
   }
+}
+template <bool DLDS>
+__global__ __launch_bounds__(256) void gemm_bwd_seq(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bwd_seq_block<DLDS>(batch, (int)blockIdx.x, smem);
+}
+
+// The head layer's weight / bias gradients (dWh[j][k] = sum_m dYh[m][j] X4[m][k], dbh[j] = sum_m dYh[m][j]) as RIDER blocks of a
+// later launch of the same net's backward.  The head-backward kernel produces dZ for that launch and used to produce dWh too — through
+// row-chunk slabs and an arrival counter whose tail (drain, barrier, counter, barrier, slab reads) was 2.5 us per launch at the end
+// of a 5-8 us kernel.  Nothing before the optimiser pass reads dWh, and a rider block (8 columns x 32 row groups, every row of its
+// columns: no cross-block reduction) is done in ~3 us.  dy: the head diffs the head-backward kernel consumed (critic: dq [rows]; actor: the post-invert diffs [rows][16]).
+struct HeadWgradRider {
+  const float* dy; int lddy;
+  const float* X4; int H, rows;
+  float* dW; float* db; float* partial;     // [NH][H], [NH], one sum-of-squares slot per rider block (H / 16)
+  int blocks;                               // H / kRiderCW rider blocks, FIRST in the grid (0: none)
+};
+constexpr int kRiderCW = 8;                    // columns per rider block (x 32 row groups)
+template <int NH>
+__device__ __forceinline__ void head_wgrad_rider(const HeadWgradRider& r, const int blk, float* smem) {
+  constexpr int CW = kRiderCW, RG = 256 / CW;
+  const int tid = threadIdx.x, kc = tid % CW, rg = tid / CW;
+  const int k = blk * CW + kc;
+  float* s_dy = smem;                          // [rows][NH]
+  float* s_acc = smem + r.rows * NH;           // [RG][NH][CW]
+  const int per = (r.rows + RG - 1) / RG, m0 = rg * per, m1 = m0 + per < r.rows ? m0 + per : r.rows;
+  constexpr int RB = 8;                        // every row of a 256-row minibatch in flight at once: the tower top was written
+                                               // many launches ago (Infinity Cache / HBM latency, not L2)
+  float xpre[RB];
+#pragma unroll
+  for (int u = 0; u < RB; ++u) xpre[u] = (m0 + u < m1) ? r.X4[(size_t)(m0 + u) * r.H + k] : 0.0f;
+  for (int i = tid; i < r.rows * NH; i += 256) s_dy[i] = r.dy[(size_t)(i / NH) * r.lddy + (i % NH)];
+  __syncthreads();
+  float acc[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
+  for (int mb = m0; mb < m1; mb += RB) {
+    float xb[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) xb[u] = (mb == m0) ? xpre[u] : ((mb + u < m1) ? r.X4[(size_t)(mb + u) * r.H + k] : 0.0f);
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int m = mb + u;
+      if (m >= m1) break;
+#pragma unroll
+      for (int j = 0; j < NH; ++j) acc[j] = fmaf(s_dy[m * NH + j], xb[u], acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NH; ++j) s_acc[(rg * NH + j) * CW + kc] = acc[j];
+  __syncthreads();
+  float ssq = 0.0f;
+  if (tid < NH * CW) {                         // row groups added in index order
+    const int j = tid / CW, c = tid % CW;
+    float v = 0.0f;
+#pragma unroll 8
+    for (int g = 0; g < RG; ++g) v += s_acc[(g * NH + j) * CW + c];
+    r.dW[(size_t)j * r.H + blk * CW + c] = v;
+    ssq = v * v;
+  } else if (blk == 0 && tid < NH * CW + NH) { // bias gradient: rows in index order
+    const int j = tid - NH * CW;
+    float v = 0.0f;
+    for (int m = 0; m < r.rows; ++m) v += s_dy[m * NH + j];
+    r.db[j] = v;
+    ssq = v * v;
+  }
+  ssq = wave_sum64(ssq);
+  __syncthreads();
+  if ((tid & 63) == 0) s_acc[tid >> 6] = ssq;
+  __syncthreads();
+  if (tid == 0 && r.partial != nullptr) r.partial[blk] = (s_acc[0] + s_acc[1]) + (s_acc[2] + s_acc[3]);
+}
+// The carrier is the FIRST tower layer's narrow wgrad launch (the last launch before the optimiser pass): 64-128 tiles, so the rider
+// blocks land on CUs of their own instead of beside a GEMM wave (as riders of the top layer's gemm_bwd_seq: +0.9 us on that launch)
+template <int NH>
+__global__ __launch_bounds__(256) void gemm_wgrad_narrow_rider(const GemmBatch batch, const HeadWgradRider rider) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < rider.blocks) { head_wgrad_rider<NH>(rider, (int)blockIdx.x, smem); return; }
+  int pi, tile_p, tile_q;
+  const int blk = (int)blockIdx.x - rider.blocks;
+  pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i) if (i < batch.n && blk >= batch.prob[i].tile_base) pi = i;
+  tile_of_problem(batch.prob[pi], blk - batch.prob[pi].tile_base, tile_p, tile_q);
+  wgrad_narrow_body<1>(batch.prob[pi], tile_p, tile_q, smem);
 }
 
 // ---- launchers ------------------------------------------------------------------------
@@ -1018,6 +1102,23 @@ inline hipError_t dgrad_narrow_launch(GemmBatch& b, hipStream_t s) {
 template <int TPB>
 inline hipError_t wgrad_narrow_launch(GemmBatch& b, hipStream_t s) {
   return direct_launch(gemm_wgrad_narrow<TPB>, b, 64 * TPB, 16, 4 * TPB * 4 * 64 * 16 + 4 * 16 * 4, s);
+}
+template <int NH>
+inline hipError_t wgrad_narrow_rider_launch(GemmBatch& batch, const HeadWgradRider& rider, hipStream_t stream) {
+  int base = 0;
+  for (int i = 0; i < batch.n; ++i) {
+    GemmProblem& p = batch.prob[i];
+    p.tiles_p = p.Pdim / 64; p.tiles_q = p.Qdim / 16; p.tile_base = base;
+    base += p.tiles_p * p.tiles_q;
+  }
+  batch.total_tiles = base;
+  const size_t need = (size_t)(rider.rows * NH + 16 * NH * 16) * sizeof(float);
+  const size_t lds = need > (size_t)(4 * 4 * 64 * 16 + 4 * 16 * 4) ? need : (size_t)(4 * 4 * 64 * 16 + 4 * 16 * 4);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  LaunchTimer& lt = launch_timer();
+  if (lt.start) { hipExtLaunchKernelGGL((gemm_wgrad_narrow_rider<NH>), dim3(base + rider.blocks), dim3(256), lds, stream, lt.start, lt.stop, 0, batch, rider); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL((gemm_wgrad_narrow_rider<NH>), dim3(base + rider.blocks), dim3(256), lds, stream, batch, rider);
+  return hipGetLastError();
 }
 template <bool DLDS>
 inline hipError_t bwd_seq_launch(GemmBatch& batch, hipStream_t stream) {

@@ -94,7 +94,7 @@ void layout_init(NetLayout& l, int in_dim, const dqnhip_config& c, bool actor) {
   l.hw_off = off; off += round_up_z((size_t)l.NH * H, 64);
   l.hb_off = off; off += 64;
   dense += (size_t)l.NH * H + l.NH;
-  l.part_off[l.L] = part; part += (H / 64) * l.NH;    // k_head_bwd uses the first H/64, k_head_wred one per (head, 64 columns)
+  l.part_off[l.L] = part; part += std::max((H / 64) * l.NH, H / kRiderCW);    // k_head_bwd uses the first H/64, head_wgrad_rider H/8, k_head_wred one per (head, 64 columns)
   // fp16 learner: the bias gradients come from their own workgroups (k_db16_cols, one per 64 columns): their slots
   l.part_db = part;
   for (int i = 0; i < l.L; ++i) part += l.dims[i + 1] / 64;
@@ -358,8 +358,20 @@ int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows) 
 // everything enqueued on `st` so far (per-layer bucketing; defined with dqnhip_dp_*)
 int dp_reduce_slice(H* h, hipStream_t st, int net, size_t off, size_t count);
 
+// does layer i's backward (dgrad + wgrad) take the side-by-side pair launch (small minibatches / narrow layers)?
+inline bool bwd_layer_is_pair(const NetLayout& l, int i, int rows) {
+  const long tiles = (long)(l.kp[i] / 64) * (rows / 16) + (long)(l.kp[i] / 64) * (l.dims[i + 1] / 64);
+  return tiles <= 256 && rows % 16 == 0 && l.kp[i] % 64 == 0 && l.dims[i + 1] % 64 == 0;
+}
+// may the head's weight / bias gradients ride in the first tower layer's wgrad launch (gemm_wgrad_narrow_rider: the last
+// launch of a net's backward, input_grad == false)?
+inline bool head_wgrad_can_ride(const NetLayout& l, int rows) {
+  const int NH = l.NH, H = l.dims[l.L];
+  return H % kRiderCW == 0 && (size_t)(rows * NH + 256 * NH) * sizeof(float) <= (size_t)64 * 1024;
+}
 int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* garena, float* partial,
-                   float** act, float** dZ, int rows, bool want_w, bool input_grad, int in_lo = 0, int in_hi = -1) {
+                   float** act, float** dZ, int rows, bool want_w, bool input_grad, int in_lo = 0, int in_hi = -1,
+                   const HeadWgradRider* rider = nullptr) {
   for (int i = l.L - 1; i >= 0; --i) {
     GemmBatch bd{}, bw{};
     const bool need_dx = (i > 0 || input_grad);
@@ -389,8 +401,7 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
       ScopedTiming t(h, 4, st);
       // small minibatches / narrow layers: when the dgrad's 64x16 tiles and the wgrad's 64x64 tiles together still fit
       // the chip in one round, they run side by side on their own workgroups (one tile's chain per launch, not two)
-      const long tiles = (long)(l.kp[i] / 64) * (rows / 16) + (long)(l.kp[i] / 64) * (l.dims[i + 1] / 64);
-      if (tiles <= 256 && rows % 16 == 0 && l.kp[i] % 64 == 0 && l.dims[i + 1] % 64 == 0) {
+      if (bwd_layer_is_pair(l, i, rows)) {
         if (lds_ok) HIPCHK((bwd_pair_direct_launch<1, true>(b, st))); else HIPCHK((bwd_pair_direct_launch<1, false>(b, st)));
       } else if (lds_ok) HIPCHK((bwd_seq_launch<true>(b, st)));
       else HIPCHK((bwd_seq_launch<false>(b, st)));
@@ -408,7 +419,9 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
     } else {
       // wgrad alone = the first layer (K_in = 64 / 128 columns): 16-output tiles, 4x the workgroups
       ScopedTiming t(h, 2, st);
-      HIPCHK((wgrad_narrow_launch<1>(bw, st)));
+      if (rider) {                                    // + the head's dW / db as rider blocks (head_wgrad_can_ride)
+        if (l.NH == 1) HIPCHK((wgrad_narrow_rider_launch<1>(bw, *rider, st))); else HIPCHK((wgrad_narrow_rider_launch<kNO>(bw, *rider, st)));
+      } else HIPCHK((wgrad_narrow_launch<1>(bw, st)));
     }
     // data parallel, bucketed: layer i's dW/db are final once this launch has run -> start their
     // all-reduce on the communication stream while the chain continues with layer i-1
@@ -823,9 +836,13 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[3][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L]; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
+      // the head's own gradients ride in the net's last backward launch (the first layer's narrow wgrad)
+      const bool ride = !head_big_ok(h, B, Hc) && head_wgrad_can_ride(lc, B);
+      HeadWgradRider r{h->dq, 1, h->act[3][L], Hc, B, a.dW, a.db, a.partial, Hc / kRiderCW};
+      if (ride) { a.dW = nullptr; a.db = nullptr; a.partial = nullptr; }
       RC(head_backward<1>(h, st, a));
+      RC(tower_backward(h, st, lc, DQNHIP_CRITIC, h->g[1], h->part[1], h->act[3], h->dZc, B, true, false, 0, -1, ride ? &r : nullptr));
     }
-    RC(tower_backward(h, st, lc, DQNHIP_CRITIC, h->g[1], h->part[1], h->act[3], h->dZc, B, true, false));
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)h->loss_partial,
                          h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr, (const DevState*)h->st);
@@ -856,9 +873,12 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;
       a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.X4 = h->act[1][L]; a.H = Hh; a.rows = B; a.dZ = h->dZa[L];
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
+      const bool ride = !head_big_ok(h, B, Hh) && head_wgrad_can_ride(la, B);
+      HeadWgradRider r{h->dA16, kAP, h->act[1][L], Hh, B, a.dW, a.db, a.partial, Hh / kRiderCW};   // dA16: the post-invert diffs this launch leaves
+      if (ride) { a.dW = nullptr; a.db = nullptr; a.partial = nullptr; }
       RC(head_backward<kNO>(h, st, a));
+      RC(tower_backward(h, st, la, DQNHIP_ACTOR, h->g[0], h->part[0], h->act[1], h->dZa, B, true, false, 0, -1, ride ? &r : nullptr));
     }
-    RC(tower_backward(h, st, la, DQNHIP_ACTOR, h->g[0], h->part[0], h->act[1], h->dZa, B, true, false));
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)nullptr, 0,
                          (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail, (const DevState*)h->st);
