@@ -827,6 +827,8 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       t.H = Hc; t.rows = B; t.reward = h->mb_reward; t.mc = h->mb_mc; t.term = h->mb_term;
       t.q_target = h->q_t; t.q = h->q1; t.y = h->y; t.dq = h->dq; t.loss_partial = h->loss_partial;
       t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch; t.st = h->st;
+      // with the head's dW / db riding in the net's last backward launch, the head's dZ comes out of this launch too
+      if (!head_big_ok(h, B, Hc) && head_wgrad_can_ride(lc, B)) t.dZ = h->dZc[L];
       hipLaunchKernelGGL(k_head_q_train, dim3((B + 3) / 4), dim3(256), 0, st, t);
       HIPCHK(hipGetLastError());
     }
@@ -839,8 +841,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       // the head's own gradients ride in the net's last backward launch (the first layer's narrow wgrad)
       const bool ride = !head_big_ok(h, B, Hc) && head_wgrad_can_ride(lc, B);
       HeadWgradRider r{h->dq, 1, h->act[3][L], Hc, B, a.dW, a.db, a.partial, Hc / kRiderCW};
-      if (ride) { a.dW = nullptr; a.db = nullptr; a.partial = nullptr; }
-      RC(head_backward<1>(h, st, a));
+      if (!ride) RC(head_backward<1>(h, st, a));          // (riding: dZ came out of k_head_q_train, dW / db come from the rider)
       RC(tower_backward(h, st, lc, DQNHIP_CRITIC, h->g[1], h->part[1], h->act[3], h->dZc, B, true, false, 0, -1, ride ? &r : nullptr));
     }
     if (dp) {

@@ -430,6 +430,11 @@ struct HeadTrainArgs {
   float* q_target; float* q; float* y; float* dq; float* loss_partial;
   double gamma, beta; float inv_batch;
   DevState* st;                                         // non-finite target flag (src/dqn.cpp:898)
+  // not null: this launch also writes the online critic's tower-top gradient dZ[row][k] = (dq[row] * W[k]) * lrelu'(X[row][k])
+  // — what k_head_bwd<1> computed from dq in a launch of its own.  The wave that forms a row's dq has just streamed that
+  // row of X and W through its registers; the head's own dW / db ride elsewhere (head_wgrad_rider), so with this the
+  // critic's head-backward launch of Step(1) is gone.
+  float* dZ;
 };
 __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
     HEAD_DISPATCH(a.X16 != nullptr, dots);
   }
   at = wave_sum64(at); ao = wave_sum64(ao);
-  float d2 = 0.0f;
+  float d2 = 0.0f, dq_row = 0.0f;
   if (row < a.rows && lane == 0) {
     const float qt = at + bt0, q = ao + b0;
     a.q_target[row] = qt; a.q[row] = q;
@@ -461,8 +466,21 @@ __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
     a.y[row] = target;
     if (!isfinite(target)) atomicOr(&a.st->flags, kFlagTarget);   // CHECK(std::isfinite(target)), src/dqn.cpp:898
     const float d = q - target;
-    a.dq[row] = a.inv_batch * d;
+    dq_row = a.inv_batch * d;
+    a.dq[row] = dq_row;
     d2 = d * d;
+  }
+  if (a.dZ != nullptr && row < a.rows) {                 // (fp32 tower top only; wave-uniform condition)
+    const float dqv = __shfl(dq_row, 0, 64);
+    const size_t x0 = (size_t)row * a.H;
+    for (int k = lane * 4; k < a.H; k += 256) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(a.X + x0 + k), wv = *reinterpret_cast<const f32x4*>(a.W + k);
+      // k_head_bwd<1>'s arithmetic: s0 = fma(d, w, 0) = d * w, then * lrelu'(x)
+      f32x4 dz;
+      dz.x = (dqv * wv.x) * lrelu_mask(xv.x); dz.y = (dqv * wv.y) * lrelu_mask(xv.y);
+      dz.z = (dqv * wv.z) * lrelu_mask(xv.z); dz.w = (dqv * wv.w) * lrelu_mask(xv.w);
+      *reinterpret_cast<f32x4*>(a.dZ + x0 + k) = dz;
+    }
   }
   if (lane == 0) s_part[wave] = d2;
   __syncthreads();
