@@ -888,7 +888,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     return 0;
   }
   if (phase == 2) {
-    // the actor's optimiser pass is the update's last launch: its last-arriving block also publishes
+    // the actor's optimiser pass is the update's last launch: its block 0 also publishes
     // (critic_loss, avg_q) and advances the iteration / sampling counters
     const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
                         dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world), h->stats_dev};
