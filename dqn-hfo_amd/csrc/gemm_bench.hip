@@ -384,13 +384,20 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
   hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, B, b_elems, 23u, -1.f, 1.f);
   hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, mask, (size_t)M * N, 31u, -1.f, 1.f);
   hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, s, bias, (size_t)N, 41u, -1.f, 1.f);
+  // the dgrad's ReLU' operand: the sign bits of the mask panel (what a forward launch would have left beside it)
+  uint8_t *sign, *sign_out, *sign_ref;
+  const size_t sign_n = hg_sign_bytes(M, N);
+  CK(hipMalloc(&sign, sign_n)); CK(hipMalloc(&sign_out, sign_n)); CK(hipMalloc(&sign_ref, sign_n));
+  CK(hipMemsetAsync(sign, 0, sign_n, s)); CK(hipMemsetAsync(sign_out, 0x5a, sign_n, s)); CK(hipMemsetAsync(sign_ref, 0x5a, sign_n, s));
+  hipLaunchKernelGGL(k_pack_sign<0>, dim3(1024), dim3(256), 0, s, (const h16*)mask, N, M, N, sign);
   CK(hipMemsetAsync(C16, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(CT16, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(C32, 0xff, (size_t)M * N * 4, s));
   HGemm g{};
   g.A = A; g.lda = ldk; g.B = B; g.ldb = ldk; g.M = M; g.N = N; g.K = K; g.scale32 = 1.0f; g.n_valid32 = N;
   if (mode == 0) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; g.C32 = C32; g.ldc32 = N; }
   else if (mode == 4) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; }
   else if (mode == 5) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; }
-  else if (mode == 1) { g.mask = mask; g.ldm = N; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 64.0f; }
+  else if (mode == 1) { g.sign = sign; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 64.0f; }
+  if (g.relu) g.sign_out = sign_out;     // forward modes: the packed ReLU' bits of the fp16 output ride along
   else { g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 1024.0f; g.n_valid32 = N / 2; }
   if (tn) { g.ta = g.tb = 1; g.lda = M + ldpad; g.ldb = N + ldpad; }
   // tile >= 10: TWO problems in one launch (the second one a copy with its own outputs), tile - 10 = the forced shape
@@ -412,7 +419,7 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   if (avg_us) *avg_us = ms * 1000.0f / iters;
   hipLaunchKernelGGL(k_ref_h, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, (const h16*)A, g.lda, (const h16*)B, g.ldb, M, N, K,
-                     (const float*)g.bias, g.relu, g.mask, g.ldm, ref, tn ? 1 : 0);
+                     (const float*)g.bias, g.relu, g.sign ? (const h16*)mask : (const h16*)nullptr, N, ref, tn ? 1 : 0);
   hipLaunchKernelGGL(k_cmp_h, dim3(256), dim3(256), 0, s, (const float*)ref, M, N, (const h16*)g.C16, N, (const h16*)g.CT16, M, (const float*)g.C32, N,
                      g.n_valid32, g.scale32, dres);
   CK(hipMemcpyAsync(hres, dres, 8, hipMemcpyDeviceToHost, s));
@@ -428,6 +435,14 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
     fprintf(stderr, "hgemm main loop of block 17: %llu shader cycles in %.2f us -> %.0f MHz, %.0f cycles per 64-deep K tile\n", hc[0], hc[1] / 100.0,
             hc[1] ? hc[0] / (hc[1] / 100.0) : 0.0, (double)hc[0] / (K / 64));
   }
+  if (g.sign_out && g.C16) {   // the forward epilogue's sign bits = the signs of the fp16 panel it wrote, byte for byte
+    hipLaunchKernelGGL(k_pack_sign<0>, dim3(1024), dim3(256), 0, s, (const h16*)C16, N, M, N, sign_ref);
+    std::vector<uint8_t> a(sign_n), b(sign_n);
+    CK(hipMemcpyAsync(a.data(), sign_out, sign_n, hipMemcpyDeviceToHost, s)); CK(hipMemcpyAsync(b.data(), sign_ref, sign_n, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    if (memcmp(a.data(), b.data(), sign_n) != 0) hres[0] = 1e30f;
+  }
+  hipFree(sign); hipFree(sign_out); hipFree(sign_ref);
   if (pair && g.C16) {   // the second problem of the launch must have produced the same fp16 panel, bit for bit
     std::vector<uint16_t> a((size_t)M * N), b((size_t)M * N);
     CK(hipMemcpy(a.data(), C16, a.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), C16b, b.size() * 2, hipMemcpyDeviceToHost));
@@ -463,7 +478,9 @@ extern "C" int dqnhip_test_hgemm_backward(int32_t rows, int32_t n_out, int32_t k
   hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, mask, (size_t)rows * k_in, 9u, -1.f, 1.f);
   HGemm gd{}, gw{};
   gd.A = dY; gd.lda = n_out; gd.B = W; gd.ldb = k_in; gd.tb = 1; gd.M = rows; gd.N = k_in; gd.K = n_out;
-  gd.mask = mask; gd.ldm = k_in; gd.C16 = dX16; gd.ldc16 = k_in; gd.C32 = dX32; gd.ldc32 = k_in; gd.n_valid32 = k_in; gd.scale32 = 1.0f / 64.0f;
+  uint8_t* sign; CK(hipMalloc(&sign, hg_sign_bytes(rows, k_in))); CK(hipMemsetAsync(sign, 0, hg_sign_bytes(rows, k_in), s));
+  hipLaunchKernelGGL(k_pack_sign<0>, dim3(1024), dim3(256), 0, s, (const h16*)mask, k_in, rows, k_in, sign);
+  gd.sign = sign; gd.C16 = dX16; gd.ldc16 = k_in; gd.C32 = dX32; gd.ldc32 = k_in; gd.n_valid32 = k_in; gd.scale32 = 1.0f / 64.0f;
   gw.A = dY; gw.lda = n_out; gw.ta = 1; gw.B = X; gw.ldb = k_in; gw.tb = 1; gw.M = n_out; gw.N = k_in; gw.K = rows;
   gw.C32 = dW32; gw.ldc32 = k_in; gw.n_valid32 = k_in; gw.scale32 = 1.0f / 1024.0f;
   hipLaunchKernelGGL(k_ref_h, dim3((unsigned)(((size_t)rows * k_in + 255) / 256)), dim3(256), 0, s, (const h16*)dY, n_out, (const h16*)W, k_in, rows, k_in, n_out,
@@ -506,6 +523,7 @@ extern "C" int dqnhip_test_hgemm_backward(int32_t rows, int32_t n_out, int32_t k
   }
   if (max_abs_err) *max_abs_err = worst;
   if (max_ref) *max_ref = big;
+  hipFree(sign);
   hipFree(dY); hipFree(W); hipFree(X); hipFree(mask); hipFree(dX16); hipFree(dX32); hipFree(dW32); hipFree(refd); hipFree(refw); hipFree(dres);
   hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
   return 0;
@@ -713,6 +731,110 @@ extern "C" int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, flo
   for (int l = 0; l < layers; ++l) { hipFree((void*)a.W[l]); hipFree((void*)a.bias[l]); }
   for (int l = 0; l <= layers; ++l) { hipFree(a.act[l]); hipFree(ref[l]); }
   hipFree(a.counters); hipFree(a.err); hipFree(dres); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+  return 0;
+}
+
+// ======================= optimiser-under-GEMM overlap probe (VERDICT r3 "Next" item 5) ============================
+// Can the HBM / Infinity-Cache-bound optimiser pass hide under MFMA-bound launches?  L dependent 256 x 1024 x 1024 forward
+// layers (the learner's gemm_fwd_lds<2,2>) and ONE k_adam_soft pass over adam_params parameters, timed
+//   us[0]  the L launches alone            us[1]  the optimiser pass alone (1536 blocks)
+//   us[2]  serial on one stream: pass, then the L launches (what the update does today)
+//   us[3]  RIDERS: launch l carries slice l of the pass as extra workgroups behind its 256 GEMM tiles.  One LDS image per
+//          wave (48 KiB) so that a rider workgroup fits on a CU beside a GEMM workgroup (with the 96-KiB build the
+//          riders of a launch cannot become resident before a GEMM workgroup retires: they would run AFTER it)
+//   us[4]  TWO STREAMS: the pass on a second stream beside the L launches (fork / join by events, one pair per iteration)
+//   us[5]  as us[3] with the 96-KiB build (the non-co-resident control)
+// All per iteration, wall time by events on the main stream.
+namespace {
+template <int NSLOT>
+__global__ __launch_bounds__(256) void k_fwd_lds_adam(const GemmBatch batch, AdamArgs a, int adam_blocks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < batch.total_tiles) {
+    int pi, tile_p, tile_q;
+    tile_of_block(batch, pi, tile_p, tile_q);
+    fwd_lds_body<2, 2, true, NSLOT>(batch.prob[pi], tile_p, tile_q, smem);
+    return;
+  }
+  adam_soft_body<1, 0>(a, (int)blockIdx.x - batch.total_tiles, adam_blocks, smem);
+}
+}  // namespace
+
+extern "C" int dqnhip_test_overlap(int32_t layers, int64_t adam_params, int32_t rider_blocks, int32_t iters, float* us /*[6]*/) {
+  if (layers < 1 || layers > 8 || iters < 1 || adam_params < 4096 || adam_params % (4 * layers) || rider_blocks < 1) return 1;
+  const int rows = 256, width = 1024;
+  hipStream_t s, s2; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  float *W[8], *bias[8], *act[9];
+  for (int l = 0; l < layers; ++l) {
+    CK(hipMalloc(&W[l], (size_t)width * width * 4)); CK(hipMalloc(&bias[l], width * 4));
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, W[l], (size_t)width * width, 100u + l, -0.05f, 0.05f);
+    hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, s, bias[l], (size_t)width, 200u + l, -0.1f, 0.1f);
+  }
+  for (int l = 0; l <= layers; ++l) CK(hipMalloc(&act[l], (size_t)rows * width * 4));
+  hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, s, act[0], (size_t)rows * width, 7u, -1.f, 1.f);
+  float *w, *g, *m, *v, *wt, *part; DevState* st;
+  const size_t nb = (size_t)adam_params * 4;
+  CK(hipMalloc(&w, nb)); CK(hipMalloc(&g, nb)); CK(hipMalloc(&m, nb)); CK(hipMalloc(&v, nb)); CK(hipMalloc(&wt, nb));
+  CK(hipMalloc(&part, 1024 * 4)); CK(hipMalloc(&st, sizeof(DevState)));
+  CK(hipMemsetAsync(st, 0, sizeof(DevState), s)); CK(hipMemsetAsync(part, 0, 1024 * 4, s));
+  CK(hipMemsetAsync(m, 0, nb, s)); CK(hipMemsetAsync(v, 0, nb, s));
+  hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, w, (size_t)adam_params, 1u, -0.1f, 0.1f);
+  hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, wt, (size_t)adam_params, 2u, -0.1f, 0.1f);
+  hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, g, (size_t)adam_params, 3u, -1e-3f, 1e-3f);
+  AdamArgs a{};
+  a.w = w; a.g = g; a.m = m; a.v = v; a.wt = wt; a.n4 = (size_t)adam_params / 4; a.partial = part; a.n_partial = 1024;
+  a.lr = 1e-3f; a.beta1 = .95f; a.beta2 = .999f; a.eps = 1e-8f; a.clip = 10.f; a.tau = .001f; a.soft_update_freq = 1; a.which = 1; a.st = st;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_lds_adam<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (fwd_lds_bytes<2, 2, true, 1>())));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_lds_adam<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (fwd_lds_bytes<2, 2, true, 2>())));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fwd_lds<2, 2, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (fwd_lds_bytes<2, 2, true, 1>())));
+  auto problem = [&](int l) { GemmBatch b{}; b.n = 1; GemmProblem& p = b.prob[0];
+    p.P = W[l]; p.ldp = width; p.Q = act[l]; p.ldq = width; p.C = act[l + 1]; p.ldc = width;
+    p.Pdim = width; p.Qdim = rows; p.Kred = width; p.bias = bias[l]; p.relu = 1;
+    p.tiles_p = width / 32; p.tiles_q = rows / 32; p.tile_base = 0; b.total_tiles = p.tiles_p * p.tiles_q; return b; };
+  auto chain = [&](hipStream_t st_) -> hipError_t {
+    for (int l = 0; l < layers; ++l) { GemmBatch b = problem(l); hipError_t e = fwd_lds_launch<2, 2, true>(b, st_); if (e != hipSuccess) return e; }
+    return hipSuccess; };
+  auto adam = [&](hipStream_t st_) -> hipError_t { hipLaunchKernelGGL(k_adam_soft, dim3(1536), dim3(256), 0, st_, a); return hipGetLastError(); };
+  auto riders = [&](int nslot) -> hipError_t {
+    const size_t slice4 = a.n4 / layers;
+    for (int l = 0; l < layers; ++l) {
+      GemmBatch b = problem(l);
+      AdamArgs al = a;
+      al.w = w + 4 * slice4 * l; al.g = g + 4 * slice4 * l; al.m = m + 4 * slice4 * l; al.v = v + 4 * slice4 * l; al.wt = wt + 4 * slice4 * l; al.n4 = slice4;
+      if (nslot == 1) hipLaunchKernelGGL(k_fwd_lds_adam<1>, dim3(b.total_tiles + rider_blocks), dim3(256), (fwd_lds_bytes<2, 2, true, 1>()), s, b, al, rider_blocks);
+      else hipLaunchKernelGGL(k_fwd_lds_adam<2>, dim3(b.total_tiles + rider_blocks), dim3(256), (fwd_lds_bytes<2, 2, true, 2>()), s, b, al, rider_blocks);
+      hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
+    }
+    return hipSuccess; };
+  hipEvent_t e0, e1, ef, ej; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+  auto timeit = [&](int which, float* out) -> int {
+    auto one = [&]() -> hipError_t {
+      switch (which) {
+        case 0: return chain(s);
+        case 1: return adam(s);
+        case 2: { hipError_t e = adam(s); return e != hipSuccess ? e : chain(s); }
+        case 3: return riders(1);
+        case 4: { hipError_t e = hipEventRecord(ef, s); if (e != hipSuccess) return e;
+                  e = hipStreamWaitEvent(s2, ef, 0); if (e != hipSuccess) return e;
+                  e = adam(s2); if (e != hipSuccess) return e;
+                  e = chain(s); if (e != hipSuccess) return e;
+                  e = hipEventRecord(ej, s2); if (e != hipSuccess) return e;
+                  return hipStreamWaitEvent(s, ej, 0); }
+        default: return riders(2);
+      } };
+    for (int i = 0; i < 5; ++i) CK(one());
+    CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) CK(one());
+    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    *out = ms * 1000.f / iters;
+    return 0; };
+  for (int which = 0; which < 6; ++which) { int rc = timeit(which, &us[which]); if (rc) return rc; }
+  for (int l = 0; l < layers; ++l) { hipFree(W[l]); hipFree(bias[l]); }
+  for (int l = 0; l <= layers; ++l) hipFree(act[l]);
+  hipFree(w); hipFree(g); hipFree(m); hipFree(v); hipFree(wt); hipFree(part); hipFree(st);
+  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ef); hipEventDestroy(ej); hipStreamDestroy(s); hipStreamDestroy(s2);
   return 0;
 }
 

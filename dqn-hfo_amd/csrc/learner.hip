@@ -174,6 +174,9 @@ struct dqnhip_learner {
   h16* w16[4][kMaxL] = {{nullptr}};          // = w16a[net] + w_off[i]: [N_out][kp]
   h16* act16[5][kMaxL + 1] = {{nullptr}};    // [B][k16]
   h16* dZ16[2][kMaxL + 1] = {{nullptr}};     // [B][k16]   per net kind
+  // ReLU' of the passes that are differentiated (1: actor(s), 3: critic(s, a), 4: critic(s, mu(s))), layers 1 .. L-1: one
+  // bit per activation (hg_sign_off layout), written by the forward launch, read by the dgrad epilogue instead of the fp16 panel
+  uint8_t* sign16[5][kMaxL + 1] = {{nullptr}};
   bool w16_dirty[4] = {true, true, true, true};
   std::vector<void*> allocs16;
   // host-staging for add_transitions / acting
@@ -556,6 +559,7 @@ HGemm fwd16_problem(H* h, int p, int net, int rows, int i) {
   g.B = h->w16[net][i]; g.ldb = h->k16[kind][i];
   g.M = rows; g.N = l.dims[i + 1]; g.K = h->k16[kind][i];
   g.C16 = h->act16[p][i + 1]; g.ldc16 = l.dims[i + 1];
+  g.sign_out = h->sign16[p][i + 1];          // (null for the target passes and for the tower top: the heads read the panel)
   // (no fp32 copy of the tower top: the head kernels read the fp16 panel, as every tower layer reads its input)
   g.bias = h->w[net] + l.b_off[i]; g.relu = 1; g.scale32 = 1.0f;
   return g;
@@ -601,7 +605,7 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
       g.B = h->w16[net][i]; g.ldb = h->k16[kind][i]; g.tb = 1;
       g.M = rows; g.N = h->k16[kind][i]; g.K = l.dims[i + 1];
       if (i > 0) {
-        g.mask = h->act16[p][i]; g.ldm = h->k16[kind][i];
+        g.sign = h->sign16[p][i];              // lrelu'(act16[p][i]) as bits: 1/16 of the panel's bytes
         g.C16 = dZ[i]; g.ldc16 = h->k16[kind][i];
       } else {
         g.C32 = dZ32_0; g.ldc32 = l.kp[0]; g.n_valid32 = l.kp[0]; g.scale32 = 1.0f / ls;
@@ -989,7 +993,13 @@ size_t dqnhip_grad_arena_bytes(const dqnhip_config* cfg) {
 }
 
 static int create_impl(H* h, const dqnhip_config* cfg);
-static void drop_graphs_fwd(H* h) { for (auto& g : h->graph_exec) if (g) { hipGraphExecDestroy(g); g = nullptr; } }
+// every captured launch sequence of this learner: the update graphs AND the data-parallel one (it bakes in the Ring
+// struct k_gather takes by value and the weight / shared-prefix pointers, exactly as the others do)
+static void drop_graphs_fwd(H* h) {
+  for (auto& g : h->graph_exec) if (g) { hipGraphExecDestroy(g); g = nullptr; }
+  if (h->dp_graph) { hipGraphExecDestroy(h->dp_graph); h->dp_graph = nullptr; }
+  h->dp_graph_failed = false; h->graph_failed = false;
+}
 
 int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   if (!out) return fail("out is null");
@@ -1097,6 +1107,13 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
     }
     for (int kind = 0; kind < 2; ++kind)
       for (int i = 0; i <= L; ++i) RC(halloc(&h->dZ16[kind][i], (size_t)B * h->k16[kind][i]));
+    for (int p : {1, 3, 4})
+      for (int i = 1; i < L; ++i) {
+        const size_t nb = hg_sign_bytes(B, h->k16[p >= 2][i]);
+        HIPCHK(hipMalloc(&h->sign16[p][i], nb));
+        HIPCHK(hipMemsetAsync(h->sign16[p][i], 0, nb, h->stream));
+        h->allocs16.push_back((void*)h->sign16[p][i]);
+      }
     HIPCHK(hgemm_prepare_all());
   }
   // weights: gaussian(std 0.01), zero bias (src/dqn.cpp:350-352); targets = hard copy (:660-661)
@@ -1357,7 +1374,11 @@ int dqnhip_update_pipelined(dqnhip_handle h, const int32_t* idx_host, float* cri
   if (avg_q) *avg_q = q;
   if (flags) {     // sticky on the device: report through the blocking path, which clears them
     float l2, q2;
-    return dqnhip_read_stats(h, &l2, &q2) ? 1 : fail("update flags raised");
+    const int rc = dqnhip_read_stats(h, &l2, &q2);      // syncs the stream: update t (enqueued above) has completed too
+    // update t's read-back into the other slot was enqueued BEFORE the flags were cleared and still carries them: this
+    // report covers it, so the next call must not raise the same flag again
+    memset(&h->pipe_stats[slot][2], 0, sizeof(float));
+    return rc ? 1 : fail("update flags raised");
   }
   if (!std::isfinite(loss)) return fail("Critic loss not finite!");
   return 0;
@@ -1378,7 +1399,7 @@ int dqnhip_apply_update(dqnhip_handle h, int32_t net) {
   hipLaunchKernelGGL(k_sumsq, dim3(h->n_part_dp), dim3(256), 0, h->stream, h->g[net], l.arena / 4, h->part_dp);
   HIPCHK(hipGetLastError());
   RC(adam_launch(h, h->stream, net, h->part_dp, h->n_part_dp, 0, l.arena, nullptr, false));   // no gather ran: the pass evaluates its own correction
-  hipLaunchKernelGGL(k_advance_iter, dim3(1), dim3(1), 0, h->stream, h->st, (int)net);
+  hipLaunchKernelGGL(k_advance_iter, dim3(1), dim3(1), 0, h->stream, h->st, (int)net, h->stats_dev);
   HIPCHK(hipGetLastError());
   if (net == DQNHIP_ACTOR) h->h_actor_iter += 1; else h->h_critic_iter += 1;
   return 0;

@@ -641,7 +641,11 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const int t = __hip_atomic_fetch_add(a.ticket + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ACQ_REL at agent scope: the slab words themselves travel write-through (sc1 stores / loads, drained above), which
+    // is what makes them visible on gfx950; the ordered ticket makes the hand-off a happens-before edge in the HIP memory
+    // model as well instead of resting on vmcnt + sc1 semantics alone.  This path only runs for shapes whose
+    // head gradients have no carrier launch (the headline's ride in the first layer's wgrad): measured cost there: none.
+    const int t = __hip_atomic_fetch_add(a.ticket + blockIdx.x, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == RC - 1);
   }
   __syncthreads();
@@ -1147,8 +1151,14 @@ __device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot /*[4]*/
   }
 }
 // ++iter of one solver (dqnhip_apply_update: set_iter(iter() + 1), src/dqn.cpp:965)
-__global__ void k_advance_iter(DevState* st, int which) {
+// It is also this path's "tick": an optimiser pass outside an update may have raised kFlagGradNorm (skipped step), and
+// dqnhip_read_stats only reads the host-mapped words — mirror the sticky flags there (loss / avg_q stay the last update's).
+__global__ void k_advance_iter(DevState* st, int which, float* host_stats) {
   if (which == 0) st->actor_iter += 1; else st->critic_iter += 1;
+  if (host_stats != nullptr) {
+    const int fl = __hip_atomic_load(&st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    host_stats[2] = __builtin_bit_cast(float, fl);
+  }
 }
 
 // ---- acting-time helpers ---------------------------------------------------------

@@ -60,6 +60,12 @@ int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, float* us_laun
 int dqnhip_test_loadpath(int32_t mode, int32_t blocks, int32_t region_kb, int32_t iters, int32_t launches,
                          float* avg_us, float* tb_per_s);
 
+/* Optimiser-under-GEMM overlap probe (see gemm_bench.hip): `layers` dependent 256 x 1024 x 1024 forward launches and one
+ * k_adam_soft pass over adam_params parameters; us[0] launches alone, [1] pass alone, [2] serial, [3] the pass as rider
+ * workgroups of the launches (48-KiB LDS build: riders co-resident), [4] on a second stream, [5] riders with the 96-KiB
+ * build (not co-resident).  rider_blocks = rider workgroups per launch. */
+int dqnhip_test_overlap(int32_t layers, int64_t adam_params, int32_t rider_blocks, int32_t iters, float* us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,3 +138,43 @@ def test_pipelined_update_returns_the_previous_updates_scalars(pkg, gpu, use_gra
         d2.UpdateActorCriticPipelined(idx[1])
     for x in (d1, d2, o1, o2):
         x.close()
+
+
+def test_pipelined_update_reports_a_skipped_step_exactly_once(pkg, gpu):
+    """update t's read-back is enqueued before the call that reports update t-1's sticky flag clears it, so the
+    next call used to fail a second time with 'update flags raised' although nothing new had happened."""
+    B = 32
+    dqn, orc, data, rng = make_pair(pkg, B=B, S=59, hidden=(64, 64), n_replay=256)
+    idx = rng.integers(0, 256, size=(5, B))
+    w = dqn.get_params(0)
+    w_bad = w.copy(); w_bad[-20] = np.nan
+    dqn.UpdateActorCriticPipelined(idx[0])                 # clean
+    dqn.read_stats()
+    dqn.set_params(0, w_bad)
+    dqn.UpdateActorCriticPipelined(idx[1])                 # enqueues the update whose actor step is skipped
+    dqn.set_params(0, w)                                   # (blocks: the weights are healthy again for what follows)
+    with pytest.raises(pkg.DQNFatal, match="not finite"):
+        dqn.UpdateActorCriticPipelined(idx[2])             # reports update 1's flag (update 2 itself is clean)
+    assert dqn.skipped_steps() == 1
+    dqn.UpdateActorCriticPipelined(idx[3])                 # must NOT report it again
+    dqn.UpdateActorCriticPipelined(idx[4])
+    assert all(np.isfinite(dqn.read_stats()))
+    dqn.close(); orc.close()
+
+
+def test_apply_update_reports_a_skipped_step(pkg, gpu):
+    """dqnhip_read_stats reads the host-mapped words a full update's last block writes; an optimiser pass
+    outside an update (dqnhip_apply_update) that skips on a non-finite norm must surface through them as well."""
+    dqn, orc, data, rng = make_pair(pkg, B=32, S=59, hidden=(64, 64), n_replay=256)
+    dqn.UpdateActorCritic(rng.integers(0, 256, size=32))
+    g = dqn.get_params(1, pkg.KIND_G)
+    g[3] = np.inf
+    dqn.set_params(1, g, pkg.KIND_G)
+    w0 = dqn.get_params(1)
+    dqn.apply_update(pkg.CRITIC)
+    with pytest.raises(pkg.DQNFatal, match="Gradient norm not finite"):
+        dqn.read_stats()
+    assert dqn.skipped_steps() == 1
+    np.testing.assert_array_equal(dqn.get_params(1), w0)
+    assert all(np.isfinite(dqn.read_stats()))              # reported once, cleared
+    dqn.close(); orc.close()

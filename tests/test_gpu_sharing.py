@@ -163,3 +163,28 @@ def test_two_agents_share_ring_and_layers_under_load(pkg, gpu):
     s = A.read_memory(0, 4999)[0]
     assert np.isfinite(s).all() and (np.abs(s) <= 1 + 1e-6).all()
     envB.close(); envA.close(); Bl.close(); A.close()
+
+
+def test_share_replay_memory_drops_the_captured_dp_graph(pkg, gpu):
+    """the captured data-parallel update bakes in the Ring struct (k_gather takes it by value); after
+    ShareReplayMemory a replay of the old graph would keep sampling the sharer's former private ring.  Every path that
+    invalidates the update graphs must invalidate that one too."""
+    A, oA, dA, _ = make_pair(pkg, B=B, S=S, hidden=HID, seed=21, n_replay=500, capacity=1000)
+    U, oU, dU, _ = make_pair(pkg, B=B, S=S, hidden=HID, seed=22, n_replay=300, capacity=2000, use_graph=True)
+    E, oE, _, _ = make_pair(pkg, B=B, S=S, hidden=HID, seed=22, n_replay=300, capacity=2000)       # U's eager twin
+    for d in (U, E):
+        d.dp_init(pkg.DQN.dp_unique_id())
+        d.dp_update(None)
+    assert U.dp_graph_active() and U.read_stats() == E.read_stats()
+    A.ShareReplayMemory(U); A.ShareReplayMemory(E)
+    assert not U.dp_graph_active()                       # dropped with the other captured launches
+    for it in range(2):
+        U.dp_update(None); E.dp_update(None)
+        assert U.read_stats() == E.read_stats()          # both sample A's 500 transitions now
+        np.testing.assert_array_equal(U.debug_read("idx"), E.debug_read("idx"))
+        np.testing.assert_array_equal(U.debug_read("y"), E.debug_read("y"))
+    assert U.dp_graph_active()
+    for net in range(4):
+        np.testing.assert_array_equal(U.get_params(net), E.get_params(net))
+    for x in (U, E, A, oA, oU, oE):
+        x.close()
