@@ -384,20 +384,13 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
   hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, B, b_elems, 23u, -1.f, 1.f);
   hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, mask, (size_t)M * N, 31u, -1.f, 1.f);
   hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, s, bias, (size_t)N, 41u, -1.f, 1.f);
-  // the dgrad's ReLU' operand: the sign bits of the mask panel (what a forward launch would have left beside it)
-  uint8_t *sign, *sign_out, *sign_ref;
-  const size_t sign_n = hg_sign_bytes(M, N);
-  CK(hipMalloc(&sign, sign_n)); CK(hipMalloc(&sign_out, sign_n)); CK(hipMalloc(&sign_ref, sign_n));
-  CK(hipMemsetAsync(sign, 0, sign_n, s)); CK(hipMemsetAsync(sign_out, 0x5a, sign_n, s)); CK(hipMemsetAsync(sign_ref, 0x5a, sign_n, s));
-  hipLaunchKernelGGL(k_pack_sign<0>, dim3(1024), dim3(256), 0, s, (const h16*)mask, N, M, N, sign);
   CK(hipMemsetAsync(C16, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(CT16, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(C32, 0xff, (size_t)M * N * 4, s));
   HGemm g{};
   g.A = A; g.lda = ldk; g.B = B; g.ldb = ldk; g.M = M; g.N = N; g.K = K; g.scale32 = 1.0f; g.n_valid32 = N;
   if (mode == 0) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; g.C32 = C32; g.ldc32 = N; }
   else if (mode == 4) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; }
   else if (mode == 5) { g.bias = bias; g.relu = 1; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; }
-  else if (mode == 1) { g.sign = sign; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 64.0f; }
-  if (g.relu) g.sign_out = sign_out;     // forward modes: the packed ReLU' bits of the fp16 output ride along
+  else if (mode == 1) { g.mask = mask; g.ldm = N; g.C16 = C16; g.ldc16 = N; g.CT16 = CT16; g.ldct16 = M; g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 64.0f; }
   else { g.C32 = C32; g.ldc32 = N; g.scale32 = 1.0f / 1024.0f; g.n_valid32 = N / 2; }
   if (tn) { g.ta = g.tb = 1; g.lda = M + ldpad; g.ldb = N + ldpad; }
   // tile >= 10: TWO problems in one launch (the second one a copy with its own outputs), tile - 10 = the forced shape
@@ -419,7 +412,7 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   if (avg_us) *avg_us = ms * 1000.0f / iters;
   hipLaunchKernelGGL(k_ref_h, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, (const h16*)A, g.lda, (const h16*)B, g.ldb, M, N, K,
-                     (const float*)g.bias, g.relu, g.sign ? (const h16*)mask : (const h16*)nullptr, N, ref, tn ? 1 : 0);
+                     (const float*)g.bias, g.relu, g.mask, g.ldm, ref, tn ? 1 : 0);
   hipLaunchKernelGGL(k_cmp_h, dim3(256), dim3(256), 0, s, (const float*)ref, M, N, (const h16*)g.C16, N, (const h16*)g.CT16, M, (const float*)g.C32, N,
                      g.n_valid32, g.scale32, dres);
   CK(hipMemcpyAsync(hres, dres, 8, hipMemcpyDeviceToHost, s));
@@ -435,14 +428,6 @@ extern "C" int dqnhip_test_hgemm(int32_t mode, int32_t tile, int32_t M, int32_t 
     fprintf(stderr, "hgemm main loop of block 17: %llu shader cycles in %.2f us -> %.0f MHz, %.0f cycles per 64-deep K tile\n", hc[0], hc[1] / 100.0,
             hc[1] ? hc[0] / (hc[1] / 100.0) : 0.0, (double)hc[0] / (K / 64));
   }
-  if (g.sign_out && g.C16) {   // the forward epilogue's sign bits = the signs of the fp16 panel it wrote, byte for byte
-    hipLaunchKernelGGL(k_pack_sign<0>, dim3(1024), dim3(256), 0, s, (const h16*)C16, N, M, N, sign_ref);
-    std::vector<uint8_t> a(sign_n), b(sign_n);
-    CK(hipMemcpyAsync(a.data(), sign_out, sign_n, hipMemcpyDeviceToHost, s)); CK(hipMemcpyAsync(b.data(), sign_ref, sign_n, hipMemcpyDeviceToHost, s));
-    CK(hipStreamSynchronize(s));
-    if (memcmp(a.data(), b.data(), sign_n) != 0) hres[0] = 1e30f;
-  }
-  hipFree(sign); hipFree(sign_out); hipFree(sign_ref);
   if (pair && g.C16) {   // the second problem of the launch must have produced the same fp16 panel, bit for bit
     std::vector<uint16_t> a((size_t)M * N), b((size_t)M * N);
     CK(hipMemcpy(a.data(), C16, a.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), C16b, b.size() * 2, hipMemcpyDeviceToHost));
@@ -478,9 +463,7 @@ extern "C" int dqnhip_test_hgemm_backward(int32_t rows, int32_t n_out, int32_t k
   hipLaunchKernelGGL(k_fill_h, dim3(1024), dim3(256), 0, s, mask, (size_t)rows * k_in, 9u, -1.f, 1.f);
   HGemm gd{}, gw{};
   gd.A = dY; gd.lda = n_out; gd.B = W; gd.ldb = k_in; gd.tb = 1; gd.M = rows; gd.N = k_in; gd.K = n_out;
-  uint8_t* sign; CK(hipMalloc(&sign, hg_sign_bytes(rows, k_in))); CK(hipMemsetAsync(sign, 0, hg_sign_bytes(rows, k_in), s));
-  hipLaunchKernelGGL(k_pack_sign<0>, dim3(1024), dim3(256), 0, s, (const h16*)mask, k_in, rows, k_in, sign);
-  gd.sign = sign; gd.C16 = dX16; gd.ldc16 = k_in; gd.C32 = dX32; gd.ldc32 = k_in; gd.n_valid32 = k_in; gd.scale32 = 1.0f / 64.0f;
+  gd.mask = mask; gd.ldm = k_in; gd.C16 = dX16; gd.ldc16 = k_in; gd.C32 = dX32; gd.ldc32 = k_in; gd.n_valid32 = k_in; gd.scale32 = 1.0f / 64.0f;
   gw.A = dY; gw.lda = n_out; gw.ta = 1; gw.B = X; gw.ldb = k_in; gw.tb = 1; gw.M = n_out; gw.N = k_in; gw.K = rows;
   gw.C32 = dW32; gw.ldc32 = k_in; gw.n_valid32 = k_in; gw.scale32 = 1.0f / 1024.0f;
   hipLaunchKernelGGL(k_ref_h, dim3((unsigned)(((size_t)rows * k_in + 255) / 256)), dim3(256), 0, s, (const h16*)dY, n_out, (const h16*)W, k_in, rows, k_in, n_out,
@@ -523,7 +506,6 @@ extern "C" int dqnhip_test_hgemm_backward(int32_t rows, int32_t n_out, int32_t k
   }
   if (max_abs_err) *max_abs_err = worst;
   if (max_ref) *max_ref = big;
-  hipFree(sign);
   hipFree(dY); hipFree(W); hipFree(X); hipFree(mask); hipFree(dX16); hipFree(dX32); hipFree(dW32); hipFree(refd); hipFree(refw); hipFree(dres);
   hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
   return 0;

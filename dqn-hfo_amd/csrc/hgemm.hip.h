@@ -55,13 +55,7 @@ struct HGemm {
   int n_valid32;
   const float* bias;           // [N] added before the activation (may be null)
   int relu;                    // leaky ReLU(0.01) on the result
-  // ReLU' as ONE BIT per activation (hg_sign_off layout: 128 x 128 blocks, a row's 128 bits = 16 consecutive bytes):
-  //   sign     (dgrad)   multiply element (m, n) by  bit ? 1 : 0.01   — lrelu'(y) with y the layer's stored OUTPUT (Caffe's
-  //                      in-place ReLU, src/dqn.cpp:292-301: only the sign of y is ever used)
-  //   sign_out (forward) the bits of this launch's fp16 output: bit = (fp16 value > 0)
-  // The dgrad used to read the whole fp16 activation panel for this (8 MiB per 4096 x 1024 layer, 1.55x the launch's
-  // algorithmic bytes); the bits are 512 KiB and cost the forward epilogue one byte store per 16-B store.
-  const uint8_t* sign; uint8_t* sign_out;
+  const h16* mask; int ldm;    // [M][ldm]: multiply by lrelu'(mask) = mask > 0 ? 1 : 0.01 (may be null)
   float scale32;               // the fp32 output is multiplied by this (loss-scale removal)
   float* sumsq_partial;        // one slot per workgroup of this problem: sum of squares of the fp32 values it wrote (may be null)
   // Operand orientation in memory.  0: k-major — [rows][ld] with the reduction index contiguous (a lane's MFMA fragment
@@ -81,15 +75,6 @@ struct HGemmBatch { HGemm g[kHGemmMax]; int n; int tile_end[kHGemmMax]; };
 // bias gradients of all tower layers of one net: db_l[n] = scale * sum_b dY_l[b][n]
 struct Db16 { const h16* dyt; int ld; int n_out; int rows; float* db; int row_base; };
 struct Db16Batch { Db16 d[8]; int n; float scale; float* sumsq_partial; /* one slot per 64-column block of k_db16_cols (may be null) */ };
-
-// byte that holds the sign bits of columns [gn, gn + 8) of row gm (gn % 8 == 0) of an [M][N] panel: 128 x 128 blocks in
-// row-major block order, 16 bytes per block row — the 64 lanes of an epilogue wave (4 rows x 16 chunks) touch 64
-// consecutive bytes.  A function of (gm, gn, N) only: the same for every tile configuration.
-__host__ __device__ __forceinline__ size_t hg_sign_off(int gm, int gn, int N) {
-  const int nb = (N + 127) >> 7;
-  return ((size_t)((gm >> 7) * nb + (gn >> 7)) * 128 + (gm & 127)) * 16 + ((gn & 127) >> 3);
-}
-__host__ __device__ __forceinline__ size_t hg_sign_bytes(int M, int N) { return (size_t)((M + 127) >> 7) * ((N + 127) >> 7) * 2048; }
 
 __device__ __forceinline__ int hg_tile_of_block(int bid, int total) {
   // XCD x (= bid % 8) gets a contiguous run of row-major tiles: they share A row panels and
@@ -380,13 +365,13 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
   constexpr int EIT = BM * CPR / NT;        // output-loop iterations of a thread
   static_assert(BM * CPR % NT == 0, "every thread runs the same number of output iterations");
   constexpr bool kMaskAhead = EIT <= 8;
-  uint8_t mk_ahead[kMaskAhead ? EIT : 1];
+  h16x8 mk_ahead[kMaskAhead ? EIT : 1];
   if constexpr (kMaskAhead) {
-    if (g.sign) {
+    if (g.mask) {
 #pragma unroll
       for (int it = 0; it < EIT; ++it) {
         const int q = tid + it * NT, row = q / CPR, c8 = q % CPR;
-        mk_ahead[it] = g.sign[hg_sign_off(m0 + row, n0 + c8 * 8, g.N)];
+        mk_ahead[it] = *reinterpret_cast<const h16x8*>(g.mask + (size_t)(m0 + row) * g.ldm + n0 + c8 * 8);
       }
     }
   }
@@ -441,24 +426,18 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
     }
-    if (g.sign) {
-      uint32_t mk;
+    if (g.mask) {
+      h16x8 mk;
       if constexpr (kMaskAhead) mk = mk_ahead[it];
-      else mk = g.sign[hg_sign_off(gm, gn, g.N)];
+      else mk = *reinterpret_cast<const h16x8*>(g.mask + (size_t)gm * g.ldm + gn);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= ((mk >> e) & 1u) ? 1.0f : 0.01f;
+      for (int e = 0; e < 8; ++e) v[e] *= ((float)mk[e] > 0.f ? 1.0f : 0.01f);
     }
     if (g.C16) {
       h16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (h16)v[e];
       *reinterpret_cast<h16x8*>(g.C16 + (size_t)gm * g.ldc16 + gn) = o;
-      if (g.sign_out) {                      // of the ROUNDED value: what a reader of the fp16 panel would have tested
-        uint32_t b = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) b |= ((float)o[e] > 0.f ? 1u : 0u) << e;
-        g.sign_out[hg_sign_off(gm, gn, g.N)] = (uint8_t)b;
-      }
     }
     if (g.C32 && gn < g.n_valid32) {
       const float s = g.scale32;
@@ -678,19 +657,6 @@ inline hipError_t cvt16_launch(const Cvt16Batch& b, hipStream_t st) {
 }
 
 #ifdef HG_WITH_CT16
-// sign bits of an fp16 panel [M][ld] in hg_sign_off layout (test build: what a forward launch's sign_out must equal)
-template <int UNUSED = 0>
-__global__ __launch_bounds__(256) void k_pack_sign(const h16* __restrict__ x, int ld, int M, int N, uint8_t* __restrict__ out) {
-  const size_t n8 = (size_t)M * (N / 8);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
-    const int m = (int)(i / (N / 8)), c = (int)(i % (N / 8));
-    const h16x8 v = *reinterpret_cast<const h16x8*>(x + (size_t)m * ld + c * 8);
-    uint32_t b = 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) b |= ((float)v[e] > 0.f ? 1u : 0u) << e;
-    out[hg_sign_off(m, c * 8, N)] = (uint8_t)b;
-  }
-}
 // bias gradients from TRANSPOSED panels (round-1 form, test build only): db_l[n] = scale * sum_b dYT_l[n][b]
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void k_db16(Db16Batch b) {

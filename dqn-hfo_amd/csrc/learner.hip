@@ -174,9 +174,6 @@ struct dqnhip_learner {
   h16* w16[4][kMaxL] = {{nullptr}};          // = w16a[net] + w_off[i]: [N_out][kp]
   h16* act16[5][kMaxL + 1] = {{nullptr}};    // [B][k16]
   h16* dZ16[2][kMaxL + 1] = {{nullptr}};     // [B][k16]   per net kind
-  // ReLU' of the passes that are differentiated (1: actor(s), 3: critic(s, a), 4: critic(s, mu(s))), layers 1 .. L-1: one
-  // bit per activation (hg_sign_off layout), written by the forward launch, read by the dgrad epilogue instead of the fp16 panel
-  uint8_t* sign16[5][kMaxL + 1] = {{nullptr}};
   bool w16_dirty[4] = {true, true, true, true};
   std::vector<void*> allocs16;
   // host-staging for add_transitions / acting
@@ -559,7 +556,6 @@ HGemm fwd16_problem(H* h, int p, int net, int rows, int i) {
   g.B = h->w16[net][i]; g.ldb = h->k16[kind][i];
   g.M = rows; g.N = l.dims[i + 1]; g.K = h->k16[kind][i];
   g.C16 = h->act16[p][i + 1]; g.ldc16 = l.dims[i + 1];
-  g.sign_out = h->sign16[p][i + 1];          // (null for the target passes and for the tower top: the heads read the panel)
   // (no fp32 copy of the tower top: the head kernels read the fp16 panel, as every tower layer reads its input)
   g.bias = h->w[net] + l.b_off[i]; g.relu = 1; g.scale32 = 1.0f;
   return g;
@@ -605,7 +601,10 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
       g.B = h->w16[net][i]; g.ldb = h->k16[kind][i]; g.tb = 1;
       g.M = rows; g.N = h->k16[kind][i]; g.K = l.dims[i + 1];
       if (i > 0) {
-        g.sign = h->sign16[p][i];              // lrelu'(act16[p][i]) as bits: 1/16 of the panel's bytes
+        // (the ReLU' operand is the whole fp16 activation panel although only its sign is used: a packed sign-bit form was
+        // built and measured in round 4 — dgrad traffic 40 -> 33 MB per launch, duration unchanged, the forward's byte
+        // stores +1 us per launch: profiles/r04_fp16_sign_mask.txt)
+        g.mask = h->act16[p][i]; g.ldm = h->k16[kind][i];
         g.C16 = dZ[i]; g.ldc16 = h->k16[kind][i];
       } else {
         g.C32 = dZ32_0; g.ldc32 = l.kp[0]; g.n_valid32 = l.kp[0]; g.scale32 = 1.0f / ls;
@@ -1107,13 +1106,6 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
     }
     for (int kind = 0; kind < 2; ++kind)
       for (int i = 0; i <= L; ++i) RC(halloc(&h->dZ16[kind][i], (size_t)B * h->k16[kind][i]));
-    for (int p : {1, 3, 4})
-      for (int i = 1; i < L; ++i) {
-        const size_t nb = hg_sign_bytes(B, h->k16[p >= 2][i]);
-        HIPCHK(hipMalloc(&h->sign16[p][i], nb));
-        HIPCHK(hipMemsetAsync(h->sign16[p][i], 0, nb, h->stream));
-        h->allocs16.push_back((void*)h->sign16[p][i]);
-      }
     HIPCHK(hgemm_prepare_all());
   }
   // weights: gaussian(std 0.01), zero bias (src/dqn.cpp:350-352); targets = hard copy (:660-661)
