@@ -5,7 +5,6 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdqnhip.so")
-TEST_LIB = os.path.join(CSRC, "libdqnhip_test.so")
 _LOCK = os.path.join(CSRC, ".build.lock")
 
 

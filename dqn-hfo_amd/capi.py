@@ -2,7 +2,7 @@
 import ctypes as C
 import os
 
-from ._build import LIB, TEST_LIB, build
+from ._build import LIB, build
 
 MAX_HIDDEN = 8
 DP_ID_BYTES = 128        # DQNHIP_DP_ID_BYTES
@@ -135,16 +135,3 @@ def load(rebuild=False):
             fn.argtypes = args
         _lib = lib
     return _lib
-
-
-_test_lib = None
-
-
-def load_test():
-    """dlopen the test/tuning harness (libdqnhip_test.so: dqnhip_test_gemm / dqnhip_test_hgemm of
-    include/dqnhip_internal.h).  Tests and scripts only — the product path never loads it."""
-    global _test_lib
-    if _test_lib is None:
-        build()
-        _test_lib = C.CDLL(TEST_LIB)
-    return _test_lib

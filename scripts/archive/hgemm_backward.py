@@ -2,7 +2,8 @@
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
-lib = load_package().capi.load_test()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import testlib
+lib = testlib.load_test()
 fn = lib.dqnhip_test_hgemm_backward; fn.restype = C.c_int
 fn.argtypes = [C.c_int32] * 4 + [C.POINTER(C.c_float)] * 3
 for (rows, n_out, k_in) in ((128, 128, 128), (256, 256, 128), (256, 1024, 1024), (512, 1024, 1024), (4096, 1024, 1024), (4096, 1024, 128)):

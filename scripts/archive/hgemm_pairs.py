@@ -2,7 +2,8 @@
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
-lib = load_package().capi.load_test()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import testlib
+lib = testlib.load_test()
 M, N, K = [int(x) for x in sys.argv[1:4]] if len(sys.argv) > 3 else (4096, 1024, 1024)
 names = {1: "128x128", 2: "64x64 split-K", 3: "256x128 (8 waves)", 4: "256x128 (4 waves, 128x64 each)"}
 for mode, mname in ((4, "fwd, fp16 out"), (5, "fwd, fp16 + transposed out"), (1, "dgrad, 3 outputs")):

@@ -3,7 +3,8 @@ import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 pkg = load_package()
-lib = pkg.capi.load_test()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import testlib
+lib = testlib.load_test()
 lib.dqnhip_test_hgemm.restype = C.c_int
 def run(mode, tile, M, N, K, iters=20):
     us, err, ref = C.c_float(), C.c_float(), C.c_float()

@@ -3,7 +3,8 @@ transposing LDS reads): python scripts/hgemm_tn.py"""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
-lib = load_package().capi.load_test()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import testlib
+lib = testlib.load_test()
 for (M, N, K) in ((64, 64, 128), (128, 128, 128), (128, 128, 64), (256, 128, 512), (1024, 1024, 512), (1024, 1024, 4096), (1024, 128, 4096)):
     for mode in (2, 6):
         for tile in (1, 2):

@@ -3,7 +3,8 @@ Times the stand-alone pieces (200 launches each, warm): dgrad_lds<1,1>, wgrad_di
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
-pkg = load_package(); lib = pkg.capi.load_test()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import testlib
+pkg = load_package(); lib = testlib.load_test()
 fn = lib.dqnhip_test_gemm; fn.restype = C.c_int
 fn.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 3
 def run(mode, variant, rows, n, k, groups, tag):

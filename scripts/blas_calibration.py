@@ -12,7 +12,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
-lib = load_package().capi.load_test()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import testlib
+lib = testlib.load_test()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 dev = torch.device("cuda:0")
 torch.backends.cuda.matmul.allow_tf32 = False

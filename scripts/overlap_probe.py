@@ -3,7 +3,8 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
-lib = load_package().capi.load_test()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import testlib
+lib = testlib.load_test()
 fn = lib.dqnhip_test_overlap; fn.restype = C.c_int
 fn.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
 names = ["L launches alone", "optimiser pass alone", "serial (today)", "riders, 48-KiB LDS (co-resident)", "two streams", "riders, 96-KiB LDS (control)"]

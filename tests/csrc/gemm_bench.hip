@@ -1,5 +1,5 @@
 // gemm_bench.hip — dqnhip_test_gemm: correctness + timing harness for the GEMM kernel
-// families (include/dqnhip_internal.h).  Test/tuning infrastructure, not on the hot path.
+// families (tests/csrc/dqnhip_internal.h).  Test/tuning infrastructure, not on the hot path.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -7,7 +7,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../include/dqnhip_internal.h"
+#include "dqnhip_internal.h"
 #include "gemm_direct.hip.h"
 #include "gemm_mfma.hip.h"
 

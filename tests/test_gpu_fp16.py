@@ -17,6 +17,8 @@ import os
 import numpy as np
 import pytest
 
+import testlib
+
 from helpers import make_pair
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -75,7 +77,7 @@ def close16(got, want, name=""):
 
 
 def test_hgemm_kernels(pkg, gpu):
-    lib = pkg.capi.load_test()
+    lib = testlib.load_test()
     lib.dqnhip_test_hgemm.restype = C.c_int
 
     def run(mode, tile, M, N, K):
@@ -115,7 +117,7 @@ def test_hgemm_kernels(pkg, gpu):
 def test_hgemm_layer_backward_without_transposed_panels(pkg, gpu):
     """dgrad with the weight operand reduction-major + wgrad with both operands reduction-major (what the learner
     launches): each alone and both in ONE launch (hgemm_nt<1,1,2,3>), against the naive device reference."""
-    lib = pkg.capi.load_test()
+    lib = testlib.load_test()
     fn = lib.dqnhip_test_hgemm_backward
     fn.restype = C.c_int
     fn.argtypes = [C.c_int32] * 4 + [C.POINTER(C.c_float)] * 3

@@ -5,13 +5,15 @@ import ctypes as C
 
 import pytest
 
+import testlib
+
 pytestmark = pytest.mark.gpu
 
 FWD, DGRAD, WGRAD = 0, 1, 2
 
 
 def _run(pkg, mode, variant, rows, n_out, k_in, groups=1):
-    lib = pkg.capi.load_test()
+    lib = testlib.load_test()
     fn = lib.dqnhip_test_gemm
     fn.restype = C.c_int
     fn.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 3
