@@ -99,12 +99,75 @@ XGMI_LINK_GBS_ONE_WAY = 76.8
 COLLECTIVE_LATENCY_US = 20.0
 
 
+def collective_us(nbytes, world, links, factor=2.0):
+    """One collective of `nbytes` over `world` ranks: factor 2 = all-reduce (reduce-scatter + all-gather volume),
+    1 = a reduce-scatter or an all-gather alone; links = 1 (ONE ring: every byte crosses one link per step) or world - 1
+    (all links busy: edge-disjoint rings / direct exchange on the full mesh)."""
+    if world < 2:
+        return 0.0
+    vol = factor * (world - 1) / world * nbytes
+    return COLLECTIVE_LATENCY_US + vol / (XGMI_LINK_GBS_ONE_WAY * 1e9 * links) * 1e6
+
+
 def allreduce_projection_us(nbytes, world):
     if world < 2:
         return {"one_ring_us": 0.0, "all_links_us": 0.0}
-    vol = 2.0 * (world - 1) / world * nbytes
-    one = vol / (XGMI_LINK_GBS_ONE_WAY * 1e9) * 1e6
-    return {"one_ring_us": round(one + COLLECTIVE_LATENCY_US, 1), "all_links_us": round(one / (world - 1) + COLLECTIVE_LATENCY_US, 1)}
+    return {"one_ring_us": round(collective_us(nbytes, world, 1), 1), "all_links_us": round(collective_us(nbytes, world, world - 1), 1)}
+
+
+def exposed_exchange_us(buckets, compute_end_us, world, links):
+    """Overlap-aware price of one net's gradient exchange.  buckets = [(ready_us, nbytes), ...] in
+    issue order: bucket i may start once its producing launch has ended (ready_us, measured from the start of the net's
+    backward chain) AND the previous collective has finished (one communication stream: collectives do not overlap each
+    other); the phase's own launches end at compute_end_us.  Returns the microseconds the main stream WAITS at the join."""
+    t = 0.0
+    for ready, nbytes in buckets:
+        t = max(t, ready) + collective_us(nbytes, world, links)
+    return max(0.0, t - compute_end_us)
+
+
+# k_adam_soft on 1/N of a 4x1024 net's arena, Infinity-Cache-resident / evicted (profiles/r04_adam_slice_probe.txt, MI355X):
+ADAM_SLICE_US = {1: (19.6, 28.2), 2: (9.2, 18.7), 4: (6.8, 12.0), 8: (5.0, 8.7)}
+
+
+def dp_projection(world, half, net_bytes, t_rank_ms, t_1gpu_ms, bwd_launch_us, narrow_launch_us, per_layer_slices):
+    """What N ranks of this rank shape would take per update, from what ONE GPU can measure + the link model
+    (76.8 GB/s one way per link, 7 links per GPU, 20 us per collective).  Four exchange forms per link model:
+      single      one all-reduce per net after its backward chain (nothing overlaps: the optimiser needs the clip norm of the
+                  WHOLE reduced gradient)
+      per_layer   one bucket per tower layer on a communication stream, started when that layer's backward launch has ended;
+                  the chain's remaining launches run beside it (exposed_exchange_us) — only the part the chain does not
+                  cover is paid, but every bucket pays the per-collective latency
+      sharded     ZeRO-1 style: reduce-scatter, a 4-float all-reduce for the clip norm + tails, clip+Adam+soft update on this
+                  rank's 1/N slice, all-gather of the updated online AND target weights (the target nets move every update:
+                  src/dqn.cpp:967-970 — twice an ordinary model's all-gather volume)
+    Returns {form: {"one_ring": ms, "all_links": ms, "speedup_one_ring": x, "speedup_all_links": x}}."""
+    out = {}
+    adam_full, adam_slice = ADAM_SLICE_US[1][0], ADAM_SLICE_US.get(world, ADAM_SLICE_US[8])[0]
+    for form in ("single", "per_layer", "sharded"):
+        r = {}
+        for name, links in (("one_ring", 1), ("all_links", max(1, world - 1))):
+            extra = 0.0
+            for nb, slices in zip(net_bytes, per_layer_slices):
+                if form == "single" or (form == "per_layer" and half):
+                    extra += collective_us(nb, world, links)
+                elif form == "per_layer":
+                    # backward order: top tower layer first; its bucket is ready when its own launch ends
+                    ready, t, bk = [], 0.0, []
+                    n_big = len(slices) - 2                    # slices = [layer L-1, ..., layer 1, layer 0, head + tail] in bytes
+                    for i, sb in enumerate(slices):
+                        t += bwd_launch_us if i < n_big else (narrow_launch_us if i == n_big else 5.0)
+                        bk.append((t, sb))
+                    extra += exposed_exchange_us(bk, t, world, links)
+                else:
+                    # all-gather: the updated online weights AND the targets, in the width the GEMMs read (fp32 learner: fp32
+                    # = the gradient's width; fp16 learner with bf16 exchange: the fp16 mirrors) = 2 x the gradient bytes
+                    extra += (collective_us(nb, world, links, 1.0) + collective_us(16, world, links)
+                              + collective_us(2 * nb, world, links, 1.0) - (adam_full - adam_slice))
+            ms = (t_rank_ms[form] if isinstance(t_rank_ms, dict) else t_rank_ms) + extra * 1e-3
+            r[name] = round(ms, 4); r["speedup_" + name] = round(t_1gpu_ms / ms, 2)
+        out[form] = r
+    return out
 
 
 def grad_bytes(S_, hidden, half):
@@ -167,6 +230,45 @@ def live_pmc_traffic(kernel, extra_args):
     return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
         "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes of this bench.py, eager, "
         "%d + %d launches averaged); 2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md" % (len(acc), len(acc)))
+
+
+def probe_captured_dp(rank, world, local_rank, precision, half, per_layer, timeout_s=150):
+    """Run tests/dp_native_worker.py --mode probe as a child of this rank (the children of all ranks form their own group).
+    Returns {"ok": bool, ...}: ok = the child finished in time, its captured update was active and bit-identical to an
+    eager group member's.  The child is killed (exactly that process) on timeout."""
+    import subprocess
+    import tempfile
+    port = os.environ.get("MASTER_PORT", "0")
+    rv = os.path.join(tempfile.gettempdir(), "dqnhip_probe_%s" % port)
+    out = "%s_rank%d.json" % (rv, rank)
+    try:
+        os.unlink(out)
+    except OSError:
+        pass
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "dp_native_worker.py"), "--rank", str(rank), "--world", str(world), "--device", str(local_rank),
+           "--rv", rv, "--out", out, "--mode", "probe", "--precision", precision, "--rows", str(B), "--hidden", ",".join(str(h) for h in HIDDEN),
+           "--state-size", str(S), "--updates", "3", "--wscale", "1.0", "--timeout", "60"]
+    if half:
+        cmd.append("--half")
+    if per_layer:
+        cmd.append("--per-layer")
+    t0 = time.perf_counter()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        log, _ = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        log, _ = p.communicate()
+        return {"ok": False, "why": "child of rank %d killed after %d s" % (rank, timeout_s), "log": log[-400:]}
+    res = {"ok": False, "why": "child of rank %d exited %d: %s" % (rank, p.returncode, log[-300:])}
+    try:
+        j = json.load(open(out))
+        good = bool(j.get("ok") and j.get("graph_active") and j.get("graph_equals_eager"))
+        res = {"ok": good, "seconds": round(time.perf_counter() - t0, 1), "graph_ms_per_update": j.get("graph_ms_per_update"),
+               "why": "" if good else "graph_active=%s graph_equals_eager=%s" % (j.get("graph_active"), j.get("graph_equals_eager"))}
+    except Exception:                 # noqa: BLE001 — reported in "why"
+        pass
+    return res
 
 
 def prefill(dqn, n, seed, chunk=131072):
@@ -306,8 +408,11 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
         rec = {}
         for prec, half in (("fp16", True), ("fp32", False)):
             r = {}
-            for name, kw, dp_kw in (("plain_graph", dict(use_graph=True), None), ("dp_eager", dict(use_graph=False), dict(half_grads=half, per_layer=not half)),
-                                    ("dp_graph", dict(use_graph=True), dict(half_grads=half, per_layer=not half))):
+            forms = [("plain_graph", dict(use_graph=True), None), ("dp_eager", dict(use_graph=False), dict(half_grads=half)),
+                     ("dp_graph", dict(use_graph=True), dict(half_grads=half))]
+            if not half:
+                forms.append(("dp_per_layer_graph", dict(use_graph=True), dict(per_layer=True)))
+            for name, kw, dp_kw in forms:
                 d = pkg.DQN(S, minibatch=512, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, precision=prec, **kw)
                 prefill(d, 150000, seed=7)
                 if dp_kw is not None:
@@ -317,22 +422,46 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
                     step = lambda d=d: d.update_async(None)
                 r[name + "_ms"] = round(timed(step, torch.cuda.synchronize, 300, 30) * 1e3, 4)
                 if dp_kw is not None and kw["use_graph"]:
-                    r["dp_graph_captured"] = d.dp_graph_active()
+                    r[name + "_captured"] = d.dp_graph_active()
+                if name == "plain_graph":
+                    # the backward chain's launch durations at this rank shape: when each per-layer bucket becomes ready
+                    d.set_kernel_timing(True)
+                    for _ in range(10):
+                        d.update_async(None)
+                    fam = {f: d.kernel_timing(f)[0] * 1e3 for f in (("hgemm_dgrad", "hgemm_wgrad") if half else ("gemm_bwd_pair", "gemm_wgrad"))}
+                    d.kernel_timing("adam", reset=True); d.set_kernel_timing(False)
+                    r["backward_launch_us"] = {k: round(v, 2) for k, v in fam.items()}
+                d.read_stats(); d.close()
+            # the rank's compute at 4096 / N rows for N = 2 and 4 (plain captured update; the data-parallel launches add what
+            # they add at 512 rows: dp_graph_ms - plain_graph_ms)
+            for rows in (1024, 2048):
+                d = pkg.DQN(S, minibatch=rows, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, precision=prec, use_graph=True)
+                prefill(d, 150000, seed=7)
+                r["plain_graph_ms_rows_%d" % rows] = round(timed(lambda d=d: d.update_async(None), torch.cuda.synchronize, 150, 20) * 1e3, 4)
                 d.read_stats(); d.close()
             gb = grad_bytes(S, HIDDEN, half)
-            pr = [allreduce_projection_us(b, 8) for b in gb]
             one = out["configs4_1gpu_b4096_%s" % prec]["ms_per_update"]
-            r["exchange"] = "bf16 gradients + fp32 tails, one collective per net" if half else "fp32, per-layer buckets on a communication stream"
-            r["projection_8gpu"] = {"allreduce_bytes": gb, "allreduce_us_one_ring": [p["one_ring_us"] for p in pr],
-                                    "allreduce_us_all_links": [p["all_links_us"] for p in pr],
-                                    "ms_per_update_one_ring": round(r["dp_graph_ms"] + sum(p["one_ring_us"] for p in pr) * 1e-3, 4),
-                                    "ms_per_update_all_links": round(r["dp_graph_ms"] + sum(p["all_links_us"] for p in pr) * 1e-3, 4),
-                                    "ms_per_update_1gpu_b4096": one,
-                                    "speedup_one_ring": round(one / (r["dp_graph_ms"] + sum(p["one_ring_us"] for p in pr) * 1e-3), 2),
-                                    "speedup_all_links": round(one / (r["dp_graph_ms"] + sum(p["all_links_us"] for p in pr) * 1e-3), 2),
-                                    "speedup_without_collectives": round(one / r["dp_graph_ms"], 2),
-                                    "note": "PROJECTION (no overlap assumed; link rate %.1f GB/s one way, %.0f us latency per collective): the first real 8-GPU "
-                                            "run checks it" % (XGMI_LINK_GBS_ONE_WAY, COLLECTIVE_LATENCY_US)}
+            per = 2 if half else 4
+            wa, wc = tower_weights(S, HIDDEN), tower_weights(S + 10, HIDDEN)
+            slices = [[(w + HIDDEN[i]) * per for i, w in reversed(list(enumerate(ws)))] + [(nh * HIDDEN[-1] + nh) * per + 16]
+                      for ws, nh in ((wc, 1), (wa, 10))]          # critic first (exchanged first), each: layer L-1 .. 0, head + tail
+            bl = r["backward_launch_us"]
+            def t_rank(n):
+                base = {8: r["plain_graph_ms"], 4: r["plain_graph_ms_rows_1024"], 2: r["plain_graph_ms_rows_2048"]}[n]
+                return {"single": base + r["dp_graph_ms"] - r["plain_graph_ms"], "sharded": base + r["dp_graph_ms"] - r["plain_graph_ms"],
+                        "per_layer": base + r.get("dp_per_layer_graph_ms", r["dp_graph_ms"]) - r["plain_graph_ms"]}
+            r["exchange"] = "bf16 gradients + fp32 tails, one collective per net" if half else "fp32, one collective per net (per-layer buckets: dp_per_layer_graph_ms)"
+            r["projection"] = {"n_gpus_%d" % n: dp_projection(n, half, gb, t_rank(n), one, bl.get("gemm_bwd_pair", bl.get("hgemm_dgrad", 0.0)),
+                                                              bl.get("gemm_wgrad", bl.get("hgemm_wgrad", 0.0)), slices) for n in (2, 4, 8)}
+            r["projection"]["ms_per_update_1gpu_b4096"] = one
+            r["projection"]["speedup_without_collectives_8gpu"] = round(one / r["dp_graph_ms"], 2)
+            r["projection"]["model"] = ("PROJECTION for a global minibatch of 4096 = N x (4096 / N) rows; rank time = the plain captured update measured at 4096 / N rows "
+                                        "+ what the data-parallel launches add at 512 rows; the backward launch durations that set the bucket-ready times are "
+                                        "the 512-row ones; xGMI %.1f GB/s one way per link, %.0f us per collective; single = one all-reduce per net, "
+                                        "nothing overlapped; per_layer = buckets on a communication stream, overlap with the rest of the backward chain credited "
+                                        "(exposed_exchange_us); sharded = reduce-scatter + 4-float all-reduce + Adam on 1/N (profiles/r04_adam_slice_probe.txt) + "
+                                        "all-gather of online AND target weights.  The first real multi-GPU run checks it."
+                                        % (XGMI_LINK_GBS_ONE_WAY, COLLECTIVE_LATENCY_US))
             rec[prec] = r
         out["configs4_rank_shape_b512"] = rec
         if not (args.test_strong_record and native):
@@ -367,7 +496,7 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
             continue
         half = prec == "fp16" and not args.dp_fp32_grads
         d, dp = par.make_native_data_parallel(pkg, S, rank, world, local_rank, minibatch=rows, hidden=HIDDEN, memory=200000,
-                                              seed=1, precision=prec, per_layer=not args.dp_single_bucket, half_grads=half,
+                                              seed=1, precision=prec, per_layer=args.dp_per_layer and prec == "fp32", half_grads=half,
                                               use_graph=not args.no_graph)
         prefill(d, 150000, seed=7 + rank)
         t_dp = timed(lambda: dp.update(None), barrier, n_it, 20)
@@ -427,7 +556,12 @@ def main():
                     help="torch.distributed backend (nccl = RCCL; gloo only for the 2-ranks-on-one-GPU flow test)")
     ap.add_argument("--share-device0", action="store_true",
                     help="testing: every rank uses GPU 0 (needs --backend gloo; RCCL refuses duplicate devices)")
-    ap.add_argument("--dp-single-bucket", action="store_true", help="native DP, fp32 learner: ONE all-reduce per net instead of per-layer buckets on a communication stream")
+    ap.add_argument("--dp-per-layer", action="store_true",
+                    help="native DP, fp32 learner: per-layer buckets on a communication stream instead of ONE all-reduce per net (the projection "
+                         "of sub_records.configs4_rank_shape_b512 prices both: with ~20 us per collective five buckets cost more than they hide)")
+    ap.add_argument("--test-dp-probe", action="store_true", help="testing: run the captured-update probe with the ranks there are (N = 1 under --force-dp)")
+    ap.add_argument("--no-dp-probe", action="store_true",
+                    help="N > 1: skip the sacrificial child group that tries the captured data-parallel update first (tests/dp_native_worker.py)")
     ap.add_argument("--dp-fp32-grads", action="store_true", help="native DP, fp16 learner: all-reduce fp32 gradients instead of bf16 (DQNHIP_DP_HALF_GRADS)")
     ap.add_argument("--dp-timeout", type=int, default=600, help="N > 1: seconds the headline measurement may take before every rank gives up")
     ap.add_argument("--tuning", type=int, default=0, help="dqnhip_config.tuning_flags (A/B switches, include/dqnhip.h DQNHIP_TUNE_*)")
@@ -475,13 +609,28 @@ def main():
         # per-shard sample streams are decorrelated by dp_rank inside the library
         common = dict(minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1, precision=args.precision, tuning=args.tuning)
         half = args.precision == "fp16" and not args.dp_fp32_grads
+        dp_probe = None
+        if native and (world > 1 or args.test_dp_probe) and not args.no_graph and not args.no_dp_probe:
+            # The captured data-parallel update (RCCL kernels inside a hipGraph) has never met more than ONE rank on this repo's
+            # build boxes, and a rank stuck in a collective cannot be interrupted from Python.  So a sacrificial child group
+            # (one child per rank, own communicator, file rendezvous, no torch) tries it first at this shape; if any child
+            # fails or has to be killed, every rank agrees to run the headline eagerly (same kernels, same collectives,
+            # stream-ordered instead of replayed).  ~20 s, outside every timed region.
+            dp_probe = probe_captured_dp(rank, world, local_rank, args.precision, half, args.dp_per_layer and not half)
+            ok = torch.tensor([1 if dp_probe.get("ok") else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                args.no_graph = True
+                if rank == 0:
+                    print("bench: the captured data-parallel update did not pass the %d-rank probe (%s): running eagerly" % (world, dp_probe.get("why", "another rank failed")),
+                          file=sys.stderr, flush=True)
         if native:
             # the communicator inside libdqnhip.so has never met more than one real GPU in this repo's own runs
             # (one-GPU boxes only): if ANY rank fails to bring it up, every rank falls back — by agreement over
             # torch.distributed — to the other transport of the same algorithm (torch's RCCL all-reduce between the
             # update phases), and the JSON line says so.  Same kernels, same numbers, a few host round trips more.
             try:
-                dqn, dp = par.make_native_data_parallel(pkg, S, rank, world, local_rank, per_layer=not args.dp_single_bucket and not half,
+                dqn, dp = par.make_native_data_parallel(pkg, S, rank, world, local_rank, per_layer=args.dp_per_layer and not half,
                                                         half_grads=half, use_graph=not args.no_graph, **common)
             except Exception as e:                                  # noqa: BLE001 — reported, not swallowed
                 native_error = repr(e)[:300]
@@ -531,7 +680,7 @@ def main():
             if rank == 0:
                 print(json.dumps({"metric": "DQN updates/sec, 1v0 HFO, 4x1024 MLP, minibatch %d" % B, "value": None, "unit": "updates/s",
                                   "n_gpus": world, "error": "data-parallel headline did not finish within %d s (graph=%s, per_layer=%s): "
-                                  "rerun with --no-graph or --dp-single-bucket" % (args.dp_timeout, not args.no_graph, not args.dp_single_bucket)}), flush=True)
+                                  "rerun with --no-graph" % (args.dp_timeout, not args.no_graph, args.dp_per_layer)}), flush=True)
             os._exit(3)
         hang_dog = threading.Timer(float(args.dp_timeout), _hung)
         hang_dog.daemon = True
@@ -684,6 +833,7 @@ def main():
                        "hip_graph": (not args.no_graph) and (not use_dp or (native and dqn.dp_graph_active())), "prewarm_updates": prewarm,
                        "tuning_flags": args.tuning,
                        **({"native_dp_error": native_error} if native_error else {}),
+                       **({"captured_dp_probe": dp_probe} if use_dp and dp_probe is not None else {}),
                        "sampling": "on-device Philox, uniform with replacement"},
             "update_gflop": round(fl / 1e9, 3),
             "update_mfma_frac": round(fl * ups / 1e12 / (MFMA_F16_PEAK_TF if args.precision == "fp16" else MFMA_F32_PEAK_TF), 4),

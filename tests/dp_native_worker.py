@@ -48,6 +48,18 @@ def digest(d):
     return h.hexdigest()
 
 
+def init_params(rng, in_dim, hidden, heads, wscale):
+    """gaussian(std 0.01 * wscale) weights, zero biases (src/dqn.cpp:350-352), dense Caffe order: (W[n][k], b[n]) per layer;
+    every head reads the tower top"""
+    parts, k = [], in_dim
+    for n in tuple(hidden) + tuple(heads):
+        parts.append((rng.standard_normal((n, k)) * 0.01 * wscale).astype(np.float32).ravel())
+        parts.append(np.zeros(n, np.float32))
+        if len(parts) // 2 <= len(hidden):
+            k = n
+    return np.concatenate(parts)
+
+
 def fro(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
@@ -68,12 +80,12 @@ def main():
     ap.add_argument("--hidden", default="256,128,64,64")
     ap.add_argument("--state-size", type=int, default=59)
     ap.add_argument("--updates", type=int, default=3)
+    ap.add_argument("--wscale", type=float, default=5.0)
     ap.add_argument("--mode", default="parity", choices=["parity", "probe"])
     ap.add_argument("--timeout", type=int, default=60, help="rendezvous timeout, seconds")
     args = ap.parse_args()
 
     from __graft_entry__ import load_package
-    from oracle import torch_ref          # only its weight-initialisation helper (numpy)
     from synth import synth_replay
     pkg = load_package()
     rank, world = args.rank, args.world
@@ -91,7 +103,7 @@ def main():
 
     write()
     rng = np.random.default_rng(3)
-    w = [torch_ref.init_params_np(rng, S, hid, a) * 5.0 for a in (True, False)]
+    w = [init_params(rng, S if a else S + 10, hid, (4, 6) if a else (1,), args.wscale) for a in (True, False)]
     shards = [synth_replay(np.random.default_rng(10 + r), N_SHARD, S, mean_len=10) for r in range(world)]
     dp_kw = dict(per_layer=args.per_layer, half_grads=args.half)
     if args.shard_opt:

@@ -89,7 +89,7 @@ def test_bench_runs_under_torchrun_one_rank(pkg, gpu):
     """The exact launch line the driver uses for N > 1, with N = 1."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"),
-           "--gpus", "1", "--steps", "20", "--warmup", "5", "--replay", "20000", "--no-cpu-baseline", "--force-dp"]
+           "--gpus", "1", "--steps", "20", "--warmup", "5", "--replay", "20000", "--no-cpu-baseline", "--force-dp", "--test-dp-probe"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     import json
@@ -97,11 +97,14 @@ def test_bench_runs_under_torchrun_one_rank(pkg, gpu):
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 100 and d["config"]["parallelism"].startswith("dp1")
     assert d["config"]["hip_graph"] is True                     # the data-parallel update (RCCL included) replayed as a graph
+    # under N > 1 a sacrificial child group tries the captured update first (tests/dp_native_worker.py --mode probe); the same
+    # code with the one rank there is: the child ran at the bench's shape, its graph was active and equal to the eager member's
+    probe = d["config"]["captured_dp_probe"]
+    assert probe["ok"] and probe["graph_ms_per_update"] > 0, probe
 
 
 def test_bench_strong_scaling_record_with_the_ranks_there_are(pkg, gpu):
-    """The N > 1 side record (a global minibatch of 4096 split over the ranks: captured native RCCL update, fp32 with per-layer
-    buckets and fp16 with the bf16 exchange, the no-collective twin, the single-GPU reference, the projection) has only ever
+    """The N > 1 side record (a global minibatch of 4096 split over the ranks: captured native RCCL update, fp32 and fp16 with the bf16 exchange, the no-collective twin, the single-GPU reference, the projection) has only ever
     been reachable on a multi-GPU node; --test-strong-record runs the same code with one rank."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29647", os.path.join(ROOT, "bench.py"),
