@@ -16,11 +16,19 @@
  * by an independent float64/autograd restatement (oracle/torch_ref.py) and by
  * hand-derived known-answer tests (tests/test_oracle_kat.py).
  *
- * Numerics: fp32 storage everywhere (as the reference), every dot product is
- * a k-ordered fmaf chain starting at 0 with the bias added last (Caffe does
- * GEMM with beta=0, then a rank-1 bias GEMM: inner_product_layer.cpp
- * Forward_cpu), doubles only where the reference uses doubles
- * (src/dqn.cpp:791, 894-897, 915).
+ * Numerics: fp32 storage everywhere (as the reference); every GEMM dot product
+ * (Caffe: cblas_sgemm, whose fp32 summation order is BLAS-implementation-
+ * defined and unknowable here) is accumulated in double over k and rounded to
+ * float ONCE, i.e. it is the correctly rounded value every fp32 summation order
+ * scatters around by a few ulp — an order-free definition of the sgemm result.
+ * (Rounds 1-3 used a k-ordered fp32 fmaf chain: one arbitrary order among many,
+ * and at 4 x 1024 units its own round-off flipped the ReLU' of a near-zero
+ * pre-activation about once per update relative to float64, which forced a
+ * 5e-3 tolerance onto a comparison that is 1e-7 otherwise.)  The bias is added
+ * last, in float (Caffe does GEMM with beta=0, then a rank-1 bias GEMM:
+ * inner_product_layer.cpp Forward_cpu); the optimiser, the TD target and the
+ * loss are float exactly where the reference's are, doubles only where the
+ * reference uses doubles (src/dqn.cpp:791, 894-897, 915).
  *
  * Each function cites the reference file:line it follows (paths relative to
  * /root/reference).
@@ -131,7 +139,7 @@ static inline float lrelu_bwd(float dy, float y) {
 }
 
 /* Y[M,N] = act(X[M,K] . W[N,K]^T + b[N])   (InnerProduct forward)
- * k-ordered fmaf chain per output; vectorised across outputs via W^T. */
+ * double accumulation over k, one rounding to float per output; vectorised across outputs via W^T. */
 static void ip_forward(int M, int N, int K, const float *X, int ldx, const float *W,
                        const float *b, float *Y, int ldy, int relu) {
   float *Wt = (float *)malloc((size_t)K * N * sizeof(float));
@@ -142,16 +150,16 @@ static void ip_forward(int M, int N, int K, const float *X, int ldx, const float
     const float *x = X + (size_t)m * ldx;
     float *y = Y + (size_t)m * ldy;
     for (int n0 = 0; n0 < N; n0 += 64) {
-      float acc[64];
+      double acc[64];
       int nb = N - n0 < 64 ? N - n0 : 64;
-      for (int j = 0; j < nb; ++j) acc[j] = 0.0f;
+      for (int j = 0; j < nb; ++j) acc[j] = 0.0;
       for (int k = 0; k < K; ++k) {
-        const float xv = x[k];
+        const double xv = (double)x[k];
         const float *wr = Wt + (size_t)k * N + n0;
-        for (int j = 0; j < nb; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+        for (int j = 0; j < nb; ++j) acc[j] += xv * (double)wr[j];      /* float x float is exact in double */
       }
       for (int j = 0; j < nb; ++j) {
-        float t = acc[j] + b[n0 + j];
+        float t = (float)acc[j] + b[n0 + j];
         y[n0 + j] = relu ? lrelu(t) : t;
       }
     }
@@ -165,12 +173,15 @@ static void ip_dgrad(int M, int N, int K, const float *dY, int lddy, const float
 #pragma omp parallel for schedule(static)
   for (int m = 0; m < M; ++m) {
     float *dx = dX + (size_t)m * lddx;
-    for (int k = 0; k < K; ++k) dx[k] = 0.0f;
+    double *acc = (double *)malloc((size_t)K * sizeof(double));
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
     for (int n = 0; n < N; ++n) {
-      const float dv = dY[(size_t)m * lddy + n];
+      const double dv = (double)dY[(size_t)m * lddy + n];
       const float *wr = W + (size_t)n * K;
-      for (int k = 0; k < K; ++k) dx[k] = fmaf(dv, wr[k], dx[k]);
+      for (int k = 0; k < K; ++k) acc[k] += dv * (double)wr[k];
     }
+    for (int k = 0; k < K; ++k) dx[k] = (float)acc[k];
+    free(acc);
   }
 }
 
@@ -181,17 +192,17 @@ static void ip_wgrad(int M, int N, int K, const float *dY, int lddy, const float
 #pragma omp parallel for schedule(static)
   for (int n = 0; n < N; ++n) {
     float *dw = dW + (size_t)n * K;
-    float *acc = (float *)malloc((size_t)K * sizeof(float));
-    for (int k = 0; k < K; ++k) acc[k] = 0.0f;
-    float bs = 0.0f;
+    double *acc = (double *)malloc((size_t)K * sizeof(double));
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    double bs = 0.0;
     for (int m = 0; m < M; ++m) {
-      const float dv = dY[(size_t)m * lddy + n];
+      const double dv = (double)dY[(size_t)m * lddy + n];
       const float *xr = X + (size_t)m * ldx;
-      for (int k = 0; k < K; ++k) acc[k] = fmaf(dv, xr[k], acc[k]);
+      for (int k = 0; k < K; ++k) acc[k] += dv * (double)xr[k];
       bs += dv;
     }
-    for (int k = 0; k < K; ++k) dw[k] += acc[k];
-    db[n] += bs;
+    for (int k = 0; k < K; ++k) dw[k] += (float)acc[k];      /* Caffe accumulates into the diff (which the caller zeroed) */
+    db[n] += (float)bs;
     free(acc);
   }
 }

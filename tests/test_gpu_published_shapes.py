@@ -122,9 +122,10 @@ def test_fp32_update_b4096_4x1024_vs_float64(pkg, gpu, frozen_critic):
         d = np.abs(dqn.get_params(net) - t64.get_params(net))
         d32 = np.abs(t32.get_params(net) - t64.get_params(net))
         assert d.max() <= 2 * lr[net] + 1e-6 and d.mean() <= max(0.01 * lr[net], 2 * d32.mean()) + 1e-8, (net, d.max(), d.mean(), d32.mean())
-    # the C oracle is the loose comparator at this width (its own ReLU' flips relative to float64)
+    # the C oracle (double-accumulated dot products) sits where float64 sits: the same bound against it
     orc.update_phase(0, idx)
-    assert _fro(gc, orc.grad_view(1)) <= 5e-3
+    assert _fro(gc, orc.grad_view(1)) <= max(1e-5, 2 * e32[1]), (_fro(gc, orc.grad_view(1)), e32)
+    assert _fro(orc.grad_view(1), t64.g[1].numpy()) <= 1e-5          # ... and the two comparators agree with each other
     dqn.close(); orc.close()
 
 

@@ -19,15 +19,15 @@ def _fro(a, b):
 
 
 def _check_grads(dqn, orc, net, ref64=None, c_tol=1e-5):
-    """Raw gradients (before clip/Adam).
+    """Raw gradients (before clip/Adam), Frobenius-relative: 1e-5 against the C oracle AND against the float64 autograd
+    restatement, at every shape including BASELINE's.
 
-    Two fp32 implementations with different summation orders can disagree on the sign of a
-    pre-activation that is ~0, which flips that unit's ReLU' between 1 and 0.01 for one row; the
-    actor gradient is a heavily cancelling sum over rows, so one flip shows up as ~1e-3 relative
-    in the layers below it (measured: at the 4x1024 shape the C oracle flips one layer-3 unit
-    relative to float64 while the HIP path does not).  Hence: tight (1e-5) against the C oracle
-    where no flip occurs (the small shapes, deterministic), tight against the float64 autograd
-    restatement at the BASELINE shape, and a loose 5e-3 bound against the C oracle there."""
+    (Rounds 1-3 needed 5e-3 against the C oracle at 4 x 1024: its GEMMs were k-ordered fp32 fmaf chains whose own round-off
+    flipped the ReLU' of a near-zero pre-activation about once per update relative to float64.  The oracle now accumulates
+    every dot product in double and rounds once — the order-free value of an sgemm — and the two comparators agree.  An fp32
+    evaluation can still flip such a unit itself: measured on this library at 4 x 1024 about once in ten updates (then
+    ~1e-4..1e-3 in the layers below it); the seeds used here are flip-free, tests/test_gpu_published_shapes.py bounds the
+    4096-row case, where flips are certain, against an independent fp32 evaluation instead.)"""
     g1, g2 = dqn.get_params(net, 3), orc.grad_view(net).copy()
     if ref64 is not None:
         assert _fro(g1, ref64) <= 1e-5, (net, _fro(g1, ref64))
@@ -55,7 +55,7 @@ def _check_update(dqn, orc, idx, t64=None, data=None, c_tol=1e-5):
     a1, a2 = dqn.debug_read("actor_out"), orc.debug_read("actor_out")
     np.testing.assert_allclose(a1, a2, rtol=1e-4, atol=1e-4)
     g1, g2 = dqn.debug_read("dq_da"), orc.debug_read("dq_da")
-    np.testing.assert_allclose(g1, g2, rtol=2e-3, atol=1e-6)
+    assert np.abs(g1 - g2).max() <= 1e-4 * max(np.abs(g2).max(), 1e-30), ("dq_da", np.abs(g1 - g2).max(), np.abs(g2).max())   # 1e-4 of its scale, element by element
     assert abs(l1 - l2) <= 1e-4 * max(1.0, abs(l2)), (l1, l2)
     assert abs(q1 - q2) <= QTOL + QRTOL * abs(q2), (q1, q2)
     if t64 is not None:
@@ -88,8 +88,7 @@ def test_update_matches_oracle(pkg, gpu, shape):
     shape = dict(shape)
     shape.setdefault("wscale", 5.0)
     use64 = shape.pop("f64", False)
-    big = shape["hidden"][0] >= 1024 and len(shape["hidden"]) == 4 and shape["hidden"][-1] >= 1024     # the BASELINE shape
-    c_tol = 5e-3 if big else 1e-5             # C oracle: loose only where its own ReLU flips relative to float64 were measured
+    c_tol = 1e-5
     dqn, orc, data, rng = make_pair(pkg, n_replay=2048, **shape)
     B = shape["B"]
     t64 = None
@@ -107,7 +106,7 @@ def test_update_matches_oracle(pkg, gpu, shape):
     # average the parameters must agree to 1% of a step.
     lr = {0: 1e-5, 1: 1e-3, 2: 1e-5 * 1e-3, 3: 1e-3 * 1e-3}
     for net in range(4):
-        refs = ([t64.get_params(net)] if use64 else []) + ([] if big else [orc.get_params(net)])
+        refs = ([t64.get_params(net)] if use64 else []) + [orc.get_params(net)]
         for ref in refs:
             d = np.abs(dqn.get_params(net) - ref)
             assert d.max() <= n_it * lr[net] + 1e-6, (net, d.max())
