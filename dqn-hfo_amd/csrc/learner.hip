@@ -2243,6 +2243,24 @@ int dqnhip_debug_read(dqnhip_handle h, const char* name, float* host, size_t cou
   else if (!strcmp(name, "actor_out")) { src = h->aout16; pad16 = true; n = B * kNO; }
   else if (!strcmp(name, "dq_da")) { src = h->dA16; pad16 = true; n = B * kNO; }
   else if (!strcmp(name, "idx")) { src = (const float*)h->mb_idx; is_int = true; }
+  else if (!strncmp(name, "act", 3) && name[3] >= '0' && name[3] <= '4' && name[4] == '_') {
+    // "act<p>_<i>": the stored (post-ReLU, in place: src/dqn.cpp:409-410) tower activations of the last update's pass p
+    // (0 actor_target(s'), 1 actor(s), 2 critic_target, 3 critic(s, a), 4 critic(s, mu(s))), layer i = 1 .. L, dense
+    // [B][width].  Parity tests compare their SIGNS with the oracle's: an fp32 evaluation may put a pre-activation that
+    // is within round-off of zero on the other side, which switches that unit's ReLU' between 1 and 0.01 for that row.
+    const int p = name[3] - '0', i = atoi(name + 5);
+    const NetLayout& l = layout_of(h, p >= 2);
+    if (i < 1 || i > h->L) return fail("debug buffer '%s': layer out of range", name);
+    const size_t W = l.dims[i];
+    if (count < B * W) return fail("buffer too small for '%s': %zu < %zu", name, count, B * W);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->fp16) {
+      std::vector<h16> t16(B * W);
+      HIPCHK(hipMemcpy(t16.data(), h->act16[p][i], t16.size() * sizeof(h16), hipMemcpyDeviceToHost));
+      for (size_t e = 0; e < t16.size(); ++e) host[e] = (float)t16[e];
+    } else HIPCHK(hipMemcpy(host, h->act[p][i], B * W * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+  }
   else return fail("unknown debug buffer '%s'", name);
   if (count < n) return fail("buffer too small for '%s': %zu < %zu", name, count, n);
   std::vector<float> tmp(pad16 ? B * kAP : B);

@@ -501,6 +501,11 @@ class DQN:
 
     def debug_read(self, name):
         B = self.kMinibatchSize
+        if name.startswith("act") and name[3:4].isdigit():      # "act<pass>_<layer>": stored tower activations [B][width]
+            width = self.cfg.hidden[int(name.split("_")[1]) - 1]
+            out = np.empty(B * width, np.float32)
+            self._ck(self.lib.dqnhip_debug_read(self.h, name.encode(), _p(out), out.size))
+            return out.reshape(B, width)
         wide = name in ("actor_out", "dq_da")
         out = np.empty(B * (10 if wide else 1), np.float32)
         self._ck(self.lib.dqnhip_debug_read(self.h, name.encode(), _p(out), out.size))

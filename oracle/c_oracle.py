@@ -141,6 +141,7 @@ class Oracle:
         self.L = lib()
         self.h = self.L.orc_create(C.byref(self.cfg))
         self.B, self.S = self.cfg.B, self.cfg.S
+        self.hidden = tuple(self.cfg.hidden[i] for i in range(self.cfg.L))
 
     def close(self):
         if self.h:
@@ -257,6 +258,12 @@ class Oracle:
         return loss.value, avgq.value
 
     def debug_read(self, name):
+        if name.startswith("actA_") or name.startswith("actC_"):      # stored tower activations of the last forward, [B][width]
+            width = self.hidden[int(name[5:]) - 1]
+            out = np.empty(self.B * width, np.float32)
+            rc = self.L.orc_debug_read(self.h, name.encode(), _fp(out), out.size)
+            assert rc == 0, (name, rc)
+            return out.reshape(self.B, width)
         n = self.B * (NOUT if name in ("actor_out", "dq_da") else 1)
         out = np.empty(n, np.float32)
         rc = self.L.orc_debug_read(self.h, name.encode(), _fp(out), n)

@@ -687,6 +687,14 @@ int orc_debug_read(orc *o, const char *name, float *dst, size_t count) {
   else if (!strcmp(name, "dq_da")) { src = o->dq_da; n = B * ORC_NO; }
   else if (!strcmp(name, "idx")) { if (count < B) return 2; for (size_t i = 0; i < B; ++i) dst[i] = (float)o->mb_idx[i]; return 0; }
   else if (!strcmp(name, "terminal")) { if (count < B) return 2; for (size_t i = 0; i < B; ++i) dst[i] = (float)o->mb_t[i]; return 0; }
+  else if ((!strncmp(name, "actA_", 5) || !strncmp(name, "actC_", 5))) {
+    /* stored (post-ReLU) tower activations of the LAST actor(s) / critic forward of the update in progress: actC holds the
+     * training forward critic(s, a) after phase 0 and critic(s, mu(s)) after phase 1.  Parity tests compare signs. */
+    const int critic = name[3] == 'C', i = atoi(name + 5);
+    const orc_layout *l = critic ? &o->lc : &o->la;
+    if (i < 1 || i > l->L) return 1;
+    src = (critic ? o->actC : o->actA)[i]; n = B * (size_t)l->dims[i];
+  }
   else return 1;
   if (count < n) return 2;
   memcpy(dst, src, n * sizeof(float));

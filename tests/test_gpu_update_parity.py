@@ -18,23 +18,41 @@ def _fro(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def _check_grads(dqn, orc, net, ref64=None, c_tol=1e-5):
-    """Raw gradients (before clip/Adam), Frobenius-relative: 1e-5 against the C oracle AND against the float64 autograd
-    restatement, at every shape including BASELINE's.
+FLIP_TOL = 5e-3   # gradient bound when the two sides provably differentiated a different ReLU branch somewhere (see _sign_flips)
 
-    (Rounds 1-3 needed 5e-3 against the C oracle at 4 x 1024: its GEMMs were k-ordered fp32 fmaf chains whose own round-off
-    flipped the ReLU' of a near-zero pre-activation about once per update relative to float64.  The oracle now accumulates
-    every dot product in double and rounds once — the order-free value of an sgemm — and the two comparators agree.  An fp32
-    evaluation can still flip such a unit itself: measured on this library at 4 x 1024 about once in ten updates (then
-    ~1e-4..1e-3 in the layers below it); the seeds used here are flip-free, tests/test_gpu_published_shapes.py bounds the
-    4096-row case, where flips are certain, against an independent fp32 evaluation instead.)"""
+
+def _sign_flips(dqn, orc, p, which):
+    """(mismatches, rows) between the SIGNS of the stored tower activations of the learner's pass p and the oracle's last
+    actor ('A') / critic ('C') forward.  ReLU is applied in place (src/dqn.cpp:409-410), so ReLU' is taken from the sign of
+    the stored output; a pre-activation within fp32 round-off of zero can land on either side — on this library about once
+    in ten updates at 256 x 4 x 1024 units per pass, almost surely at 4096 rows — and then that unit's derivative for that row
+    is 1 on one side and 0.01 on the other: ~1e-4..1e-3 of the gradient norm in the layers below it.  Counting them makes
+    the exception explicit instead of resting on flip-free seeds."""
+    n, rows = 0, set()
+    for i in range(1, len(orc.hidden) + 1):
+        a, b = dqn.debug_read("act%d_%d" % (p, i)), orc.debug_read("act%s_%d" % (which, i))
+        bad = (a > 0) != (b > 0)
+        n += int(bad.sum()); rows.update(np.nonzero(bad.any(axis=1))[0].tolist())
+    return n, rows
+
+
+def _check_grads(dqn, orc, net, ref64=None, flips=0):
+    """Raw gradients (before clip/Adam), Frobenius-relative: 1e-5 against the C oracle AND against the float64 autograd
+    restatement at every shape including BASELINE's, whenever the two sides differentiated the same ReLU branches (flips == 0:
+    every case these seeds produce except one update of the 1024-row shape); FLIP_TOL otherwise, with at most 3 such units.
+
+    (Rounds 1-3 needed 5e-3 against the C oracle at 4 x 1024 regardless: its GEMMs were k-ordered fp32 fmaf chains whose
+    own round-off flipped about one unit per update relative to float64.  The oracle now accumulates every dot product in
+    double and rounds once — the order-free value of an sgemm — and the two comparators agree.)"""
+    assert flips <= 3, flips
+    tol = 1e-5 if flips == 0 else FLIP_TOL
     g1, g2 = dqn.get_params(net, 3), orc.grad_view(net).copy()
     if ref64 is not None:
-        assert _fro(g1, ref64) <= 1e-5, (net, _fro(g1, ref64))
-    assert _fro(g1, g2) <= c_tol, (net, _fro(g1, g2))
+        assert _fro(g1, ref64) <= tol, (net, _fro(g1, ref64), flips)
+    assert _fro(g1, g2) <= tol, (net, _fro(g1, g2), flips)
 
 
-def _check_update(dqn, orc, idx, t64=None, data=None, c_tol=1e-5):
+def _check_update(dqn, orc, idx, t64=None, data=None):
     """One update, phase by phase (the phases are where gradients are complete)."""
     g64 = [None, None]
     if t64 is not None:
@@ -42,9 +60,12 @@ def _check_update(dqn, orc, idx, t64=None, data=None, c_tol=1e-5):
         t64.update(s[idx], a[idx], r[idx], mc[idx], nx[idx], term[idx])
         g64 = [t64.g[0].numpy(), t64.g[1].numpy()]
     dqn.update_phase(0, idx); orc.update_phase(0, idx)
-    _check_grads(dqn, orc, 1, g64[1], c_tol)        # critic dW/db of Step(1)
+    f_c1, _ = _sign_flips(dqn, orc, 3, "C")         # critic(s, a): the training forward
+    _check_grads(dqn, orc, 1, g64[1], f_c1)        # critic dW/db of Step(1)
     dqn.update_phase(1); orc.update_phase(1, idx)
-    _check_grads(dqn, orc, 0, g64[0], c_tol)        # actor dW/db
+    f_a, rows_a = _sign_flips(dqn, orc, 1, "A")     # actor(s)
+    f_c2, rows_c2 = _sign_flips(dqn, orc, 4, "C")   # critic(s, mu(s)) with the updated critic
+    _check_grads(dqn, orc, 0, g64[0], f_c1 + f_a + f_c2)        # actor dW/db (a flip in the critic's step moves its weights, hence everything after)
     dqn.update_phase(2); orc.update_phase(2, idx)
     l1, q1 = dqn.read_stats()
     l2, q2 = orc.last_stats()
@@ -54,19 +75,25 @@ def _check_update(dqn, orc, idx, t64=None, data=None, c_tol=1e-5):
     np.testing.assert_array_equal(dqn.debug_read("terminal"), orc.debug_read("terminal"))
     a1, a2 = dqn.debug_read("actor_out"), orc.debug_read("actor_out")
     np.testing.assert_allclose(a1, a2, rtol=1e-4, atol=1e-4)
+    # post-invert dQ/da: 1e-4 of its scale element by element, in every row whose critic(s, mu(s)) pass took the same branches
+    ok = np.ones(len(a1), bool); ok[list(rows_c2)] = False
+    if f_c1:
+        ok[:] = False                                # the critic's own step differed: every row's dQ/da moves a little
     g1, g2 = dqn.debug_read("dq_da"), orc.debug_read("dq_da")
-    assert np.abs(g1 - g2).max() <= 1e-4 * max(np.abs(g2).max(), 1e-30), ("dq_da", np.abs(g1 - g2).max(), np.abs(g2).max())   # 1e-4 of its scale, element by element
+    assert np.abs(g1 - g2)[ok].max(initial=0.0) <= 1e-4 * max(np.abs(g2).max(), 1e-30), ("dq_da", np.abs(g1 - g2)[ok].max(), np.abs(g2).max())
+    assert np.abs(g1 - g2).max() <= 0.2 * np.abs(g2).max()
     assert abs(l1 - l2) <= 1e-4 * max(1.0, abs(l2)), (l1, l2)
     assert abs(q1 - q2) <= QTOL + QRTOL * abs(q2), (q1, q2)
     if t64 is not None:
         for name in ("q_target", "y", "q_train", "q_policy"):
             np.testing.assert_allclose(dqn.debug_read(name), t64.dbg[name].numpy(), rtol=QRTOL, atol=QTOL, err_msg=name)
-        # against float64 the per-row quantities are TIGHT (no shared fp32 rounding to flip a ReLU the same way twice):
-        # mu(s) to 1e-5 of its scale, the post-invert dQ/da to 1e-4 of its scale per element
-        for name, tol in (("actor_out", 1e-5), ("dq_da", 1e-4)):
-            ref = t64.dbg[name].numpy()
-            err = np.abs(dqn.debug_read(name) - ref).max()
-            assert err <= tol * max(np.abs(ref).max(), 1e-30), (name, err, np.abs(ref).max())
+        # against float64 the per-row quantities are TIGHT: mu(s) to 1e-5 of its scale, the post-invert dQ/da to 1e-4 of its
+        # scale per element (same rows as above: float64 sits where the oracle sits)
+        ref = t64.dbg["actor_out"].numpy()
+        assert np.abs(a1 - ref).max() <= 1e-5 * np.abs(ref).max(), ("actor_out", np.abs(a1 - ref).max())
+        ref = t64.dbg["dq_da"].numpy()
+        assert np.abs(g1 - ref)[ok].max(initial=0.0) <= 1e-4 * max(np.abs(ref).max(), 1e-30), ("dq_da vs float64", np.abs(g1 - ref)[ok].max())
+    return f_c1 + f_a + f_c2
 
 
 @pytest.mark.parametrize("shape", [
@@ -88,7 +115,6 @@ def test_update_matches_oracle(pkg, gpu, shape):
     shape = dict(shape)
     shape.setdefault("wscale", 5.0)
     use64 = shape.pop("f64", False)
-    c_tol = 1e-5
     dqn, orc, data, rng = make_pair(pkg, n_replay=2048, **shape)
     B = shape["B"]
     t64 = None
@@ -98,9 +124,21 @@ def test_update_matches_oracle(pkg, gpu, shape):
         for net in range(4):
             t64.set_params(net, orc.get_params(net))
     n_it = 3 if use64 else 4
+    flips = 0
     for it in range(n_it):
         idx = rng.integers(0, 2048, size=B)
-        _check_update(dqn, orc, idx, t64, data, c_tol)
+        f = _check_update(dqn, orc, idx, t64, data)
+        flips += f
+        if f:       # the two sides took different branches: their states now differ by a legitimate O(lr) in a few elements,
+            #         which would put MORE near-zero units on different sides next time — continue from identical states
+            for ref in [orc] + ([t64] if t64 is not None else []):
+                for net in range(4):
+                    ref.set_params(net, dqn.get_params(net))
+                for kind in (1, 2):
+                    for net in (0, 1):
+                        ref.set_params(net, dqn.get_params(net, kind), kind)
+    if B <= 256:
+        assert flips == 0, flips          # (so the 1e-5 bound was the one applied at BASELINE's and the reference's shapes)
     # Adam's normalised step m/(sqrt(v)+eps) is O(1) whatever |g| is, so an element whose gradient
     # is at fp32-roundoff level may legitimately move differently by up to lr per update; on
     # average the parameters must agree to 1% of a step.
