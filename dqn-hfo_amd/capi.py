@@ -6,7 +6,7 @@ from ._build import LIB, build
 
 MAX_HIDDEN = 8
 DP_ID_BYTES = 128        # DQNHIP_DP_ID_BYTES
-DP_PER_LAYER, DP_HALF_GRADS = 1, 2                  # dqnhip_dp_init flags
+DP_PER_LAYER, DP_HALF_GRADS, DP_SHARD_OPT = 1, 2, 4    # dqnhip_dp_init flags
 TUNE_FP16_WGRAD_PER_LAYER = 1                       # dqnhip_config.tuning_flags bits
 ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET = 0, 1, 2, 3
 KIND_W, KIND_M, KIND_V, KIND_G = 0, 1, 2, 3
@@ -47,6 +47,7 @@ SIGNATURES = {
     "dqnhip_update_phase": (C.c_int, [H, C.c_int32, ip]),
     "dqnhip_update_abort": (C.c_int, [H]),
     "dqnhip_apply_update": (C.c_int, [H, C.c_int32]),
+    "dqnhip_apply_update_sharded": (C.c_int, [H, C.c_int32, C.c_int32]),
     "dqnhip_grad_buffer": (C.c_int, [H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "dqnhip_read_stats": (C.c_int, [H, fp, fp]),
     "dqnhip_dp_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "dqnhip_dp_graph_active": (C.c_int, [H, ip]),
     "dqnhip_dp_broadcast_params": (C.c_int, [H, C.c_int32]),
     "dqnhip_dp_update": (C.c_int, [H, ip]),
+    "dqnhip_dp_gather_state": (C.c_int, [H]),
     "dqnhip_dp_destroy": (C.c_int, [H]),
     "dqnhip_skipped_steps": (C.c_int, [H, C.POINTER(C.c_int64)]),
     "dqnhip_reduce_gradients_local": (C.c_int, [C.POINTER(H), C.c_int32, C.c_int32]),

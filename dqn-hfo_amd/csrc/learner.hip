@@ -140,6 +140,10 @@ struct dqnhip_learner {
   ncclComm_t comm = nullptr;
   bool dp_per_layer = false;            // bucket the gradient all-reduce per layer on comm_stream
   bool dp_half = false;                 // gradients cross the links as bf16 (half the bytes); [loss, q, flag] tails stay fp32
+  // DQNHIP_DP_SHARD_OPT: reduce-scatter -> clip + Adam + soft update on this rank's 1/N slice of each arena -> all-gather of
+  // the updated online and target weights (m, v of the other slices go stale until dqnhip_dp_gather_state)
+  bool dp_shard = false;
+  float* shard_total = nullptr;         // dqnhip_apply_update_sharded: the group's sum of squares, accumulated rank by rank
   uint16_t* g16[2] = {nullptr, nullptr};   // bf16 transfer image of each gradient arena (dp_half)
   float* dp_tails = nullptr;            // dp_half: {critic tail[4], actor tail[4]}, one fp32 all-reduce with the actor's gradients
   hipStream_t comm_stream = nullptr;
@@ -513,12 +517,32 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
 
 // clip norm of the REDUCED gradient (data parallel); under DQNHIP_DP_HALF_GRADS the same pass widens the bf16
 // transfer image back into the fp32 arena
-int sumsq_launch(H* h, int net) {
+int sumsq_launch(H* h, int net, size_t begin = 0, size_t end = 0) {
   const NetLayout& l = layout_of(h, net);
-  if (h->dp_half) hipLaunchKernelGGL(k_sumsq_bf16, dim3(h->n_part_dp), dim3(256), 0, h->stream, (const uint16_t*)h->g16[net], h->g[net], l.arena / 4, h->part_dp);
-  else hipLaunchKernelGGL(k_sumsq, dim3(h->n_part_dp), dim3(256), 0, h->stream, h->g[net], l.arena / 4, h->part_dp);
+  if (end == 0) end = l.arena;
+  if (h->dp_half) hipLaunchKernelGGL(k_sumsq_bf16, dim3(h->n_part_dp), dim3(256), 0, h->stream, (const uint16_t*)h->g16[net] + begin, h->g[net] + begin, (end - begin) / 4, h->part_dp);
+  else hipLaunchKernelGGL(k_sumsq, dim3(h->n_part_dp), dim3(256), 0, h->stream, h->g[net] + begin, (end - begin) / 4, h->part_dp);
   HIPCHK(hipGetLastError());
   return 0;
+}
+// this rank's slice of a net's arena under the sharded optimiser: floats [lo, hi)
+inline void shard_range(const H* h, int net, size_t& lo, size_t& hi, int rank = -1) {
+  const size_t slice = layout_of(h, net).arena / (size_t)h->cfg.dp_world;
+  const size_t r = (size_t)(rank < 0 ? h->cfg.dp_rank : rank);
+  lo = r * slice; hi = lo + slice;
+}
+// the optimiser step of one net inside a data-parallel update (phase 1: critic, phase 2: actor + bookkeeping)
+int dp_allgather_weights(H* h, int net);
+int dp_optimiser_step(H* h, hipStream_t st, int net, float* tail, const TickArgs* tick) {
+  const NetLayout& l = layout_of(h, net);
+  if (h->dp_shard) {
+    // the exchange left this rank's slice of the reduced gradient in place and the group's sum of squares in tail[3]
+    size_t lo, hi; shard_range(h, net, lo, hi);
+    RC(adam_launch(h, st, net, tail + 3, 1, lo, hi, tick));
+    return dp_allgather_weights(h, net);
+  }
+  RC(sumsq_launch(h, net));
+  return adam_launch(h, st, net, h->part_dp, h->n_part_dp, 0, l.arena, tick);
 }
 
 // ---- mixed-precision building blocks (hgemm.hip.h) --------------------------------------------
@@ -661,10 +685,10 @@ inline uint64_t sample_key(const H* h) { return (uint64_t)h->cfg.seed + 0x9E3779
 int run_phase16(H* h, int phase, const int* idx_dev) {
   const int B = h->B, L = h->L;
   const NetLayout &la = h->la, &lc = h->lc;
-  const bool dp = h->cfg.dp_world > 1 || h->dp_half;     // (a one-rank group with bf16 exchange runs the N-rank code path)
+  const bool dp = h->cfg.dp_world > 1 || h->dp_half || h->dp_shard;     // (a one-rank group with bf16 exchange / a sharded optimiser runs the N-rank code path)
   const float inv_batch = 1.0f / (float)(B * h->cfg.dp_world);
-  float* actor_tail = h->dp_half ? h->dp_tails + 4 : h->g[0] + la.arena;
-  float* critic_tail = h->dp_half ? h->dp_tails : h->g[1] + lc.arena;
+  float* actor_tail = (h->dp_half || h->dp_shard) ? h->dp_tails + 4 : h->g[0] + la.arena;
+  float* critic_tail = (h->dp_half || h->dp_shard) ? h->dp_tails : h->g[1] + lc.arena;
   const int Hh = la.dims[L], Hc = lc.dims[L];
   hipStream_t st = h->stream;
   const bool split = phase == 10;
@@ -730,7 +754,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
   if (phase == 1) {
     // the Adam pass writes the fp16 mirrors of the critic and its target itself
     if (part16) RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
-    else { RC(sumsq_launch(h, 1)); RC(adam_launch(h, st, 1, h->part_dp, h->n_part_dp, 0, lc.arena)); }
+    else RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr));
     RC(tower_forward16(h, st, 4, DQNHIP_CRITIC, B));
     {
       // q(s, mu(s)) rides in the dq = -1 head launch (rider blocks), as on the fp32 path
@@ -760,7 +784,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
                         dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world), h->stats_dev};
     if (part16) RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick));
-    else { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena, &tick)); }   // + iteration counters / statistics
+    else RC(dp_optimiser_step(h, st, 0, actor_tail, &tick));        // + iteration counters / statistics
     h->h_actor_iter += 1; h->h_critic_iter += 1;
     return 0;
   }
@@ -778,10 +802,10 @@ int run_phase(H* h, int phase, const int* idx_dev) {
   if (h->fp16) return run_phase16(h, phase, idx_dev);
   const int B = h->B, L = h->L;
   const NetLayout &la = h->la, &lc = h->lc;
-  const bool dp = h->cfg.dp_world > 1 || h->dp_half;     // (a one-rank group with bf16 exchange runs the N-rank code path)
+  const bool dp = h->cfg.dp_world > 1 || h->dp_half || h->dp_shard;     // (a one-rank group with bf16 exchange / a sharded optimiser runs the N-rank code path)
   const float inv_batch = 1.0f / (float)(B * h->cfg.dp_world);
-  float* actor_tail = h->dp_half ? h->dp_tails + 4 : h->g[0] + la.arena;
-  float* critic_tail = h->dp_half ? h->dp_tails : h->g[1] + lc.arena;
+  float* actor_tail = (h->dp_half || h->dp_shard) ? h->dp_tails + 4 : h->g[0] + la.arena;
+  float* critic_tail = (h->dp_half || h->dp_shard) ? h->dp_tails : h->g[1] + lc.arena;
   const int Hh = la.dims[L], Hc = lc.dims[L];
   hipStream_t st = h->stream;
   const bool split = phase == 10;          // phase 10 = phase 0 without the online actor's forward, 11 = that forward
@@ -856,11 +880,10 @@ int run_phase(H* h, int phase, const int* idx_dev) {
   }
   if (phase == 1) {
     // ClipGradients + Adam + Net::Update of the critic, soft update of critic_target fused (one pass)
-    const float* part = h->part[1]; int n_part = lc.n_part;
-    if (dp) { RC(sumsq_launch(h, 1)); part = h->part_dp; n_part = h->n_part_dp; }
     FwdPass pC2{DQNHIP_CRITIC, &lc, h->act[4]};
     h->act[4][0] = h->Xc_pl;
-    RC(adam_launch(h, st, 1, part, n_part, 0, lc.arena));
+    if (dp) RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr));
+    else RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
     RC(tower_forward(h, st, &pC2, 1, B));                // critic(s, mu(s)), UPDATED weights [:913-916]
     // q(s, mu(s)) with the updated critic [:913-916] and, in the same launch, the seed of
     // BackwardFrom(q_values_layer): q diff = -1 per row, input gradient only (the reference's
@@ -895,7 +918,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // (critic_loss, avg_q) and advances the iteration / sampling counters
     const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
                         dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world), h->stats_dev};
-    if (dp) { RC(sumsq_launch(h, 0)); RC(adam_launch(h, st, 0, h->part_dp, h->n_part_dp, 0, la.arena, &tick)); }
+    if (dp) RC(dp_optimiser_step(h, st, 0, actor_tail, &tick));
     else RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick));
     h->h_actor_iter += 1; h->h_critic_iter += 1;
     return 0;
@@ -1177,6 +1200,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp); hipFree(h->head_slab); hipFree(h->head_ticket); if (h->head_slab2) hipFree(h->head_slab2);
   for (void* p : h->allocs16) hipFree(p);
   if (h->stage_dev) hipFree(h->stage_dev);
+  if (h->shard_total) hipFree(h->shard_total);
   if (h->act_buf) hipFree(h->act_buf);
   if (h->own_stream) hipStreamDestroy(h->stream);
   delete h;
@@ -1211,6 +1235,7 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
   HIPCHK(hipSetDevice(h->cfg.device));
   if (h->cfg.dp_world > 1) return fail("dqnhip_update_async: dp_world > 1 requires dqnhip_update_phase + all-reduce (or dqnhip_dp_update)");
   if (h->dp_half) return fail("dqnhip_update_async: this learner exchanges bf16 gradients (DQNHIP_DP_HALF_GRADS): use dqnhip_dp_update");
+  if (h->dp_shard) return fail("dqnhip_update_async: this learner's optimiser is sharded over its group (DQNHIP_DP_SHARD_OPT): use dqnhip_dp_update");
   if (h->next_phase != 0) return fail("dqnhip_update_async: a phased update is in progress (next phase %d)", h->next_phase);
   RingUse ring_use(h);
   RC(sync_dirty16(h));
@@ -1245,6 +1270,7 @@ int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host)
   // (with DQNHIP_DP_HALF_GRADS the exchange — bf16 image, all-reduce, widening by the clip-norm pass — lives inside
   // dqnhip_dp_update: a caller-driven exchange between phases would leave phase 1 / 2 reading a stale bf16 image)
   if (h->dp_half) return fail("dqnhip_update_phase: this learner exchanges bf16 gradients (DQNHIP_DP_HALF_GRADS): use dqnhip_dp_update");
+  if (h->dp_shard) return fail("dqnhip_update_phase: this learner's optimiser is sharded over its group (DQNHIP_DP_SHARD_OPT): use dqnhip_dp_update");
   // 0 -> 1 -> 2 or 10 -> 11 -> 1 -> 2: a phase run out of order would apply stale gradients
   // and advance the iteration counters
   const int expect = h->next_phase;
@@ -1314,7 +1340,7 @@ int dqnhip_update(dqnhip_handle h, const int32_t* idx_host, float* critic_loss, 
 int dqnhip_update_pipelined(dqnhip_handle h, const int32_t* idx_host, float* critic_loss, float* avg_q) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
-  if (h->cfg.dp_world > 1 || h->dp_half) return fail("dqnhip_update_pipelined: data-parallel learners use dqnhip_update_phase / dqnhip_dp_update");
+  if (h->cfg.dp_world > 1 || h->dp_half || h->dp_shard) return fail("dqnhip_update_pipelined: data-parallel learners use dqnhip_update_phase / dqnhip_dp_update");
   if (h->next_phase != 0) return fail("dqnhip_update_pipelined: a phased update is in progress (next phase %d)", h->next_phase);
   if (!h->pipe_ev[0]) {
     for (int i = 0; i < 2; ++i) {
@@ -1391,6 +1417,37 @@ int dqnhip_apply_update(dqnhip_handle h, int32_t net) {
   hipLaunchKernelGGL(k_sumsq, dim3(h->n_part_dp), dim3(256), 0, h->stream, h->g[net], l.arena / 4, h->part_dp);
   HIPCHK(hipGetLastError());
   RC(adam_launch(h, h->stream, net, h->part_dp, h->n_part_dp, 0, l.arena, nullptr, false));   // no gather ran: the pass evaluates its own correction
+  hipLaunchKernelGGL(k_advance_iter, dim3(1), dim3(1), 0, h->stream, h->st, (int)net, h->stats_dev);
+  HIPCHK(hipGetLastError());
+  if (net == DQNHIP_ACTOR) h->h_actor_iter += 1; else h->h_critic_iter += 1;
+  return 0;
+}
+
+// Solver::ApplyUpdate() of one net evaluated the way a `world`-rank group with a SHARDED optimiser evaluates it
+// (DQNHIP_DP_SHARD_OPT), by this one learner standing in for every rank in turn: per slice r the sum of squares of the
+// gradient's floats [r, r + 1) * arena / world (k_sumsq + k_shard_scal — each rank's share of the clip norm), their sum in
+// rank order (what the 4-float all-reduce leaves on every rank), then clip + Adam + Net::Update + soft update on slice r with
+// that norm (k_adam_soft on the sub-range), then set_iter(iter + 1).  No exchange is needed because the gradient in the
+// arena already IS the reduced one.  world = 1 is dqnhip_apply_update bit for bit; world > 1 differs from it only through
+// the order in which the clip norm is summed (identical bits whenever the clip is inactive).
+int dqnhip_apply_update_sharded(dqnhip_handle h, int32_t net, int32_t world) {
+  if (!h) return fail("null handle");
+  if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return fail("net must be ACTOR or CRITIC");
+  if (h->next_phase != 0) return fail("dqnhip_apply_update_sharded: a phased update is in progress (next phase %d)", h->next_phase);
+  const NetLayout& l = layout_of(h, net);
+  if (world < 1 || l.arena % ((size_t)4 * world)) return fail("apply_update_sharded: the arena (%zu floats) must be divisible by 4 x world = %d", l.arena, 4 * world);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RC(sync_dirty16(h));
+  if (!h->shard_total) HIPCHK(hipMalloc(&h->shard_total, 8 * sizeof(float)));
+  const size_t slice = l.arena / (size_t)world;
+  float* tail = h->shard_total + 4;
+  for (int r = 0; r < world; ++r) {
+    hipLaunchKernelGGL(k_sumsq, dim3(h->n_part_dp), dim3(256), 0, h->stream, h->g[net] + r * slice, slice / 4, h->part_dp);
+    hipLaunchKernelGGL(k_shard_scal, dim3(1), dim3(256), 0, h->stream, (const float*)h->part_dp, h->n_part_dp, tail);
+    hipLaunchKernelGGL(k_shard_accumulate, dim3(1), dim3(1), 0, h->stream, h->shard_total, (const float*)tail, r == 0 ? 1 : 0);
+    HIPCHK(hipGetLastError());
+  }
+  for (int r = 0; r < world; ++r) RC(adam_launch(h, h->stream, net, h->shard_total, 1, r * slice, (r + 1) * slice, nullptr, false));
   hipLaunchKernelGGL(k_advance_iter, dim3(1), dim3(1), 0, h->stream, h->st, (int)net, h->stats_dev);
   HIPCHK(hipGetLastError());
   if (net == DQNHIP_ACTOR) h->h_actor_iter += 1; else h->h_critic_iter += 1;
@@ -1499,10 +1556,48 @@ int dp_reduce_slice(H* h, hipStream_t st, int net, size_t off, size_t count) {
   return 0;
 }
 
+// all-gather (in place) of what the sharded optimiser step of `net` wrote on each rank's slice: the online weights and the
+// target's — the targets move on every update (SoftUpdateNet, src/dqn.cpp:967-970), so they cannot be left to an occasional
+// broadcast — and, for the fp16 learner, the two fp16 mirrors the GEMMs read.  m and v stay per slice.
+int dp_allgather_weights(H* h, int net) {
+  size_t lo, hi; shard_range(h, net, lo, hi);
+  const size_t n = hi - lo;
+  hipStream_t st = h->stream;
+  ncclResult_t r = ncclGroupStart();
+  if (r == ncclSuccess) r = ncclAllGather(h->w[net] + lo, h->w[net], n, ncclFloat, h->comm, st);
+  if (r == ncclSuccess) r = ncclAllGather(h->w[net + 2] + lo, h->w[net + 2], n, ncclFloat, h->comm, st);
+  if (h->fp16) {
+    if (r == ncclSuccess) r = ncclAllGather(h->w16a[net] + lo, h->w16a[net], n, ncclHalf, h->comm, st);
+    if (r == ncclSuccess) r = ncclAllGather(h->w16a[net + 2] + lo, h->w16a[net + 2], n, ncclHalf, h->comm, st);
+  }
+  const ncclResult_t r2 = ncclGroupEnd();
+  if (r != ncclSuccess || r2 != ncclSuccess) return fail("ncclAllGather (sharded optimiser, net %d) failed: %s", net, ncclGetErrorString(r != ncclSuccess ? r : r2));
+  return 0;
+}
+
 // the exchange step after phase 0 (net = critic) / phase 1 (net = actor)
 int dp_exchange(H* h, int net) {
   const NetLayout& l = layout_of(h, net);
   hipStream_t st = h->stream;
+  if (h->dp_shard) {
+    // reduce-scatter: rank r ends up with floats [r, r + 1) * arena / N of the summed gradient (in place; bf16 on the links
+    // under DQNHIP_DP_HALF_GRADS), takes the sum of squares of that slice (the same pass widens a bf16 slice back to fp32),
+    // and the ranks all-reduce the 4-float tail {loss, q, target flag, sum of squares}: the clip norm every rank's Adam uses
+    size_t lo, hi; shard_range(h, net, lo, hi);
+    float* tail = h->dp_tails + (net == DQNHIP_CRITIC ? 0 : 4);
+    if (h->dp_half) {
+      hipLaunchKernelGGL(k_to_bf16, dim3(1024), dim3(256), 0, st, (const float*)h->g[net], l.arena / 4, h->g16[net]);
+      HIPCHK(hipGetLastError());
+      NCCLCHK(ncclReduceScatter(h->g16[net], h->g16[net] + lo, hi - lo, ncclBfloat16, ncclSum, h->comm, st));
+    } else {
+      NCCLCHK(ncclReduceScatter(h->g[net], h->g[net] + lo, hi - lo, ncclFloat, ncclSum, h->comm, st));
+    }
+    RC(sumsq_launch(h, net, lo, hi));
+    hipLaunchKernelGGL(k_shard_scal, dim3(1), dim3(256), 0, st, (const float*)h->part_dp, h->n_part_dp, tail);
+    HIPCHK(hipGetLastError());
+    NCCLCHK(ncclAllReduce(tail, tail, 4, ncclFloat, ncclSum, h->comm, st));
+    return 0;
+  }
   if (h->dp_half) {
     // bf16 image of the arena -> sum all-reduce -> (phase 1 / 2 widen it again inside k_sumsq_bf16).  The fp32
     // tails of both nets travel once, with the actor's gradients (nothing reads them before the tick of phase 2).
@@ -1651,13 +1746,21 @@ int dqnhip_dp_init(dqnhip_handle h, const void* id, size_t bytes, int32_t flags)
   ncclUniqueId uid; memcpy(&uid, id, sizeof uid);
   NCCLCHK(ncclCommInitRank(&h->comm, h->cfg.dp_world, uid, h->cfg.dp_rank));
   h->dp_half = (flags & DQNHIP_DP_HALF_GRADS) != 0;
+  h->dp_shard = (flags & DQNHIP_DP_SHARD_OPT) != 0;
+  if (h->dp_shard)
+    for (int net = 0; net < 2; ++net)
+      if (layout_of(h, net).arena % ((size_t)4 * h->cfg.dp_world)) {
+        ncclCommDestroy(h->comm); h->comm = nullptr; h->dp_half = h->dp_shard = false;
+        return fail("dp_init: DQNHIP_DP_SHARD_OPT needs a parameter arena (%zu floats) divisible by 4 x dp_world = %d", layout_of(h, net).arena, 4 * h->cfg.dp_world);
+      }
   // per-layer buckets need each layer's dW AND db final when its backward launch has run: true for the fp32 path;
   // the fp16 path produces all wgrads of a net in one launch at the end and keeps one collective per net
-  h->dp_per_layer = (flags & DQNHIP_DP_PER_LAYER) != 0 && !h->fp16 && !h->dp_half;
+  h->dp_per_layer = (flags & DQNHIP_DP_PER_LAYER) != 0 && !h->fp16 && !h->dp_half && !h->dp_shard;
   HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
   for (auto& e : h->comm_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  if (h->dp_half) {
+  if (h->dp_half)
     for (int net = 0; net < 2; ++net) HIPCHK(hipMalloc(&h->g16[net], layout_of(h, net).arena * sizeof(uint16_t)));
+  if (h->dp_half || h->dp_shard) {
     HIPCHK(hipMalloc(&h->dp_tails, 8 * sizeof(float)));
     HIPCHK(hipMemsetAsync(h->dp_tails, 0, 8 * sizeof(float), h->stream));
   }
@@ -1717,9 +1820,27 @@ int dqnhip_dp_graph_active(dqnhip_handle h, int32_t* active) {
   return 0;
 }
 
+// Sharded optimiser: every rank holds m and v of its own slice only; this all-gathers them (collective: every rank of the
+// group calls it) so that dqnhip_get_params(KIND_M / KIND_V), a snapshot, or a later replicated / single-learner update
+// see the whole Adam history.  No-op without DQNHIP_DP_SHARD_OPT.
+int dqnhip_dp_gather_state(dqnhip_handle h) {
+  if (!h) return fail("null handle");
+  if (!h->comm) return fail("dp_gather_state: no communicator (call dqnhip_dp_init first)");
+  if (!h->dp_shard) return 0;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  for (int net = 0; net < 2; ++net) {
+    size_t lo, hi; shard_range(h, net, lo, hi);
+    NCCLCHK(ncclAllGather(h->m[net] + lo, h->m[net], hi - lo, ncclFloat, h->comm, h->stream));
+    NCCLCHK(ncclAllGather(h->v[net] + lo, h->v[net], hi - lo, ncclFloat, h->comm, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 int dqnhip_dp_destroy(dqnhip_handle h) {
   if (!h || !h->comm) return 0;
   hipSetDevice(h->cfg.device);
+  if (h->dp_shard) dqnhip_dp_gather_state(h);          // (collective, like the communicator's own teardown: the whole Adam history back on every rank)
   hipStreamSynchronize(h->stream);
   hipStreamSynchronize(h->comm_stream);
   if (h->dp_graph) { hipGraphExecDestroy(h->dp_graph); h->dp_graph = nullptr; }
@@ -1729,7 +1850,7 @@ int dqnhip_dp_destroy(dqnhip_handle h) {
   for (auto& e : h->comm_ev) { if (e) hipEventDestroy(e); e = nullptr; }
   for (int net = 0; net < 2; ++net) if (h->g16[net]) { hipFree(h->g16[net]); h->g16[net] = nullptr; }
   if (h->dp_tails) { hipFree(h->dp_tails); h->dp_tails = nullptr; }
-  h->dp_half = false; h->dp_per_layer = false;
+  h->dp_half = false; h->dp_per_layer = false; h->dp_shard = false;
   return 0;
 }
 

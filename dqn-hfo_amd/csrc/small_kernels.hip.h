@@ -1084,6 +1084,23 @@ __global__ __launch_bounds__(256) void k_local_reduce(LocalReduce a) {
   }
 }
 
+// Sharded optimiser (DQNHIP_DP_SHARD_OPT): the sum of squares of THIS rank's slice of the reduced gradient, folded from
+// k_sumsq's partials with the tree adam_scalars uses (strided sums, butterfly, fixed cross-wave order: a one-rank group
+// then derives the same bits as the replicated form) into tail[3]; the 4-float tail is what the ranks all-reduce.
+__global__ __launch_bounds__(256) void k_shard_scal(const float* __restrict__ partial, int n_partial, float* tail) {
+  __shared__ float s[4];
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
+  acc = wave_sum64(acc);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) tail[3] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+// dqnhip_apply_update_sharded (one process standing in for every rank of a group in turn): total += the slice's sum
+__global__ void k_shard_accumulate(float* total, const float* tail, int first) {
+  total[0] = first ? tail[3] : total[0] + tail[3];
+}
+
 // Reduce the per-block loss / q partials into the gradient-arena tails
 // ([loss_sum, q_sum, 0, 0]) so they ride in the gradient all-reduce.
 // tail[2] carries this rank's non-finite-target flag (0 / 1): the flag is raised from the rank's OWN replay shard,

@@ -388,6 +388,10 @@ class DQN:
         """Solver::ApplyUpdate of one net on the gradient in its arena (src/dqn.cpp:904 tail, :964-965)."""
         self._ck(self.lib.dqnhip_apply_update(self.h, net))
 
+    def apply_update_sharded(self, net, world):
+        """The same step, evaluated as a `world`-rank group with a sharded optimiser evaluates it (one slice after the other)."""
+        self._ck(self.lib.dqnhip_apply_update_sharded(self.h, net, int(world)))
+
     # -- native data parallelism (RCCL inside the library, include/dqnhip.h dqnhip_dp_*) -------
     @staticmethod
     def dp_unique_id():
@@ -398,16 +402,21 @@ class DQN:
         return buf.raw
 
     @staticmethod
-    def _dp_flags(per_layer, half_grads):
-        return (capi.DP_PER_LAYER if per_layer else 0) | (capi.DP_HALF_GRADS if half_grads else 0)
+    def _dp_flags(per_layer, half_grads, shard_opt=False):
+        return ((capi.DP_PER_LAYER if per_layer else 0) | (capi.DP_HALF_GRADS if half_grads else 0) |
+                (capi.DP_SHARD_OPT if shard_opt else 0))
 
-    def dp_init(self, unique_id, per_layer=False, half_grads=False):
+    def dp_init(self, unique_id, per_layer=False, half_grads=False, shard_opt=False):
         assert len(unique_id) == capi.DP_ID_BYTES
         buf = C.create_string_buffer(bytes(unique_id), capi.DP_ID_BYTES)
-        self._ck(self.lib.dqnhip_dp_init(self.h, buf, capi.DP_ID_BYTES, self._dp_flags(per_layer, half_grads)))
+        self._ck(self.lib.dqnhip_dp_init(self.h, buf, capi.DP_ID_BYTES, self._dp_flags(per_layer, half_grads, shard_opt)))
 
-    def dp_init_file(self, path, per_layer=False, timeout_s=120, half_grads=False):
-        self._ck(self.lib.dqnhip_dp_init_file(self.h, os.fsencode(path), self._dp_flags(per_layer, half_grads), int(timeout_s)))
+    def dp_init_file(self, path, per_layer=False, timeout_s=120, half_grads=False, shard_opt=False):
+        self._ck(self.lib.dqnhip_dp_init_file(self.h, os.fsencode(path), self._dp_flags(per_layer, half_grads, shard_opt), int(timeout_s)))
+
+    def dp_gather_state(self):
+        """sharded optimiser: all-gather of the Adam history (collective; no-op otherwise)"""
+        self._ck(self.lib.dqnhip_dp_gather_state(self.h))
 
     def dp_graph_active(self):
         v = C.c_int32()

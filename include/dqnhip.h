@@ -187,6 +187,13 @@ int dqnhip_update_abort(dqnhip_handle h);
  * The optimiser pass of dqnhip_update is this same kernel: tests pin it here on identical (w, g, m, v,
  * w', iter) to a few ulp. */
 int dqnhip_apply_update(dqnhip_handle h, int32_t net);
+/* The same step evaluated the way a `world`-rank group with a SHARDED optimiser (DQNHIP_DP_SHARD_OPT, below) evaluates it,
+ * this one learner standing in for every rank in turn: each slice's share of the clip norm, their sum in rank order (what
+ * the group's 4-float all-reduce leaves on every rank), clip + Adam + soft update slice by slice with that norm.  The
+ * gradient in the arena already is the reduced one, so no exchange is involved: this pins the slice arithmetic and the
+ * norm's composition on ONE GPU.  world = 1 equals dqnhip_apply_update bit for bit; world > 1 differs only through the
+ * summation order of the norm (identical bits whenever the clip is inactive). */
+int dqnhip_apply_update_sharded(dqnhip_handle h, int32_t net, int32_t world);
 
 /* Device pointer + length (floats) of one net's gradient arena, including a
  * 4-float tail [loss_sum, q_sum, 0, 0] so the two reported scalars ride in the
@@ -214,10 +221,21 @@ int dqnhip_grad_buffer(dqnhip_handle h, int32_t net, void** dptr, size_t* nfloat
  * net at 4x1024); the [loss, q, flag] tails stay fp32 and travel once, with the actor's gradients.  The reduced
  * gradient then carries 8 significant bits (tests/test_gpu_dp_hip.py bounds the effect); meant for the fp16 learner.
  * cfg.use_graph: dqnhip_dp_update captures phase 0 / all-reduce / phase 1 / all-reduce / phase 2 ONCE and replays
- * it as a hipGraph (eager if RCCL refuses the capture: dqnhip_dp_graph_active tells). */
+ * it as a hipGraph (eager if RCCL refuses the capture: dqnhip_dp_graph_active tells).
+ * DQNHIP_DP_SHARD_OPT: the optimiser is sharded over the group (ZeRO-1 style) instead of replicated: per net, a
+ * reduce-scatter leaves rank r with slice r of the summed gradient, the ranks all-reduce a 4-float tail {loss, q, target
+ * flag, sum of squares of their slice} — the clip norm — each rank runs clip + Adam + soft update on its 1/N slice only, and
+ * the updated online AND target weights (the targets move every update, src/dqn.cpp:967-970; fp16 learner: the fp16 mirrors
+ * too) are all-gathered.  What SURVEY 8(e) calls "identical Adam on every rank" is relaxed to "every parameter's Adam on
+ * exactly one rank, identical weights everywhere afterwards".  m and v of foreign slices go stale: dqnhip_dp_gather_state
+ * (collective) brings them back before a snapshot / dqnhip_get_params(KIND_M, KIND_V); dqnhip_dp_destroy does it too.
+ * Combines with DQNHIP_DP_HALF_GRADS, not with DQNHIP_DP_PER_LAYER.  Priced in DESIGN.md 6: it does not pay at 4 x 1024
+ * (the target nets double the all-gather, the clip norm needs its own latency-bound collective); off by default.
+ * The arena must be divisible by 4 x dp_world. */
 #define DQNHIP_DP_ID_BYTES 128
 #define DQNHIP_DP_PER_LAYER 1
 #define DQNHIP_DP_HALF_GRADS 2
+#define DQNHIP_DP_SHARD_OPT 4
 int dqnhip_dp_unique_id(void* id_out, size_t bytes);
 int dqnhip_dp_init(dqnhip_handle h, const void* id, size_t bytes, int32_t flags);
 int dqnhip_dp_init_file(dqnhip_handle h, const char* path, int32_t flags, int32_t timeout_s);
@@ -226,6 +244,7 @@ int dqnhip_dp_rendezvous_cleanup(const char* path, int32_t world);
 int dqnhip_dp_graph_active(dqnhip_handle h, int32_t* active);
 int dqnhip_dp_broadcast_params(dqnhip_handle h, int32_t root);
 int dqnhip_dp_update(dqnhip_handle h, const int32_t* idx_host);
+int dqnhip_dp_gather_state(dqnhip_handle h);
 int dqnhip_dp_destroy(dqnhip_handle h);
 
 /* Waits for the stream and returns the scalars of the last update.  Fails — the reference

@@ -128,6 +128,8 @@ def main():
             e.dp_update(idx_all[u, rank])
             stats.append(e.read_stats())
         res["eager_stats"] = stats
+        if args.shard_opt:
+            e.dp_gather_state()           # (collective) the Adam history of the other ranks' slices
         res["eager_digest"] = digest(e)
         res["iters"] = [e.actor_iter(), e.critic_iter()]
         if rank == 0:
@@ -166,6 +168,8 @@ def main():
         e2.dp_update(None); se = e2.read_stats()
         same = same and (sg == se)
     res["graph_active"] = bool(g.dp_graph_active())
+    if args.shard_opt:
+        g.dp_gather_state(); e2.dp_gather_state()
     res["graph_equals_eager"] = bool(same and digest(g) == digest(e2))
     res["graph_digest"] = digest(g)
     res["graph_stats"] = list(g.read_stats())

@@ -154,3 +154,77 @@ def test_apply_update_fp16_learner_keeps_its_mirrors(pkg, gpu):
     a = d.SelectActionGreedily(st)             # fp32 acting path on the stepped master weights
     np.testing.assert_allclose(a, o.actor_forward(st), atol=1e-3, rtol=1e-3)
     d.close(); o.close()
+
+
+@pytest.mark.parametrize("net", [0, 1])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("gnorm,clip", [(3.0, 10.0), (250.0, 10.0)])     # clip inactive / active
+def test_sharded_optimiser_step_equals_the_replicated_one(pkg, gpu, net, world, gnorm, clip):
+    """DQNHIP_DP_SHARD_OPT on ONE GPU: dqnhip_apply_update_sharded runs, for every rank of a `world`-rank group in turn, exactly
+    what that rank runs between the reduce-scatter and the all-gather — the sum of squares of its slice of the (already
+    reduced) gradient, the clip norm from the slice sums in rank order, clip + Adam + soft update on its slice — and must
+    reproduce dqnhip_apply_update (the replicated form: every rank on the whole arena): bit for bit when the clip does not
+    rescale (or world = 1: same summation tree), to a few ulp of the terms when it does (the norm is summed in another order)."""
+    S, hidden = 59, (256, 128, 64, 64)
+    a, oa = _pair(pkg, S, hidden, clip_grad=clip)
+    b, ob = _pair(pkg, S, hidden, clip_grad=clip)
+    t = 3
+    before = _load(pkg, a, oa, np.random.default_rng(7 + net), S, hidden, net, gnorm, t - 1, t - 1)
+    _load(pkg, b, ob, np.random.default_rng(7 + net), S, hidden, net, gnorm, t - 1, t - 1)
+    a.apply_update(net); b.apply_update_sharded(net, world); ob.apply_update(net)
+    exact = gnorm <= clip or world == 1
+    if exact:
+        for kind in (pkg.KIND_W, pkg.KIND_M, pkg.KIND_V):
+            np.testing.assert_array_equal(a.get_params(net, kind), b.get_params(net, kind))
+        np.testing.assert_array_equal(a.get_params(net + 2), b.get_params(net + 2))
+    _check(pkg, b, ob, net, before, exact_scale=gnorm <= clip, t=t, clip=clip)        # and against the oracle, like the replicated form
+    assert (a.actor_iter(), a.critic_iter()) == (b.actor_iter(), b.critic_iter())
+    with pytest.raises(pkg.DQNFatal, match="divisible"):
+        b.apply_update_sharded(net, 7)
+    for x in (a, b, oa, ob):
+        x.close()
+
+
+@pytest.mark.parametrize("precision,half", [("fp32", False), ("fp16", False), ("fp16", True)])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_native_rccl_sharded_optimiser_one_rank(pkg, gpu, precision, half, use_graph):
+    """The sharded form through the real communicator with ONE rank (reduce-scatter / all-reduce / all-gather are identities):
+    the slice is the whole arena and the clip norm is folded by the same tree, so the result is the plain update bit for
+    bit (bf16 exchange: the bf16-exchange group member's), eager and as one captured hipGraph; the Adam history is complete
+    after dqnhip_dp_gather_state."""
+    from synth import synth_replay
+    B, S, hid = 128, 59, (256, 128, 128)
+    rng = np.random.default_rng(6)
+    w = [torch_ref.init_params_np(rng, S, hid, act) * 5 for act in (True, False)]
+    data = synth_replay(rng, 1024, S, mean_len=10)
+    ds = [pkg.DQN(S, minibatch=B, hidden=hid, memory=4096, seed=2, dp_world=1, dp_rank=0, precision=precision, use_graph=use_graph)
+          for _ in range(2)]
+    for d in ds:
+        for net in (0, 1):
+            d.set_params(net, w[net]); d.CloneNet(net)
+        d.add_transitions_arrays(*data)
+    ds[0].dp_init(pkg.DQN.dp_unique_id(), half_grads=half, shard_opt=True)
+    if half:
+        ds[1].dp_init(pkg.DQN.dp_unique_id(), half_grads=True)         # the replicated bf16-exchange form is the twin
+    for u in range(4):
+        ds[0].dp_update(None)
+        if half:
+            ds[1].dp_update(None)
+        else:
+            ds[1].update_async(None)
+        assert ds[0].read_stats() == ds[1].read_stats()
+    assert ds[0].dp_graph_active() == use_graph
+    ds[0].dp_gather_state()
+    for net in range(4):
+        np.testing.assert_array_equal(ds[0].get_params(net), ds[1].get_params(net))
+    for kind in (pkg.KIND_M, pkg.KIND_V):
+        for net in (0, 1):
+            np.testing.assert_array_equal(ds[0].get_params(net, kind), ds[1].get_params(net, kind))
+    assert ds[0].skipped_steps() == 0 and ds[0].actor_iter() == 4
+    for call in (lambda: ds[0].update_async(None), lambda: ds[0].update_phase(0, None)):
+        with pytest.raises(pkg.DQNFatal, match="dqnhip_dp_update"):
+            call()
+    ds[0].dp_destroy()
+    ds[0].UpdateActorCritic(rng.integers(0, 1024, B))           # a plain learner again
+    for d in ds:
+        d.close()
