@@ -412,6 +412,10 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
                      ("dp_graph", dict(use_graph=True), dict(half_grads=half))]
             if not half:
                 forms.append(("dp_per_layer_graph", dict(use_graph=True), dict(per_layer=True)))
+            # the sharded optimiser (DQNHIP_DP_SHARD_OPT): with ONE rank its slice is the whole arena, so this measures what
+            # its extra launches cost (reduce-scatter + 4-float all-reduce + all-gathers instead of one all-reduce per net),
+            # not what a 1/N slice saves — the projection takes that from profiles/r04_adam_slice_probe.txt
+            forms.append(("dp_shard_graph", dict(use_graph=True), dict(half_grads=half, shard_opt=True)))
             for name, kw, dp_kw in forms:
                 d = pkg.DQN(S, minibatch=512, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, precision=prec, **kw)
                 prefill(d, 150000, seed=7)
@@ -448,7 +452,7 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
             bl = r["backward_launch_us"]
             def t_rank(n):
                 base = {8: r["plain_graph_ms"], 4: r["plain_graph_ms_rows_1024"], 2: r["plain_graph_ms_rows_2048"]}[n]
-                return {"single": base + r["dp_graph_ms"] - r["plain_graph_ms"], "sharded": base + r["dp_graph_ms"] - r["plain_graph_ms"],
+                return {"single": base + r["dp_graph_ms"] - r["plain_graph_ms"], "sharded": base + r["dp_shard_graph_ms"] - r["plain_graph_ms"],
                         "per_layer": base + r.get("dp_per_layer_graph_ms", r["dp_graph_ms"]) - r["plain_graph_ms"]}
             r["exchange"] = "bf16 gradients + fp32 tails, one collective per net" if half else "fp32, one collective per net (per-layer buckets: dp_per_layer_graph_ms)"
             r["projection"] = {"n_gpus_%d" % n: dp_projection(n, half, gb, t_rank(n), one, bl.get("gemm_bwd_pair", bl.get("hgemm_dgrad", 0.0)),
@@ -559,6 +563,7 @@ def main():
     ap.add_argument("--dp-per-layer", action="store_true",
                     help="native DP, fp32 learner: per-layer buckets on a communication stream instead of ONE all-reduce per net (the projection "
                          "of sub_records.configs4_rank_shape_b512 prices both: with ~20 us per collective five buckets cost more than they hide)")
+    ap.add_argument("--dp-shard-opt", action="store_true", help="native DP: sharded optimiser (DQNHIP_DP_SHARD_OPT) instead of the replicated one")
     ap.add_argument("--test-dp-probe", action="store_true", help="testing: run the captured-update probe with the ranks there are (N = 1 under --force-dp)")
     ap.add_argument("--no-dp-probe", action="store_true",
                     help="N > 1: skip the sacrificial child group that tries the captured data-parallel update first (tests/dp_native_worker.py)")
@@ -630,8 +635,8 @@ def main():
             # torch.distributed — to the other transport of the same algorithm (torch's RCCL all-reduce between the
             # update phases), and the JSON line says so.  Same kernels, same numbers, a few host round trips more.
             try:
-                dqn, dp = par.make_native_data_parallel(pkg, S, rank, world, local_rank, per_layer=args.dp_per_layer and not half,
-                                                        half_grads=half, use_graph=not args.no_graph, **common)
+                dqn, dp = par.make_native_data_parallel(pkg, S, rank, world, local_rank, per_layer=args.dp_per_layer and not half and not args.dp_shard_opt,
+                                                        half_grads=half, shard_opt=args.dp_shard_opt, use_graph=not args.no_graph, **common)
             except Exception as e:                                  # noqa: BLE001 — reported, not swallowed
                 native_error = repr(e)[:300]
                 dqn = dp = None

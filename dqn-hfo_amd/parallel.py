@@ -110,13 +110,14 @@ class NativeDataParallel:
 
 
 def make_native_data_parallel(pkg, state_size, rank, world, device, group=None, per_layer=False, half_grads=False,
-                              **dqn_kwargs):
+                              shard_opt=False, **dqn_kwargs):
     """One learner per rank with an RCCL communicator inside the library.  Needs an initialised
     torch.distributed group only to ship the id when world > 1.  use_graph=True (a DQN keyword) makes
-    dqnhip_dp_update replay the whole update, collectives included, as one captured hipGraph."""
+    dqnhip_dp_update replay the whole update, collectives included, as one captured hipGraph; shard_opt=True shards
+    the optimiser over the group (DQNHIP_DP_SHARD_OPT: reduce-scatter / Adam on 1/N / all-gather)."""
     dqn = pkg.DQN(state_size, device=device, dp_world=world, dp_rank=rank, **dqn_kwargs)
     box = [pkg.DQN.dp_unique_id() if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(box, src=0, group=group)
-    dqn.dp_init(box[0], per_layer=per_layer, half_grads=half_grads)
+    dqn.dp_init(box[0], per_layer=per_layer, half_grads=half_grads, shard_opt=shard_opt)
     return dqn, NativeDataParallel(dqn)
