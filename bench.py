@@ -160,10 +160,12 @@ def dp_projection(world, half, net_bytes, t_rank_ms, t_1gpu_ms, bwd_launch_us, n
                         bk.append((t, sb))
                     extra += exposed_exchange_us(bk, t, world, links)
                 else:
-                    # all-gather: the updated online weights AND the targets, in the width the GEMMs read (fp32 learner: fp32
-                    # = the gradient's width; fp16 learner with bf16 exchange: the fp16 mirrors) = 2 x the gradient bytes
+                    # all-gather, as built: the updated online weights AND the targets in fp32 (2 x 4 B/param) and, for the fp16
+                    # learner, their two fp16 mirrors as well (2 x 2 B/param) — against gradient bytes nb of 4 B/param (fp32
+                    # exchange) or 2 B/param (bf16 exchange): 2 x nb resp. 6 x nb.  (A leaner fp16 form — mirrors + the fp32
+                    # bias / head slices only — would move 2 x nb; it still loses to the single all-reduce)
                     extra += (collective_us(nb, world, links, 1.0) + collective_us(16, world, links)
-                              + collective_us(2 * nb, world, links, 1.0) - (adam_full - adam_slice))
+                              + collective_us((6 if half else 2) * nb, world, links, 1.0) - (adam_full - adam_slice))
             ms = (t_rank_ms[form] if isinstance(t_rank_ms, dict) else t_rank_ms) + extra * 1e-3
             r[name] = round(ms, 4); r["speedup_" + name] = round(t_1gpu_ms / ms, 2)
         out[form] = r
