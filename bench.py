@@ -89,7 +89,7 @@ KERNEL_NAMES = {"hgemm_fwd": "hgemm_nt<2,2>/<1,1> (forward epilogue)", "hgemm_dg
                 "gemm_dgrad": "gemm_dgrad_lds<1,1>", "gemm_wgrad": "gemm_wgrad_narrow<1>"}
 
 
-PMC_SUMMARY = "profiles/r03_pmc_summary.json"
+PMC_SUMMARY = "profiles/r04_pmc_summary.json"
 
 # xGMI (MI355X, 8 GPUs fully connected): 7 links per GPU, 153.6 GB/s per link counting both directions = 76.8 GB/s
 # each way.  Two bounds for a sum all-reduce of S bytes over N ranks: ONE ring = every byte crosses one
@@ -183,7 +183,7 @@ def grad_bytes(S_, hidden, half):
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel`.  PMC counters cannot be read from inside this process
     (rocprofv3 wraps the command), so the figure comes from the committed PMC passes of the SAME
-    kernels (scripts/r03_pmc.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    kernels (scripts/pmc.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
     bench.py; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads on
     gfx950) and is labelled with its source.  (None, None) if that kernel is not in the file."""
     try:

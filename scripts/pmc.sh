@@ -1,10 +1,12 @@
 #!/bin/bash
-# PMC passes of round 3 -> gpurun_out/r03prof/r03_pmc_summary.json (per-kernel means per launch).
+# PMC passes -> gpurun_out/rNNprof/rNN_pmc_summary.json (per-kernel means per launch); ROUND=r04 (default) names the round.
 # One rocprofv3 run per counter group, --kernel-trace + --pmc only (no other trace domain: gpurun refuses the mix),
 # FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 #   workloads: the fp32 headline (B = 256) and the fp16 learner at minibatch 4096 (configs[4] on one GPU), eager launches
 export TMPDIR=/tmp
-O=gpurun_out/r03prof; mkdir -p $O
+R=${ROUND:-r04}
+export R
+O=gpurun_out/${R}prof; mkdir -p $O
 rm -rf /tmp/pmc3; mkdir -p /tmp/pmc3
 C="--no-graph --no-cpu-baseline --no-env --no-subrecords --replay 200000"
 i=0
@@ -32,13 +34,14 @@ for f in glob.glob("/tmp/pmc3/*/**/*counter_collection.csv", recursive=True):
 def mean(d): return {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(d.items())}
 head = open(".git_head").read().strip() if os.path.exists(".git_head") else "unknown"
 kv = json.load(open(".kernel_versions.json")) if os.path.exists(".kernel_versions.json") else {}
-out = {"source": "scripts/r03_pmc.sh: rocprofv3 --kernel-trace --pmc <one pass per counter group> -- python bench.py ... --no-graph (MI355X, round 3)",
+R = os.environ.get("R", "r04")
+out = {"source": "scripts/pmc.sh: rocprofv3 --kernel-trace --pmc <one pass per counter group> -- python bench.py ... --no-graph (MI355X, round %s)" % R[1:].lstrip("0"),
        "head": head,
        "kernels_version": "HEAD %s; kernel sources last changed at: %s" % (head, ", ".join("%s %s" % (k, v) for k, v in sorted(kv.items())) or "not recorded"),
        "units": {"FETCH_SIZE": "KB as reported (double it for wide coalesced reads on gfx950, MI355X_MICROARCH.md HBM section)", "WRITE_SIZE": "KB",
                  "SQ_VALU_MFMA_BUSY_CYCLES": "cycles summed over SIMDs", "SQ_WAVE_CYCLES/SQ_WAIT_*": "quad-cycles summed over waves"},
        "kernels": mean(acc["fp32_b256"]), "kernels_fp16_b4096": mean(acc["fp16_b4096"])}
-json.dump(out, open("gpurun_out/r03prof/r03_pmc_summary.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/%sprof/%s_pmc_summary.json" % (R, R), "w"), indent=1)
 for wl in ("kernels", "kernels_fp16_b4096"):
     print(wl)
     for k, d in out[wl].items():
