@@ -42,6 +42,17 @@ DEFINE_string(precision, "fp32", "fp32 (exact-fp32 MFMA, the parity path) or fp1
 DEFINE_bool(device_sampling, false, "Sample minibatch indices on the device (counter-based) instead of the host std::mt19937.");
 DEFINE_bool(pipelined_stats, false, "UpdateActorCritic() returns the (loss, avg_q) of the PREVIOUS update (dqnhip_update_pipelined): "
                                     "the device does not idle on the per-update read-back; the logged / smoothed values lag by one update.");
+// Data parallelism for the UNCHANGED driver: start one process of this binary per GPU — each with its own HFO
+// workers, its own replay shard, its own -save prefix and -hip_device — and the ranks' gradients are summed by RCCL inside
+// libdqnhip.so twice per update (after the critic's backward and after the actor's).  Every rank's k-th UpdateActorCritic()
+// pairs with every other rank's k-th: a rank that asks for an update early simply waits inside the collective until the
+// others ask for theirs (episodes differ in length), and once max_iter is reached Update() becomes a no-op on every rank at
+// the same update, so nobody is left waiting at the end.
+DEFINE_int32(dp_world, 1, "Data-parallel group size (processes of this binary, one per GPU). 1: no group unless -dp_rendezvous is given.");
+DEFINE_int32(dp_rank, 0, "This process's rank in the data-parallel group.");
+DEFINE_string(dp_rendezvous, "", "File path shared by the ranks of the group (dqnhip_dp_init_file; needs no launcher). Empty: no data parallelism.");
+DEFINE_bool(dp_half_grads, false, "Exchange gradients as bf16 (half the bytes on the links; meant for -precision fp16).");
+
 
 #define DQNHIP_CK(call) CHECK((call) == 0) << dqnhip_last_error()
 
@@ -223,7 +234,19 @@ DQN::DQN(caffe::SolverParameter& actor_solver_param, caffe::SolverParameter& cri
   c.seed = seed;
   CHECK(FLAGS_precision == "fp32" || FLAGS_precision == "fp16") << "-precision must be fp32 or fp16";
   c.precision = FLAGS_precision == "fp16" ? DQNHIP_FP16 : DQNHIP_FP32;
+  dp_ = !FLAGS_dp_rendezvous.empty();
+  CHECK(dp_ || FLAGS_dp_world == 1) << "-dp_world > 1 needs -dp_rendezvous <path shared by the ranks>";
+  if (dp_) {
+    CHECK(!FLAGS_pipelined_stats) << "-pipelined_stats is a single-learner option (the data-parallel update reports its own scalars)";
+    c.dp_world = FLAGS_dp_world; c.dp_rank = FLAGS_dp_rank;
+  }
   DQNHIP_CK(dqnhip_create(&c, &h_));
+  if (dp_) {
+    // one communicator per agent thread's learner: agents are independent DQNs (src/dqn_main.cpp:264), each its own group
+    const std::string rv = FLAGS_dp_rendezvous + "_agent" + std::to_string(tid);
+    LOG(INFO) << "[Agent" << tid << "] data-parallel rank " << FLAGS_dp_rank << " of " << FLAGS_dp_world << " (rendezvous " << rv << ")";
+    DQNHIP_CK(dqnhip_dp_init_file(h_, rv.c_str(), FLAGS_dp_half_grads ? DQNHIP_DP_HALF_GRADS : 0, 300));
+  }
 }
 
 DQN::~DQN() { DQNHIP_CK(dqnhip_destroy(h_)); }
@@ -347,6 +370,10 @@ void DQN::LabelTransitions(std::vector<Transition>& ts) {
 }
 
 void DQN::Update() {
+  // data parallel: every rank's iteration counters advance together, so every rank stops updating at the same update — the
+  // driver's own loops only look at max_iter() between bursts of Update() calls (src/dqn_main.cpp:354-362), and a rank left
+  // alone in a collective would wait for ever
+  if (dp_ && actor_solver_param_.max_iter() > 0 && max_iter() >= actor_solver_param_.max_iter()) return;
   if (memory_size() < FLAGS_memory_threshold) return;
   const std::pair<float, float> res = UpdateActorCritic();
   if (critic_iter() % FLAGS_loss_display_iter == 0) {
@@ -385,7 +412,8 @@ std::vector<InputStates> DQN::SampleStatesFromMemory(int n) {
 std::pair<float, float> DQN::UpdateActorCritic() {
   if (FLAGS_device_sampling) {
     float loss = 0, avgq = 0;
-    DQNHIP_CK(dqnhip_update(h_, nullptr, &loss, &avgq));                      // CHECK(isfinite(target / loss)): the call fails
+    if (dp_) { DQNHIP_CK(dqnhip_dp_update(h_, nullptr)); DQNHIP_CK(dqnhip_read_stats(h_, &loss, &avgq)); }
+    else DQNHIP_CK(dqnhip_update(h_, nullptr, &loss, &avgq));                 // CHECK(isfinite(target / loss)): the call fails
     return std::make_pair(loss, avgq);
   }
   return UpdateActorCritic(SampleTransitionsFromMemory(minibatch_));
@@ -395,7 +423,10 @@ std::pair<float, float> DQN::UpdateActorCritic(const std::vector<int>& transitio
   CHECK_EQ((int)transitions.size(), minibatch_);
   float loss = 0, avgq = 0;
   static_assert(sizeof(int) == sizeof(int32_t), "indices travel as int32");
-  if (FLAGS_pipelined_stats) DQNHIP_CK(dqnhip_update_pipelined(h_, reinterpret_cast<const int32_t*>(transitions.data()), &loss, &avgq));
+  if (dp_) {   // this rank's rows of the global minibatch: phase 0 / all-reduce / phase 1 / all-reduce / phase 2 inside the library
+    DQNHIP_CK(dqnhip_dp_update(h_, reinterpret_cast<const int32_t*>(transitions.data())));
+    DQNHIP_CK(dqnhip_read_stats(h_, &loss, &avgq));
+  } else if (FLAGS_pipelined_stats) DQNHIP_CK(dqnhip_update_pipelined(h_, reinterpret_cast<const int32_t*>(transitions.data()), &loss, &avgq));
   else DQNHIP_CK(dqnhip_update(h_, reinterpret_cast<const int32_t*>(transitions.data()), &loss, &avgq));
   return std::make_pair(loss, avgq);
 }

@@ -143,6 +143,7 @@ class DQN {
   int tid_;
   int unum_;
   int minibatch_;
+  bool dp_ = false;                                    // -dp_rendezvous given: UpdateActorCritic() is one rank's share of a data-parallel update
   dqnhip_handle h_;
 };
 

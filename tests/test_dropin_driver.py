@@ -147,3 +147,68 @@ def test_unchanged_driver_trains_on_the_gpu(pkg, gpu, tmp_path):
     for extra in (["-pipelined_stats"], ["-device_sampling"]):
         r6 = subprocess.run(cmd + ["-benchmark", "-minibatch", "256"] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
         assert r6.returncode == 0 and "Average Update: " in r6.stderr + "".join(open(f).read() for f in glob.glob(save + "_INFO_*")), r6.stderr[-2000:]
+
+
+def _driver_cmd(save, extra):
+    return [db.EXE, "-save", save, "-server_cmd", "true", "-seed", "3", "-memory", "20000", "-memory_threshold", "200",
+            "-max_iter", "120", "-update_ratio", "0.5", "-evaluate_freq", "60", "-repeat_games", "3", "-loss_display_iter", "50",
+            "-snapshot_freq", "1000", "-explore", "100"] + extra
+
+
+@pytest.mark.gpu
+def test_unchanged_driver_data_parallel_one_rank(pkg, gpu, tmp_path):
+    """The drop-in's -dp_* flags: the unchanged driver as ONE rank of a data-parallel group (RCCL inside libdqnhip.so, file
+    rendezvous): online training to max_iter, then -benchmark, through dqnhip_dp_update."""
+    if not os.path.exists(db.EXE):
+        if not db.reference_present():
+            pytest.skip("the driver binary is built in the build container (needs /root/reference)")
+        db.build(pkg.build())
+    save = str(tmp_path / "state")
+    env = dict(os.environ, HFO_SHIM_P_END="0.05", HFO_SHIM_FRAMES="60", HFO_SHIM_FEATURES="59", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = _driver_cmd(save, ["-dp_world", "1", "-dp_rank", "0", "-dp_rendezvous", str(tmp_path / "rv")])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    log = r.stderr + "".join(open(f).read() for f in glob.glob(save + "_INFO_*"))
+    assert r.returncode == 0, (r.returncode, log[-3000:])
+    assert "data-parallel rank 0 of 1" in log and "Critic Iteration 100, loss =" in log and "Snapshotting Finished!" in log
+    files = os.listdir(str(tmp_path))
+    assert any("_actor_iter_120.solverstate" in f for f in files), files       # stopped exactly at max_iter: later Update() calls were no-ops
+    r = subprocess.run(cmd + ["-benchmark", "-minibatch", "256"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0 and "Average Update: " in r.stderr + "".join(open(f).read() for f in glob.glob(save + "_INFO_*")), r.stderr[-2000:]
+    with pytest.raises(AssertionError):                                        # -dp_world 2 without a rendezvous path is refused
+        r = subprocess.run(_driver_cmd(save + "x", ["-dp_world", "2"]), capture_output=True, text=True, timeout=120, env=env, cwd=str(tmp_path))
+        assert r.returncode == 0
+
+
+@pytest.mark.gpu
+def test_unchanged_driver_data_parallel_two_processes(pkg, gpu, tmp_path):
+    """Two processes of the UNCHANGED driver, one per GPU, each with its own (synthetic) HFO workers and replay shard, training
+    one data-parallel group online: episodes differ in length between the ranks, so their update bursts interleave — nobody
+    may hang, both stop at the same update, and the replicas' weights are identical.  Needs 2 GPUs."""
+    from test_gpu_dp_native import device_count
+    if device_count() < 2:
+        pytest.skip("needs 2 GPUs, hipGetDeviceCount() = %d: runs the day a multi-GPU lease appears" % device_count())
+    if not os.path.exists(db.EXE):
+        pytest.skip("the driver binary is built in the build container (needs /root/reference)")
+    env = dict(os.environ, HFO_SHIM_P_END="0.05", HFO_SHIM_FRAMES="60", HFO_SHIM_FEATURES="59", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(2):
+        d = tmp_path / ("rank%d" % r); d.mkdir()
+        cmd = _driver_cmd(str(d / "state"), ["-dp_world", "2", "-dp_rank", str(r), "-hip_device", str(r), "-dp_rendezvous", str(tmp_path / "rv"),
+                                            "-seed", str(3 + r)])
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=str(d)))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill(); out, _ = p.communicate()
+            raise AssertionError("a rank of the driver group hung:\n" + out[-3000:])
+        outs.append(out)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, outs[r][-3000:]
+    models = []
+    for r in range(2):
+        f = glob.glob(str(tmp_path / ("rank%d" % r) / "state_agent0_actor_iter_120.caffemodel"))
+        assert f, os.listdir(str(tmp_path / ("rank%d" % r)))
+        models.append(open(f[0], "rb").read())
+    assert models[0] == models[1]                      # identical replicas
