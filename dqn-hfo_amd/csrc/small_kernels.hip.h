@@ -202,21 +202,34 @@ __global__ void k_gather(Ring ring, const DevState* rs, const DevState* st, cons
   const float* np = ring.next + slot * ring.SP;
   const float* ap = ring.act + slot * kAP;
   const int S = ring.S;
+  if (o.Xa_s != nullptr)                       // (fp16 learner: nothing reads the fp32 panels — not written)
   for (int c = lane; c < o.KcP; c += 64) {
     const float sv = c < S ? sp[c] : 0.0f;
     const float nv = c < S ? np[c] : 0.0f;
     const float av = (c >= S && c < S + kNO) ? ap[c - S] : 0.0f;
-    if (o.Xa_s != nullptr) {                   // (fp16 learner: nothing reads the fp32 panels — not written)
+    {
       if (c < o.KaP) { o.Xa_s[(size_t)row * o.KaP + c] = sv; o.Xa_n[(size_t)row * o.KaP + c] = nv; }
       o.Xc_tr[(size_t)row * o.KcP + c] = c < S ? sv : av;
       o.Xc_pl[(size_t)row * o.KcP + c] = sv;
       o.Xc_nx[(size_t)row * o.KcP + c] = nv;
     }
-    if (o.Ha_s != nullptr) {
-      if (c < o.KaP) { o.Ha_s[(size_t)row * o.KaP + c] = (_Float16)sv; o.Ha_n[(size_t)row * o.KaP + c] = (_Float16)nv; }
-      o.Hc_tr[(size_t)row * o.KcP + c] = (_Float16)(c < S ? sv : av);
-      o.Hc_pl[(size_t)row * o.KcP + c] = (_Float16)sv;
-      o.Hc_nx[(size_t)row * o.KcP + c] = (_Float16)nv;
+  }
+  if (o.Ha_s != nullptr) {
+    // fp16 learner: the five panels as fp16, two columns per lane (4-byte stores; 2-byte stores cost ~2x per byte and this
+    // kernel writes 5 panels x 256 B per row).  Ring rows are whole 256-B lines (SP = roundup(S, 64) floats), so the pair
+    // (c, c + 1) is one 8-byte load wherever c < S.  KaP, KcP are multiples of 128 in fp16 mode.
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    for (int c = lane * 2; c < o.KcP; c += 128) {
+      f2 sv = f2{0.f, 0.f}, nv = f2{0.f, 0.f};
+      if (c < S) { sv = *reinterpret_cast<const f2*>(sp + c); nv = *reinterpret_cast<const f2*>(np + c); }      // (c even, rows padded to SP >= S + 1: in bounds)
+      if (c + 1 >= S) { sv.y = 0.0f; nv.y = 0.0f; }      // whatever the ring holds beyond S never reaches a panel
+      const float a0 = (c >= S && c < S + kNO) ? ap[c - S] : 0.0f, a1 = (c + 1 >= S && c + 1 < S + kNO) ? ap[c + 1 - S] : 0.0f;
+      const h2 hs = h2{(_Float16)sv.x, (_Float16)sv.y}, hn = h2{(_Float16)nv.x, (_Float16)nv.y};
+      if (c < o.KaP) { *reinterpret_cast<h2*>(o.Ha_s + (size_t)row * o.KaP + c) = hs; *reinterpret_cast<h2*>(o.Ha_n + (size_t)row * o.KaP + c) = hn; }
+      *reinterpret_cast<h2*>(o.Hc_tr + (size_t)row * o.KcP + c) = h2{(_Float16)(c < S ? sv.x : a0), (_Float16)(c + 1 < S ? sv.y : a1)};
+      *reinterpret_cast<h2*>(o.Hc_pl + (size_t)row * o.KcP + c) = hs;
+      *reinterpret_cast<h2*>(o.Hc_nx + (size_t)row * o.KcP + c) = hn;
     }
   }
   if (lane == 0) {
@@ -336,6 +349,9 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
   }
 }
 
+// (Round 4: a form with the head weights staged once per block in LDS, 16 rows per block, all of a wave's rows in flight
+// at once was built and measured — 13.4 us against 12.5 for two 4096-row fp16 passes, no change at 2048 fp32 rows: the
+// per-wave weight reload is not what this kernel waits for; it streams its panel at ~2.7 TB/s either way.  Not kept.)
 // Large minibatches (rows >= 1024): one WAVE per row, no block-level synchronisation; the head weights
 // stay in registers across the rows of a wave (H <= 1024: NH x 4 float4 per lane).
 template <int NH, int MODE>
@@ -761,6 +777,21 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
   }
   const int m0 = blockIdx.x * 64, kb = blockIdx.y * 256, k0 = kb + lane * 4;
   const bool want_w = a.dW != nullptr;
+  // the head weights and all 16 rows of this wave's strip of the tower top go out BEFORE the head diffs are staged: neither
+  // depends on them, and the staging (two dependent loads, the inverting-gradients arithmetic, a barrier) is a memory round
+  // trip of its own that used to sit in front of these loads (round 4: one exposed latency less per launch)
+  f32x4 wv[NH], acc[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) { wv[j] = *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k0); acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  f32x4 xr[16];
+  head_h4 hr[16];
+  if (a.X416 != nullptr) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hr[r] = *reinterpret_cast<const head_h4*>(a.X416 + (size_t)(m0 + w * 16 + r) * a.H + k0);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xr[r] = *reinterpret_cast<const f32x4*>(a.X4 + (size_t)(m0 + w * 16 + r) * a.H + k0);
+  }
   for (int i = tid; i < 64 * NH; i += 256) {
     const int m = m0 + i / NH, j = i % NH;
     float d;
@@ -779,21 +810,9 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
     s_dy[i] = d;
   }
   __syncthreads();
-  f32x4 wv[NH], acc[NH];
-#pragma unroll
-  for (int j = 0; j < NH; ++j) { wv[j] = *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + k0); acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  // all 16 rows of the wave's strip in flight before the first use (the stores below may alias as far as the
-  // compiler knows, so it would not hoist the loads itself: 4 in flight per thread made the kernel latency-bound)
-  f32x4 xr[16];
   if (a.X416 != nullptr) {
-    head_h4 hr[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) hr[r] = *reinterpret_cast<const head_h4*>(a.X416 + (size_t)(m0 + w * 16 + r) * a.H + k0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) xr[r] = f32x4{(float)hr[r].x, (float)hr[r].y, (float)hr[r].z, (float)hr[r].w};
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xr[r] = *reinterpret_cast<const f32x4*>(a.X4 + (size_t)(m0 + w * 16 + r) * a.H + k0);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
