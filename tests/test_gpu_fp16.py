@@ -134,6 +134,8 @@ def test_hgemm_layer_backward_without_transposed_panels(pkg, gpu):
     dict(B=1024, S=58, hidden=(256, 256), wscale=4.0),      # large minibatch: head kernels emit the fp16 panels
     dict(B=128, S=58, hidden=(2048, 1536), wscale=2.0),     # wider than 1024
     dict(B=4096, S=58, hidden=(1024, 1024, 1024, 1024), wscale=2.0),   # BASELINE.json configs[4]: its own shape
+    dict(B=512, S=58, hidden=(1024, 1024, 1024, 1024), wscale=2.0),    # ... and its rank shapes on 8 / 2 GPUs, which bench.py times
+    dict(B=2048, S=58, hidden=(1024, 1024, 1024, 1024), wscale=2.0),   #     (64x64 split-K tiles + grouped wgrads; 128x128 tiles)
 ])
 def test_fp16_pipeline_matches_emulation(pkg, gpu, shape):
     shape = dict(shape)

@@ -51,8 +51,8 @@ def test_select_actions_greedily_at_env_worker_counts(pkg, gpu, n):
     dqn.close(); orc.close()
 
 
-@pytest.mark.parametrize("frozen_critic", [False, True])
-def test_fp32_update_b4096_4x1024_vs_float64(pkg, gpu, frozen_critic):
+@pytest.mark.parametrize("B,frozen_critic", [(4096, False), (4096, True), (2048, False), (1024, False), (512, False)])
+def test_fp32_update_large_rows_4x1024_vs_float64(pkg, gpu, B, frozen_critic):
     """BASELINE.json configs[4]'s minibatch on the fp32 learner with the 4x1024 tower: gemm_fwd_lds<4,2,true,2> single
     launches at M = 4096, gemm_bwd_seq at 4096 rows, the bandwidth-tiled head kernels (k_head_bwd_big + k_head_wred,
     k_head_fwd_rows), the optimiser pass evicted from the Infinity Cache — one update against float64 autograd.
@@ -62,8 +62,12 @@ def test_fp32_update_b4096_4x1024_vs_float64(pkg, gpu, frozen_critic):
     enabled those two per-row quantities inherit a weight difference of O(lr) per such element from ANY fp32
     evaluation (measured: 43 % of the rows then differ from float64 by more than 1e-4 of the scale, for this library
     and for PyTorch-fp32 alike).  With the critic frozen they depend on the forward / backward arithmetic alone and
-    are held to 1e-4 of their scale row by row."""
-    B, S = 4096, 58
+    are held to 1e-4 of their scale row by row.
+
+    2048 / 1024 / 512 rows: the rank shapes of a 4096-row minibatch on 2 / 4 / 8 GPUs, which bench.py times
+    (`configs4_rank_shape_b512.*.plain_graph_ms*`) — other tile choices again (64x32 forward tiles from 512 rows, the
+    bandwidth-tiled head kernels from 1024)."""
+    S = 58
     lrs = dict(critic_lr=0.0) if frozen_critic else {}
     dqn, orc, data, rng = make_pair(pkg, B=B, S=S, hidden=H4, n_replay=8192, wscale=2.0, **lrs)
     tkw = dict(lr_critic=0.0) if frozen_critic else {}
