@@ -144,6 +144,7 @@ struct dqnhip_learner {
   // the updated online and target weights (m, v of the other slices go stale until dqnhip_dp_gather_state)
   bool dp_shard = false;
   float* shard_total = nullptr;         // dqnhip_apply_update_sharded: the group's sum of squares, accumulated rank by rank
+  bool shard_stale = false;             // a sharded update ran since the last dqnhip_dp_gather_state: m, v of foreign slices are stale
   uint16_t* g16[2] = {nullptr, nullptr};   // bf16 transfer image of each gradient arena (dp_half)
   float* dp_tails = nullptr;            // dp_half: {critic tail[4], actor tail[4]}, one fp32 all-reduce with the actor's gradients
   hipStream_t comm_stream = nullptr;
@@ -1015,6 +1016,9 @@ size_t dqnhip_grad_arena_bytes(const dqnhip_config* cfg) {
 }
 
 static int create_impl(H* h, const dqnhip_config* cfg);
+}  // extern "C"
+namespace { int dp_destroy_impl(H* h, bool keep_learner); }
+extern "C" {
 // every captured launch sequence of this learner: the update graphs AND the data-parallel one (it bakes in the Ring
 // struct k_gather takes by value and the weight / shared-prefix pointers, exactly as the others do)
 static void drop_graphs_fwd(H* h) {
@@ -1176,7 +1180,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   if (h->ring_owner) h->ring_owner->sharers -= 1;
   if (h->ring_ev) hipEventDestroy(h->ring_ev);
   hipSetDevice(h->cfg.device);
-  dqnhip_dp_destroy(h);
+  dp_destroy_impl(h, false);
   hipStreamSynchronize(h->stream);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (auto& g : h->graph_exec) if (g) hipGraphExecDestroy(g);
@@ -1797,6 +1801,7 @@ int dqnhip_dp_update(dqnhip_handle h, const int32_t* idx_host) {
   if (h->next_phase != 0) return fail("dqnhip_dp_update: a phased update is in progress (next phase %d)", h->next_phase);
   RingUse ring_use(h);
   RC(sync_dirty16(h));
+  if (h->dp_shard) h->shard_stale = true;
   // cfg.use_graph: the whole update — 30-40 launches and both collectives — replays as ONE hipGraph (every rank
   // captures the same sequence).  Explicit indices, kernel timing, or a capture that RCCL refuses: eager.
   if (h->cfg.use_graph && !idx_host && !h->timing && !h->dp_graph_failed) {
@@ -1834,13 +1839,20 @@ int dqnhip_dp_gather_state(dqnhip_handle h) {
     NCCLCHK(ncclAllGather(h->v[net] + lo, h->v[net], hi - lo, ncclFloat, h->comm, h->stream));
   }
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->shard_stale = false;
   return 0;
 }
 
-int dqnhip_dp_destroy(dqnhip_handle h) {
+}  // extern "C"
+namespace {
+// keep_learner: the learner lives on as a plain one -> its Adam history must be whole.  The gather that makes it whole is a
+// COLLECTIVE, and a teardown must never block on peers that may be gone: it is asked for, not done implicitly.
+int dp_destroy_impl(H* h, bool keep_learner) {
   if (!h || !h->comm) return 0;
+  if (keep_learner && h->dp_shard && h->shard_stale)
+    return fail("dqnhip_dp_destroy: the optimiser is sharded and updates ran since the last dqnhip_dp_gather_state — call it on every rank first "
+                "(this rank holds the Adam history of its own slice only)");
   hipSetDevice(h->cfg.device);
-  if (h->dp_shard) dqnhip_dp_gather_state(h);          // (collective, like the communicator's own teardown: the whole Adam history back on every rank)
   hipStreamSynchronize(h->stream);
   hipStreamSynchronize(h->comm_stream);
   if (h->dp_graph) { hipGraphExecDestroy(h->dp_graph); h->dp_graph = nullptr; }
@@ -1850,9 +1862,12 @@ int dqnhip_dp_destroy(dqnhip_handle h) {
   for (auto& e : h->comm_ev) { if (e) hipEventDestroy(e); e = nullptr; }
   for (int net = 0; net < 2; ++net) if (h->g16[net]) { hipFree(h->g16[net]); h->g16[net] = nullptr; }
   if (h->dp_tails) { hipFree(h->dp_tails); h->dp_tails = nullptr; }
-  h->dp_half = false; h->dp_per_layer = false; h->dp_shard = false;
+  h->dp_half = false; h->dp_per_layer = false; h->dp_shard = false; h->shard_stale = false;
   return 0;
 }
+}  // namespace
+extern "C" {
+int dqnhip_dp_destroy(dqnhip_handle h) { return dp_destroy_impl(h, true); }
 
 // ---- acting ------------------------------------------------------------------------
 

@@ -228,7 +228,8 @@ int dqnhip_grad_buffer(dqnhip_handle h, int32_t net, void** dptr, size_t* nfloat
  * the updated online AND target weights (the targets move every update, src/dqn.cpp:967-970; fp16 learner: the fp16 mirrors
  * too) are all-gathered.  What SURVEY 8(e) calls "identical Adam on every rank" is relaxed to "every parameter's Adam on
  * exactly one rank, identical weights everywhere afterwards".  m and v of foreign slices go stale: dqnhip_dp_gather_state
- * (collective) brings them back before a snapshot / dqnhip_get_params(KIND_M, KIND_V); dqnhip_dp_destroy does it too.
+ * (collective) brings them back before a snapshot / dqnhip_get_params(KIND_M, KIND_V); dqnhip_dp_destroy refuses until it has
+ * been called since the last update (a teardown never blocks on peers: dqnhip_destroy itself just frees).
  * Combines with DQNHIP_DP_HALF_GRADS, not with DQNHIP_DP_PER_LAYER.  Priced in DESIGN.md 6: it does not pay at 4 x 1024
  * (the target nets double the all-gather, the clip norm needs its own latency-bound collective); off by default.
  * The arena must be divisible by 4 x dp_world. */

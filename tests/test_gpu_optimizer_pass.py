@@ -225,6 +225,10 @@ def test_native_rccl_sharded_optimiser_one_rank(pkg, gpu, precision, half, use_g
     for call in (lambda: ds[0].update_async(None), lambda: ds[0].update_phase(0, None)):
         with pytest.raises(pkg.DQNFatal, match="dqnhip_dp_update"):
             call()
+    ds[0].dp_update(None)
+    with pytest.raises(pkg.DQNFatal, match="dqnhip_dp_gather_state"):
+        ds[0].dp_destroy()                                       # never an implicit collective at teardown: it is asked for
+    ds[0].dp_gather_state()
     ds[0].dp_destroy()
     ds[0].UpdateActorCritic(rng.integers(0, 1024, B))           # a plain learner again
     for d in ds:
