@@ -52,6 +52,8 @@ DEFINE_int32(dp_world, 1, "Data-parallel group size (processes of this binary, o
 DEFINE_int32(dp_rank, 0, "This process's rank in the data-parallel group.");
 DEFINE_string(dp_rendezvous, "", "File path shared by the ranks of the group (dqnhip_dp_init_file; needs no launcher). Empty: no data parallelism.");
 DEFINE_bool(dp_half_grads, false, "Exchange gradients as bf16 (half the bytes on the links; meant for -precision fp16).");
+DEFINE_int32(hip_agent_device_stride, 0, "Agent thread t of this process uses HIP device -hip_device + t * stride (0: all agents on -hip_device). "
+                                         "BASELINE configs[3] on 4 GPUs = 2 processes x 2 agents, -dp_world 2, stride 2: agent a's rank r on GPU 2a + r.");
 
 
 #define DQNHIP_CK(call) CHECK((call) == 0) << dqnhip_last_error()
@@ -229,7 +231,7 @@ DQN::DQN(caffe::SolverParameter& actor_solver_param, caffe::SolverParameter& cri
   c.momentum = critic_solver_param_.momentum(); c.momentum2 = critic_solver_param_.momentum2();
   c.delta = critic_solver_param_.delta(); c.clip_gradients = critic_solver_param_.clip_gradients();
   CHECK(actor_solver_param_.type() == "Adam" && critic_solver_param_.type() == "Adam") << "only the Adam solver is implemented (-solver Adam, the reference's default)";
-  c.device = FLAGS_hip_device;
+  c.device = FLAGS_hip_device + tid * FLAGS_hip_agent_device_stride;
   c.use_graph = FLAGS_hip_graph ? 1 : 0;
   c.seed = seed;
   CHECK(FLAGS_precision == "fp32" || FLAGS_precision == "fp16") << "-precision must be fp32 or fp16";
