@@ -567,6 +567,7 @@ def main():
                          "of sub_records.configs4_rank_shape_b512 prices both: with ~20 us per collective five buckets cost more than they hide)")
     ap.add_argument("--dp-shard-opt", action="store_true", help="native DP: sharded optimiser (DQNHIP_DP_SHARD_OPT) instead of the replicated one")
     ap.add_argument("--test-dp-probe", action="store_true", help="testing: run the captured-update probe with the ranks there are (N = 1 under --force-dp)")
+    ap.add_argument("--test-dp-probe-fail", action="store_true", help="testing: pretend the probe failed (exercises the agreed fall-back to the eager update)")
     ap.add_argument("--no-dp-probe", action="store_true",
                     help="N > 1: skip the sacrificial child group that tries the captured data-parallel update first (tests/dp_native_worker.py)")
     ap.add_argument("--dp-fp32-grads", action="store_true", help="native DP, fp16 learner: all-reduce fp32 gradients instead of bf16 (DQNHIP_DP_HALF_GRADS)")
@@ -623,7 +624,8 @@ def main():
             # (one child per rank, own communicator, file rendezvous, no torch) tries it first at this shape; if any child
             # fails or has to be killed, every rank agrees to run the headline eagerly (same kernels, same collectives,
             # stream-ordered instead of replayed).  ~20 s, outside every timed region.
-            dp_probe = probe_captured_dp(rank, world, local_rank, args.precision, half, args.dp_per_layer and not half)
+            dp_probe = (probe_captured_dp(rank, world, local_rank, args.precision, half, args.dp_per_layer and not half) if not args.test_dp_probe_fail
+                        else {"ok": False, "why": "forced by --test-dp-probe-fail"})
             ok = torch.tensor([1 if dp_probe.get("ok") else 0], dtype=torch.int32, device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:

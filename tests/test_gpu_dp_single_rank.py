@@ -103,6 +103,21 @@ def test_bench_runs_under_torchrun_one_rank(pkg, gpu):
     assert probe["ok"] and probe["graph_ms_per_update"] > 0, probe
 
 
+def test_bench_falls_back_to_eager_when_the_probe_fails(pkg, gpu):
+    """If the sacrificial child group does not get through the captured data-parallel update, every rank agrees to run the
+    headline eagerly: same kernels, same collectives, a line with hip_graph false and the reason on record."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29649", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "20", "--warmup", "5", "--replay", "20000", "--no-cpu-baseline", "--no-env", "--no-subrecords", "--no-live-pmc",
+           "--force-dp", "--test-dp-probe", "--test-dp-probe-fail"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    import json
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["value"] > 100 and d["config"]["hip_graph"] is False
+    assert d["config"]["captured_dp_probe"]["ok"] is False and "running eagerly" in r.stderr
+
+
 def test_bench_strong_scaling_record_with_the_ranks_there_are(pkg, gpu):
     """The N > 1 side record (a global minibatch of 4096 split over the ranks: captured native RCCL update, fp32 and fp16 with the bf16 exchange, the no-collective twin, the single-GPU reference, the projection) has only ever
     been reachable on a multi-GPU node; --test-strong-record runs the same code with one rank."""
