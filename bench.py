@@ -461,6 +461,16 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
                                                               bl.get("gemm_wgrad", bl.get("hgemm_wgrad", 0.0)), slices) for n in (2, 4, 8)}
             r["projection"]["ms_per_update_1gpu_b4096"] = one
             r["projection"]["speedup_without_collectives_8gpu"] = round(one / r["dp_graph_ms"], 2)
+            if not half:
+                # where north_star's ">= 6x strong scaling 1 -> 8" becomes reachable: the same model at a global minibatch of 16384
+                # (2048 rows per rank: the collectives are the same bytes, the rank's compute 3x longer)
+                d = pkg.DQN(S, minibatch=16384, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, precision=prec, use_graph=True)
+                prefill(d, 150000, seed=7)
+                one16 = timed(lambda d=d: d.update_async(None), torch.cuda.synchronize, 20, 3) * 1e3
+                d.read_stats(); d.close()
+                t8 = {k: r["plain_graph_ms_rows_2048"] + r["dp_graph_ms"] - r["plain_graph_ms"] for k in ("single", "per_layer", "sharded")}
+                p16 = dp_projection(8, half, gb, t8, one16, bl.get("gemm_bwd_pair", 0.0), bl.get("gemm_wgrad", 0.0), slices)["single"]
+                r["projection"]["global_minibatch_16384_n_gpus_8"] = {"ms_per_update_1gpu": round(one16, 3), "rank_rows": 2048, **p16}
             r["projection"]["model"] = ("PROJECTION for a global minibatch of 4096 = N x (4096 / N) rows; rank time = the plain captured update measured at 4096 / N rows "
                                         "+ what the data-parallel launches add at 512 rows; the backward launch durations that set the bucket-ready times are "
                                         "the 512-row ones; xGMI %.1f GB/s one way per link, %.0f us per collective; single = one all-reduce per net, "
