@@ -657,11 +657,14 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    // ACQ_REL at agent scope: the slab words themselves travel write-through (sc1 stores / loads, drained above), which
-    // is what makes them visible on gfx950; the ordered ticket makes the hand-off a happens-before edge in the HIP memory
-    // model as well instead of resting on vmcnt + sc1 semantics alone.  This path only runs for shapes whose
-    // head gradients have no carrier launch (the headline's ride in the first layer's wgrad): measured cost there: none.
-    const int t = __hip_atomic_fetch_add(a.ticket + blockIdx.x, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    // The hand-off is MI355X_MICROARCH.md's "handoff-flag" form for gfx950: write-through (sc1) payload stores, the storing
+    // waves' `s_waitcnt vmcnt(0)` above, a barrier, then a relaxed agent-scope counter; the last arriver reads the slabs with
+    // sc1 (L1-bypassing) loads.  No release / acquire fence: an agent-scope release writes the whole L2 back — this launch's
+    // dZ rows included — once per block (measured round 4 with ACQ_REL here: k_head_bwd<10> 9.6 -> 10.7 us, <1> 6.2 -> 6.8
+    // at 512 fp16 rows).  That is an ISA-level guarantee, not one of the HIP memory model, so it is pinned by
+    // a stress test that checks every word of the reduced gradient under uneven load from a second stream
+    // (tests/test_gpu_head_handoff.py); shapes whose head gradients ride in a carrier launch never come here.
+    const int t = __hip_atomic_fetch_add(a.ticket + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == RC - 1);
   }
   __syncthreads();
