@@ -33,6 +33,10 @@ struct GemmProblem {
   float* db;                 // WGRAD: bias gradient [q] (null: skip)
   float* partial;            // WGRAD: one sum-of-squares partial per tile (null: skip)
   int relu;                  // FWD: apply leaky ReLU
+  // FWD, top tower layer of the critic(s, mu(s)) pass: the epilogue also writes the seed of BackwardFrom(q_values_layer)
+  // (src/dqn.cpp:918-923: q diff = -1 per row) taken through the head and this layer's ReLU,
+  // C2[q][p] = (-seed_w[p]) * lrelu'(C[q][p]) — what a head-backward launch of its own used to compute from C (null: none)
+  const float* seed_w; float* C2;
   int mode;                  // mixed-mode launches (gemm_bwd_pair_direct): GEMM_DGRAD / GEMM_WGRAD
   int tiles_p, tiles_q, tile_base;
 };

@@ -81,6 +81,15 @@ __device__ __forceinline__ f32x4 reduce_accumulator(const float* smem, int e, in
 // (collapsing the register ring: measured); pin the COMPUTE/LOAD interleave.
 #define DQN_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// GemmProblem::seed_w: the tower-top gradient of the dq = -1 pass, from the finished activations v of this lane
+// (k_head_bwd<1>'s arithmetic: s0 = fma(-1, w, 0) = -w, then * lrelu'(x))
+__device__ __forceinline__ void store_head_seed(const GemmProblem& pr, int q, int p, const f32x4& v, const f32x4& sw) {
+  f32x4 dz;
+  dz.x = (-sw.x) * lrelu_mask(v.x); dz.y = (-sw.y) * lrelu_mask(v.y);
+  dz.z = (-sw.z) * lrelu_mask(v.z); dz.w = (-sw.w) * lrelu_mask(v.w);
+  *reinterpret_cast<f32x4*>(pr.C2 + (size_t)q * pr.ldc + p) = dz;
+}
+
 // ================================ FWD ================================================
 // Y[m][n] = lrelu(sum_k X[m][k] W[n][k] + b[n]).  P = W (KC, 16-row blocks), Q = X (KC).
 // Tile = (16*TP) x (16*TQ).  Kred % 64 == 0.
@@ -145,14 +154,21 @@ __device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_
 #undef FWD_LOAD
 #undef FWD_COMPUTE
 
-  // this wave's bias pieces, requested ahead of the cross-wave reduction
+  // this wave's bias (and head-seed) pieces, requested ahead of the cross-wave reduction
   constexpr int NBV = (NACC + 3) / 4;
-  f32x4 bvp[NBV];
+  f32x4 bvp[NBV], swp[NBV];
   if (pr.bias != nullptr) {
 #pragma unroll
     for (int j = 0; j < NBV; ++j) {
       const int e = j * 4 + wave;
       if (e < NACC) bvp[j] = *reinterpret_cast<const f32x4*>(pr.bias + p0 + (e % TP) * 16 + (lg << 2));
+    }
+  }
+  if (pr.seed_w != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) {
+      const int e = j * 4 + wave;
+      if (e < NACC) swp[j] = *reinterpret_cast<const f32x4*>(pr.seed_w + p0 + (e % TP) * 16 + (lg << 2));
     }
   }
   park_accumulators<NACC>(smem, acc, wave, lane);
@@ -169,6 +185,7 @@ __device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_
       }
       if (pr.relu) { v.x = lrelu_fwd(v.x); v.y = lrelu_fwd(v.y); v.z = lrelu_fwd(v.z); v.w = lrelu_fwd(v.w); }
       *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
+      if (pr.seed_w != nullptr) store_head_seed(pr, q, p, v, swp[e >> 2]);
     }
   }
 }
@@ -671,12 +688,19 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
 
   // this wave's bias pieces, requested ahead of the cross-wave reduction
   constexpr int NBV = (NACC + 3) / 4;
-  f32x4 bvp[NBV];
+  f32x4 bvp[NBV], swp[NBV];
   if (pr.bias != nullptr) {
 #pragma unroll
     for (int j = 0; j < NBV; ++j) {
       const int e = j * 4 + wave;
       if (e < NACC) bvp[j] = *reinterpret_cast<const f32x4*>(pr.bias + p0 + (e % TP) * 16 + (lg << 2));
+    }
+  }
+  if (pr.seed_w != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) {
+      const int e = j * 4 + wave;
+      if (e < NACC) swp[j] = *reinterpret_cast<const f32x4*>(pr.seed_w + p0 + (e % TP) * 16 + (lg << 2));
     }
   }
   // park into this wave's own (now idle) staging region, reduce across waves in fixed order
@@ -708,6 +732,7 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
       } else {
         *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
       }
+      if (pr.seed_w != nullptr) store_head_seed(pr, q, p, v, swp[e >> 2]);
     }
   }
 }
@@ -893,6 +918,37 @@ __global__ __launch_bounds__(256) void gemm_wgrad_direct(const GemmBatch batch) 
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void gemm_dgrad_narrow(const GemmBatch batch) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  dgrad_narrow_body(batch.prob[pi], tile_p, tile_q, smem);
+}
+// q(s, mu(s)) = q_values(critic tower top) and its avg-Q partials (src/dqn.cpp:913-916) as RIDER blocks of the narrow dgrad
+// launch: a handful of 16 x 16 tiles (16 workgroups at 256 rows) that leaves most of the chip idle.  Nothing on the
+// backward chain reads q — only the update's statistics do — so it needs no launch of its own (it used to ride in the
+// dq = -1 head-backward launch, which is gone: the seed comes out of the top layer's forward epilogue, GemmProblem::seed_w).
+// One wave per row, k-strips of float4; the riders come LAST in the grid.
+struct QHeadRider {
+  const float* X4; const float* W; const float* bias;   // tower top [rows][H], head weights [H], head bias [1]
+  float* q_out; double* qsum_partial;                   // [rows] each
+  int H, rows, blocks;                                  // blocks = ceil(rows / 4) (0: none)
+};
+__device__ __forceinline__ void q_head_rider(const QHeadRider& r, const int blk) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blk * 4 + wave;
+  if (row >= r.rows) return;
+  const size_t x0 = (size_t)row * r.H;
+  float acc = 0.0f;
+  for (int k = lane * 4; k < r.H; k += 256) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(r.X4 + x0 + k), wv = *reinterpret_cast<const f32x4*>(r.W + k);
+    acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+  }
+  acc = wave_sum64(acc);
+  if (lane == 0) { const float v = acc + r.bias[0]; r.q_out[row] = v; r.qsum_partial[row] = (double)v; }
+}
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void gemm_dgrad_narrow_qrider(const GemmBatch batch, const QHeadRider rider) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x >= batch.total_tiles) { q_head_rider(rider, (int)blockIdx.x - batch.total_tiles); return; }
   int pi, tile_p, tile_q;
   tile_of_block(batch, pi, tile_p, tile_q);
   dgrad_narrow_body(batch.prob[pi], tile_p, tile_q, smem);
@@ -1098,6 +1154,19 @@ inline hipError_t bwd_pair_direct_launch(GemmBatch& batch, hipStream_t stream) {
 }
 inline hipError_t dgrad_narrow_launch(GemmBatch& b, hipStream_t s) {
   return direct_launch(gemm_dgrad_narrow<0>, b, 16, 16, 4 * 64 * 16, s);
+}
+inline hipError_t dgrad_narrow_qrider_launch(GemmBatch& batch, const QHeadRider& rider, hipStream_t stream) {
+  int base = 0;
+  for (int i = 0; i < batch.n; ++i) {
+    GemmProblem& p = batch.prob[i];
+    p.tiles_p = p.Pdim / 16; p.tiles_q = p.Qdim / 16; p.tile_base = base;
+    base += p.tiles_p * p.tiles_q;
+  }
+  batch.total_tiles = base;
+  LaunchTimer& lt = launch_timer();
+  if (lt.start) { hipExtLaunchKernelGGL(gemm_dgrad_narrow_qrider<0>, dim3(base + rider.blocks), dim3(256), 4 * 64 * 16, stream, lt.start, lt.stop, 0, batch, rider); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL(gemm_dgrad_narrow_qrider<0>, dim3(base + rider.blocks), dim3(256), 4 * 64 * 16, stream, batch, rider);
+  return hipGetLastError();
 }
 template <int TPB>
 inline hipError_t wgrad_narrow_launch(GemmBatch& b, hipStream_t s) {

@@ -309,7 +309,8 @@ size_t grad_arena_floats(const NetLayout& la, const NetLayout& lc) { return la.a
 
 // ---- forward / backward building blocks ----------------------------------------
 
-struct FwdPass { int net; const NetLayout* l; float** act; };
+// seed_w / seed_out: the TOP layer's launch also writes the dq = -1 pass's tower-top gradient (GemmProblem::seed_w)
+struct FwdPass { int net; const NetLayout* l; float** act; const float* seed_w = nullptr; float* seed_out = nullptr; };
 
 // One tower layer forward for up to kMaxGroup passes of identical shape.
 int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, int i) {
@@ -322,6 +323,7 @@ int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, 
     p.C = passes[j].act[i + 1]; p.ldc = l.kp[i + 1];
     p.Pdim = l.dims[i + 1]; p.Qdim = rows; p.Kred = l.kp[i];
     p.bias = wat(h, passes[j].net, l.b_off[i]); p.relu = 1;
+    if (i == l.L - 1 && passes[j].seed_w != nullptr) { p.seed_w = passes[j].seed_w; p.C2 = passes[j].seed_out; }
   }
   // K >= 512 and K % 256 == 0: full-line loads + wave-private LDS transpose; else (first
   // layer, narrow towers) the plain direct kernel.  One problem: 32x32 tiles (256 workgroups
@@ -376,7 +378,7 @@ inline bool head_wgrad_can_ride(const NetLayout& l, int rows) {
 }
 int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* garena, float* partial,
                    float** act, float** dZ, int rows, bool want_w, bool input_grad, int in_lo = 0, int in_hi = -1,
-                   const HeadWgradRider* rider = nullptr) {
+                   const HeadWgradRider* rider = nullptr, const QHeadRider* qrider = nullptr) {
   for (int i = l.L - 1; i >= 0; --i) {
     GemmBatch bd{}, bw{};
     const bool need_dx = (i > 0 || input_grad);
@@ -416,7 +418,8 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
       p.P += c0; p.C += c0; p.Pdim = c1 - c0;
       if (p.mask) p.mask += c0;
       ScopedTiming t(h, 1, st);
-      HIPCHK(dgrad_narrow_launch(bd, st));
+      if (qrider) { HIPCHK(dgrad_narrow_qrider_launch(bd, *qrider, st)); qrider = nullptr; }
+      else HIPCHK(dgrad_narrow_launch(bd, st));
     } else if (need_dx) {
       ScopedTiming t(h, 1, st);
       if (lds_ok) HIPCHK((dgrad_lds_launch<1, 1>(bd, st)));
@@ -432,6 +435,7 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
     // all-reduce on the communication stream while the chain continues with layer i-1
     if (want_w && h->comm && h->dp_per_layer) RC(dp_reduce_slice(h, st, net, l.w_off[i], (i + 1 < l.L ? l.w_off[i + 1] : l.hw_off) - l.w_off[i]));
   }
+  if (qrider) return fail("internal: the q-head rider found no carrier launch");
   return 0;
 }
 
@@ -885,17 +889,22 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     h->act[4][0] = h->Xc_pl;
     if (dp) RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr));
     else RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
+    // The seed of BackwardFrom(q_values_layer) [:918-923] — q diff = -1 per row, taken through the head and the top
+    // layer's ReLU, input gradient only (the reference's discarded critic dW, SURVEY a11, is never computed) — does not
+    // depend on q: it comes out of the top tower layer's forward epilogue, and q(s, mu(s)) itself [:913-916], which only
+    // the statistics read, rides in the chain's last launch.  DQNHIP_TUNE_SEPARATE_HEAD_SEED: the head-backward launch
+    // that used to sit between the forward and the backward chain (same arithmetic, one launch more).
+    const bool fused_seed = !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_HEAD_SEED);
+    if (fused_seed) { pC2.seed_w = wat(h, DQNHIP_CRITIC, lc.hw_off); pC2.seed_out = h->dZc[L]; }
     RC(tower_forward(h, st, &pC2, 1, B));                // critic(s, mu(s)), UPDATED weights [:913-916]
-    // q(s, mu(s)) with the updated critic [:913-916] and, in the same launch, the seed of
-    // BackwardFrom(q_values_layer): q diff = -1 per row, input gradient only (the reference's
-    // discarded critic dW, SURVEY a11, is never computed).  The seed does not depend on q.
-    {
+    const QHeadRider qr{h->act[4][L], wat(h, DQNHIP_CRITIC, lc.hw_off), wat(h, DQNHIP_CRITIC, lc.hb_off), h->q2, h->q_partial, Hc, B, (B + 3) / 4};
+    if (!fused_seed) {
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L];
       a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial;
       RC(head_backward<1>(h, st, a));
     }
-    RC(tower_backward(h, st, lc, DQNHIP_CRITIC, nullptr, nullptr, h->act[4], h->dZc, B, false, true, h->S, h->S + kNO));
+    RC(tower_backward(h, st, lc, DQNHIP_CRITIC, nullptr, nullptr, h->act[4], h->dZc, B, false, true, h->S, h->S + kNO, nullptr, fused_seed ? &qr : nullptr));
     // inverting gradients (src/dqn.cpp:924-957) + actor heads backward (src/dqn.cpp:960-963)
     {
       HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;

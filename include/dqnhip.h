@@ -113,6 +113,9 @@ typedef struct dqnhip_config {
 /* fp16 learner: one wgrad launch per layer (a layer's dgrad + wgrad sharing a launch at small
  * minibatches) instead of ALL wgrads of a net + the bias-gradient sums in one launch. */
 #define DQNHIP_TUNE_FP16_WGRAD_PER_LAYER 1
+/* fp32 learner: the seed of the critic's dq = -1 backward pass (src/dqn.cpp:918-923) and q(s, mu(s)) from a head-backward
+ * launch of their own instead of the top layer's forward epilogue / rider blocks of the chain's last launch. */
+#define DQNHIP_TUNE_SEPARATE_HEAD_SEED 2
 
 typedef struct dqnhip_learner* dqnhip_handle;
 

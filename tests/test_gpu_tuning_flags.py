@@ -63,3 +63,46 @@ def test_fp16_grouped_wgrad_under_graph_replay(pkg, gpu):
     for n in range(4):
         np.testing.assert_array_equal(d.get_params(n).astype(np.float64), a[2][n])     # replayed = eager, bit for bit
     d.close()
+
+
+def _run32(pkg, tuning, B, hidden, S=58, n_up=3, use_graph=False):
+    d = pkg.DQN(S, minibatch=B, hidden=hidden, memory=4096, seed=3, tuning=tuning, use_graph=use_graph)
+    d.add_transitions_arrays(*synth_replay(np.random.default_rng(5), 2000, S))
+    rng = np.random.default_rng(7)
+    stats, dbg = [], []
+    for _ in range(n_up):
+        idx = rng.integers(0, 2000, B).astype(np.int32)
+        stats.append(d.UpdateActorCritic(idx))
+        dbg.append((d.debug_read("q_policy"), d.debug_read("dq_da")))
+    w = [d.get_params(n) for n in range(4)] + [d.get_params(n, k) for n in (0, 1) for k in (pkg.KIND_M, pkg.KIND_V, pkg.KIND_G)]
+    d.close()
+    return stats, dbg, w
+
+
+@pytest.mark.parametrize("B,hidden,S", [
+    (256, (1024, 1024, 1024, 1024), 58),       # BASELINE configs[1]: seed from gemm_fwd_lds<2,2,true,2>'s epilogue
+    (32, (1024, 512, 256, 128), 59),           # the reference's defaults: top layer K = 256 -> the direct forward kernel
+    (64, (256, 128, 64, 64), 59),              # narrow top layer (gemm_fwd_direct)
+    (512, (1024, 1024), 68),                   # 64x32 forward tiles
+    (1024, (256, 256), 58),                    # rows >= 1024: the separate form takes k_head_bwd_big
+    (128, (512,), 58),                         # one tower layer: it carries the seed AND its dgrad carries the q rider
+])
+def test_fused_head_seed_equals_separate_launch(pkg, gpu, B, hidden, S):
+    """fp32 learner, critic(s, mu(s)) pass: the dq = -1 seed from the top layer's forward epilogue + q(s, mu(s)) as rider
+    blocks of the narrow dgrad launch (default) against the head-backward launch of their own
+    (DQNHIP_TUNE_SEPARATE_HEAD_SEED).  Same arithmetic on the same values: every result bit-identical."""
+    a = _run32(pkg, 0, B, hidden, S)
+    b = _run32(pkg, pkg.capi.TUNE_SEPARATE_HEAD_SEED, B, hidden, S)
+    assert a[0] == b[0], (a[0], b[0])
+    for (qa, da), (qb, db) in zip(a[1], b[1]):
+        np.testing.assert_array_equal(qa, qb); np.testing.assert_array_equal(da, db)
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_fused_head_seed_under_graph_replay(pkg, gpu):
+    a = _run32(pkg, 0, 256, (1024, 1024, 1024, 1024), n_up=4)
+    g = _run32(pkg, 0, 256, (1024, 1024, 1024, 1024), n_up=4, use_graph=True)
+    assert a[0] == g[0]
+    for x, y in zip(a[2], g[2]):
+        np.testing.assert_array_equal(x, y)
