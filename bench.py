@@ -346,6 +346,16 @@ def timed(step, sync, n, warm):
     return (time.perf_counter() - t0) / n
 
 
+def timed_n(d, sync, n, warm):
+    """n device-sampled updates of one learner, enqueued the way the headline is (dqnhip_update_async_n)"""
+    d.update_async_n(warm)
+    sync()
+    t0 = time.perf_counter()
+    d.update_async_n(n)
+    sync()
+    return (time.perf_counter() - t0) / n
+
+
 def env_roofline(S_, workers, us_per_step):
     """a batched env step is one actor forward per worker = 2 * Wa FLOP (tower + heads), fp32 MFMA"""
     wa = sum(tower_weights(S_, HIDDEN)) + 10 * HIDDEN[-1]
@@ -365,7 +375,7 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
         for prec in ("fp16", "fp32"):
             d = pkg.DQN(S, minibatch=GB, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, use_graph=True, precision=prec)
             prefill(d, 150000, seed=7)
-            dt = timed(lambda: d.update_async(None), torch.cuda.synchronize, n_it, 20)
+            dt = timed_n(d, torch.cuda.synchronize, n_it + 4, 24)
             fl = sum((family_flops16 if prec == "fp16" else family_flops)(GB, S, HIDDEN).values())
             peak = MFMA_F16_PEAK_TF if prec == "fp16" else MFMA_F32_PEAK_TF
             out["configs4_1gpu_b4096_%s" % prec] = {"ms_per_update": round(dt * 1e3, 4), "updates_per_s": round(1 / dt, 1),
@@ -390,11 +400,11 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
         d = pkg.DQN(59, minibatch=32, hidden=(1024, 512, 256, 128), memory=100000, seed=1, device=local_rank, use_graph=True)
         from synth import synth_replay
         d.add_transitions_arrays(*synth_replay(np.random.default_rng(3), 50000, 59))
-        dt = timed(lambda: d.update_async(None), torch.cuda.synchronize, 1000, 100)
+        dt = timed_n(d, torch.cuda.synchronize, 1000, 104)
         ms_b = d.BenchmarkBlocking(1000, 100, seed=1, pipelined=False)
         out["configs0_ref_defaults_b32"] = {"ms_per_update": round(dt * 1e3, 4), "updates_per_s": round(1 / dt, 1),
                                             "blocking_ms_per_update": round(ms_b, 4), "blocking_updates_per_s": round(1e3 / ms_b, 1),
-                                            "note": "launch-bound: 31 launches per update"}
+                                            "note": "launch-bound: 30 launches per update"}
         d.read_stats(); d.close()
         # configs[2]: 1v1 (S = 68), 64 parallel workers feeding one replay buffer
         d = pkg.DQN(68, minibatch=B, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, use_graph=True)
@@ -559,6 +569,8 @@ def main():
     ap.add_argument("--replay", type=int, default=REPLAY)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--one-update-per-launch", action="store_true",
+                    help="N = 1: enqueue the K steps as K calls of dqnhip_update_async (one hipGraph launch each) instead of one dqnhip_update_async_n(K)")
     ap.add_argument("--prewarm-ms", type=float, default=100.0, help="untimed load before the W warm-up steps (clock ramp, graph capture); 0: one update")
     ap.add_argument("--minibatch", type=int, default=B, help="rows per GPU (BASELINE metric: 256)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
@@ -679,6 +691,17 @@ def main():
         dqn = pkg.DQN(S, minibatch=B, hidden=HIDDEN, memory=args.replay, seed=1 + rank, device=local_rank,
                       use_graph=not args.no_graph, precision=args.precision, tuning=args.tuning)
         step = lambda: dqn.update_async(None)
+    # K updates in a row: ONE call where the library has one (dqnhip_update_async_n — the reference's own inner loop
+    # `for (i < n_updates) dqn->Update()`, src/dqn_main.cpp:359-361 / DQN::Benchmark, src/dqn.cpp:487-498 — which replays eight
+    # updates per hipGraph launch), else K calls.  --one-update-per-launch: K calls of dqnhip_update_async also at N = 1.
+    batched_enqueue = not use_dp and not args.one_update_per_launch
+
+    def steps(k):
+        if batched_enqueue:
+            dqn.update_async_n(k)
+        else:
+            for _ in range(k):
+                step()
     prefill(dqn, args.replay - 1, seed=100 + rank)     # AddTransitions keeps <= capacity-1 (src/dqn.cpp:776)
 
     def barrier():
@@ -712,20 +735,26 @@ def main():
     prewarm = 0
     t_pw = time.perf_counter()
     while time.perf_counter() - t_pw < args.prewarm_ms * 1e-3 or prewarm < 1:
-        for _ in range(16):
-            step()
+        steps(16)
         prewarm += 16
         if dist_on:
             break                       # collectives: every rank must run the same count
     barrier()
-    for _ in range(args.warmup):
-        step()
+    steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    one_per_launch_ms = None
+    if batched_enqueue and not args.no_graph:
+        # the same K updates as K calls of dqnhip_update_async (one update per hipGraph launch), for the record
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        one_per_launch_ms = (time.perf_counter() - t1) / args.steps * 1e3
     if hang_dog is not None:
         hang_dog.cancel()
     if dist_on:
@@ -850,6 +879,9 @@ def main():
                                           "global-minibatch updates" if args.strong else "minibatch-%d updates" % B)) if use_dp else
                                       ("replicas x%d" % world if world > 1 else "single"),
                        "hip_graph": (not args.no_graph) and (not use_dp or (native and dqn.dp_graph_active())), "prewarm_updates": prewarm,
+                       "enqueue": ("dqnhip_update_async_n(K): K updates in one call, replayed eight per hipGraph launch" if batched_enqueue
+                                   else "one call (one hipGraph launch) per update"),
+                       **({"ms_per_step_one_update_per_graph_launch": round(one_per_launch_ms, 5)} if one_per_launch_ms else {}),
                        "tuning_flags": args.tuning,
                        **({"native_dp_error": native_error} if native_error else {}),
                        **({"captured_dp_probe": dp_probe} if use_dp and dp_probe is not None else {}),

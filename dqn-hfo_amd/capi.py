@@ -43,6 +43,7 @@ SIGNATURES = {
     "dqnhip_destroy": (C.c_int, [H]),
     "dqnhip_update": (C.c_int, [H, ip, fp, fp]),
     "dqnhip_update_async": (C.c_int, [H, ip]),
+    "dqnhip_update_async_n": (C.c_int, [H, C.c_int32]),
     "dqnhip_update_pipelined": (C.c_int, [H, ip, fp, fp]),
     "dqnhip_benchmark_blocking": (C.c_int, [H, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, fp]),
     "dqnhip_update_phase": (C.c_int, [H, C.c_int32, ip]),

@@ -258,7 +258,13 @@ DQN::~DQN() { DQNHIP_CK(dqnhip_destroy(h_)); }
 void DQN::Benchmark(int iterations) {
   LOG(INFO) << "*** Benchmark begins ***";
   const auto t0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < iterations; ++i) UpdateActorCritic();
+  if (FLAGS_device_sampling && !FLAGS_pipelined_stats && !dp_ && iterations > 0) {
+    // nothing between the updates needs the host: the whole loop is one call (eight updates per hipGraph launch)
+    float loss = 0.0f, avg_q = 0.0f;
+    DQNHIP_CK(dqnhip_update_async_n(h_, iterations));
+    DQNHIP_CK(dqnhip_read_stats(h_, &loss, &avg_q));          // blocks until the last update is done
+  } else
+    for (int i = 0; i < iterations; ++i) UpdateActorCritic();
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   LOG(INFO) << "Average Update: " << ms / iterations << " ms.";
   LOG(INFO) << "*** Benchmark ends ***";

@@ -189,7 +189,7 @@ struct dqnhip_learner {
   bool timing = false;
   std::vector<TimingRec> recs;
   // graph
-  hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};  // [0]: device-sampled, [1]: explicit idx (pinned buffer -> memcpy node), [2], [3]: explicit idx in the pipelined slots
+  hipGraphExec_t graph_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0]: device-sampled, [1]: explicit idx (pinned buffer -> memcpy node), [2], [3]: explicit idx in the pipelined slots, [4]: kMultiU device-sampled updates (dqnhip_update_async_n)
   bool graph_failed = false;
   // dqnhip_update_pipelined
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};
@@ -1222,6 +1222,10 @@ int dqnhip_destroy(dqnhip_handle h) {
 
 // ---- update -----------------------------------------------------------------------
 
+// Updates per replay of graph_exec[4].  Two consecutive hipGraphLaunch calls leave the GPU idle for ~8.4 us between the
+// last kernel of one and the first kernel of the next (kernel trace, profiles/r04_graph_gap.txt; two instances of the
+// graph launched alternately: the same) - 2.8 % of a 300-us update; inside a graph the same boundary is a plain kernel boundary.
+constexpr int kMultiU = 8;
 static int capture_graph(H* h, int which, const int* idx_fixed = nullptr) {
   // Capture phases 0,1,2 once; replays re-read every changing scalar from DevState
   // and (which == 1) the indices from the fixed pinned buffer through a memcpy node; which == 2, 3: the indices
@@ -1232,7 +1236,8 @@ static int capture_graph(H* h, int which, const int* idx_fixed = nullptr) {
   const int* idx_dev = idx_fixed;
   if (which == 1) idx_dev = h->idx_pinned_dev;
   const int it_a = h->h_actor_iter, it_c = h->h_critic_iter;
-  for (int p = 0; p < 3 && !rc; ++p) rc = run_phase(h, p, idx_dev);
+  for (int u = 0; u < (which == 4 ? kMultiU : 1); ++u)
+    for (int p = 0; p < 3 && !rc; ++p) rc = run_phase(h, p, idx_dev);
   h->h_actor_iter = it_a; h->h_critic_iter = it_c;   // capture does not execute
   hipError_t e = hipStreamEndCapture(h->stream, &graph);
   if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
@@ -1274,6 +1279,33 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
   const int* idx_dev = nullptr;
   RC(stage_indices(h, idx_host, &idx_dev));
   for (int p = 0; p < 3; ++p) RC(run_phase(h, p, idx_dev));
+  return 0;
+}
+
+int dqnhip_update_async_n(dqnhip_handle h, int32_t n) {
+  if (!h) return fail("null handle");
+  if (n < 0) return fail("dqnhip_update_async_n: n must be >= 0");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->cfg.dp_world > 1 || h->dp_half || h->dp_shard) return fail("dqnhip_update_async_n: data-parallel learners use dqnhip_dp_update");
+  if (h->next_phase != 0) return fail("dqnhip_update_async_n: a phased update is in progress (next phase %d)", h->next_phase);
+  RingUse ring_use(h);
+  RC(sync_dirty16(h));
+  if (RO(h)->h_size < 1) RC(refresh_ring(h));
+  if (RO(h)->h_size < 1) return fail("replay memory is empty");
+  if (h->cfg.use_graph && !h->timing && !h->graph_failed) {
+    if (n >= kMultiU && !h->graph_exec[4] && capture_graph(h, 4)) h->graph_failed = true;
+    while (n >= kMultiU && h->graph_exec[4]) {
+      HIPCHK(hipGraphLaunch(h->graph_exec[4], h->stream));
+      h->h_actor_iter += kMultiU; h->h_critic_iter += kMultiU; n -= kMultiU;
+    }
+    if (n > 0 && !h->graph_failed && !h->graph_exec[0] && capture_graph(h, 0)) h->graph_failed = true;
+    while (n > 0 && h->graph_exec[0]) {
+      HIPCHK(hipGraphLaunch(h->graph_exec[0], h->stream));
+      h->h_actor_iter += 1; h->h_critic_iter += 1; n -= 1;
+    }
+  }
+  for (; n > 0; --n)
+    for (int p = 0; p < 3; ++p) RC(run_phase(h, p, nullptr));
   return 0;
 }
 

@@ -376,6 +376,10 @@ class DQN:
         keep, ip = self._idx(idx)
         self._ck(self.lib.dqnhip_update_async(self.h, ip))
 
+    def update_async_n(self, n):
+        """n updates with on-device sampling in one call (dqnhip_update_async_n)."""
+        self._ck(self.lib.dqnhip_update_async_n(self.h, int(n)))
+
     def update_phase(self, phase, idx=None):
         keep, ip = self._idx(idx)
         self._ck(self.lib.dqnhip_update_phase(self.h, phase, ip))
