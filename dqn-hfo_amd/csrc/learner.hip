@@ -189,6 +189,7 @@ struct dqnhip_learner {
   bool timing = false;
   std::vector<TimingRec> recs;
   // graph
+  int cap_u = -1;              // while capturing a multi-update graph: the position of the update being captured (else -1)
   hipGraphExec_t graph_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0]: device-sampled, [1]: explicit idx (pinned buffer -> memcpy node), [2], [3]: explicit idx in the pipelined slots, [4]: kMultiU device-sampled updates (dqnhip_update_async_n)
   bool graph_failed = false;
   // dqnhip_update_pipelined
@@ -485,12 +486,39 @@ int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
   return 0;
 }
 
+constexpr int kMultiU = 8;     // updates per replay of the multi-update graph (dqnhip_update_async_n; see capture_graph)
+// Philox key of SampleTransitionsFromMemory: cfg.seed on rank 0 (what oracle/c_oracle.philox_indices
+// reproduces); data-parallel ranks get distinct streams from the SAME cfg.seed, so that the weight
+// initialisation (also keyed by cfg.seed) stays identical across the group
+inline uint64_t sample_key(const H* h) { return (uint64_t)h->cfg.seed + 0x9E3779B97F4A7C15ull * (uint64_t)h->cfg.dp_rank; }
+// The gather of one update (src/dqn.cpp:846-887).  pos: -1 outside multi-update graphs; else the update's position in the
+// graph being captured (0: a launch of its own that also stores DevState::gbase; k >= 1: rides in update k-1's last launch)
+GatherArgs gather_args(H* h, const int* idx_dev, int pos) {
+  const NetLayout &la = h->la, &lc = h->lc;
+  GatherArgs g{};
+  g.ring = RO(h)->ring; g.rs = RO(h)->st; g.st = h->st; g.idx_in = idx_dev; g.seed = sample_key(h); g.B = h->B;
+  if (h->fp16)
+    // the gather writes the five minibatch panels in fp16 (what the GEMMs read: no conversion launch); the action columns
+    // of the two critic panels the actor heads fill are zero here — the heads write mu / mu' straight into the panels
+    g.o = GatherOut{nullptr, nullptr, la.kp[0], nullptr, nullptr, nullptr, lc.kp[0], h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx,
+                    h->act16[1][0], h->act16[0][0], h->act16[3][0], h->act16[4][0], h->act16[2][0]};
+  else
+    g.o = GatherOut{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0], h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
+  const int slot = pos > 0 ? (pos & 1) : 0;
+  g.corr = h->st->adam_corr[slot]; g.soft_now = &h->st->soft_now[slot];
+  g.beta1 = h->cfg.momentum; g.beta2 = h->cfg.momentum2; g.soft_update_freq = h->cfg.soft_update_freq;
+  g.ahead = pos > 0 ? pos : -1; g.store_base = pos == 0 ? 1 : 0;
+  g.blocks = (h->B + 3) / 4 + 1;
+  return g;
+}
+
 // clip + Adam + Net::Update + soft target update over arena floats [begin, end)
 // corr_pre: the update's first launch (k_gather) has left this step's bias correction in DevState::adam_corr
 int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick = nullptr,
                 bool corr_pre = true) {
   AdamArgs a{};
-  a.corr_pre = corr_pre ? &h->st->adam_corr[net] : nullptr; a.soft_pre = corr_pre ? &h->st->soft_now : nullptr;
+  const int slot = h->cap_u > 0 ? (h->cap_u & 1) : 0;      // DevState::adam_corr
+  a.corr_pre = corr_pre ? &h->st->adam_corr[slot][net] : nullptr; a.soft_pre = corr_pre ? &h->st->soft_now[slot] : nullptr;
   a.w = h->w[net] + begin; a.g = h->g[net] + begin; a.m = h->m[net] + begin; a.v = h->v[net] + begin;
   a.wt = h->w[net + 2] + begin;
   if (h->fp16) { a.w16 = h->w16a[net] + begin; a.wt16 = h->w16a[net + 2] + begin; }
@@ -514,7 +542,14 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   // same-box A/B gives 18.4 us per launch against 19.3 at 2048 (a second, short round of blocks), 19.4 at 1792, 18.7 at
   // 1280, 21.5 at 4096 (round 2, before the hoist: 512 .. 8192 within +-3 %, profiles/r02_adam_probe.txt)
   const int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)1536);
-  if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
+  if (tick && h->cap_u >= 0 && h->cap_u + 1 < kMultiU) {
+    // inside a multi-update graph: the next update's gather rides in this, the update's last launch (k_adam_soft_gather);
+    // the grid stays at what is resident at once
+    const GatherArgs g = gather_args(h, nullptr, h->cap_u + 1);
+    const int ablocks = std::max(1, std::min(blocks, 1536 - g.blocks));
+    hipLaunchKernelGGL(k_adam_soft_gather, dim3(g.blocks + ablocks), dim3(256), 0, st, a, g);
+  }
+  else if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
   else hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
   return 0;
@@ -682,11 +717,6 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
   return 0;
 }
 
-// Philox key of SampleTransitionsFromMemory: cfg.seed on rank 0 (what oracle/c_oracle.philox_indices
-// reproduces); data-parallel ranks get distinct streams from the SAME cfg.seed, so that the weight
-// initialisation (also keyed by cfg.seed) stays identical across the group
-inline uint64_t sample_key(const H* h) { return (uint64_t)h->cfg.seed + 0x9E3779B97F4A7C15ull * (uint64_t)h->cfg.dp_rank; }
-
 int run_phase16(H* h, int phase, const int* idx_dev) {
   const int B = h->B, L = h->L;
   const NetLayout &la = h->la, &lc = h->lc;
@@ -710,15 +740,11 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     return 0;
   }
   if (phase == 0 || phase == 10) {
-    // the gather writes the five minibatch panels in fp16 as well (what the GEMMs read: no conversion launch); the
-    // action columns of the two critic panels the actor heads fill are still zero here — the heads write mu / mu'
-    // straight into the fp32 AND the fp16 panels
-    GatherOut go{nullptr, nullptr, la.kp[0], nullptr, nullptr, nullptr, lc.kp[0],
-                 h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx,
-                 h->act16[1][0], h->act16[0][0], h->act16[3][0], h->act16[4][0], h->act16[2][0]};
-    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4 + 1), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
-                       (const DevState*)h->st, idx_dev, sample_key(h), go, B, h->st->adam_corr, h->cfg.momentum, h->cfg.momentum2, &h->st->soft_now, h->cfg.soft_update_freq);
-    HIPCHK(hipGetLastError());
+    if (h->cap_u <= 0) {       // (later updates of a multi-update graph: the gather rode in the previous update's last launch)
+      const GatherArgs g = gather_args(h, idx_dev, h->cap_u);
+      hipLaunchKernelGGL(k_gather, dim3(g.blocks), dim3(256), 0, st, g);
+      HIPCHK(hipGetLastError());
+    }
     if (split) RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B));
     else RC(tower_forward16_pair(h, st, 0, DQNHIP_ACTOR_TARGET, 1, DQNHIP_ACTOR, B));
     HeadArgs hAT{}; hAT.X16 = h->act16[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
@@ -825,11 +851,11 @@ int run_phase(H* h, int phase, const int* idx_dev) {
   }
   if (phase == 0 || phase == 10) {
     // 1-2: sample + gather (src/dqn.cpp:846-887)
-    GatherOut go{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0],
-                 h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
-    hipLaunchKernelGGL(k_gather, dim3((B + 3) / 4 + 1), dim3(256), 0, st, RO(h)->ring, (const DevState*)RO(h)->st,
-                       (const DevState*)h->st, idx_dev, sample_key(h), go, B, h->st->adam_corr, h->cfg.momentum, h->cfg.momentum2, &h->st->soft_now, h->cfg.soft_update_freq);
-    HIPCHK(hipGetLastError());
+    if (h->cap_u <= 0) {       // (later updates of a multi-update graph: the gather rode in the previous update's last launch)
+      const GatherArgs g = gather_args(h, idx_dev, h->cap_u);
+      hipLaunchKernelGGL(k_gather, dim3(g.blocks), dim3(256), 0, st, g);
+      HIPCHK(hipGetLastError());
+    }
     FwdPass pAT{DQNHIP_ACTOR_TARGET, &la, h->act[0]}, pA{DQNHIP_ACTOR, &la, h->act[1]};
     FwdPass pCT{DQNHIP_CRITIC_TARGET, &lc, h->act[2]}, pC1{DQNHIP_CRITIC, &lc, h->act[3]};
     HeadArgs hAT{}; hAT.X = h->act[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
@@ -1222,10 +1248,10 @@ int dqnhip_destroy(dqnhip_handle h) {
 
 // ---- update -----------------------------------------------------------------------
 
-// Updates per replay of graph_exec[4].  Two consecutive hipGraphLaunch calls leave the GPU idle for ~8.4 us between the
+// kMultiU updates per replay of graph_exec[4].  Two consecutive hipGraphLaunch calls leave the GPU idle for ~8.4 us between the
 // last kernel of one and the first kernel of the next (kernel trace, profiles/r04_graph_gap.txt; two instances of the
 // graph launched alternately: the same) - 2.8 % of a 300-us update; inside a graph the same boundary is a plain kernel boundary.
-constexpr int kMultiU = 8;
+// Inside it the gather of update u + 1 rides in update u's last launch (adam_launch, DevState::gbase).
 static int capture_graph(H* h, int which, const int* idx_fixed = nullptr) {
   // Capture phases 0,1,2 once; replays re-read every changing scalar from DevState
   // and (which == 1) the indices from the fixed pinned buffer through a memcpy node; which == 2, 3: the indices
@@ -1236,8 +1262,11 @@ static int capture_graph(H* h, int which, const int* idx_fixed = nullptr) {
   const int* idx_dev = idx_fixed;
   if (which == 1) idx_dev = h->idx_pinned_dev;
   const int it_a = h->h_actor_iter, it_c = h->h_critic_iter;
-  for (int u = 0; u < (which == 4 ? kMultiU : 1); ++u)
+  for (int u = 0; u < (which == 4 ? kMultiU : 1); ++u) {
+    h->cap_u = which == 4 ? u : -1;
     for (int p = 0; p < 3 && !rc; ++p) rc = run_phase(h, p, idx_dev);
+  }
+  h->cap_u = -1;
   h->h_actor_iter = it_a; h->h_critic_iter = it_c;   // capture does not execute
   hipError_t e = hipStreamEndCapture(h->stream, &graph);
   if (rc) { if (graph) hipGraphDestroy(graph); return rc; }

@@ -34,11 +34,19 @@ struct DevState {
   // Adam's bias correction sqrt(1 - beta2^t) / (1 - beta1^t) of THIS update's actor / critic step, evaluated by a spare
   // block of the update's first launch (k_gather): two double pow() are a ~2 us dependent chain, which every block of
   // k_adam_soft otherwise sits through before its first load (measured: 23.2 -> 21.3 us per launch without it)
-  float adam_corr[2];
+  // Two slots: inside a multi-update graph (dqnhip_update_async_n) update u uses slot u & 1, because the gather of
+  // update u + 1 — which writes that update's scalars — rides in update u's LAST launch, the optimiser pass that still
+  // reads update u's.  Everything else uses slot 0.
+  float adam_corr[2][2];   // [slot][actor, critic]
   // ... and the soft-update switch of this update (max_iter() % soft_update_freq == 0 AFTER both increments,
   // src/dqn.cpp:967), from the same block: with both in DevState no block of k_adam_soft reads an iteration counter,
   // so the update's bookkeeping (tick_body) no longer has to wait for the last block of the last launch
-  int soft_now;
+  int soft_now[2];
+  // multi-update graphs: (update_counter, actor_iter, critic_iter) as the graph's FIRST gather found them.  A gather
+  // that rides ahead in the previous update's last launch runs beside the block that advances the live counters, so it
+  // takes its own from here: base + its position in the graph (a capture-time constant).
+  unsigned long long gbase_counter;
+  int gbase_it[2];
 };
 constexpr int kFlagTarget = 1;     // a TD target of the last update(s) was not finite
 constexpr int kFlagGradNorm = 2;   // a gradient L2 norm was not finite: that clip+Adam step was skipped
@@ -164,40 +172,54 @@ struct GatherOut {
 __device__ __forceinline__ float adam_correction(float beta1, float beta2, int t) {
   return (float)(sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t)));
 }
-// corr: when not null the launch has ONE extra block (the last) whose first two lanes evaluate this update's Adam
-// corrections (t = iter + 1 of the actor / the critic: the counters only move in the update's last block)
-__global__ void k_gather(Ring ring, const DevState* rs, const DevState* st, const int* __restrict__ idx_in,
-                         uint64_t seed, GatherOut o, int B, float* corr, float beta1, float beta2, int* soft_now, int soft_update_freq) {
-  if (corr != nullptr && blockIdx.x == gridDim.x - 1) {
-    if (threadIdx.x == 64) {
-      const int it_a = st->actor_iter + 1, it_c = st->critic_iter + 1;
-      *soft_now = ((it_a > it_c ? it_a : it_c) % soft_update_freq) == 0;
-    }
+// One gather: `blocks` - 1 row blocks (4 transitions each) + ONE scalars block (the last) whose first lanes evaluate this
+// update's Adam corrections (t = iter + 1 of the actor / the critic: the counters only move in the update's last block)
+// and its soft-update switch.
+struct GatherArgs {
+  Ring ring; const DevState* rs; DevState* st; const int* idx_in; uint64_t seed; GatherOut o; int B;
+  float* corr; int* soft_now;       // DevState::adam_corr[slot], &DevState::soft_now[slot]
+  float beta1, beta2; int soft_update_freq;
+  // -1: a launch of its own — the live counters are this update's.  k >= 1: the gather of the k-th update of a
+  // multi-update graph riding in update k-1's last launch — counters = DevState::gbase + k (see DevState).
+  int ahead;
+  int store_base;                   // 1 (first update of a multi-update graph): also store the live counters to gbase
+  int blocks;
+};
+__device__ __forceinline__ void gather_block(const GatherArgs& g, const int blk) {
+  const DevState* st = g.st;
+  if (blk == g.blocks - 1) {
+    int it_a, it_c;
+    if (g.ahead < 0) { it_a = st->actor_iter; it_c = st->critic_iter; }
+    else { it_a = st->gbase_it[0] + g.ahead; it_c = st->gbase_it[1] + g.ahead; }
+    if (threadIdx.x == 64) *g.soft_now = ((((it_a + 1) > (it_c + 1) ? (it_a + 1) : (it_c + 1)) % g.soft_update_freq) == 0);
+    if (threadIdx.x == 65 && g.store_base) { g.st->gbase_counter = st->update_counter; g.st->gbase_it[0] = it_a; g.st->gbase_it[1] = it_c; }
     // four lanes, one pow() each (the two powers of a correction side by side: half the dependent chain), same
     // expression as adam_correction() from there on
     if (threadIdx.x < 64) {
       const int which = (threadIdx.x >> 1) & 1, isb1 = threadIdx.x & 1;
-      const int t = (which == 0 ? st->actor_iter : st->critic_iter) + 1;
-      const double pw = pow((double)(isb1 ? beta1 : beta2), (double)t);
+      const int t = (which == 0 ? it_a : it_c) + 1;
+      const double pw = pow((double)(isb1 ? g.beta1 : g.beta2), (double)t);
       const double p1 = __shfl_down(pw, 1, 64);          // lane 2*which: pw = beta2^t, p1 = beta1^t
-      if (threadIdx.x < 4 && !isb1) corr[which] = (float)(sqrt(1.0 - pw) / (1.0 - p1));
+      if (threadIdx.x < 4 && !isb1) g.corr[which] = (float)(sqrt(1.0 - pw) / (1.0 - p1));
     }
     return;
   }
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const GatherOut& o = g.o; const Ring& ring = g.ring;
+  const int row = blk * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (row >= B) return;
-  const int size = rs->ring_size;
+  if (row >= g.B) return;
+  const int size = g.rs->ring_size;
   int li;
-  if (idx_in != nullptr) li = idx_in[row];
+  if (g.idx_in != nullptr) li = g.idx_in[row];
   else {
     // SampleTransitionsFromMemory (src/dqn.cpp:501-509): uniform in [0,size-1] with
     // replacement; counter-based so the draw depends only on (seed, update, row)
-    const uint32_t u = philox_u32(seed, st->update_counter, (uint32_t)row);
+    const unsigned long long ctr = g.ahead < 0 ? st->update_counter : st->gbase_counter + (unsigned long long)g.ahead;
+    const uint32_t u = philox_u32(g.seed, ctr, (uint32_t)row);
     li = (int)(((uint64_t)u * (uint64_t)size) >> 32);
   }
   li = li < 0 ? 0 : (li >= size ? size - 1 : li);
-  const long long slot = ((long long)rs->ring_head + li) % ring.cap;
+  const long long slot = ((long long)g.rs->ring_head + li) % ring.cap;
   const float* sp = ring.state + slot * ring.SP;
   const float* np = ring.next + slot * ring.SP;
   const float* ap = ring.act + slot * kAP;
@@ -237,6 +259,7 @@ __global__ void k_gather(Ring ring, const DevState* rs, const DevState* st, cons
     o.term[row] = ring.term[slot] ? 1.0f : 0.0f; o.idx[row] = li;
   }
 }
+__global__ void k_gather(GatherArgs g) { gather_block(g, (int)blockIdx.x); }
 
 
 // ---- skinny head layers ------------------------------------------------------
@@ -1090,6 +1113,23 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   // update's first launch, no block of this launch reads anything tick_body writes, so block 0 runs it as soon as its
   // own slice is done, beside the other 2047 blocks.
   if (a.tick_on && blockIdx.x == 0) {
+    const bool skipped = s[7] != 0.0f;
+    __syncthreads();
+    tick_body(a.tick, s, sq, skipped);
+  }
+}
+
+// The update's last launch inside a multi-update graph: the first g.blocks workgroups are the NEXT update's gather
+// (nothing it reads or writes is touched by this optimiser pass: the minibatch panels are dead until that update's first
+// forward, its scalars go to the other DevState slot, its counters come from DevState::gbase), the rest is k_adam_soft.
+// Takes the gather (a ~5-us launch of two dependent HBM round trips) off the chain of seven of every eight updates.
+__global__ __launch_bounds__(256) void k_adam_soft_gather(AdamArgs a, GatherArgs g) {
+  __shared__ float s[8];
+  __shared__ double sq[4];
+  if ((int)blockIdx.x < g.blocks) { gather_block(g, (int)blockIdx.x); return; }
+  const int blk = (int)blockIdx.x - g.blocks;
+  adam_soft_body<1, 0>(a, blk, (int)gridDim.x - g.blocks, s);
+  if (a.tick_on && blk == 0) {
     const bool skipped = s[7] != 0.0f;
     __syncthreads();
     tick_body(a.tick, s, sq, skipped);
