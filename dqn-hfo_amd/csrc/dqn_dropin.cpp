@@ -259,7 +259,7 @@ void DQN::Benchmark(int iterations) {
   LOG(INFO) << "*** Benchmark begins ***";
   const auto t0 = std::chrono::steady_clock::now();
   if (FLAGS_device_sampling && !FLAGS_pipelined_stats && !dp_ && iterations > 0) {
-    // nothing between the updates needs the host: the whole loop is one call (eight updates per hipGraph launch)
+    // nothing between the updates needs the host: the whole loop is one call (sixteen updates per hipGraph launch)
     float loss = 0.0f, avg_q = 0.0f;
     DQNHIP_CK(dqnhip_update_async_n(h_, iterations));
     DQNHIP_CK(dqnhip_read_stats(h_, &loss, &avg_q));          // blocks until the last update is done

@@ -486,7 +486,7 @@ int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
   return 0;
 }
 
-constexpr int kMultiU = 8;     // updates per replay of the multi-update graph (dqnhip_update_async_n; see capture_graph)
+constexpr int kMultiU = 16;    // updates per replay of the multi-update graph (dqnhip_update_async_n; see capture_graph)
 // Philox key of SampleTransitionsFromMemory: cfg.seed on rank 0 (what oracle/c_oracle.philox_indices
 // reproduces); data-parallel ranks get distinct streams from the SAME cfg.seed, so that the weight
 // initialisation (also keyed by cfg.seed) stays identical across the group

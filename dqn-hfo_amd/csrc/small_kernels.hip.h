@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
 // The update's last launch inside a multi-update graph: the first g.blocks workgroups are the NEXT update's gather
 // (nothing it reads or writes is touched by this optimiser pass: the minibatch panels are dead until that update's first
 // forward, its scalars go to the other DevState slot, its counters come from DevState::gbase), the rest is k_adam_soft.
-// Takes the gather (a ~5-us launch of two dependent HBM round trips) off the chain of seven of every eight updates.
+// Takes the gather (a ~5-us launch of two dependent HBM round trips) off the chain of all but the first update of such a graph.
 __global__ __launch_bounds__(256) void k_adam_soft_gather(AdamArgs a, GatherArgs g) {
   __shared__ float s[8];
   __shared__ double sq[4];

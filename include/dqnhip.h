@@ -166,7 +166,8 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host);
 /* n such updates back to back with on-device sampling — the reference's inner loops `for (i < n_updates)
  * dqn->Update()` (src/dqn_main.cpp:359-361) and DQN::Benchmark (src/dqn.cpp:487-498) as ONE call.  Exactly the
  * state n calls of dqnhip_update_async(h, NULL) leave (bit for bit); with use_graph the updates are replayed
- * eight to a hipGraph launch, which removes seven of eight graph-to-graph gaps (~8 us each on MI355X). */
+ * sixteen to a hipGraph launch: the GPU idles ~8 us between two graph launches, and inside such a graph the minibatch
+ * gather of update u + 1 rides in update u's last launch instead of heading the next chain (~5 us). */
 int dqnhip_update_async_n(dqnhip_handle h, int32_t n);
 
 /* Data-parallel form of the same update, cut at its two exchange points:

@@ -1,5 +1,5 @@
 """How much of an update's wall clock is the gap between two hipGraph launches?  (inside gpurun)
-   single: one update per hipGraphLaunch (dqnhip_update_async); multi: dqnhip_update_async_n (eight updates per launch,
+   single: one update per hipGraphLaunch (dqnhip_update_async); multi: dqnhip_update_async_n (sixteen updates per launch,
    the gather of update u + 1 riding in update u's last launch).  (A third mode — two instances of the single-update graph
    launched alternately — measured the same as single and was removed: profiles/r04_graph_gap.txt.)"""
 import sys, time
