@@ -694,10 +694,13 @@ def main():
     # K updates in a row: ONE call where the library has one (dqnhip_update_async_n — the reference's own inner loop
     # `for (i < n_updates) dqn->Update()`, src/dqn_main.cpp:359-361 / DQN::Benchmark, src/dqn.cpp:487-498 — which replays sixteen
     # updates per hipGraph launch), else K calls.  --one-update-per-launch: K calls of dqnhip_update_async also at N = 1.
-    batched_enqueue = not use_dp and not args.one_update_per_launch
+    # Data parallel, native transport: dqnhip_dp_update_n, the same for a group.
+    batched_enqueue = not args.one_update_per_launch and (not use_dp or native)
 
     def steps(k):
-        if batched_enqueue:
+        if batched_enqueue and use_dp:
+            dp.update_n(k)
+        elif batched_enqueue:
             dqn.update_async_n(k)
         else:
             for _ in range(k):
@@ -879,7 +882,8 @@ def main():
                                           "global-minibatch updates" if args.strong else "minibatch-%d updates" % B)) if use_dp else
                                       ("replicas x%d" % world if world > 1 else "single"),
                        "hip_graph": (not args.no_graph) and (not use_dp or (native and dqn.dp_graph_active())), "prewarm_updates": prewarm,
-                       "enqueue": ("dqnhip_update_async_n(K): K updates in one call, replayed sixteen per hipGraph launch, each gather riding in the previous update's last launch" if batched_enqueue
+                       "enqueue": ("%s(K): K updates in one call, replayed sixteen per hipGraph launch, each gather riding in the previous update's last launch"
+                                   % ("dqnhip_dp_update_n" if use_dp else "dqnhip_update_async_n") if batched_enqueue
                                    else "one call (one hipGraph launch) per update"),
                        **({"ms_per_step_one_update_per_graph_launch": round(one_per_launch_ms, 5)} if one_per_launch_ms else {}),
                        "tuning_flags": args.tuning,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "dqnhip_dp_graph_active": (C.c_int, [H, ip]),
     "dqnhip_dp_broadcast_params": (C.c_int, [H, C.c_int32]),
     "dqnhip_dp_update": (C.c_int, [H, ip]),
+    "dqnhip_dp_update_n": (C.c_int, [H, C.c_int32]),
     "dqnhip_dp_gather_state": (C.c_int, [H]),
     "dqnhip_dp_destroy": (C.c_int, [H]),
     "dqnhip_skipped_steps": (C.c_int, [H, C.POINTER(C.c_int64)]),

@@ -151,6 +151,8 @@ struct dqnhip_learner {
   hipEvent_t comm_ev[2] = {nullptr, nullptr};
   hipGraphExec_t dp_graph = nullptr;    // the whole data-parallel update (collectives included), captured
   bool dp_graph_failed = false;
+  hipGraphExec_t dp_graph_n = nullptr;  // kMultiU of them (dqnhip_dp_update_n)
+  bool dp_graph_n_failed = false;
   int next_phase = 0;                   // dqnhip_update_phase order check (0: an update may start)
   // minibatch panels / activations: pass 0 AT, 1 A, 2 CT, 3 C1, 4 C2
   float* Xa_s = nullptr; float* Xa_n = nullptr; float* Xc_tr = nullptr; float* Xc_pl = nullptr; float* Xc_nx = nullptr;
@@ -1059,7 +1061,8 @@ extern "C" {
 static void drop_graphs_fwd(H* h) {
   for (auto& g : h->graph_exec) if (g) { hipGraphExecDestroy(g); g = nullptr; }
   if (h->dp_graph) { hipGraphExecDestroy(h->dp_graph); h->dp_graph = nullptr; }
-  h->dp_graph_failed = false; h->graph_failed = false;
+  if (h->dp_graph_n) { hipGraphExecDestroy(h->dp_graph_n); h->dp_graph_n = nullptr; }
+  h->dp_graph_failed = false; h->dp_graph_n_failed = false; h->graph_failed = false;
 }
 
 int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
@@ -1709,18 +1712,25 @@ int dp_sequence(H* h, const int* idx_dev) {
   return run_phase(h, 2, nullptr);
 }
 
-int dp_capture(H* h) {
+// multi: kMultiU updates in one graph, each gather riding in the previous update's last launch (capture_graph)
+int dp_capture(H* h, bool multi = false) {
   hipGraph_t graph = nullptr;
+  hipGraphExec_t* out = multi ? &h->dp_graph_n : &h->dp_graph;
   HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   const int it_a = h->h_actor_iter, it_c = h->h_critic_iter;
-  const int rc = dp_sequence(h, nullptr);
+  int rc = 0;
+  for (int u = 0; u < (multi ? kMultiU : 1) && !rc; ++u) {
+    h->cap_u = multi ? u : -1;
+    rc = dp_sequence(h, nullptr);
+  }
+  h->cap_u = -1;
   h->h_actor_iter = it_a; h->h_critic_iter = it_c;   // capture does not execute
   hipError_t e = hipStreamEndCapture(h->stream, &graph);
   if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
   if (e != hipSuccess) return fail("hipStreamEndCapture (dp): %s", hipGetErrorString(e));
-  e = hipGraphInstantiate(&h->dp_graph, graph, nullptr, nullptr, 0);
+  e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
   hipGraphDestroy(graph);
-  if (e != hipSuccess) { h->dp_graph = nullptr; return fail("hipGraphInstantiate (dp): %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { *out = nullptr; return fail("hipGraphInstantiate (dp): %s", hipGetErrorString(e)); }
   return 0;
 }
 
@@ -1889,6 +1899,29 @@ int dqnhip_dp_update(dqnhip_handle h, const int32_t* idx_host) {
   return dp_sequence(h, idx_dev);
 }
 
+// n data-parallel updates with on-device sampling (dqnhip_update_async_n for a group: every rank calls it with the same n)
+int dqnhip_dp_update_n(dqnhip_handle h, int32_t n) {
+  if (!h) return fail("null handle");
+  if (!h->comm) return fail("dp_update_n: no communicator (call dqnhip_dp_init first)");
+  if (n < 0) return fail("dqnhip_dp_update_n: n must be >= 0");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->next_phase != 0) return fail("dqnhip_dp_update_n: a phased update is in progress (next phase %d)", h->next_phase);
+  if (h->cfg.use_graph && !h->timing && !h->dp_graph_failed && !h->dp_graph_n_failed && n >= kMultiU) {
+    RingUse ring_use(h);
+    RC(sync_dirty16(h));
+    if (RO(h)->h_size < 1) RC(refresh_ring(h));
+    if (RO(h)->h_size < 1) return fail("replay memory is empty");
+    if (!h->dp_graph_n && dp_capture(h, true)) h->dp_graph_n_failed = true;
+    while (n >= kMultiU && h->dp_graph_n) {
+      if (h->dp_shard) h->shard_stale = true;
+      HIPCHK(hipGraphLaunch(h->dp_graph_n, h->stream));
+      h->h_actor_iter += kMultiU; h->h_critic_iter += kMultiU; n -= kMultiU;
+    }
+  }
+  for (; n > 0; --n) RC(dqnhip_dp_update(h, nullptr));
+  return 0;
+}
+
 int dqnhip_dp_graph_active(dqnhip_handle h, int32_t* active) {
   if (!h || !active) return fail("null argument");
   *active = h->dp_graph != nullptr;
@@ -1926,7 +1959,8 @@ int dp_destroy_impl(H* h, bool keep_learner) {
   hipStreamSynchronize(h->stream);
   hipStreamSynchronize(h->comm_stream);
   if (h->dp_graph) { hipGraphExecDestroy(h->dp_graph); h->dp_graph = nullptr; }
-  h->dp_graph_failed = false;
+  if (h->dp_graph_n) { hipGraphExecDestroy(h->dp_graph_n); h->dp_graph_n = nullptr; }
+  h->dp_graph_failed = false; h->dp_graph_n_failed = false;
   ncclCommDestroy(h->comm); h->comm = nullptr;
   hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr;
   for (auto& e : h->comm_ev) { if (e) hipEventDestroy(e); e = nullptr; }

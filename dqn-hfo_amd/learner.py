@@ -437,6 +437,10 @@ class DQN:
         keep, ip = self._idx(idx)
         self._ck(self.lib.dqnhip_dp_update(self.h, ip))
 
+    def dp_update_n(self, n):
+        """n data-parallel updates with on-device sampling in one call (every rank: the same n)."""
+        self._ck(self.lib.dqnhip_dp_update_n(self.h, int(n)))
+
     def skipped_steps(self):
         n = C.c_int64()
         self._ck(self.lib.dqnhip_skipped_steps(self.h, C.byref(n)))

@@ -108,6 +108,9 @@ class NativeDataParallel:
     def update(self, idx=None):
         self.backend.dp_update(idx)
 
+    def update_n(self, n):
+        self.backend.dp_update_n(n)
+
 
 def make_native_data_parallel(pkg, state_size, rank, world, device, group=None, per_layer=False, half_grads=False,
                               shard_opt=False, **dqn_kwargs):

@@ -255,6 +255,9 @@ int dqnhip_dp_rendezvous_cleanup(const char* path, int32_t world);
 int dqnhip_dp_graph_active(dqnhip_handle h, int32_t* active);
 int dqnhip_dp_broadcast_params(dqnhip_handle h, int32_t root);
 int dqnhip_dp_update(dqnhip_handle h, const int32_t* idx_host);
+/* n of them with on-device sampling: dqnhip_update_async_n for a group (every rank calls it with the same n; sixteen
+ * updates, collectives included, per hipGraph launch). */
+int dqnhip_dp_update_n(dqnhip_handle h, int32_t n);
 int dqnhip_dp_gather_state(dqnhip_handle h);
 int dqnhip_dp_destroy(dqnhip_handle h);
 

@@ -168,19 +168,32 @@ def main():
         e2.dp_update(None); se = e2.read_stats()
         same = same and (sg == se)
     res["graph_active"] = bool(g.dp_graph_active())
+    # dqnhip_dp_update_n: sixteen updates (collectives included) per hipGraph launch, gathers riding ahead — against single
+    # eager updates (one communicator at a time: read_stats blocks)
+    n_multi = 16 + 3
+    g.dp_update_n(n_multi); sg = g.read_stats()
+    for _ in range(n_multi):
+        e2.dp_update(None)
+    se = e2.read_stats()
+    multi_same = (sg == se)
     if args.shard_opt:
         g.dp_gather_state(); e2.dp_gather_state()
-    res["graph_equals_eager"] = bool(same and digest(g) == digest(e2))
+    res["graph_equals_eager"] = bool(same and multi_same and digest(g) == digest(e2))
+    res["multi_equals_eager"] = bool(multi_same and digest(g) == digest(e2))
     res["graph_digest"] = digest(g)
     res["graph_stats"] = list(g.read_stats())
     # how long one captured update takes with this many ranks (the probe's by-product)
     if args.mode == "probe":
         g.read_stats()
         t1 = time.time()
-        for _ in range(50):
+        for _ in range(48):
             g.dp_update(None)
         g.read_stats()
-        res["graph_ms_per_update"] = (time.time() - t1) / 50 * 1e3
+        res["graph_ms_per_update"] = (time.time() - t1) / 48 * 1e3
+        t1 = time.time()
+        g.dp_update_n(48)
+        g.read_stats()
+        res["graph_n_ms_per_update"] = (time.time() - t1) / 48 * 1e3
     g.close(); e2.close()
     res["seconds"] = time.time() - t0
     res["ok"] = True

@@ -82,3 +82,27 @@ def test_n_updates_refusals(pkg, gpu):
     with pytest.raises(RuntimeError, match="dqnhip_dp_update"):
         g.update_async_n(2)
     g.close()
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+@pytest.mark.parametrize("precision,flags", [("fp32", {}), ("fp32", {"per_layer": True}), ("fp32", {"shard_opt": True}),
+                                             ("fp16", {"half_grads": True}), ("fp16", {"half_grads": True, "shard_opt": True})])
+def test_dp_n_updates_equal_n_single_calls(pkg, gpu, use_graph, precision, flags):
+    """dqnhip_dp_update_n on a one-rank RCCL group (every exchange form): sixteen updates — collectives included — per
+    hipGraph launch, each gather riding in the previous update's last launch, against single dqnhip_dp_update calls."""
+    B, hidden = (128, (256, 128, 128)) if precision == "fp16" else (64, (256, 128, 64, 64))
+    st = []
+    for grouped in (False, True):
+        d = pkg.DQN(59, minibatch=B, hidden=hidden, memory=4096, seed=11, use_graph=use_graph, precision=precision, dp_world=1, dp_rank=0)
+        d.add_transitions_arrays(*synth_replay(np.random.default_rng(2), 3000, 59))
+        d.dp_init(pkg.DQN.dp_unique_id(), **flags)
+        d.dp_update(None)
+        (d.dp_update_n(37) if grouped else [d.dp_update(None) for _ in range(37)])
+        if use_graph:
+            assert d.dp_graph_active()
+        if flags.get("shard_opt"):
+            d.dp_gather_state()
+        st.append(_state(d, pkg)); d.close()
+    assert st[0][1] == st[1][1] and st[0][2] == st[1][2] == (38, 38)
+    for x, y in zip(st[0][0], st[1][0]):
+        np.testing.assert_array_equal(x, y)
