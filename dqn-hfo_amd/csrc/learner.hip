@@ -1543,12 +1543,12 @@ int dqnhip_benchmark(dqnhip_handle h, int32_t warmup, int32_t iterations, float*
   if (!h) return fail("null handle");
   if (iterations < 1) return fail("iterations must be >= 1");
   HIPCHK(hipSetDevice(h->cfg.device));
-  for (int i = 0; i < warmup; ++i) RC(dqnhip_update_async(h, nullptr));
+  if (warmup > 0) RC(dqnhip_update_async_n(h, warmup));
   hipEvent_t a, b;
   HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipEventRecord(a, h->stream));
-  for (int i = 0; i < iterations; ++i) RC(dqnhip_update_async(h, nullptr));
+  RC(dqnhip_update_async_n(h, iterations));
   HIPCHK(hipEventRecord(b, h->stream));
   HIPCHK(hipEventSynchronize(b));
   float ms = 0;
