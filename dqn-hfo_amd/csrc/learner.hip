@@ -545,10 +545,12 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   // 1280, 21.5 at 4096 (round 2, before the hoist: 512 .. 8192 within +-3 %, profiles/r02_adam_probe.txt)
   const int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)1536);
   if (tick && h->cap_u >= 0 && h->cap_u + 1 < kMultiU) {
-    // inside a multi-update graph: the next update's gather rides in this, the update's last launch (k_adam_soft_gather);
-    // the grid stays at what is resident at once
+    // inside a multi-update graph: the next update's gather rides in this, the update's last launch (k_adam_soft_gather).
+    // At small minibatches the grid stays at what is resident at once; a large minibatch's gather (1025 workgroups at 4096
+    // rows) must not thin the optimiser's own grid — its blocks drain within a few us and the rest of the grid moves in
+    // (511 optimiser blocks beside it: 35.4 against 27.3 us per launch at 4096 rows)
     const GatherArgs g = gather_args(h, nullptr, h->cap_u + 1);
-    const int ablocks = std::max(1, std::min(blocks, 1536 - g.blocks));
+    const int ablocks = std::min(blocks, std::max(1536 - g.blocks, 1280));
     hipLaunchKernelGGL(k_adam_soft_gather, dim3(g.blocks + ablocks), dim3(256), 0, st, a, g);
   }
   else if (lt.start) { hipExtLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a); lt.start = lt.stop = nullptr; }
