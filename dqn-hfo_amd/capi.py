@@ -9,6 +9,7 @@ DP_ID_BYTES = 128        # DQNHIP_DP_ID_BYTES
 DP_PER_LAYER, DP_HALF_GRADS, DP_SHARD_OPT = 1, 2, 4    # dqnhip_dp_init flags
 TUNE_FP16_WGRAD_PER_LAYER = 1                       # dqnhip_config.tuning_flags bits
 TUNE_SEPARATE_HEAD_SEED = 2
+TUNE_BWD_UNSHIFTED = 4
 ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET = 0, 1, 2, 3
 KIND_W, KIND_M, KIND_V, KIND_G = 0, 1, 2, 3
 

@@ -1083,6 +1083,25 @@ __global__ __launch_bounds__(256) void gemm_wgrad_narrow_rider(const GemmBatch b
   wgrad_narrow_body<1>(batch.prob[pi], tile_p, tile_q, smem);
 }
 
+// The LAST launch of a net's backward under the shifted schedule (learner.hip tower_backward): layer 1's wgrad (prob[0]:
+// 64 x 64 tiles), the first layer's narrow wgrad (prob[1]: 16-output tiles) and the head's dW / db rider blocks.  The
+// first layer's wgrad alone is 64-128 short workgroups — a 6-us launch of launch floor; beside a full wgrad it costs ~1.
+// Long workgroups first in the grid.
+template <int NH>
+__global__ __launch_bounds__(256) void gemm_wgrad_tail(const GemmBatch batch, const HeadWgradRider rider) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int blk = (int)blockIdx.x;
+  int tile_p, tile_q;
+  if (blk < rider.blocks) { head_wgrad_rider<NH>(rider, blk, smem); return; }
+  blk -= rider.blocks;
+  const GemmProblem& p0 = batch.prob[1];
+  const int n0 = p0.tiles_p * p0.tiles_q;
+  if (blk < n0) { tile_of_problem(p0, blk, tile_p, tile_q); wgrad_narrow_body<1>(p0, tile_p, tile_q, smem); return; }
+  blk -= n0;
+  const GemmProblem& p1 = batch.prob[0];
+  tile_of_problem(p1, blk, tile_p, tile_q); wgrad_direct_body<1, 1>(p1, tile_p, tile_q, smem);
+}
+
 // ---- launchers ------------------------------------------------------------------------
 
 // When set (by the learner's timing mode), the next launch is bracketed by these events through
@@ -1187,6 +1206,22 @@ inline hipError_t wgrad_narrow_rider_launch(GemmBatch& batch, const HeadWgradRid
   LaunchTimer& lt = launch_timer();
   if (lt.start) { hipExtLaunchKernelGGL((gemm_wgrad_narrow_rider<NH>), dim3(base + rider.blocks), dim3(256), lds, stream, lt.start, lt.stop, 0, batch, rider); lt.start = lt.stop = nullptr; }
   else hipLaunchKernelGGL((gemm_wgrad_narrow_rider<NH>), dim3(base + rider.blocks), dim3(256), lds, stream, batch, rider);
+  return hipGetLastError();
+}
+// prob[0]: wgrad on 64 x 64 tiles, prob[1]: narrow wgrad on 64 x 16 tiles; rider.blocks may be 0
+template <int NH>
+inline hipError_t wgrad_tail_launch(GemmBatch& batch, const HeadWgradRider& rider, hipStream_t stream) {
+  GemmProblem& w1 = batch.prob[0]; GemmProblem& w0 = batch.prob[1];
+  w1.tiles_p = w1.Pdim / 64; w1.tiles_q = w1.Qdim / 64; w1.tile_base = 0;
+  w0.tiles_p = w0.Pdim / 64; w0.tiles_q = w0.Qdim / 16; w0.tile_base = w1.tiles_p * w1.tiles_q;
+  const int grid = w0.tile_base + w0.tiles_p * w0.tiles_q + rider.blocks;
+  batch.total_tiles = grid;
+  const size_t need = rider.blocks ? (size_t)(rider.rows * NH + 16 * NH * 16) * sizeof(float) : 0;
+  const size_t lds = std::max(need, (size_t)(4 * 16 * 64 * 16 + 4 * 16 * 16));
+  if (lds > 80 * 1024) return hipErrorInvalidValue;          // two workgroups per CU
+  LaunchTimer& lt = launch_timer();
+  if (lt.start) { hipExtLaunchKernelGGL((gemm_wgrad_tail<NH>), dim3(grid), dim3(256), lds, stream, lt.start, lt.stop, 0, batch, rider); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL((gemm_wgrad_tail<NH>), dim3(grid), dim3(256), lds, stream, batch, rider);
   return hipGetLastError();
 }
 template <bool DLDS>

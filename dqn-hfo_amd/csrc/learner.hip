@@ -382,30 +382,65 @@ inline bool head_wgrad_can_ride(const NetLayout& l, int rows) {
 int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* garena, float* partial,
                    float** act, float** dZ, int rows, bool want_w, bool input_grad, int in_lo = 0, int in_hi = -1,
                    const HeadWgradRider* rider = nullptr, const QHeadRider* qrider = nullptr) {
+  auto dgrad_of = [&](int i) {             // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
+    GemmProblem p{};
+    p.mode = GEMM_DGRAD;
+    p.P = wat(h, net, l.w_off[i]); p.ldp = l.kp[i];
+    p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
+    p.C = dZ[i]; p.ldc = l.kp[i];
+    p.Pdim = l.kp[i]; p.Qdim = rows; p.Kred = l.dims[i + 1];
+    p.mask = i > 0 ? act[i] : nullptr; p.ldm = l.kp[i];
+    return p;
+  };
+  auto wgrad_of = [&](int i) {             // dW_i = dZ[i+1]^T . act[i] ; db_i = colsum(dZ[i+1])
+    GemmProblem p{};
+    p.mode = GEMM_WGRAD;
+    p.P = act[i]; p.ldp = l.kp[i];
+    p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
+    p.C = garena + l.w_off[i]; p.ldc = l.kp[i];
+    p.Pdim = l.kp[i]; p.Qdim = l.dims[i + 1]; p.Kred = rows;
+    p.db = garena + l.b_off[i];
+    p.partial = partial ? partial + l.part_off[i] : nullptr;
+    return p;
+  };
+  // reduction width (the layer's outputs) wide enough: dY through the LDS transpose, scheduled form
+  auto lds_ok_of = [&](int i) { return l.dims[i + 1] >= 512 && l.dims[i + 1] % 256 == 0; };
+  auto layer_slice = [&](int i) { return (i + 1 < l.L ? l.w_off[i + 1] : l.hw_off) - l.w_off[i]; };
+  // SHIFTED schedule (weights wanted, no input gradient, every layer above the first on the one-workgroup-type form):
+  //   dgrad(L-1) | wgrad(L-1) + dgrad(L-2) | ... | wgrad(2) + dgrad(1) | wgrad(1) + wgrad(0) + the head's riders
+  // instead of  wgrad(i) + dgrad(i) per layer and a last launch with the first layer's narrow wgrad alone.  Same launch
+  // count, same workgroups, same arithmetic: the chain's last launch — 64-128 short workgroups, 6 us of launch floor —
+  // is absorbed into a full wgrad launch (+~1 us), at the price of splitting one pair (8.3 + 7.9 instead of 14.5 us).
+  bool shifted = want_w && !input_grad && l.L >= 2 && rows % 16 == 0 && !(h->cfg.tuning_flags & DQNHIP_TUNE_BWD_UNSHIFTED);
+  for (int i = 1; i < l.L && shifted; ++i) shifted = !bwd_layer_is_pair(l, i, rows) && l.kp[i] % 64 == 0 && l.dims[i + 1] % 64 == 0;
+  if (shifted) {
+    {
+      GemmBatch bd{}; bd.n = 1; bd.prob[0] = dgrad_of(l.L - 1);
+      ScopedTiming t(h, 1, st);
+      if (lds_ok_of(l.L - 1)) HIPCHK((dgrad_lds_launch<1, 1>(bd, st))); else HIPCHK((dgrad_direct_launch<1, 1>(bd, st)));
+    }
+    for (int i = l.L - 2; i >= 1; --i) {
+      GemmBatch b{}; b.n = 2; b.prob[0] = dgrad_of(i); b.prob[1] = wgrad_of(i + 1);
+      ScopedTiming t(h, 4, st);
+      if (lds_ok_of(i)) HIPCHK((bwd_seq_launch<true>(b, st))); else HIPCHK((bwd_seq_launch<false>(b, st)));
+      if (h->comm && h->dp_per_layer) RC(dp_reduce_slice(h, st, net, l.w_off[i + 1], layer_slice(i + 1)));
+    }
+    {
+      GemmBatch b{}; b.n = 2; b.prob[0] = wgrad_of(1); b.prob[1] = wgrad_of(0);
+      const HeadWgradRider none{};
+      ScopedTiming t(h, 2, st);
+      if (l.NH == 1) HIPCHK((wgrad_tail_launch<1>(b, rider ? *rider : none, st))); else HIPCHK((wgrad_tail_launch<kNO>(b, rider ? *rider : none, st)));
+      if (h->comm && h->dp_per_layer) RC(dp_reduce_slice(h, st, net, l.w_off[0], layer_slice(0) + layer_slice(1)));
+    }
+    if (qrider) return fail("internal: the q-head rider found no carrier launch");
+    return 0;
+  }
   for (int i = l.L - 1; i >= 0; --i) {
     GemmBatch bd{}, bw{};
     const bool need_dx = (i > 0 || input_grad);
-    if (need_dx) {                         // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
-      GemmProblem& p = bd.prob[bd.n++];
-      p.mode = GEMM_DGRAD;
-      p.P = wat(h, net, l.w_off[i]); p.ldp = l.kp[i];
-      p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
-      p.C = dZ[i]; p.ldc = l.kp[i];
-      p.Pdim = l.kp[i]; p.Qdim = rows; p.Kred = l.dims[i + 1];
-      p.mask = i > 0 ? act[i] : nullptr; p.ldm = l.kp[i];
-    }
-    if (want_w) {                          // dW_i = dZ[i+1]^T . act[i] ; db_i = colsum(dZ[i+1])
-      GemmProblem& p = bw.prob[bw.n++];
-      p.mode = GEMM_WGRAD;
-      p.P = act[i]; p.ldp = l.kp[i];
-      p.Q = dZ[i + 1]; p.ldq = l.kp[i + 1];
-      p.C = garena + l.w_off[i]; p.ldc = l.kp[i];
-      p.Pdim = l.kp[i]; p.Qdim = l.dims[i + 1]; p.Kred = rows;
-      p.db = garena + l.b_off[i];
-      p.partial = partial ? partial + l.part_off[i] : nullptr;
-    }
-    // reduction width (the layer's outputs) wide enough: dY through the LDS transpose, scheduled form
-    const bool lds_ok = l.dims[i + 1] >= 512 && l.dims[i + 1] % 256 == 0;
+    if (need_dx) bd.prob[bd.n++] = dgrad_of(i);
+    if (want_w) bw.prob[bw.n++] = wgrad_of(i);
+    const bool lds_ok = lds_ok_of(i);
     if (need_dx && want_w) {               // ONE workgroup type: its wgrad tile, then its dgrad tile (gemm_bwd_seq)
       GemmBatch b{}; b.n = 2; b.prob[0] = bd.prob[0]; b.prob[1] = bw.prob[0];
       ScopedTiming t(h, 4, st);
@@ -436,7 +471,7 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
     }
     // data parallel, bucketed: layer i's dW/db are final once this launch has run -> start their
     // all-reduce on the communication stream while the chain continues with layer i-1
-    if (want_w && h->comm && h->dp_per_layer) RC(dp_reduce_slice(h, st, net, l.w_off[i], (i + 1 < l.L ? l.w_off[i + 1] : l.hw_off) - l.w_off[i]));
+    if (want_w && h->comm && h->dp_per_layer) RC(dp_reduce_slice(h, st, net, l.w_off[i], layer_slice(i)));
   }
   if (qrider) return fail("internal: the q-head rider found no carrier launch");
   return 0;
@@ -1204,6 +1239,8 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
   }
   HIPCHK(direct_prepare(gemm_bwd_seq<true>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_bwd_seq<false>, 4 * 16 * 64 * 16 + 4 * 16 * 16));
+  HIPCHK(direct_prepare(gemm_wgrad_tail<1>, 80 * 1024));
+  HIPCHK(direct_prepare(gemm_wgrad_tail<kNO>, 80 * 1024));
   HIPCHK(direct_prepare((gemm_bwd_pair_direct<1, true>), 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare((gemm_bwd_pair_direct<1, false>), 4 * 16 * 64 * 16 + 4 * 16 * 16));
   HIPCHK(direct_prepare(gemm_fwd_lds<4, 2, false>, 4 * 2 * 6 * 512 * 4));

@@ -116,6 +116,9 @@ typedef struct dqnhip_config {
 /* fp32 learner: the seed of the critic's dq = -1 backward pass (src/dqn.cpp:918-923) and q(s, mu(s)) from a head-backward
  * launch of their own instead of the top layer's forward epilogue / rider blocks of the chain's last launch. */
 #define DQNHIP_TUNE_SEPARATE_HEAD_SEED 2
+/* fp32 learner: a tower's backward as wgrad(i) + dgrad(i) per layer and a last launch with the first layer's wgrad alone,
+ * instead of the shifted schedule dgrad(L-1) | wgrad(i+1) + dgrad(i) ... | wgrad(1) + wgrad(0) (same launch count). */
+#define DQNHIP_TUNE_BWD_UNSHIFTED 4
 
 typedef struct dqnhip_learner* dqnhip_handle;
 

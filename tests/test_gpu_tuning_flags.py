@@ -106,3 +106,21 @@ def test_fused_head_seed_under_graph_replay(pkg, gpu):
     assert a[0] == g[0]
     for x, y in zip(a[2], g[2]):
         np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("B,hidden,S", [
+    (256, (1024, 1024, 1024, 1024), 58),       # BASELINE configs[1]
+    (512, (1024, 1024), 68),                   # two layers: dgrad(1) | wgrad(1) + wgrad(0)
+    (256, (1024, 512, 256, 128), 59),          # the reference's tower: layers of different widths share a launch
+    (1024, (256, 256), 58),                    # rows >= 1024 (no head rider: k_head_bwd_big + k_head_wred)
+    (32, (1024, 512, 256, 128), 59),           # the reference's defaults: side-by-side pair launches -> not shifted (identical)
+])
+def test_shifted_backward_schedule_equals_per_layer_launches(pkg, gpu, B, hidden, S):
+    """fp32 learner: dgrad(L-1) | wgrad(i+1) + dgrad(i) | ... | wgrad(1) + wgrad(0) + head riders (default) against
+    wgrad(i) + dgrad(i) per layer + a last launch with the first layer's wgrad alone (DQNHIP_TUNE_BWD_UNSHIFTED): the same
+    workgroups doing the same arithmetic in different launches — every result bit-identical."""
+    a = _run32(pkg, 0, B, hidden, S)
+    b = _run32(pkg, pkg.capi.TUNE_BWD_UNSHIFTED, B, hidden, S)
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
