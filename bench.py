@@ -47,12 +47,29 @@ def tower_weights(in_dim, hidden):
     return [dims[i] * dims[i + 1] for i in range(len(hidden))]
 
 
-def family_flops(B, S, hidden):
+def family_flops(B, S, hidden, shifted=True):
     """Algorithmic GEMM FLOPs per update, per kernel (tower layers only; the skinny heads are
-    separate kernels).  See DESIGN.md §5.  Keys are the learner's timing families."""
+    separate kernels).  See DESIGN.md §5.  Keys are the learner's timing families.
+    shifted: the backward schedule of learner.hip tower_backward (default for >= 2 tower layers at minibatches whose layers
+    take the one-workgroup-type form): dgrad(L-1) | wgrad(i+1) + dgrad(i) ... | wgrad(1) + wgrad(0); else wgrad(i) + dgrad(i)
+    per layer and the first layer's wgrad alone (DQNHIP_TUNE_BWD_UNSHIFTED, or the side-by-side pair launches of small shapes)."""
     wa = tower_weights(S, hidden)
     wc = tower_weights(S + 10, hidden)
     h1 = hidden[0]
+    L = len(hidden)
+    if shifted and L >= 2:
+        pair = lambda w: sum(w[j + 1] + w[j] for j in range(1, L - 1))
+        return {
+            "gemm_fwd_lds_4x2": 2 * B * (2 * sum(wa[1:]) + 2 * sum(wc[1:])),
+            "gemm_fwd_lds_2x2": 2 * B * sum(wc[1:]),
+            "gemm_fwd_direct": 2 * B * (2 * wa[0] + 3 * wc[0]),
+            # wgrad(i+1) + dgrad(i), i = L-2 .. 1: critic train + actor
+            "gemm_bwd_pair": 2 * B * (pair(wc) + pair(wa)),
+            # critic dQ/da chain (layers 2..L + the 10 action columns of layer 1) + the top layer's dgrad of both backward passes
+            "gemm_dgrad": 2 * B * (sum(wc[1:]) + 10 * h1 + wc[L - 1] + wa[L - 1]),
+            # the tails: wgrad(1) + wgrad(0), critic + actor
+            "gemm_wgrad": 2 * B * (wc[1] + wc[0] + wa[1] + wa[0]),
+        }
     return {
         # {actor_target, actor} and {critic_target, critic} layers 2..L, two layers per launch
         "gemm_fwd_lds_4x2": 2 * B * (2 * sum(wa[1:]) + 2 * sum(wc[1:])),
@@ -84,9 +101,9 @@ def family_flops16(B, S, hidden):
 MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: fp16/bf16 dense MFMA peak
 
 KERNEL_NAMES = {"hgemm_fwd": "hgemm_nt<2,2>/<1,1> (forward epilogue)", "hgemm_dgrad": "hgemm_nt (dgrad epilogue)",
-                "hgemm_wgrad": "hgemm_nt (wgrad epilogue)","gemm_fwd_lds_4x2": "gemm_fwd_lds<4,2,true,2>", "gemm_fwd_lds_2x2": "gemm_fwd_lds<2,2,true,2>",
+                "hgemm_wgrad": "hgemm_nt (wgrad epilogue)","gemm_fwd_lds_4x2": "gemm_fwd_lds<4,2,true,1>", "gemm_fwd_lds_2x2": "gemm_fwd_lds<2,2,true,2>",
                 "gemm_fwd_direct": "gemm_fwd_direct<4,2>", "gemm_bwd_pair": "gemm_bwd_seq<true>",
-                "gemm_dgrad": "gemm_dgrad_lds<1,1>", "gemm_wgrad": "gemm_wgrad_narrow<1>"}
+                "gemm_dgrad": "gemm_dgrad_lds<1,1>", "gemm_wgrad": "gemm_wgrad_tail<1>"}
 
 
 PMC_SUMMARY = "profiles/r04_pmc_summary.json"
@@ -779,7 +796,7 @@ def main():
         step()
     if rank == 0:
         fp16 = args.precision == "fp16"
-        fam_flops = family_flops16(B, S, HIDDEN) if fp16 else family_flops(B, S, HIDDEN)
+        fam_flops = family_flops16(B, S, HIDDEN) if fp16 else family_flops(B, S, HIDDEN, shifted=not (args.tuning & 4) and B >= 64)
         peak = MFMA_F16_PEAK_TF if fp16 else MFMA_F32_PEAK_TF
         stats = {}
         for fam in list(fam_flops) + ["adam"]:
@@ -806,7 +823,9 @@ def main():
                 "traffic_source": traffic_src,
                 "avg_launch_us": round(ms * 1e3, 2), "launches_per_update": per_update_launches,
                 "flops_per_launch": flops_per_launch,
-                "families_us": {f: [round(stats[f][0] * 1e3, 2), stats[f][1] / n_t] for f in stats}}
+                "families_us": {f: [round(stats[f][0] * 1e3, 2), stats[f][1] / n_t] for f in stats},
+                # every GEMM family's own fraction of the peak (algorithmic FLOPs of its launches / their summed duration)
+                "families_frac": {f: round(fam_flops[f] * n_t / (stats[f][0] * 1e-3 * stats[f][1]) / 1e12 / peak, 4) for f in fam_flops if stats[f][1]}}
     torch.cuda.synchronize()
 
     # What the reference's UNCHANGED driver gets through the drop-in (src/dqn_main.cpp:361 -> DQN::Update ->
