@@ -65,6 +65,9 @@ int dqnhip_test_loadpath(int32_t mode, int32_t blocks, int32_t region_kb, int32_
  * workgroups of the launches (48-KiB LDS build: riders co-resident), [4] on a second stream, [5] riders with the 96-KiB
  * build (not co-resident).  rider_blocks = rider workgroups per launch. */
 int dqnhip_test_overlap(int32_t layers, int64_t adam_params, int32_t rider_blocks, int32_t iters, float* us);
+/* launch-floor probe: us per kernel of a `chain`-long dependent chain inside a replayed hipGraph (variant bits: 1 = 640-byte
+ * kernarg, 2 = lds_bytes of dynamic LDS, 4 = one dependent global round trip in the body, 8 = 1024 threads per block) */
+int dqnhip_test_launch_floor(int32_t variant, int32_t blocks, int32_t lds_bytes, int32_t chain, int32_t iters, float* us_per_kernel);
 
 #ifdef __cplusplus
 }

@@ -1051,3 +1051,59 @@ extern "C" int dqnhip_test_loadpath(int32_t mode, int32_t blocks, int32_t region
   hipFree(src); hipFree(sink); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
   return 0;
 }
+
+
+// ---- launch-floor probe: what one link of a dependent kernel chain costs inside a replayed hipGraph, by launch shape ----
+// variant bits: 1 = 640-byte kernarg (a GemmBatch by value) instead of one pointer; 2 = dynamic LDS (lds_bytes) ; 4 = a body with
+// one dependent global round trip (load -> store); 8 = 1024 threads per block.  blocks = grid size.
+namespace {
+struct FloorArgs { float* p; int pad[158]; };
+__global__ void k_floor_small(float* p, int dep) {
+  if (dep) { const float v = p[(blockIdx.x * blockDim.x + threadIdx.x) & 0xFFFF]; if (v == 123.456f) p[0] = v; }
+}
+__global__ void k_floor_big(FloorArgs a, int dep) {
+  if (dep) { const float v = a.p[(blockIdx.x * blockDim.x + threadIdx.x) & 0xFFFF]; if (v == 123.456f) a.p[0] = v + a.pad[7]; }
+}
+__global__ void k_floor_lds(float* p, int dep) {
+  extern __shared__ float fl_sm[];
+  if (dep) { const float v = p[(blockIdx.x * blockDim.x + threadIdx.x) & 0xFFFF]; fl_sm[threadIdx.x] = v; if (v == 123.456f) p[0] = fl_sm[(threadIdx.x + 1) & 255]; }
+}
+__global__ void k_floor_big_lds(FloorArgs a, int dep) {
+  extern __shared__ float fl_sm[];
+  if (dep) { const float v = a.p[(blockIdx.x * blockDim.x + threadIdx.x) & 0xFFFF]; fl_sm[threadIdx.x] = v; if (v == 123.456f) a.p[0] = fl_sm[(threadIdx.x + 1) & 255] + a.pad[7]; }
+}
+}  // namespace
+extern "C" int dqnhip_test_launch_floor(int32_t variant, int32_t blocks, int32_t lds_bytes, int32_t chain, int32_t iters, float* us_per_kernel) {
+  if (blocks < 1 || chain < 1 || iters < 1 || lds_bytes < 0 || lds_bytes > 160 * 1024) return 1;
+  hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  float* buf; CK(hipMalloc(&buf, 65536 * 4)); CK(hipMemsetAsync(buf, 0, 65536 * 4, s));
+  const bool big = variant & 1, lds = variant & 2; const int dep = (variant & 4) ? 1 : 0; const int nt = (variant & 8) ? 1024 : 256;
+  if (lds) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_floor_lds), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_floor_big_lds), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  }
+  FloorArgs fa{}; fa.p = buf;
+  auto one = [&]() {
+    if (big && lds) hipLaunchKernelGGL(k_floor_big_lds, dim3(blocks), dim3(nt), lds_bytes, s, fa, dep);
+    else if (big) hipLaunchKernelGGL(k_floor_big, dim3(blocks), dim3(nt), 0, s, fa, dep);
+    else if (lds) hipLaunchKernelGGL(k_floor_lds, dim3(blocks), dim3(nt), lds_bytes, s, buf, dep);
+    else hipLaunchKernelGGL(k_floor_small, dim3(blocks), dim3(nt), 0, s, buf, dep);
+  };
+  hipGraph_t graph; hipGraphExec_t exec;
+  CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < chain; ++i) one();
+  CK(hipStreamEndCapture(s, &graph));
+  CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  CK(hipGraphDestroy(graph));
+  for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(exec, s));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipStreamSynchronize(s));
+  CK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) CK(hipGraphLaunch(exec, s));
+  CK(hipEventRecord(e1, s));
+  CK(hipEventSynchronize(e1));
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+  *us_per_kernel = ms * 1e3f / ((float)iters * chain);
+  hipGraphExecDestroy(exec); hipEventDestroy(e0); hipEventDestroy(e1); hipFree(buf); hipStreamDestroy(s);
+  return 0;
+}

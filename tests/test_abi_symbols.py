@@ -41,7 +41,7 @@ def test_every_declared_symbol_is_exported(pkg):
     # the test hooks live in their own library and are NOT in the product library
     tdecl = declared_functions(internal=True)
     assert tdecl == {"dqnhip_test_gemm", "dqnhip_test_hgemm", "dqnhip_test_adam", "dqnhip_test_chain",
-                     "dqnhip_test_loadpath", "dqnhip_test_hgemm_backward", "dqnhip_test_overlap"}
+                     "dqnhip_test_loadpath", "dqnhip_test_hgemm_backward", "dqnhip_test_overlap", "dqnhip_test_launch_floor"}
     assert not (tdecl & exported)
     tlib = testlib.load_test()
     assert all(hasattr(tlib, n) for n in tdecl)
