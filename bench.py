@@ -278,13 +278,22 @@ def probe_captured_dp(rank, world, local_rank, precision, half, per_layer, timeo
     except subprocess.TimeoutExpired:
         p.kill()
         log, _ = p.communicate()
-        return {"ok": False, "why": "child of rank %d killed after %d s" % (rank, timeout_s), "log": log[-400:]}
-    res = {"ok": False, "why": "child of rank %d exited %d: %s" % (rank, p.returncode, log[-300:])}
+        return _probe_result(out, {"ok": False, "multi_ok": False, "why": "child of rank %d killed after %d s" % (rank, timeout_s), "log": log[-400:]}, t0)
+    res = {"ok": False, "multi_ok": False, "why": "child of rank %d exited %d: %s" % (rank, p.returncode, log[-300:])}
+    return _probe_result(out, res, t0)
+
+
+def _probe_result(out, res, t0):
+    """ok: the one-update graph was active and bit-identical to eager; multi_ok: so was dqnhip_dp_update_n's sixteen-update graph.
+    The child writes its findings stage by stage, so a child killed in the second stage still reports the first."""
     try:
         j = json.load(open(out))
-        good = bool(j.get("ok") and j.get("graph_active") and j.get("graph_equals_eager"))
-        res = {"ok": good, "seconds": round(time.perf_counter() - t0, 1), "graph_ms_per_update": j.get("graph_ms_per_update"),
-               "why": "" if good else "graph_active=%s graph_equals_eager=%s" % (j.get("graph_active"), j.get("graph_equals_eager"))}
+        single = bool(j.get("graph_active") and j.get("single_graph_equals_eager"))
+        multi = bool(j.get("ok") and single and j.get("multi_equals_eager"))
+        res = {"ok": single, "multi_ok": multi, "seconds": round(time.perf_counter() - t0, 1), "graph_ms_per_update": j.get("graph_ms_per_update"),
+               "graph_n_ms_per_update": j.get("graph_n_ms_per_update"),
+               "why": "" if multi else "%s; graph_active=%s single_graph_equals_eager=%s multi_equals_eager=%s" % (
+                   res.get("why", ""), j.get("graph_active"), j.get("single_graph_equals_eager"), j.get("multi_equals_eager"))}
     except Exception:                 # noqa: BLE001 — reported in "why"
         pass
     return res
@@ -607,6 +616,7 @@ def main():
     ap.add_argument("--dp-shard-opt", action="store_true", help="native DP: sharded optimiser (DQNHIP_DP_SHARD_OPT) instead of the replicated one")
     ap.add_argument("--test-dp-probe", action="store_true", help="testing: run the captured-update probe with the ranks there are (N = 1 under --force-dp)")
     ap.add_argument("--test-dp-probe-fail", action="store_true", help="testing: pretend the probe failed (exercises the agreed fall-back to the eager update)")
+    ap.add_argument("--test-dp-probe-multi-fail", action="store_true", help="testing: pretend only the sixteen-update graph failed the probe (fall-back: one update per graph launch)")
     ap.add_argument("--no-dp-probe", action="store_true",
                     help="N > 1: skip the sacrificial child group that tries the captured data-parallel update first (tests/dp_native_worker.py)")
     ap.add_argument("--dp-fp32-grads", action="store_true", help="native DP, fp16 learner: all-reduce fp32 gradients instead of bf16 (DQNHIP_DP_HALF_GRADS)")
@@ -665,12 +675,19 @@ def main():
             # stream-ordered instead of replayed).  ~20 s, outside every timed region.
             dp_probe = (probe_captured_dp(rank, world, local_rank, args.precision, half, args.dp_per_layer and not half) if not args.test_dp_probe_fail
                         else {"ok": False, "why": "forced by --test-dp-probe-fail"})
-            ok = torch.tensor([1 if dp_probe.get("ok") else 0], dtype=torch.int32, device="cuda")
+            if args.test_dp_probe_multi_fail:
+                dp_probe["multi_ok"] = False; dp_probe["why"] = "forced by --test-dp-probe-multi-fail"
+            ok = torch.tensor([1 if dp_probe.get("ok") else 0, 1 if dp_probe.get("multi_ok") else 0], dtype=torch.int32, device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
+            if int(ok[0].item()) == 0:
                 args.no_graph = True
                 if rank == 0:
                     print("bench: the captured data-parallel update did not pass the %d-rank probe (%s): running eagerly" % (world, dp_probe.get("why", "another rank failed")),
+                          file=sys.stderr, flush=True)
+            elif int(ok[1].item()) == 0:
+                args.one_update_per_launch = True
+                if rank == 0:
+                    print("bench: the sixteen-update data-parallel graph did not pass the %d-rank probe (%s): one update per graph launch" % (world, dp_probe.get("why", "another rank failed")),
                           file=sys.stderr, flush=True)
         if native:
             # the communicator inside libdqnhip.so has never met more than one real GPU in this repo's own runs

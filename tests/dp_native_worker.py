@@ -168,6 +168,10 @@ def main():
         e2.dp_update(None); se = e2.read_stats()
         same = same and (sg == se)
     res["graph_active"] = bool(g.dp_graph_active())
+    if args.shard_opt:
+        g.dp_gather_state(); e2.dp_gather_state()
+    res["single_graph_equals_eager"] = bool(same and digest(g) == digest(e2))
+    write()                                  # (a parent that has to kill this process during the next stage still learns this much)
     # dqnhip_dp_update_n: sixteen updates (collectives included) per hipGraph launch, gathers riding ahead — against single
     # eager updates (one communicator at a time: read_stats blocks)
     n_multi = 16 + 3

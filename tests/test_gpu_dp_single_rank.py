@@ -100,7 +100,8 @@ def test_bench_runs_under_torchrun_one_rank(pkg, gpu):
     # under N > 1 a sacrificial child group tries the captured update first (tests/dp_native_worker.py --mode probe); the same
     # code with the one rank there is: the child ran at the bench's shape, its graph was active and equal to the eager member's
     probe = d["config"]["captured_dp_probe"]
-    assert probe["ok"] and probe["graph_ms_per_update"] > 0, probe
+    assert probe["ok"] and probe["multi_ok"] and probe["graph_ms_per_update"] > 0 and probe["graph_n_ms_per_update"] > 0, probe
+    assert d["config"]["enqueue"].startswith("dqnhip_dp_update_n")
 
 
 def test_bench_falls_back_to_eager_when_the_probe_fails(pkg, gpu):
@@ -116,6 +117,22 @@ def test_bench_falls_back_to_eager_when_the_probe_fails(pkg, gpu):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["value"] > 100 and d["config"]["hip_graph"] is False
     assert d["config"]["captured_dp_probe"]["ok"] is False and "running eagerly" in r.stderr
+
+
+def test_bench_falls_back_to_one_update_per_graph_when_only_the_multi_update_graph_fails(pkg, gpu):
+    """The probe child reports stage by stage: if the one-update graph is fine but dqnhip_dp_update_n's sixteen-update graph is
+    not, the ranks keep replaying graphs, one update per launch."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29651", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "20", "--warmup", "5", "--replay", "20000", "--no-cpu-baseline", "--no-env", "--no-subrecords", "--no-live-pmc",
+           "--force-dp", "--test-dp-probe", "--test-dp-probe-multi-fail"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    import json
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["value"] > 100 and d["config"]["hip_graph"] is True
+    assert d["config"]["captured_dp_probe"]["ok"] is True and d["config"]["captured_dp_probe"]["multi_ok"] is False
+    assert "one call (one hipGraph launch) per update" in d["config"]["enqueue"] and "one update per graph launch" in r.stderr
 
 
 def test_bench_strong_scaling_record_with_the_ranks_there_are(pkg, gpu):
