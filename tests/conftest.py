@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The tests that start REAL multi-rank RCCL groups (tests/test_gpu_dp_native.py, world > 1) have never met a box with
+    more than one GPU: they go last, so that under `-x` a first failure there cannot hide the result of anything else."""
+    def multi_rank(item):
+        return "test_gpu_dp_native" in item.nodeid and not any(t in item.nodeid for t in ("[1-", "world1", "one_rank"))
+    items[:] = [i for i in items if not multi_rank(i)] + [i for i in items if multi_rank(i)]
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return load_package()
