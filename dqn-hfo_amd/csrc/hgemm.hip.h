@@ -58,6 +58,11 @@ struct HGemm {
   const h16* mask; int ldm;    // [M][ldm]: multiply by lrelu'(mask) = mask > 0 ? 1 : 0.01 (may be null)
   float scale32;               // the fp32 output is multiplied by this (loss-scale removal)
   float* sumsq_partial;        // one slot per workgroup of this problem: sum of squares of the fp32 values it wrote (may be null)
+  // forward, top tower layer of the critic(s, mu(s)) pass (may be null): also write the seed of BackwardFrom(q_values_layer)
+  // (src/dqn.cpp:918-923: q diff = -1 per row) taken through the head and this layer's ReLU, as the scaled fp16 panel the dgrad
+  // chain reads: CS16[m][n] = fp16(((-seed_w[n]) * lrelu'(fp16(C[m][n]))) * seed_scale) — k_head_bwd(_big)<1>'s arithmetic
+  // on the fp16-rounded activation, without its launch
+  const float* seed_w; h16* CS16; int ldcs16; float seed_scale;
   // Operand orientation in memory.  0: k-major — [rows][ld] with the reduction index contiguous (a lane's MFMA fragment
   // is one 16-B piece).  1: REDUCTION-major — [K][ld] with the M (resp. N) index contiguous; fragments then come out of
   // LDS through the transposing read ds_read_b64_tr_b16.  With it the three layer GEMMs read the SAME batch-major panels
@@ -400,6 +405,11 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
     const int gn = n0 + (tid % CPR) * 8;
     bias0 = *reinterpret_cast<const hg_f32x4*>(g.bias + gn); bias1 = *reinterpret_cast<const hg_f32x4*>(g.bias + gn + 4);
   }
+  hg_f32x4 seed0 = hg_f32x4{0.f, 0.f, 0.f, 0.f}, seed1 = seed0;
+  if (g.seed_w) {
+    const int gn = n0 + (tid % CPR) * 8;
+    seed0 = *reinterpret_cast<const hg_f32x4*>(g.seed_w + gn); seed1 = *reinterpret_cast<const hg_f32x4*>(g.seed_w + gn + 4);
+  }
   float sq = 0.f;                           // sum of squares of the fp32 values this thread writes (clip norm)
 #pragma unroll
   for (int it = 0; it < EIT; ++it) {
@@ -438,6 +448,13 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (h16)v[e];
       *reinterpret_cast<h16x8*>(g.C16 + (size_t)gm * g.ldc16 + gn) = o;
+      if (g.seed_w) {
+        const float sw[8] = {seed0.x, seed0.y, seed0.z, seed0.w, seed1.x, seed1.y, seed1.z, seed1.w};
+        h16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (h16)(((-sw[e]) * ((float)o[e] > 0.f ? 1.0f : 0.01f)) * g.seed_scale);
+        *reinterpret_cast<h16x8*>(g.CS16 + (size_t)gm * g.ldcs16 + gn) = z;
+      }
     }
     if (g.C32 && gn < g.n_valid32) {
       const float s = g.scale32;

@@ -493,7 +493,7 @@ template <int NH>
 int head_backward_big(H* h, hipStream_t st, HeadBwdArgs a, h16* dZ16, float scale16) {
   HeadBwdBigArgs b{}; b.a = a; b.dZ16 = dZ16; b.scale16 = scale16; b.slab2 = h->head_slab2;
   const int chunks = a.rows / 64;
-  const int riders = (NH == 1 && a.q_out != nullptr) ? chunks : 0;     // as many rider blocks again: 4 rows per block and round
+  const int riders = a.q_out != nullptr ? chunks : 0;     // as many rider blocks again: 4 rows per block and round
   b.chunks = riders ? chunks : 0;
   const size_t lds = (size_t)(64 * NH + 4 * NH * 256) * sizeof(float);
   static bool prepared = false;
@@ -825,9 +825,17 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     // the Adam pass writes the fp16 mirrors of the critic and its target itself
     if (part16) RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
     else RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr));
-    RC(tower_forward16(h, st, 4, DQNHIP_CRITIC, B));
-    {
-      // q(s, mu(s)) rides in the dq = -1 head launch (rider blocks), as on the fp32 path
+    // As on the fp32 path: the seed of the dq = -1 pass comes out of the top layer's forward epilogue (HGemm::seed_w, the
+    // scaled fp16 panel the dgrad chain reads) and q(s, mu(s)) rides in a later launch-floor launch — here the actor heads'
+    // backward (HeadBwdArgs::qr_*).  DQNHIP_TUNE_SEPARATE_HEAD_SEED: the head-backward launch of their own.
+    const bool fused_seed = !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_HEAD_SEED);
+    for (int i = 0; i < L; ++i) {
+      HGemm g = fwd16_problem(h, 4, DQNHIP_CRITIC, B, i);
+      if (fused_seed && i == L - 1) { g.seed_w = wat(h, DQNHIP_CRITIC, lc.hw_off); g.CS16 = h->dZ16[1][L]; g.ldcs16 = Hc; g.seed_scale = h->ls_q; }
+      RC(hgemm_timed(h, st, g, 7));
+    }
+    if (!fused_seed) {
+      // q(s, mu(s)) rides in the dq = -1 head launch (rider blocks)
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X416 = h->act16[4][L];
       a.H = Hc; a.rows = B; a.dZ = nullptr;
       a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial;
@@ -838,6 +846,10 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     {
       HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;
       a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.X416 = h->act16[1][L]; a.H = Hh; a.rows = B; a.dZ = nullptr;
+      if (fused_seed) {
+        a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial;
+        a.qr_W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.qr_X416 = h->act16[4][L]; a.qr_H = Hc;
+      }
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
       if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->ls_a)); }
       else { a.dZ16 = h->dZ16[0][L]; a.scale16 = h->ls_a; RC(head_backward<kNO>(h, st, a)); }

@@ -550,6 +550,9 @@ struct HeadBwdArgs {
   // two used to be separate dependent launches for no reason.
   int rc_blocks;                       // row chunks of the backward part (0: gridDim.y)
   const float* q_bias; float* q_out; double* qsum_partial;
+  // the rider's own head (fp16 learner: the critic(s, mu(s)) head rides in the ACTOR heads' backward launch — its seed comes
+  // out of the critic's top forward layer, HGemm::seed_w); null: the launch's own W / X4 / X416 / H (the dq = -1 launch)
+  const float* qr_W; const float* qr_X4; const _Float16* qr_X416; int qr_H;
   // fp16 learner: also emit the tower-top gradient as the scaled fp16 panel the fp16 GEMMs read (dZ16 [rows][H])
   // instead of a separate conversion launch
   _Float16* dZ16; float scale16;
@@ -565,19 +568,21 @@ template <int NH>
 __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int RC = a.rc_blocks > 0 ? a.rc_blocks : gridDim.y, rc = blockIdx.y, nkb = gridDim.x;
-  if (NH == 1 && rc >= RC) {                           // rider blocks: one wave per row, k-strips of float4
+  if (a.q_out != nullptr && rc >= RC) {                // rider blocks: one wave per row, k-strips of float4
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = (((int)blockIdx.y - RC) * (int)gridDim.x + (int)blockIdx.x) * 16 + wave;
     if (row >= a.rows) return;
-    const size_t x0 = (size_t)row * a.H;
+    const float* rW = a.qr_W ? a.qr_W : a.W; const float* rX = a.qr_W ? a.qr_X4 : a.X4;
+    const _Float16* rX16 = a.qr_W ? a.qr_X416 : a.X416; const int rH = a.qr_W ? a.qr_H : a.H;
+    const size_t x0 = (size_t)row * rH;
     float acc = 0.0f;
     auto dots = [&](auto tag) {
-      for (int k = lane * 4; k < a.H; k += 256) {
-        const f32x4 xv = head_ld4t<decltype(tag)::value>(a.X4, a.X416, x0 + k), wv = *reinterpret_cast<const f32x4*>(a.W + k);
+      for (int k = lane * 4; k < rH; k += 256) {
+        const f32x4 xv = head_ld4t<decltype(tag)::value>(rX, rX16, x0 + k), wv = *reinterpret_cast<const f32x4*>(rW + k);
         acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
       }
     };
-    HEAD_DISPATCH(a.X416 != nullptr, dots);
+    HEAD_DISPATCH(rX16 != nullptr, dots);
     acc = wave_sum64(acc);
     if (lane == 0) { const float v = acc + a.q_bias[0]; a.q_out[row] = v; a.qsum_partial[row] = (double)v; }
     return;
@@ -739,28 +744,32 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
   float* s_dy = sm;                                    // [64][NH]
   float* s_red = sm + 64 * NH;                         // [4][NH][256]
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  if (NH == 1 && b.chunks > 0 && (int)blockIdx.x >= b.chunks) {
+  if (b.chunks > 0 && (int)blockIdx.x >= b.chunks) {
+    // (rider: the q head of HeadBwdArgs::qr_* when given — the fp16 learner's critic(s, mu(s)) head in the ACTOR heads' launch —
+    // else this launch's own head, the dq = -1 launch)
+    const float* rW = a.qr_W ? a.qr_W : a.W; const float* rX4 = a.qr_W ? a.qr_X4 : a.X4;
+    const _Float16* rX416 = a.qr_W ? a.qr_X416 : a.X416; const int rH = a.qr_W ? a.qr_H : a.H;
     // one wave per row, four rows of the wave in flight at once (16 x 16-B loads per lane before the first use:
     // with one row at a time the rider was a chain of exposed memory latencies, 9 us at 4096 rows)
     const int nwave = ((int)gridDim.x - b.chunks) * (int)gridDim.y * 4;
     const int wv = (((int)blockIdx.x - b.chunks) * (int)gridDim.y + (int)blockIdx.y) * 4 + w;
-    const bool hoist = a.H <= 1024;
+    const bool hoist = rH <= 1024;
     f32x4 wreg[4];
     if (hoist) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { const int k = lane * 4 + 256 * t; wreg[t] = k < a.H ? *reinterpret_cast<const f32x4*>(a.W + k) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int t = 0; t < 4; ++t) { const int k = lane * 4 + 256 * t; wreg[t] = k < rH ? *reinterpret_cast<const f32x4*>(rW + k) : f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
     for (int r0 = wv * 4; r0 < a.rows; r0 += nwave * 4) {
       if (hoist) {
         f32x4 xr[4][4];
-        if (a.X416 != nullptr) {
+        if (rX416 != nullptr) {
           head_h4 hr[4][4];
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               const int k = lane * 4 + 256 * t;
-              hr[j][t] = (r0 + j < a.rows && k < a.H) ? *reinterpret_cast<const head_h4*>(a.X416 + (size_t)(r0 + j) * a.H + k) : head_h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+              hr[j][t] = (r0 + j < a.rows && k < rH) ? *reinterpret_cast<const head_h4*>(rX416 + (size_t)(r0 + j) * rH + k) : head_h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
             }
 #pragma unroll
           for (int j = 0; j < 4; ++j)
@@ -772,7 +781,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               const int k = lane * 4 + 256 * t;
-              xr[j][t] = (r0 + j < a.rows && k < a.H) ? *reinterpret_cast<const f32x4*>(a.X4 + (size_t)(r0 + j) * a.H + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+              xr[j][t] = (r0 + j < a.rows && k < rH) ? *reinterpret_cast<const f32x4*>(rX4 + (size_t)(r0 + j) * rH + k) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll
@@ -788,10 +797,10 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
         }
       } else {
         for (int j = 0; j < 4 && r0 + j < a.rows; ++j) {
-          const size_t x0 = (size_t)(r0 + j) * a.H;
+          const size_t x0 = (size_t)(r0 + j) * rH;
           float acc = 0.0f;
-          for (int k = lane * 4; k < a.H; k += 256) {
-            const f32x4 xv = head_ld4(a.X4, a.X416, x0 + k), wv4 = *reinterpret_cast<const f32x4*>(a.W + k);
+          for (int k = lane * 4; k < rH; k += 256) {
+            const f32x4 xv = head_ld4(rX4, rX416, x0 + k), wv4 = *reinterpret_cast<const f32x4*>(rW + k);
             acc = fmaf(xv.x, wv4.x, acc); acc = fmaf(xv.y, wv4.y, acc); acc = fmaf(xv.z, wv4.z, acc); acc = fmaf(xv.w, wv4.w, acc);
           }
           acc = wave_sum64(acc);
@@ -875,7 +884,8 @@ __global__ __launch_bounds__(256) void k_head_bwd_big(HeadBwdBigArgs b) {
   if (blockIdx.y == 0 && tid < NH) {
     float v = 0.0f;
     for (int m = 0; m < 64; ++m) v += s_dy[m * NH + tid];
-    b.slab2[(size_t)gridDim.x * NH * a.H + blockIdx.x * 16 + tid] = v;
+    const size_t n_chunks = b.chunks > 0 ? (size_t)b.chunks : (size_t)gridDim.x;      // (rider blocks extend the grid beyond the row chunks)
+    b.slab2[n_chunks * NH * a.H + blockIdx.x * 16 + tid] = v;
   }
 }
 // adds the row-chunk slabs of k_head_bwd_big: block = (64 columns, head j); the 4 waves take every

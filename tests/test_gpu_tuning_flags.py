@@ -124,3 +124,22 @@ def test_shifted_backward_schedule_equals_per_layer_launches(pkg, gpu, B, hidden
     assert a[0] == b[0], (a[0], b[0])
     for x, y in zip(a[2], b[2]):
         np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("B,hidden", [
+    (128, (256, 128, 128)),                    # k_head_bwd<10> carries the q rider
+    (512, (1024, 1024, 1024, 1024)),           # the rank shape of BASELINE configs[4] on 8 GPUs
+    (1024, (256, 256)),                        # rows >= 1024: k_head_bwd_big<10> carries it
+    (2048, (1024, 1024, 1024, 1024)),          # 256x128 / 128x128 forward tiles emit the seed
+])
+def test_fp16_fused_head_seed_equals_separate_launch(pkg, gpu, B, hidden):
+    """fp16 learner, critic(s, mu(s)) pass: the scaled fp16 seed panel from the top layer's forward epilogue (HGemm::seed_w) +
+    q(s, mu(s)) as rider blocks of the actor heads' backward launch (default) against the dq = -1 head-backward launch of
+    their own (DQNHIP_TUNE_SEPARATE_HEAD_SEED): the same arithmetic on the same fp16-rounded activations, bit-identical."""
+    a = _run(pkg, 0, B, hidden)
+    b = _run(pkg, pkg.capi.TUNE_SEPARATE_HEAD_SEED, B, hidden)
+    assert a[0] == b[0], (a[0], b[0])
+    for (ga, gc), (gb_a, gb_c) in zip(a[1], b[1]):
+        np.testing.assert_array_equal(ga, gb_a); np.testing.assert_array_equal(gc, gb_c)
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
