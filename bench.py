@@ -417,8 +417,17 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
             for d in agents:
                 d.update_async(None)
         dt = timed(both, torch.cuda.synchronize, 500, 50)
-        out["two_agents_one_gpu_b256_fp32"] = {"aggregate_updates_per_s": round(2 / dt, 1), "per_agent_updates_per_s": round(1 / dt, 1),
-                                               "note": "independent streams overlap each other's launch floors"}
+
+        def both_n(k):
+            for lo in range(0, k, 64):            # interleave the agents' enqueues: 64 updates (four graph launches) at a time
+                for d in agents:
+                    d.update_async_n(min(64, k - lo))
+        both_n(64); torch.cuda.synchronize()
+        t1 = time.perf_counter(); both_n(512); torch.cuda.synchronize()
+        dt_n = (time.perf_counter() - t1) / 512
+        out["two_agents_one_gpu_b256_fp32"] = {"aggregate_updates_per_s": round(2 / dt_n, 1), "per_agent_updates_per_s": round(1 / dt_n, 1),
+                                               "aggregate_updates_per_s_one_update_per_graph_launch": round(2 / dt, 1),
+                                               "note": "independent streams overlap each other's launch floors; dqnhip_update_async_n per agent"}
         for d in agents:
             d.read_stats(); d.close()
         # configs[0]'s workload (the reference's compile-time defaults: minibatch 32, S = 59, tower 1024-512-256-128,
