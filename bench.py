@@ -637,6 +637,11 @@ def main():
     ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],
                     help="N>1: dp = gradient all-reduce (weak scaling), replicas = independent learners")
     args = ap.parse_args()
+    if args.gpus > 1 and (args.dp_per_layer or args.dp_shard_opt):
+        # the per-layer and sharded exchange forms have never run on more than one rank (dqnhip_dp_init refuses them for real
+        # groups); the N-GPU line is measured on the one supported form: replicated optimiser, ONE all-reduce per net
+        print("bench: --dp-per-layer / --dp-shard-opt are unverified on real links and ignored under --gpus > 1 (one bucket per net, replicated optimiser)", file=sys.stderr, flush=True)
+        args.dp_per_layer = args.dp_shard_opt = False
     B = args.minibatch
     if args.strong:
         w_ = int(os.environ.get("WORLD_SIZE", "1"))

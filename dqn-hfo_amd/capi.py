@@ -7,6 +7,7 @@ from ._build import LIB, build
 MAX_HIDDEN = 8
 DP_ID_BYTES = 128        # DQNHIP_DP_ID_BYTES
 DP_PER_LAYER, DP_HALF_GRADS, DP_SHARD_OPT = 1, 2, 4    # dqnhip_dp_init flags
+DP_UNVERIFIED_OK = 256   # lets DP_PER_LAYER / DP_SHARD_OPT through for dp_world > 1 (never run on real links)
 TUNE_FP16_WGRAD_PER_LAYER = 1                       # dqnhip_config.tuning_flags bits
 TUNE_SEPARATE_HEAD_SEED = 2
 TUNE_BWD_UNSHIFTED = 4
@@ -64,6 +65,7 @@ SIGNATURES = {
     "dqnhip_dp_update_n": (C.c_int, [H, C.c_int32]),
     "dqnhip_dp_gather_state": (C.c_int, [H]),
     "dqnhip_dp_destroy": (C.c_int, [H]),
+    "dqnhip_dp_info": (C.c_int, [ip, C.c_char_p, C.c_size_t]),
     "dqnhip_skipped_steps": (C.c_int, [H, C.POINTER(C.c_int64)]),
     "dqnhip_reduce_gradients_local": (C.c_int, [C.POINTER(H), C.c_int32, C.c_int32]),
     "dqnhip_sample_states": (C.c_int, [H, ip, C.c_int32, fp]),

@@ -36,6 +36,8 @@ DEFINE_bool(snapshot_memory, true, "Snapshot the replay memory along with the ne
 DEFINE_double(beta, .5, "Mix between off-policy and on-policy updates.");
 // MI355X learner flags (no counterpart in the reference; defaults reproduce its behaviour)
 DEFINE_int32(minibatch, kMinibatchSize, "Minibatch size of the HIP learner (reference: kMinibatchSize = 32); multiple of 32.");
+DEFINE_int32(select_actions_cap, 0, "Largest batch SelectActions accepts. 0: the reference's CHECK_LE(states_batch.size(), kMinibatchSize) "
+                                    "(src/dqn.cpp:699) with this learner's -minibatch; -1: any batch (the device path has no MemoryData layer); n > 0: n.");
 DEFINE_int32(hip_device, 0, "HIP device ordinal of this process's learners.");
 DEFINE_bool(hip_graph, true, "Replay each update as one captured hipGraph.");
 DEFINE_string(precision, "fp32", "fp32 (exact-fp32 MFMA, the parity path) or fp16 (fp16 MFMA operands, fp32 accumulate).");
@@ -206,9 +208,13 @@ DQN::DQN(caffe::SolverParameter& actor_solver_param, caffe::SolverParameter& cri
     LOG(INFO) << "Seeding RNG with seed = " << FLAGS_seed;
   }
   random_engine.seed(seed);
-  // -gpu=false selects Caffe's CPU mode in the reference (src/dqn_main.cpp:208-212); this learner is
-  // the MI355X path and has no CPU fallback by design
-  CHECK(caffe::Caffe::mode() == caffe::Caffe::GPU) << "the HIP learner needs -gpu=true (there is no CPU backend)";
+  // -gpu=false selects Caffe's CPU solver in the reference (KeepPlayingGames: Caffe::set_mode(Caffe::CPU),
+  // src/dqn_main.cpp:208-212).  This library replaces the GPU path only and by design has no CPU fallback — a learner that
+  // silently computed somewhere else would void every measurement — so the flag ends here, through the driver's own logging
+  // path, with what to do instead of a bare CHECK on an internal condition.
+  if (caffe::Caffe::mode() != caffe::Caffe::GPU)
+    LOG(FATAL) << "[Agent" << tid << "] -gpu=false: Caffe CPU mode (src/dqn_main.cpp:208-212) is not provided by the MI355X drop-in "
+               << "(libdqnhip.so has no CPU backend). Run the reference's own Caffe build for the CPU solver, or start this binary with -gpu=true.";
   std::vector<int> wa = TowerWidths(actor_solver_param_.net_param()), wc = TowerWidths(critic_solver_param_.net_param());
   if (wa.empty()) wa = kDefaultTower;
   if (wc.empty()) wc = kDefaultTower;
@@ -240,6 +246,14 @@ DQN::DQN(caffe::SolverParameter& actor_solver_param, caffe::SolverParameter& cri
   CHECK(dp_ || FLAGS_dp_world == 1) << "-dp_world > 1 needs -dp_rendezvous <path shared by the ranks>";
   if (dp_) {
     CHECK(!FLAGS_pipelined_stats) << "-pipelined_stats is a single-learner option (the data-parallel update reports its own scalars)";
+    // Every agent thread's learner is its own group with its own communicator.  Two communicators whose collectives are
+    // enqueued on ONE device in an order nothing coordinates is what RCCL documents as unsafe, and with a shared replay the
+    // driver's global MTX around every Update() burst (src/dqn_main.cpp:358-362) closes a cross-process cycle (rank 0's agent 0
+    // holds MTX inside a collective whose peer waits for rank 1's MTX, held by agent 1, whose peer waits for rank 0's MTX).
+    // So: a second agent needs its own device, and ShareReplayMemory refuses data-parallel learners (below).
+    CHECK(tid == 0 || FLAGS_hip_agent_device_stride > 0)
+        << "-dp_rendezvous with more than one agent thread needs -hip_agent_device_stride > 0 (one device per agent: each agent's "
+        << "data-parallel group has its own RCCL communicator, and two communicators must not share a device)";
     c.dp_world = FLAGS_dp_world; c.dp_rank = FLAGS_dp_rank;
   }
   DQNHIP_CK(dqnhip_create(&c, &h_));
@@ -248,7 +262,23 @@ DQN::DQN(caffe::SolverParameter& actor_solver_param, caffe::SolverParameter& cri
     const std::string rv = FLAGS_dp_rendezvous + "_agent" + std::to_string(tid);
     LOG(INFO) << "[Agent" << tid << "] data-parallel rank " << FLAGS_dp_rank << " of " << FLAGS_dp_world << " (rendezvous " << rv << ")";
     DQNHIP_CK(dqnhip_dp_init_file(h_, rv.c_str(), FLAGS_dp_half_grads ? DQNHIP_DP_HALF_GRADS : 0, 300));
+    int32_t ver = 0; char path[1024] = {0};
+    if (dqnhip_dp_info(&ver, path, sizeof path) == 0) LOG(INFO) << "[Agent" << tid << "] RCCL " << ver << " from " << path;
   }
+}
+
+// The driver restores / preloads AFTER construction (RestoreActorSolver, RestoreCriticSolver, LoadActorWeights, LoadCriticWeights:
+// src/dqn_main.cpp:268-282), i.e. after dqnhip_dp_init's broadcast.  Ranks that resume from their own -save prefixes would then
+// train diverged replicas on summed gradients, and ranks whose iteration counters differ would leave the max_iter gate of
+// Update() at different updates — one of them waiting in a collective for ever.  So every such call re-arms a broadcast of
+// rank 0's weights, Adam history and iterations, taken at the next Update() / UpdateActorCritic(): the first point every rank
+// passes in the same order.
+void DQN::SyncReplicasIfPending() {
+  if (!dp_ || !dp_sync_pending_) return;
+  LOG(INFO) << "[Agent" << tid_ << "] data-parallel: re-synchronising the replicas from rank 0 (weights, Adam history, iterations)";
+  DQNHIP_CK(dqnhip_dp_broadcast_params(h_, 0));
+  dp_sync_pending_ = false;
+  last_snapshot_iter_ = max_iter();
 }
 
 DQN::~DQN() { DQNHIP_CK(dqnhip_destroy(h_)); }
@@ -270,10 +300,10 @@ void DQN::Benchmark(int iterations) {
   LOG(INFO) << "*** Benchmark ends ***";
 }
 
-void DQN::RestoreActorSolver(const std::string& f) { DQNHIP_CK(dqnhip_solver_restore(h_, DQNHIP_ACTOR, f.c_str())); last_snapshot_iter_ = max_iter(); }
-void DQN::RestoreCriticSolver(const std::string& f) { DQNHIP_CK(dqnhip_solver_restore(h_, DQNHIP_CRITIC, f.c_str())); last_snapshot_iter_ = max_iter(); }
-void DQN::LoadActorWeights(const std::string& f) { DQNHIP_CK(dqnhip_load_caffemodel(h_, DQNHIP_ACTOR, f.c_str())); }
-void DQN::LoadCriticWeights(const std::string& f) { DQNHIP_CK(dqnhip_load_caffemodel(h_, DQNHIP_CRITIC, f.c_str())); }
+void DQN::RestoreActorSolver(const std::string& f) { DQNHIP_CK(dqnhip_solver_restore(h_, DQNHIP_ACTOR, f.c_str())); last_snapshot_iter_ = max_iter(); dp_sync_pending_ = dp_; }
+void DQN::RestoreCriticSolver(const std::string& f) { DQNHIP_CK(dqnhip_solver_restore(h_, DQNHIP_CRITIC, f.c_str())); last_snapshot_iter_ = max_iter(); dp_sync_pending_ = dp_; }
+void DQN::LoadActorWeights(const std::string& f) { DQNHIP_CK(dqnhip_load_caffemodel(h_, DQNHIP_ACTOR, f.c_str())); dp_sync_pending_ = dp_; }
+void DQN::LoadCriticWeights(const std::string& f) { DQNHIP_CK(dqnhip_load_caffemodel(h_, DQNHIP_CRITIC, f.c_str())); dp_sync_pending_ = dp_; }
 void DQN::LoadReplayMemory(const std::string& f) {
   LOG(INFO) << "Loading replay memory from " << f;
   DQNHIP_CK(dqnhip_load_replay_memory(h_, f.c_str()));
@@ -307,8 +337,10 @@ ActorOutput DQN::SelectAction(const InputStates& last_states, const double epsil
 
 std::vector<ActorOutput> DQN::SelectActions(const std::vector<InputStates>& states_batch, const double epsilon) {
   CHECK(epsilon >= 0.0 && epsilon <= 1.0);
-  // (the reference caps the batch at kMinibatchSize, :699, because its MemoryData layer is that wide; the
-  // device path takes any n)
+  // :699 CHECK_LE(states_batch.size(), kMinibatchSize): the MemoryData layer is that wide there; here the cap is kept as the
+  // reference's behaviour with this learner's minibatch, and -select_actions_cap widens it (the device path takes any n)
+  const int cap = FLAGS_select_actions_cap == 0 ? minibatch_ : FLAGS_select_actions_cap;
+  if (cap >= 0) CHECK_LE((int)states_batch.size(), cap);
   std::vector<ActorOutput> out(states_batch.size());
   if (std::uniform_real_distribution<double>(0.0, 1.0)(random_engine) < epsilon) {      // ONE draw per call (:700)
     for (auto& o : out) o = GetRandomActorOutput();
@@ -378,6 +410,7 @@ void DQN::LabelTransitions(std::vector<Transition>& ts) {
 }
 
 void DQN::Update() {
+  SyncReplicasIfPending();       // (before the gates below: they read the iteration counters the broadcast carries)
   // data parallel: every rank's iteration counters advance together, so every rank stops updating at the same update — the
   // driver's own loops only look at max_iter() between bursts of Update() calls (src/dqn_main.cpp:354-362), and a rank left
   // alone in a collective would wait for ever
@@ -418,6 +451,7 @@ std::vector<InputStates> DQN::SampleStatesFromMemory(int n) {
 }
 
 std::pair<float, float> DQN::UpdateActorCritic() {
+  SyncReplicasIfPending();
   if (FLAGS_device_sampling) {
     float loss = 0, avgq = 0;
     if (dp_) { DQNHIP_CK(dqnhip_dp_update(h_, nullptr)); DQNHIP_CK(dqnhip_read_stats(h_, &loss, &avgq)); }
@@ -429,6 +463,7 @@ std::pair<float, float> DQN::UpdateActorCritic() {
 
 std::pair<float, float> DQN::UpdateActorCritic(const std::vector<int>& transitions) {
   CHECK_EQ((int)transitions.size(), minibatch_);
+  SyncReplicasIfPending();
   float loss = 0, avgq = 0;
   static_assert(sizeof(int) == sizeof(int32_t), "indices travel as int32");
   if (dp_) {   // this rank's rows of the global minibatch: phase 0 / all-reduce / phase 1 / all-reduce / phase 2 inside the library
@@ -452,6 +487,11 @@ void DQN::ShareParameters(DQN& other, int num_actor_layers_to_share, int num_cri
 void DQN::ShareLayer(caffe::Layer<float>&, caffe::Layer<float>&) {
   LOG(FATAL) << "DQN::ShareLayer: no caffe::Layer objects exist behind this DQN; use ShareParameters(other, n_actor, n_critic)";
 }
-void DQN::ShareReplayMemory(DQN& other) { DQNHIP_CK(dqnhip_share_replay_memory(h_, other.h_)); }
+void DQN::ShareReplayMemory(DQN& other) {
+  // (see the constructor: a shared replay puts the driver's global MTX around collectives of two independent groups)
+  CHECK(!dp_ && !other.dp_) << "ShareReplayMemory cannot be combined with -dp_rendezvous: the driver holds one mutex around every agent's "
+                            << "Update() burst (src/dqn_main.cpp:358-362) and each agent's updates are collectives of its own group";
+  DQNHIP_CK(dqnhip_share_replay_memory(h_, other.h_));
+}
 
 }  // namespace dqn

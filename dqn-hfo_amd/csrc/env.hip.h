@@ -126,7 +126,7 @@ __device__ __forceinline__ void env_reset_worker(const EnvDev& e, int w, int lan
   }
 }
 
-__global__ void k_env_init(EnvDev e) {
+static __global__ void k_env_init(EnvDev e) {
   extern __shared__ float s_state[];
   env_reset_worker(e, blockIdx.x, threadIdx.x, s_state);
 }
@@ -138,7 +138,7 @@ __global__ void k_env_init(EnvDev e) {
 // (Also computing the first tower layer of the NEXT step here, from the state row the block has just produced — one
 // launch fewer per step — was built and measured: 77 instead of 29 us per step at 64 workers.  64 blocks on 64 CUs
 // each pull all of W0 (512 KB) through one CU's load path, where the separate launch spreads it over 256.)
-__global__ __launch_bounds__(256) void k_env_step(EnvDev e) {
+static __global__ __launch_bounds__(256) void k_env_step(EnvDev e) {
   const float epsilon = e.eps[0];
   extern __shared__ float s_next[];                  // [2 SP]: next state | first state of the next episode
   __shared__ float s_ao[16];
@@ -277,7 +277,7 @@ __device__ __forceinline__ void env_flush_block(const EnvDev& e, const Ring& rin
   __syncthreads();
   if (s_last) env_commit_body(e, ring, const_cast<DevState*>(st));
 }
-__global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const DevState* st, double gamma) {
+static __global__ __launch_bounds__(256) void k_env_flush(EnvDev e, Ring ring, const DevState* st, double gamma) {
   extern __shared__ float sm[];          // [T] mc labels
   env_flush_block(e, ring, st, gamma, blockIdx.x, gridDim.x, sm);
 }
@@ -390,6 +390,6 @@ __device__ __forceinline__ void env_commit_body(const EnvDev& e, const Ring& rin
   st->ring_head = (int)((tail - size) % ring.cap);
   st->ring_size = (int)size;
 }
-__global__ __launch_bounds__(256) void k_env_commit(EnvDev e, Ring ring, DevState* st) { env_commit_body(e, ring, st); }
+static __global__ __launch_bounds__(256) void k_env_commit(EnvDev e, Ring ring, DevState* st) { env_commit_body(e, ring, st); }
 
 }  // namespace dqnhip

@@ -523,7 +523,7 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_nt(HGemmBatch ba
 // fewer LDS fragment bytes and DMA bytes per FLOP than the 64 x 64 wave tile.  Measured (profiles/r03_fp16_gemm_tiles.txt):
 // 607 TF against 668 TF for the eight-wave 256 x 128 tile on two 4096 x 1024 x 1024 problems, 784 against 805 TF at K = 4096
 // (128 x 128 tiles: 833 TF): the plateau is not set by LDS read traffic.  The learner does not launch it.
-__global__ __launch_bounds__(256, 1) void hgemm_nt_tall(HGemmBatch batch) {
+static __global__ __launch_bounds__(256, 1) void hgemm_nt_tall(HGemmBatch batch) {
   int bid;
   const int sel = hg_select(batch, (int)blockIdx.x, bid);
   hgemm_body<2, 2, 0, 2>(batch.g[sel], bid);

@@ -4,77 +4,16 @@
 // as a fixed sequence of gfx950 kernels on one HIP stream with no host sync:
 // nothing crosses PCIe per update except (optionally) B sampled indices in and
 // two floats out.  See DESIGN.md for the data layout and the kernel list.
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
-#include <zlib.h>
-#include <unistd.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <random>
-#include <string>
-#include <vector>
-#include <mutex>
-#include <chrono>
-#include <thread>
-
-#include "../../include/dqnhip.h"
-#include "../../include/dqnhip_env.h"
-#include "env.hip.h"
-#include "gemm_direct.hip.h"
-#include "hgemm.hip.h"
-#include "small_kernels.hip.h"
+// This translation unit: the update itself.  The data-parallel exchange is in learner_dp.hip, acting / replay / parameters /
+// sharing / introspection in learner_io.hip, the env front-end's host side in learner_env.hip (learner_internal.hip.h).
+#include "learner_internal.hip.h"
 
 using namespace dqnhip;
+using namespace dqnhip_host;
 
-namespace {
+namespace dqnhip_host {
 
 thread_local std::string g_err;
-
-int fail(const char* fmt, ...) {
-  char buf[1024];
-  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-  g_err = buf;
-  return 1;
-}
-
-#define HIPCHK(expr)                                                                  \
-  do {                                                                                \
-    hipError_t e__ = (expr);                                                          \
-    if (e__ != hipSuccess)                                                            \
-      return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
-  } while (0)
-#define RC(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
-
-inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-inline size_t round_up_z(size_t x, size_t m) { return (x + m - 1) / m * m; }
-
-constexpr int kMaxL = DQNHIP_MAX_HIDDEN;
-// fp16 learner: ALL wgrads of a net in one launch of 128x128 tiles from this many minibatch rows (the reduction
-// length); below, the per-layer form (a layer's dgrad + wgrad sharing a launch of 64x64 split-K tiles) is as fast or
-// faster (measured at 256 / 512 / 1024 / 2048 / 4096 rows: +0.7 / -6 / -28 / -37 / -68 us per update)
-constexpr int kGroupMinRows = 512;
-
-// Internal parameter arena of one net: tower layer l has W_l[dims[l+1]][kp[l]] (K
-// padded to a multiple of 64 so every GEMM tile is whole) and b_l[dims[l+1]];
-// the head(s) are stored as one [NH][H] matrix (action_layer rows 0-3,
-// actionpara_layer rows 4-9: the Split layer disappears) and bh[16].
-struct NetLayout {
-  int L = 0, in_dim = 0, NH = 0;
-  int dims[kMaxL + 1] = {0};   // logical widths: dims[0] = in_dim
-  int kp[kMaxL + 1] = {0};     // padded widths of each activation panel
-  size_t w_off[kMaxL] = {0}, b_off[kMaxL] = {0}, hw_off = 0, hb_off = 0;
-  size_t arena = 0;            // floats, multiple of 64
-  size_t dense = 0;            // dense (Caffe-order) parameter count
-  // sum-of-squares partial slots
-  int part_off[kMaxL + 1] = {0};  // per tower layer, then head
-  int part_db = 0;                // fp16 learner: first slot of the bias-gradient workgroups
-  int n_part = 0;
-};
 
 void layout_init(NetLayout& l, int in_dim, const dqnhip_config& c, bool actor) {
   l.L = c.num_hidden; l.in_dim = in_dim; l.NH = actor ? kNO : 1;
@@ -103,147 +42,8 @@ void layout_init(NetLayout& l, int in_dim, const dqnhip_config& c, bool actor) {
   l.n_part = part;
 }
 
-struct TimingRec { int family; hipEvent_t a, b; };
-
-}  // namespace
-
-struct dqnhip_learner {
-  dqnhip_config cfg;
-  int B = 0, S = 0, L = 0;
-  NetLayout la, lc;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  // parameter arenas
-  float* w[4] = {nullptr, nullptr, nullptr, nullptr};
-  float* m[2] = {nullptr, nullptr};
-  float* v[2] = {nullptr, nullptr};
-  float* g[2] = {nullptr, nullptr};     // inside grad_base
-  float* grad_base = nullptr; bool own_grad = false;
-  // replay
-  Ring ring{};
-  DevState* st = nullptr;
-  int* done_counter = nullptr;
-  long long h_head = 0, h_size = 0;     // host mirror of (head,size)
-  bool ring_stale = false;              // the device changed (head,size) on its own (env front-end)
-  // sharing (DQN::ShareParameters / ShareReplayMemory, src/dqn.cpp:1036-1083): a sharer keeps
-  // its own allocations and reads the owner's through these
-  dqnhip_learner* ring_owner = nullptr; // whose ring / (head,size) this learner uses (nullptr: own)
-  dqnhip_learner* w_owner = nullptr;    // owner of the shared first layers
-  size_t shared_fl[2] = {0, 0};         // arena floats [0, shared_fl) of actor / critic (+targets) live in w_owner
-  int sharers = 0;                      // learners that reference this one
-  bool ring_shared = false;             // more than one learner uses this ring: order users across streams
-  hipEvent_t ring_ev = nullptr; hipStream_t ring_last = nullptr; bool ring_ev_valid = false;
-  std::mutex ring_mu;
-  int h_actor_iter = 0, h_critic_iter = 0;
-  unsigned long long sample_states_calls = 0;
-  // native data parallelism (dqnhip_dp_*): one RCCL communicator per learner
-  ncclComm_t comm = nullptr;
-  bool dp_per_layer = false;            // bucket the gradient all-reduce per layer on comm_stream
-  bool dp_half = false;                 // gradients cross the links as bf16 (half the bytes); [loss, q, flag] tails stay fp32
-  // DQNHIP_DP_SHARD_OPT: reduce-scatter -> clip + Adam + soft update on this rank's 1/N slice of each arena -> all-gather of
-  // the updated online and target weights (m, v of the other slices go stale until dqnhip_dp_gather_state)
-  bool dp_shard = false;
-  float* shard_total = nullptr;         // dqnhip_apply_update_sharded: the group's sum of squares, accumulated rank by rank
-  bool shard_stale = false;             // a sharded update ran since the last dqnhip_dp_gather_state: m, v of foreign slices are stale
-  uint16_t* g16[2] = {nullptr, nullptr};   // bf16 transfer image of each gradient arena (dp_half)
-  float* dp_tails = nullptr;            // dp_half: {critic tail[4], actor tail[4]}, one fp32 all-reduce with the actor's gradients
-  hipStream_t comm_stream = nullptr;
-  hipEvent_t comm_ev[2] = {nullptr, nullptr};
-  hipGraphExec_t dp_graph = nullptr;    // the whole data-parallel update (collectives included), captured
-  bool dp_graph_failed = false;
-  hipGraphExec_t dp_graph_n = nullptr;  // kMultiU of them (dqnhip_dp_update_n)
-  bool dp_graph_n_failed = false;
-  int next_phase = 0;                   // dqnhip_update_phase order check (0: an update may start)
-  // minibatch panels / activations: pass 0 AT, 1 A, 2 CT, 3 C1, 4 C2
-  float* Xa_s = nullptr; float* Xa_n = nullptr; float* Xc_tr = nullptr; float* Xc_pl = nullptr; float* Xc_nx = nullptr;
-  float* act[5][kMaxL + 1] = {{nullptr}};
-  float* dZa[kMaxL + 1] = {nullptr};
-  float* dZc[kMaxL + 1] = {nullptr};
-  float *mb_reward = nullptr, *mb_mc = nullptr, *mb_term = nullptr;
-  int* mb_idx = nullptr;
-  int* idx_pinned = nullptr;
-  const int* idx_pinned_dev = nullptr;  // device alias of idx_pinned: the gather reads explicit indices straight from host memory (no H2D copy)
-  float* stats_dev = nullptr;           // device alias of pinned_stats: the update's last block writes {loss, avg_q, flags} there
-  float *aout_t16 = nullptr, *aout16 = nullptr, *dA16 = nullptr;
-  float *q_t = nullptr, *q1 = nullptr, *q2 = nullptr, *y = nullptr, *dq = nullptr;
-  float* loss_partial = nullptr; double* q_partial = nullptr; int n_head_blocks = 0;
-  float* part[2] = {nullptr, nullptr};  // GEMM-epilogue sumsq partials per net
-  float* part_dp = nullptr; int n_part_dp = 0;
-  float* head_slab = nullptr; int* head_ticket = nullptr;   // k_head_bwd cross-block reduction
-  float* head_slab2 = nullptr;                               // k_head_bwd_big row-chunk slabs (minibatch >= 1024)
-  // mixed precision (cfg.precision == DQNHIP_FP16): ONE fp16 mirror of each weight arena and batch-major fp16
-  // activation / gradient panels; the dgrad and wgrad GEMMs read them reduction-major (hgemm.hip.h), so no
-  // transposed copy of anything exists
-  bool fp16 = false;
-  float ls_c = 1.f, ls_q = 1.f, ls_a = 1.f;  // static loss scales: critic step, dQ/da pass, actor step
-  int k16[2][kMaxL + 1] = {{0}};             // fp16 panel widths per net kind (k16[.][0] = in_dim rounded to 128)
-  h16* w16a[4] = {nullptr, nullptr, nullptr, nullptr};   // fp16 mirror of each weight arena (written by the Adam pass)
-  h16* w16[4][kMaxL] = {{nullptr}};          // = w16a[net] + w_off[i]: [N_out][kp]
-  h16* act16[5][kMaxL + 1] = {{nullptr}};    // [B][k16]
-  h16* dZ16[2][kMaxL + 1] = {{nullptr}};     // [B][k16]   per net kind
-  bool w16_dirty[4] = {true, true, true, true};
-  std::vector<void*> allocs16;
-  // host-staging for add_transitions / acting
-  void* stage_dev = nullptr; size_t stage_bytes = 0;
-  float* act_buf = nullptr; size_t act_floats = 0;
-  float* pinned_stats = nullptr;
-  // timing
-  bool timing = false;
-  std::vector<TimingRec> recs;
-  // graph
-  int cap_u = -1;              // while capturing a multi-update graph: the position of the update being captured (else -1)
-  hipGraphExec_t graph_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0]: device-sampled, [1]: explicit idx (pinned buffer -> memcpy node), [2], [3]: explicit idx in the pipelined slots, [4]: kMultiU device-sampled updates (dqnhip_update_async_n)
-  bool graph_failed = false;
-  // dqnhip_update_pipelined
-  hipEvent_t pipe_ev[2] = {nullptr, nullptr};
-  int* pipe_idx_dev[2] = {nullptr, nullptr}; int* pipe_idx_pinned[2] = {nullptr, nullptr};
-  float* pipe_stats[2] = {nullptr, nullptr};
-  unsigned long long pipe_count = 0;
-};
-
-namespace {
-
-using H = dqnhip_learner;
-
-// ring owner / weight views under sharing
-inline H* RO(H* h) { return h->ring_owner ? h->ring_owner : h; }
-inline const H* RO(const H* h) { return h->ring_owner ? h->ring_owner : h; }
-inline float* wat(const H* h, int net, size_t off) {
-  return ((off < h->shared_fl[net & 1]) ? h->w_owner->w[net] : h->w[net]) + off;
-}
-
-// Orders the users of a SHARED ring across their streams in host-call order: each user waits
-// for the previous user's completion event.  No-op (no lock, no event) for a private ring.
-struct RingUse {
-  H* o; hipStream_t st; bool on;
-  RingUse(H* h) : o(RO(h)), st(h->stream), on(RO(h)->ring_shared) {
-    if (!on) return;
-    o->ring_mu.lock();
-    if (o->ring_ev_valid && o->ring_last != st) hipStreamWaitEvent(st, o->ring_ev, 0);
-  }
-  ~RingUse() {
-    if (!on) return;
-    hipEventRecord(o->ring_ev, st); o->ring_last = st; o->ring_ev_valid = true;
-    o->ring_mu.unlock();
-  }
-};
-
-const char* kFamily[] = {"gemm_fwd_lds_4x2", "gemm_dgrad", "gemm_wgrad", "adam", "gemm_bwd_pair", "gemm_fwd_lds_2x2", "gemm_fwd_direct",
-                         "hgemm_fwd", "hgemm_dgrad", "hgemm_wgrad"};
-constexpr int kNumFamily = 10;
-
-// Timing mode: the NEXT kernel launch (through direct_launch / adam_launch) is bracketed by the
-// dispatch packet's own timestamps (hipExtLaunchKernelGGL start/stop events).
-struct ScopedTiming {
-  ScopedTiming(H* h, int fam, hipStream_t) {
-    if (h->timing) {
-      hipEvent_t a = nullptr, b = nullptr;
-      hipEventCreate(&a); hipEventCreate(&b);
-      launch_timer().start = a; launch_timer().stop = b;
-      h->recs.push_back({fam, a, b});
-    }
-  }
-};
+const char* const kFamily[] = {"gemm_fwd_lds_4x2", "gemm_dgrad", "gemm_wgrad", "adam", "gemm_bwd_pair", "gemm_fwd_lds_2x2", "gemm_fwd_direct",
+                               "hgemm_fwd", "hgemm_dgrad", "hgemm_wgrad"};
 
 // ---- dense (Caffe order) <-> internal arena ----------------------------------
 void dense_to_arena(const NetLayout& l, const float* dense, std::vector<float>& arena) {
@@ -286,7 +86,6 @@ void arena_to_dense(const NetLayout& l, const std::vector<float>& arena, float* 
   }
 }
 
-const NetLayout& layout_of(const H* h, int net) { return (net & 1) ? h->lc : h->la; }
 
 int validate(const dqnhip_config* c) {
   if (!c) return fail("config is null");
@@ -308,12 +107,8 @@ int validate(const dqnhip_config* c) {
   return 0;
 }
 
-size_t grad_arena_floats(const NetLayout& la, const NetLayout& lc) { return la.arena + 64 + lc.arena + 64; }
 
 // ---- forward / backward building blocks ----------------------------------------
-
-// seed_w / seed_out: the TOP layer's launch also writes the dq = -1 pass's tower-top gradient (GemmProblem::seed_w)
-struct FwdPass { int net; const NetLayout* l; float** act; const float* seed_w = nullptr; float* seed_out = nullptr; };
 
 // One tower layer forward for up to kMaxGroup passes of identical shape.
 int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, int i) {
@@ -366,8 +161,6 @@ int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows) 
 // first layer's dgrad computes just the 16-column tiles that cover them.
 // RCCL sum all-reduce of one slice of a gradient arena on the communication stream, ordered after
 // everything enqueued on `st` so far (per-layer bucketing; defined with dqnhip_dp_*)
-int dp_reduce_slice(H* h, hipStream_t st, int net, size_t off, size_t count);
-
 // does layer i's backward (dgrad + wgrad) take the side-by-side pair launch (small minibatches / narrow layers)?
 inline bool bwd_layer_is_pair(const NetLayout& l, int i, int rows) {
   const long tiles = (long)(l.kp[i] / 64) * (rows / 16) + (long)(l.kp[i] / 64) * (l.dims[i + 1] / 64);
@@ -477,17 +270,6 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
   return 0;
 }
 
-template <int NH, int MODE>
-int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nullptr) {
-  HeadArgs2 a2{}; a2.p[0] = a; if (b) a2.p[1] = *b;
-  if (NH > 1 && a.rows >= 1024 && a.H <= 1024 && a.H % 4 == 0)   // (single-head: the block-per-row form measured faster, 6.6 vs 8.8 us)
-    hipLaunchKernelGGL((k_head_fwd_rows<NH, MODE>), dim3(256, b ? 2 : 1), dim3(256), 0, st, a2);
-  else
-    hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(std::min(a.rows, 1024), b ? 2 : 1), dim3(256), 0, st, a2);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
 // rows >= 1024: the bandwidth-tiled kernel pair; optionally emits the scaled fp16 panels itself
 template <int NH>
 int head_backward_big(H* h, hipStream_t st, HeadBwdArgs a, h16* dZ16, float scale16) {
@@ -523,11 +305,6 @@ int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
   return 0;
 }
 
-constexpr int kMultiU = 16;    // updates per replay of the multi-update graph (dqnhip_update_async_n; see capture_graph)
-// Philox key of SampleTransitionsFromMemory: cfg.seed on rank 0 (what oracle/c_oracle.philox_indices
-// reproduces); data-parallel ranks get distinct streams from the SAME cfg.seed, so that the weight
-// initialisation (also keyed by cfg.seed) stays identical across the group
-inline uint64_t sample_key(const H* h) { return (uint64_t)h->cfg.seed + 0x9E3779B97F4A7C15ull * (uint64_t)h->cfg.dp_rank; }
 // The gather of one update (src/dqn.cpp:846-887).  pos: -1 outside multi-update graphs; else the update's position in the
 // graph being captured (0: a launch of its own that also stores DevState::gbase; k >= 1: rides in update k-1's last launch)
 GatherArgs gather_args(H* h, const int* idx_dev, int pos) {
@@ -551,8 +328,8 @@ GatherArgs gather_args(H* h, const int* idx_dev, int pos) {
 
 // clip + Adam + Net::Update + soft target update over arena floats [begin, end)
 // corr_pre: the update's first launch (k_gather) has left this step's bias correction in DevState::adam_corr
-int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick = nullptr,
-                bool corr_pre = true) {
+int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick,
+                bool corr_pre) {
   AdamArgs a{};
   const int slot = h->cap_u > 0 ? (h->cap_u & 1) : 0;      // DevState::adam_corr
   a.corr_pre = corr_pre ? &h->st->adam_corr[slot][net] : nullptr; a.soft_pre = corr_pre ? &h->st->soft_now[slot] : nullptr;
@@ -596,7 +373,7 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
 
 // clip norm of the REDUCED gradient (data parallel); under DQNHIP_DP_HALF_GRADS the same pass widens the bf16
 // transfer image back into the fp32 arena
-int sumsq_launch(H* h, int net, size_t begin = 0, size_t end = 0) {
+int sumsq_launch(H* h, int net, size_t begin, size_t end) {
   const NetLayout& l = layout_of(h, net);
   if (end == 0) end = l.arena;
   if (h->dp_half) hipLaunchKernelGGL(k_sumsq_bf16, dim3(h->n_part_dp), dim3(256), 0, h->stream, (const uint16_t*)h->g16[net] + begin, h->g[net] + begin, (end - begin) / 4, h->part_dp);
@@ -604,14 +381,7 @@ int sumsq_launch(H* h, int net, size_t begin = 0, size_t end = 0) {
   HIPCHK(hipGetLastError());
   return 0;
 }
-// this rank's slice of a net's arena under the sharded optimiser: floats [lo, hi)
-inline void shard_range(const H* h, int net, size_t& lo, size_t& hi, int rank = -1) {
-  const size_t slice = layout_of(h, net).arena / (size_t)h->cfg.dp_world;
-  const size_t r = (size_t)(rank < 0 ? h->cfg.dp_rank : rank);
-  lo = r * slice; hi = lo + slice;
-}
 // the optimiser step of one net inside a data-parallel update (phase 1: critic, phase 2: actor + bookkeeping)
-int dp_allgather_weights(H* h, int net);
 int dp_optimiser_step(H* h, hipStream_t st, int net, float* tail, const TickArgs* tick) {
   const NetLayout& l = layout_of(h, net);
   if (h->dp_shard) {
@@ -1060,7 +830,25 @@ int ensure_act(H* h, int rows) {
   return 0;
 }
 
-}  // namespace
+
+void drop_graphs(H* h) {
+  for (auto& g : h->graph_exec) if (g) { hipGraphExecDestroy(g); g = nullptr; }
+  if (h->dp_graph) { hipGraphExecDestroy(h->dp_graph); h->dp_graph = nullptr; }
+  if (h->dp_graph_n) { hipGraphExecDestroy(h->dp_graph_n); h->dp_graph_n = nullptr; }
+  h->dp_graph_failed = false; h->dp_graph_n_failed = false; h->graph_failed = false;
+}
+int to_bf16_launch(H* h, int net) {
+  hipLaunchKernelGGL(k_to_bf16, dim3(1024), dim3(256), 0, h->stream, (const float*)h->g[net], layout_of(h, net).arena / 4, h->g16[net]);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int shard_scal_launch(H* h, float* tail) {
+  hipLaunchKernelGGL(k_shard_scal, dim3(1), dim3(256), 0, h->stream, (const float*)h->part_dp, h->n_part_dp, tail);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dqnhip_host
 
 // ================================ C ABI =========================================
 extern "C" {
@@ -1102,17 +890,6 @@ size_t dqnhip_grad_arena_bytes(const dqnhip_config* cfg) {
 }
 
 static int create_impl(H* h, const dqnhip_config* cfg);
-}  // extern "C"
-namespace { int dp_destroy_impl(H* h, bool keep_learner); }
-extern "C" {
-// every captured launch sequence of this learner: the update graphs AND the data-parallel one (it bakes in the Ring
-// struct k_gather takes by value and the weight / shared-prefix pointers, exactly as the others do)
-static void drop_graphs_fwd(H* h) {
-  for (auto& g : h->graph_exec) if (g) { hipGraphExecDestroy(g); g = nullptr; }
-  if (h->dp_graph) { hipGraphExecDestroy(h->dp_graph); h->dp_graph = nullptr; }
-  if (h->dp_graph_n) { hipGraphExecDestroy(h->dp_graph_n); h->dp_graph_n = nullptr; }
-  h->dp_graph_failed = false; h->dp_graph_n_failed = false; h->graph_failed = false;
-}
 
 int dqnhip_create(const dqnhip_config* cfg, dqnhip_handle* out) {
   if (!out) return fail("out is null");
@@ -1639,1227 +1416,4 @@ int dqnhip_benchmark_blocking(dqnhip_handle h, int32_t warmup, int32_t iteration
   return 0;
 }
 
-// ---- native data parallelism: RCCL over xGMI inside the library --------------------
-// The reference has no collective (threads + one mutex, src/dqn_main.cpp:62-63, 359-363).  Here a
-// data-parallel group is one learner per GPU; each rank gathers its own minibatch slice from its
-// own replay shard, and the update has exactly two exchange points (the actor step reads the
-// UPDATED critic, src/dqn.cpp:904 -> 914): a sum all-reduce of the critic gradient arena after
-// phase 0 and of the actor's after phase 1, in place, on the learner's stream — no host sync, no
-// Python in the loop.  (q - y)/B uses the global B, the actor gradient is an un-normalised sum
-// (src/dqn.cpp:918-921), the clip norm is recomputed on the reduced gradient: every rank applies
-// the identical Adam step.  [loss_sum, q_sum] ride in the 4-float arena tails.
-
-#define NCCLCHK(expr)                                                                     \
-  do {                                                                                    \
-    ncclResult_t r__ = (expr);                                                            \
-    if (r__ != ncclSuccess)                                                               \
-      return fail("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r__), __FILE__, __LINE__); \
-  } while (0)
-
-}  // extern "C"
-
-namespace {
-int dp_broadcast(H* h, int root) {
-  for (int net = 0; net < 4; ++net) NCCLCHK(ncclBroadcast(h->w[net], h->w[net], layout_of(h, net).arena, ncclFloat, root, h->comm, h->stream));
-  for (int net = 0; net < 2; ++net) {
-    NCCLCHK(ncclBroadcast(h->m[net], h->m[net], layout_of(h, net).arena, ncclFloat, root, h->comm, h->stream));
-    NCCLCHK(ncclBroadcast(h->v[net], h->v[net], layout_of(h, net).arena, ncclFloat, root, h->comm, h->stream));
-  }
-  NCCLCHK(ncclBroadcast(&h->st->actor_iter, &h->st->actor_iter, 2, ncclInt32, root, h->comm, h->stream));
-  int it[2];
-  HIPCHK(hipMemcpyAsync(it, &h->st->actor_iter, sizeof it, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->h_actor_iter = it[0]; h->h_critic_iter = it[1];
-  for (int net = 0; net < 4; ++net) h->w16_dirty[net] = true;
-  return 0;
-}
-
-// per-layer bucket: floats [off, off + count) of net's gradient arena, on the communication stream, ordered after
-// everything enqueued on `st` so far
-int dp_reduce_slice(H* h, hipStream_t st, int net, size_t off, size_t count) {
-  HIPCHK(hipEventRecord(h->comm_ev[0], st));
-  HIPCHK(hipStreamWaitEvent(h->comm_stream, h->comm_ev[0], 0));
-  float* ptr = h->g[net] + off;
-  NCCLCHK(ncclAllReduce(ptr, ptr, count, ncclFloat, ncclSum, h->comm, h->comm_stream));
-  return 0;
-}
-
-// all-gather (in place) of what the sharded optimiser step of `net` wrote on each rank's slice: the online weights and the
-// target's — the targets move on every update (SoftUpdateNet, src/dqn.cpp:967-970), so they cannot be left to an occasional
-// broadcast — and, for the fp16 learner, the two fp16 mirrors the GEMMs read.  m and v stay per slice.
-int dp_allgather_weights(H* h, int net) {
-  size_t lo, hi; shard_range(h, net, lo, hi);
-  const size_t n = hi - lo;
-  hipStream_t st = h->stream;
-  ncclResult_t r = ncclGroupStart();
-  if (r == ncclSuccess) r = ncclAllGather(h->w[net] + lo, h->w[net], n, ncclFloat, h->comm, st);
-  if (r == ncclSuccess) r = ncclAllGather(h->w[net + 2] + lo, h->w[net + 2], n, ncclFloat, h->comm, st);
-  if (h->fp16) {
-    if (r == ncclSuccess) r = ncclAllGather(h->w16a[net] + lo, h->w16a[net], n, ncclHalf, h->comm, st);
-    if (r == ncclSuccess) r = ncclAllGather(h->w16a[net + 2] + lo, h->w16a[net + 2], n, ncclHalf, h->comm, st);
-  }
-  const ncclResult_t r2 = ncclGroupEnd();
-  if (r != ncclSuccess || r2 != ncclSuccess) return fail("ncclAllGather (sharded optimiser, net %d) failed: %s", net, ncclGetErrorString(r != ncclSuccess ? r : r2));
-  return 0;
-}
-
-// the exchange step after phase 0 (net = critic) / phase 1 (net = actor)
-int dp_exchange(H* h, int net) {
-  const NetLayout& l = layout_of(h, net);
-  hipStream_t st = h->stream;
-  if (h->dp_shard) {
-    // reduce-scatter: rank r ends up with floats [r, r + 1) * arena / N of the summed gradient (in place; bf16 on the links
-    // under DQNHIP_DP_HALF_GRADS), takes the sum of squares of that slice (the same pass widens a bf16 slice back to fp32),
-    // and the ranks all-reduce the 4-float tail {loss, q, target flag, sum of squares}: the clip norm every rank's Adam uses
-    size_t lo, hi; shard_range(h, net, lo, hi);
-    float* tail = h->dp_tails + (net == DQNHIP_CRITIC ? 0 : 4);
-    if (h->dp_half) {
-      hipLaunchKernelGGL(k_to_bf16, dim3(1024), dim3(256), 0, st, (const float*)h->g[net], l.arena / 4, h->g16[net]);
-      HIPCHK(hipGetLastError());
-      NCCLCHK(ncclReduceScatter(h->g16[net], h->g16[net] + lo, hi - lo, ncclBfloat16, ncclSum, h->comm, st));
-    } else {
-      NCCLCHK(ncclReduceScatter(h->g[net], h->g[net] + lo, hi - lo, ncclFloat, ncclSum, h->comm, st));
-    }
-    RC(sumsq_launch(h, net, lo, hi));
-    hipLaunchKernelGGL(k_shard_scal, dim3(1), dim3(256), 0, st, (const float*)h->part_dp, h->n_part_dp, tail);
-    HIPCHK(hipGetLastError());
-    NCCLCHK(ncclAllReduce(tail, tail, 4, ncclFloat, ncclSum, h->comm, st));
-    return 0;
-  }
-  if (h->dp_half) {
-    // bf16 image of the arena -> sum all-reduce -> (phase 1 / 2 widen it again inside k_sumsq_bf16).  The fp32
-    // tails of both nets travel once, with the actor's gradients (nothing reads them before the tick of phase 2).
-    hipLaunchKernelGGL(k_to_bf16, dim3(1024), dim3(256), 0, st, (const float*)h->g[net], l.arena / 4, h->g16[net]);
-    HIPCHK(hipGetLastError());
-    if (net == DQNHIP_CRITIC) {
-      NCCLCHK(ncclAllReduce(h->g16[net], h->g16[net], l.arena, ncclBfloat16, ncclSum, h->comm, st));
-    } else {
-      // one grouped call: the actor's bf16 image and the 8 fp32 tail floats (a failure inside the group still closes it)
-      NCCLCHK(ncclGroupStart());
-      ncclResult_t r1 = ncclAllReduce(h->g16[net], h->g16[net], l.arena, ncclBfloat16, ncclSum, h->comm, st);
-      ncclResult_t r2 = r1 == ncclSuccess ? ncclAllReduce(h->dp_tails, h->dp_tails, 8, ncclFloat, ncclSum, h->comm, st) : r1;
-      ncclResult_t r3 = ncclGroupEnd();
-      if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess)
-        return fail("grouped ncclAllReduce (actor gradients + tails) failed: %s", ncclGetErrorString(r1 != ncclSuccess ? r1 : r2 != ncclSuccess ? r2 : r3));
-    }
-  } else if (h->dp_per_layer) {
-    // the tower slices are already in flight on comm_stream; what is left is the head + tail slice, then the main
-    // stream waits for the communication stream
-    RC(dp_reduce_slice(h, st, net, l.hw_off, l.arena + 4 - l.hw_off));
-    HIPCHK(hipEventRecord(h->comm_ev[1], h->comm_stream));
-    HIPCHK(hipStreamWaitEvent(st, h->comm_ev[1], 0));
-  } else {
-    NCCLCHK(ncclAllReduce(h->g[net], h->g[net], l.arena + 4, ncclFloat, ncclSum, h->comm, st));
-  }
-  return 0;
-}
-
-// phase 0, exchange, phase 1, exchange, phase 2 on the learner's stream; no host sync (capturable)
-int dp_sequence(H* h, const int* idx_dev) {
-  RC(run_phase(h, 0, idx_dev));
-  RC(dp_exchange(h, DQNHIP_CRITIC));
-  RC(run_phase(h, 1, nullptr));
-  RC(dp_exchange(h, DQNHIP_ACTOR));
-  return run_phase(h, 2, nullptr);
-}
-
-// multi: kMultiU updates in one graph, each gather riding in the previous update's last launch (capture_graph)
-int dp_capture(H* h, bool multi = false) {
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t* out = multi ? &h->dp_graph_n : &h->dp_graph;
-  HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-  const int it_a = h->h_actor_iter, it_c = h->h_critic_iter;
-  int rc = 0;
-  for (int u = 0; u < (multi ? kMultiU : 1) && !rc; ++u) {
-    h->cap_u = multi ? u : -1;
-    rc = dp_sequence(h, nullptr);
-  }
-  h->cap_u = -1;
-  h->h_actor_iter = it_a; h->h_critic_iter = it_c;   // capture does not execute
-  hipError_t e = hipStreamEndCapture(h->stream, &graph);
-  if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-  if (e != hipSuccess) return fail("hipStreamEndCapture (dp): %s", hipGetErrorString(e));
-  e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
-  if (e != hipSuccess) { *out = nullptr; return fail("hipGraphInstantiate (dp): %s", hipGetErrorString(e)); }
-  return 0;
-}
-
-// ---- file rendezvous (one node, no launcher support) ----------------------------------------------
-// Rank r > 0 publishes a request <path>.req<r> holding a fresh random nonce and re-publishes it if it disappears;
-// rank 0 first removes whatever an earlier job left behind (<path>, <path>.req*), waits for the world-1 requests,
-// and publishes <path> = {id, nonce_1 .. nonce_{world-1}}.  A waiter accepts <path> only if it carries ITS nonce:
-// a file left by an earlier job, or written before this waiter existed, can never hand it a dead id.  After the
-// group is up (ncclCommInitRank is collective: every rank has read the file by then) rank 0 removes all of it,
-// so the same path serves the next group.
-struct RvFile { unsigned char id[DQNHIP_DP_ID_BYTES]; uint64_t nonce[64]; };
-
-bool rv_write(const std::string& path, const void* data, size_t n) {
-  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-  FILE* f = fopen(tmp.c_str(), "wb");
-  if (!f) return false;
-  const bool ok = fwrite(data, 1, n, f) == n;
-  fclose(f);
-  if (!ok || rename(tmp.c_str(), path.c_str())) { unlink(tmp.c_str()); return false; }
-  return true;
-}
-bool rv_read(const std::string& path, void* data, size_t n) {
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) return false;
-  const size_t got = fread(data, 1, n, f);
-  fclose(f);
-  return got == n;
-}
-}  // namespace
-
-extern "C" {
-
-int dqnhip_dp_unique_id(void* id_out, size_t bytes) {
-  if (!id_out) return fail("null argument");
-  if (bytes != sizeof(ncclUniqueId)) return fail("dp_unique_id: buffer must be DQNHIP_DP_ID_BYTES = %zu bytes", sizeof(ncclUniqueId));
-  ncclUniqueId id;
-  NCCLCHK(ncclGetUniqueId(&id));
-  memcpy(id_out, &id, sizeof id);
-  return 0;
-}
-
-int dqnhip_dp_rendezvous_file(const char* path, int32_t rank, int32_t world, int32_t timeout_s, void* id, size_t bytes) {
-  if (!path || !id) return fail("null argument");
-  if (bytes != DQNHIP_DP_ID_BYTES) return fail("dp_rendezvous_file: id must be DQNHIP_DP_ID_BYTES bytes");
-  if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail("dp_rendezvous_file: bad rank %d / world %d (<= 64)", rank, world);
-  const std::string p(path);
-  const auto t0 = std::chrono::steady_clock::now();
-  auto expired = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s; };
-  auto nap = [] { std::this_thread::sleep_for(std::chrono::milliseconds(10)); };
-  if (rank == 0) {
-    unlink(p.c_str());
-    for (int r = 1; r < world; ++r) unlink((p + ".req" + std::to_string(r)).c_str());
-    RvFile f{};
-    memcpy(f.id, id, sizeof f.id);
-    for (int r = 1; r < world; ++r) {
-      const std::string rq = p + ".req" + std::to_string(r);
-      while (!rv_read(rq, &f.nonce[r], sizeof(uint64_t)) || f.nonce[r] == 0) {
-        if (expired()) return fail("dp_rendezvous_file: rank 0 timed out after %d s waiting for rank %d (%s)", timeout_s, r, rq.c_str());
-        nap();
-      }
-    }
-    if (!rv_write(p, &f, sizeof f)) return fail("dp_rendezvous_file: cannot publish %s", path);
-    return 0;
-  }
-  std::random_device rd;
-  uint64_t nonce = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)getpid() << 17) ^
-                   (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
-  if (nonce == 0) nonce = 1;
-  const std::string rq = p + ".req" + std::to_string(rank);
-  for (;;) {
-    uint64_t seen = 0;
-    if (!rv_read(rq, &seen, sizeof seen) || seen != nonce) {            // not there (yet, or rank 0 cleaned up): (re)publish
-      if (!rv_write(rq, &nonce, sizeof nonce)) return fail("dp_rendezvous_file: cannot write %s", rq.c_str());
-    }
-    RvFile f{};
-    if (rv_read(p, &f, sizeof f) && f.nonce[rank] == nonce) { memcpy(id, f.id, sizeof f.id); return 0; }
-    if (expired()) return fail("dp_rendezvous_file: rank %d timed out after %d s waiting for %s", rank, timeout_s, path);
-    nap();
-  }
-}
-
-int dqnhip_dp_rendezvous_cleanup(const char* path, int32_t world) {
-  if (!path) return fail("null argument");
-  const std::string p(path);
-  unlink(p.c_str());
-  for (int r = 1; r < world; ++r) unlink((p + ".req" + std::to_string(r)).c_str());
-  return 0;
-}
-
-int dqnhip_dp_init(dqnhip_handle h, const void* id, size_t bytes, int32_t flags) {
-  if (!h || !id) return fail("null argument");
-  if (bytes != sizeof(ncclUniqueId)) return fail("dp_init: id must be DQNHIP_DP_ID_BYTES = %zu bytes", sizeof(ncclUniqueId));
-  if (h->comm) return fail("dp_init: this learner already has a communicator");
-  if (h->w_owner || h->sharers) return fail("dp_init: learners that share layers cannot join a data-parallel group");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  ncclUniqueId uid; memcpy(&uid, id, sizeof uid);
-  NCCLCHK(ncclCommInitRank(&h->comm, h->cfg.dp_world, uid, h->cfg.dp_rank));
-  h->dp_half = (flags & DQNHIP_DP_HALF_GRADS) != 0;
-  h->dp_shard = (flags & DQNHIP_DP_SHARD_OPT) != 0;
-  if (h->dp_shard)
-    for (int net = 0; net < 2; ++net)
-      if (layout_of(h, net).arena % ((size_t)4 * h->cfg.dp_world)) {
-        ncclCommDestroy(h->comm); h->comm = nullptr; h->dp_half = h->dp_shard = false;
-        return fail("dp_init: DQNHIP_DP_SHARD_OPT needs a parameter arena (%zu floats) divisible by 4 x dp_world = %d", layout_of(h, net).arena, 4 * h->cfg.dp_world);
-      }
-  // per-layer buckets need each layer's dW AND db final when its backward launch has run: true for the fp32 path;
-  // the fp16 path produces all wgrads of a net in one launch at the end and keeps one collective per net
-  h->dp_per_layer = (flags & DQNHIP_DP_PER_LAYER) != 0 && !h->fp16 && !h->dp_half && !h->dp_shard;
-  HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-  for (auto& e : h->comm_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  if (h->dp_half)
-    for (int net = 0; net < 2; ++net) HIPCHK(hipMalloc(&h->g16[net], layout_of(h, net).arena * sizeof(uint16_t)));
-  if (h->dp_half || h->dp_shard) {
-    HIPCHK(hipMalloc(&h->dp_tails, 8 * sizeof(float)));
-    HIPCHK(hipMemsetAsync(h->dp_tails, 0, 8 * sizeof(float), h->stream));
-  }
-  drop_graphs_fwd(h);
-  // replicas start from rank 0's state: weights of the four nets, Adam history, iterations
-  return dp_broadcast(h, 0);
-}
-
-// Single-node rendezvous without any launcher support (dqnhip_dp_rendezvous_file), then dqnhip_dp_init.
-// (A launcher that has its own channel — MPI, torch.distributed's store — passes the id to dqnhip_dp_init directly.)
-int dqnhip_dp_init_file(dqnhip_handle h, const char* path, int32_t flags, int32_t timeout_s) {
-  if (!h || !path) return fail("null argument");
-  ncclUniqueId uid;
-  if (h->cfg.dp_rank == 0) RC(dqnhip_dp_unique_id(&uid, sizeof uid));
-  RC(dqnhip_dp_rendezvous_file(path, h->cfg.dp_rank, h->cfg.dp_world, timeout_s, &uid, sizeof uid));
-  const int rc = dqnhip_dp_init(h, &uid, sizeof uid, flags);
-  // ncclCommInitRank is collective: once it has returned on rank 0 every rank has read the file
-  if (h->cfg.dp_rank == 0) { const std::string msg = g_err; dqnhip_dp_rendezvous_cleanup(path, h->cfg.dp_world); g_err = msg; }
-  return rc;
-}
-
-int dqnhip_dp_broadcast_params(dqnhip_handle h, int32_t root) {
-  if (!h) return fail("null handle");
-  if (!h->comm) return fail("dp_broadcast_params: no communicator (call dqnhip_dp_init first)");
-  if (root < 0 || root >= h->cfg.dp_world) return fail("bad root %d", root);
-  HIPCHK(hipSetDevice(h->cfg.device));
-  return dp_broadcast(h, root);
-}
-
-int dqnhip_dp_update(dqnhip_handle h, const int32_t* idx_host) {
-  if (!h) return fail("null handle");
-  if (!h->comm) return fail("dp_update: no communicator (call dqnhip_dp_init first)");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  if (h->next_phase != 0) return fail("dqnhip_dp_update: a phased update is in progress (next phase %d)", h->next_phase);
-  RingUse ring_use(h);
-  RC(sync_dirty16(h));
-  if (h->dp_shard) h->shard_stale = true;
-  // cfg.use_graph: the whole update — 30-40 launches and both collectives — replays as ONE hipGraph (every rank
-  // captures the same sequence).  Explicit indices, kernel timing, or a capture that RCCL refuses: eager.
-  if (h->cfg.use_graph && !idx_host && !h->timing && !h->dp_graph_failed) {
-    if (RO(h)->h_size < 1) RC(refresh_ring(h));
-    if (RO(h)->h_size < 1) return fail("replay memory is empty");
-    if (!h->dp_graph && dp_capture(h)) h->dp_graph_failed = true;
-    if (h->dp_graph) {
-      HIPCHK(hipGraphLaunch(h->dp_graph, h->stream));
-      h->h_actor_iter += 1; h->h_critic_iter += 1;
-      return 0;
-    }
-  }
-  const int* idx_dev = nullptr;
-  RC(stage_indices(h, idx_host, &idx_dev));
-  return dp_sequence(h, idx_dev);
-}
-
-// n data-parallel updates with on-device sampling (dqnhip_update_async_n for a group: every rank calls it with the same n)
-int dqnhip_dp_update_n(dqnhip_handle h, int32_t n) {
-  if (!h) return fail("null handle");
-  if (!h->comm) return fail("dp_update_n: no communicator (call dqnhip_dp_init first)");
-  if (n < 0) return fail("dqnhip_dp_update_n: n must be >= 0");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  if (h->next_phase != 0) return fail("dqnhip_dp_update_n: a phased update is in progress (next phase %d)", h->next_phase);
-  if (h->cfg.use_graph && !h->timing && !h->dp_graph_failed && !h->dp_graph_n_failed && n >= kMultiU) {
-    RingUse ring_use(h);
-    RC(sync_dirty16(h));
-    if (RO(h)->h_size < 1) RC(refresh_ring(h));
-    if (RO(h)->h_size < 1) return fail("replay memory is empty");
-    if (!h->dp_graph_n && dp_capture(h, true)) h->dp_graph_n_failed = true;
-    while (n >= kMultiU && h->dp_graph_n) {
-      if (h->dp_shard) h->shard_stale = true;
-      HIPCHK(hipGraphLaunch(h->dp_graph_n, h->stream));
-      h->h_actor_iter += kMultiU; h->h_critic_iter += kMultiU; n -= kMultiU;
-    }
-  }
-  for (; n > 0; --n) RC(dqnhip_dp_update(h, nullptr));
-  return 0;
-}
-
-int dqnhip_dp_graph_active(dqnhip_handle h, int32_t* active) {
-  if (!h || !active) return fail("null argument");
-  *active = h->dp_graph != nullptr;
-  return 0;
-}
-
-// Sharded optimiser: every rank holds m and v of its own slice only; this all-gathers them (collective: every rank of the
-// group calls it) so that dqnhip_get_params(KIND_M / KIND_V), a snapshot, or a later replicated / single-learner update
-// see the whole Adam history.  No-op without DQNHIP_DP_SHARD_OPT.
-int dqnhip_dp_gather_state(dqnhip_handle h) {
-  if (!h) return fail("null handle");
-  if (!h->comm) return fail("dp_gather_state: no communicator (call dqnhip_dp_init first)");
-  if (!h->dp_shard) return 0;
-  HIPCHK(hipSetDevice(h->cfg.device));
-  for (int net = 0; net < 2; ++net) {
-    size_t lo, hi; shard_range(h, net, lo, hi);
-    NCCLCHK(ncclAllGather(h->m[net] + lo, h->m[net], hi - lo, ncclFloat, h->comm, h->stream));
-    NCCLCHK(ncclAllGather(h->v[net] + lo, h->v[net], hi - lo, ncclFloat, h->comm, h->stream));
-  }
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->shard_stale = false;
-  return 0;
-}
-
-}  // extern "C"
-namespace {
-// keep_learner: the learner lives on as a plain one -> its Adam history must be whole.  The gather that makes it whole is a
-// COLLECTIVE, and a teardown must never block on peers that may be gone: it is asked for, not done implicitly.
-int dp_destroy_impl(H* h, bool keep_learner) {
-  if (!h || !h->comm) return 0;
-  if (keep_learner && h->dp_shard && h->shard_stale)
-    return fail("dqnhip_dp_destroy: the optimiser is sharded and updates ran since the last dqnhip_dp_gather_state — call it on every rank first "
-                "(this rank holds the Adam history of its own slice only)");
-  hipSetDevice(h->cfg.device);
-  hipStreamSynchronize(h->stream);
-  hipStreamSynchronize(h->comm_stream);
-  if (h->dp_graph) { hipGraphExecDestroy(h->dp_graph); h->dp_graph = nullptr; }
-  if (h->dp_graph_n) { hipGraphExecDestroy(h->dp_graph_n); h->dp_graph_n = nullptr; }
-  h->dp_graph_failed = false; h->dp_graph_n_failed = false;
-  ncclCommDestroy(h->comm); h->comm = nullptr;
-  hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr;
-  for (auto& e : h->comm_ev) { if (e) hipEventDestroy(e); e = nullptr; }
-  for (int net = 0; net < 2; ++net) if (h->g16[net]) { hipFree(h->g16[net]); h->g16[net] = nullptr; }
-  if (h->dp_tails) { hipFree(h->dp_tails); h->dp_tails = nullptr; }
-  h->dp_half = false; h->dp_per_layer = false; h->dp_shard = false; h->shard_stale = false;
-  return 0;
-}
-}  // namespace
-extern "C" {
-int dqnhip_dp_destroy(dqnhip_handle h) { return dp_destroy_impl(h, true); }
-
-// ---- acting ------------------------------------------------------------------------
-
-static int actor_forward_dev(H* h, int net, const float* states_dev, int n, float* out_dev) {
-  if (n < 1) return fail("n must be >= 1");
-  if (net != DQNHIP_ACTOR && net != DQNHIP_ACTOR_TARGET) return fail("net must be an actor");
-  const int rows = round_up(n, 32);
-  RC(ensure_act(h, rows));
-  const NetLayout& l = h->la;
-  float* acts[kMaxL + 1];
-  float* p = h->act_buf;
-  for (int i = 0; i <= l.L; ++i) { acts[i] = p; p += (size_t)rows * std::max(h->la.kp[i], h->lc.kp[i]); }
-  float* out16 = p;
-  hipLaunchKernelGGL(k_pack_rows, dim3((rows * l.kp[0] + 255) / 256), dim3(256), 0, h->stream, states_dev, n,
-                     h->S, acts[0], rows, l.kp[0]);
-  HIPCHK(hipGetLastError());
-  FwdPass fp[1] = {{net, &l, acts}};
-  RC(tower_forward(h, h->stream, fp, 1, rows));
-  HeadArgs a{}; a.X = acts[l.L]; a.ldx = l.dims[l.L]; a.H = l.dims[l.L]; a.rows = rows;
-  a.W = wat(h, net, l.hw_off); a.b = wat(h, net, l.hb_off); a.out16 = out16;
-  RC((head_forward<kNO, HEAD_ACTOR>(h, h->stream, a)));
-  hipLaunchKernelGGL(k_unpack_out, dim3((n * kNO + 255) / 256), dim3(256), 0, h->stream, (const float*)out16, n, out_dev);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-int dqnhip_select_actions_device(dqnhip_handle h, const float* states_dev, int32_t n, float* actor_out_dev) {
-  if (!h) return fail("null handle");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  return actor_forward_dev(h, DQNHIP_ACTOR, states_dev, n, actor_out_dev);
-}
-
-int dqnhip_select_actions_net(dqnhip_handle h, int32_t net, const float* states_host, int32_t n, float* actor_out_host) {
-  if (!h) return fail("null handle");
-  if (n < 1) return fail("n must be >= 1");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  const size_t sb = (size_t)n * h->S * sizeof(float), ob = (size_t)n * kNO * sizeof(float);
-  RC(ensure_stage(h, round_up_z(sb, 256) + ob));
-  float* sdev = (float*)h->stage_dev;
-  float* odev = (float*)((char*)h->stage_dev + round_up_z(sb, 256));
-  HIPCHK(hipMemcpyAsync(sdev, states_host, sb, hipMemcpyHostToDevice, h->stream));
-  RC(actor_forward_dev(h, net, sdev, n, odev));
-  HIPCHK(hipMemcpyAsync(actor_out_host, odev, ob, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return 0;
-}
-
-int dqnhip_select_actions(dqnhip_handle h, const float* states_host, int32_t n, float* actor_out_host) {
-  return dqnhip_select_actions_net(h, DQNHIP_ACTOR, states_host, n, actor_out_host);
-}
-
-int dqnhip_critic_forward(dqnhip_handle h, int32_t net, const float* states_host, const float* actor_out_host,
-                          int32_t n, float* q_host) {
-  if (!h) return fail("null handle");
-  if (n < 1) return fail("n must be >= 1");
-  if (net != DQNHIP_CRITIC && net != DQNHIP_CRITIC_TARGET) return fail("net must be a critic");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  const int rows = round_up(n, 32);
-  const size_t sb = round_up_z((size_t)n * h->S * sizeof(float), 256), ab = round_up_z((size_t)n * kNO * sizeof(float), 256);
-  RC(ensure_stage(h, sb + ab + (size_t)rows * sizeof(float)));
-  float* sdev = (float*)h->stage_dev;
-  float* adev = (float*)((char*)h->stage_dev + sb);
-  float* qdev = (float*)((char*)h->stage_dev + sb + ab);
-  HIPCHK(hipMemcpyAsync(sdev, states_host, (size_t)n * h->S * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(adev, actor_out_host, (size_t)n * kNO * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  RC(ensure_act(h, rows));
-  const NetLayout& l = h->lc;
-  float* acts[kMaxL + 1];
-  float* p = h->act_buf;
-  for (int i = 0; i <= l.L; ++i) { acts[i] = p; p += (size_t)rows * std::max(h->la.kp[i], h->lc.kp[i]); }
-  hipLaunchKernelGGL(k_pack_critic, dim3((rows * l.kp[0] + 255) / 256), dim3(256), 0, h->stream, (const float*)sdev,
-                     (const float*)adev, n, h->S, acts[0], rows, l.kp[0]);
-  HIPCHK(hipGetLastError());
-  FwdPass fp[1] = {{net, &l, acts}};
-  RC(tower_forward(h, h->stream, fp, 1, rows));
-  HeadArgs a{}; a.X = acts[l.L]; a.ldx = l.dims[l.L]; a.H = l.dims[l.L]; a.rows = rows;
-  a.W = wat(h, net, l.hw_off); a.b = wat(h, net, l.hb_off); a.q = qdev;
-  RC((head_forward<1, HEAD_Q>(h, h->stream, a)));
-  HIPCHK(hipMemcpyAsync(q_host, qdev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return 0;
-}
-
-// ---- replay memory -------------------------------------------------------------------
-
-static int add_dev(H* h, const float* s, const float* a, const float* r, const float* mc, const float* nx,
-                   const uint8_t* term, int n, int single) {
-  if (n < 1) return fail("n must be >= 1");
-  RingUse ring_use(h);
-  RC(refresh_ring(h));
-  const long long cap = RO(h)->ring.cap;
-  if (single == 0 && n >= cap) return fail("AddTransitions: batch of %d does not fit capacity %lld (the reference would pop an empty deque)", n, cap);
-  if (single == 2 && RO(h)->h_size + n > cap) return fail("LoadReplayMemory: %lld transitions exceed the capacity %lld", RO(h)->h_size + n, cap);
-  hipLaunchKernelGGL(k_add_transitions, dim3((n + 3) / 4), dim3(256), 0, h->stream, RO(h)->ring, RO(h)->st, s, a, r, mc, nx,
-                     term, n, single, RO(h)->done_counter);
-  HIPCHK(hipGetLastError());
-  // host mirror of the same deque arithmetic (src/dqn.cpp:768-781)
-  if (single == 2) { }
-  else if (single) { if (RO(h)->h_size == cap) { RO(h)->h_head = (RO(h)->h_head + 1) % cap; RO(h)->h_size -= 1; } }
-  else {
-    long long pops = RO(h)->h_size + n - cap + 1;
-    pops = std::max(0LL, std::min(pops, RO(h)->h_size));
-    RO(h)->h_head = (RO(h)->h_head + pops) % cap; RO(h)->h_size -= pops;
-  }
-  RO(h)->h_size += n;
-  return 0;
-}
-
-int dqnhip_add_transitions_device(dqnhip_handle h, const float* states, const float* actor_out, const float* rewards,
-                                  const float* on_policy_targets, const float* next_states, const uint8_t* terminal,
-                                  int32_t n) {
-  if (!h) return fail("null handle");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  return add_dev(h, states, actor_out, rewards, on_policy_targets, next_states, terminal, n, 0);
-}
-
-static int add_host(H* h, const float* s, const float* a, const float* r, const float* mc, const float* nx,
-                    const uint8_t* term, int n, int single) {
-  if (!h) return fail("null handle");
-  if (n < 1) return fail("n must be >= 1");
-  if (!s || !a || !r || !mc || !term) return fail("null input array");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  const size_t sb = round_up_z((size_t)n * h->S * 4, 256), ab = round_up_z((size_t)n * kNO * 4, 256), vb = round_up_z((size_t)n * 4, 256);
-  // staging is reused: wait for the previous scatter to drain before overwriting
-  HIPCHK(hipStreamSynchronize(h->stream));
-  RC(ensure_stage(h, 2 * sb + ab + 3 * vb));
-  char* base = (char*)h->stage_dev;
-  float* ds = (float*)base; float* dn = (float*)(base + sb); float* da = (float*)(base + 2 * sb);
-  float* dr = (float*)(base + 2 * sb + ab); float* dm = (float*)(base + 2 * sb + ab + vb);
-  uint8_t* dt = (uint8_t*)(base + 2 * sb + ab + 2 * vb);
-  HIPCHK(hipMemcpyAsync(ds, s, (size_t)n * h->S * 4, hipMemcpyHostToDevice, h->stream));
-  if (nx) HIPCHK(hipMemcpyAsync(dn, nx, (size_t)n * h->S * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(da, a, (size_t)n * kNO * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(dr, r, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(dm, mc, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(dt, term, (size_t)n, hipMemcpyHostToDevice, h->stream));
-  return add_dev(h, ds, da, dr, dm, nx ? dn : nullptr, dt, n, single);
-}
-
-int dqnhip_add_transitions(dqnhip_handle h, const float* states, const float* actor_out, const float* rewards,
-                           const float* on_policy_targets, const float* next_states, const uint8_t* terminal, int32_t n) {
-  return add_host(h, states, actor_out, rewards, on_policy_targets, next_states, terminal, n, 0);
-}
-
-int dqnhip_add_transition(dqnhip_handle h, const float* state, const float* actor_out, float reward,
-                          float on_policy_target, const float* next_state, uint8_t terminal) {
-  return add_host(h, state, actor_out, &reward, &on_policy_target, next_state, &terminal, 1, 1);
-}
-
-int dqnhip_label_transitions(double gamma, const float* rewards, int32_t n, float* mc) {
-  if (n < 1) return fail("Need at least one transition to label.");   // CHECK_GT, src/dqn.cpp:784
-  if (!rewards || !mc) return fail("null array");
-  mc[n - 1] = rewards[n - 1];
-  for (int i = n - 2; i >= 0; --i) mc[i] = (float)((double)rewards[i] + gamma * (double)mc[i + 1]);
-  return 0;
-}
-
-int dqnhip_memory_size(dqnhip_handle h, int32_t* size) {
-  if (!h || !size) return fail("null argument");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  RingUse ring_use(h);
-  RC(refresh_ring(h));
-  *size = (int32_t)RO(h)->h_size;
-  return 0;
-}
-
-int dqnhip_clear_memory(dqnhip_handle h) {
-  if (!h) return fail("null handle");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  RingUse ring_use(h);
-  HIPCHK(hipMemsetAsync(RO(h)->st, 0, 2 * sizeof(int), h->stream));   // ring_head, ring_size
-  RO(h)->h_head = 0; RO(h)->h_size = 0; RO(h)->ring_stale = false;
-  return 0;
-}
-
-static bool same_nets(const dqnhip_learner* a, const dqnhip_learner* b);
-
-// caller holds the RingUse of h and has refreshed (head,size)
-static int read_memory_impl(H* h, int32_t first, int32_t n, float* states, float* actor_out, float* rewards,
-                            float* on_policy_targets, float* next_states, uint8_t* terminal) {
-  if (n < 1 || first < 0 || (long long)first + n > RO(h)->h_size) return fail("read_memory range [%d,%d) outside [0,%lld)", first, first + n, RO(h)->h_size);
-  const size_t sb = round_up_z((size_t)n * h->S * 4, 256), ab = round_up_z((size_t)n * kNO * 4, 256), vb = round_up_z((size_t)n * 4, 256);
-  HIPCHK(hipStreamSynchronize(h->stream));
-  RC(ensure_stage(h, 2 * sb + ab + 3 * vb));
-  char* base = (char*)h->stage_dev;
-  float* ds = (float*)base; float* dn = (float*)(base + sb); float* da = (float*)(base + 2 * sb);
-  float* dr = (float*)(base + 2 * sb + ab); float* dm = (float*)(base + 2 * sb + ab + vb);
-  uint8_t* dt = (uint8_t*)(base + 2 * sb + ab + 2 * vb);
-  hipLaunchKernelGGL(k_read_memory, dim3((n + 3) / 4), dim3(256), 0, h->stream, RO(h)->ring, (const DevState*)RO(h)->st, first, n,
-                     ds, da, dr, dm, dn, dt);
-  HIPCHK(hipGetLastError());
-  if (states) HIPCHK(hipMemcpyAsync(states, ds, (size_t)n * h->S * 4, hipMemcpyDeviceToHost, h->stream));
-  if (next_states) HIPCHK(hipMemcpyAsync(next_states, dn, (size_t)n * h->S * 4, hipMemcpyDeviceToHost, h->stream));
-  if (actor_out) HIPCHK(hipMemcpyAsync(actor_out, da, (size_t)n * kNO * 4, hipMemcpyDeviceToHost, h->stream));
-  if (rewards) HIPCHK(hipMemcpyAsync(rewards, dr, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-  if (on_policy_targets) HIPCHK(hipMemcpyAsync(on_policy_targets, dm, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-  if (terminal) HIPCHK(hipMemcpyAsync(terminal, dt, (size_t)n, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return 0;
-}
-
-int dqnhip_read_memory(dqnhip_handle h, int32_t first, int32_t n, float* states, float* actor_out, float* rewards,
-                       float* on_policy_targets, float* next_states, uint8_t* terminal) {
-  if (!h) return fail("null handle");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  RingUse ring_use(h);
-  RC(refresh_ring(h));
-  return read_memory_impl(h, first, n, states, actor_out, rewards, on_policy_targets, next_states, terminal);
-}
-
-// DQN::SampleStatesFromMemory (src/dqn.cpp:511-523): n states of uniformly sampled transitions.
-// idx_host = the explicit form of SampleTransitionsFromMemory (as in dqnhip_update); NULL draws on
-// the device from the counter-based generator (its own key stream, one counter tick per call).
-int dqnhip_sample_states(dqnhip_handle h, const int32_t* idx_host, int32_t n, float* states_host) {
-  if (!h || !states_host) return fail("null argument");
-  if (n < 1) return fail("n must be >= 1");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  RingUse ring_use(h);
-  RC(refresh_ring(h));
-  const long long size = RO(h)->h_size;
-  if (size < 1) return fail("replay memory is empty");
-  const size_t ib = round_up_z((size_t)n * sizeof(int), 256), sb = (size_t)n * h->S * sizeof(float);
-  HIPCHK(hipStreamSynchronize(h->stream));
-  RC(ensure_stage(h, ib + sb));
-  int* di = (int*)h->stage_dev; float* ds = (float*)((char*)h->stage_dev + ib);
-  if (idx_host) {
-    for (int i = 0; i < n; ++i)
-      if (idx_host[i] < 0 || idx_host[i] >= size) return fail("sampled index %d = %d out of range [0,%lld)", i, idx_host[i], size);
-    HIPCHK(hipMemcpyAsync(di, idx_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  }
-  hipLaunchKernelGGL(k_sample_states, dim3((n + 3) / 4), dim3(256), 0, h->stream, RO(h)->ring, (const DevState*)RO(h)->st,
-                     idx_host ? (const int*)di : (const int*)nullptr, sample_key(h) ^ 0x5354415445535F5Full, h->sample_states_calls, n, ds);
-  HIPCHK(hipGetLastError());
-  if (!idx_host) h->sample_states_calls += 1;
-  HIPCHK(hipMemcpyAsync(states_host, ds, sb, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return 0;
-}
-
-// getActorOutput (src/dqn.cpp:719-732): the first `batch_size` rows of an actor's output blobs as
-// left by its last forward — here the last update's minibatch forward (ACTOR: mu(s), ACTOR_TARGET: mu'(s')).
-int dqnhip_get_actor_output(dqnhip_handle h, int32_t net, int32_t batch_size, float* actor_out_host) {
-  if (!h || !actor_out_host) return fail("null argument");
-  if (net != DQNHIP_ACTOR && net != DQNHIP_ACTOR_TARGET) return fail("net must be an actor");
-  if (batch_size < 1 || batch_size > h->B) return fail("batch_size %d outside [1, %d]", batch_size, h->B);
-  HIPCHK(hipSetDevice(h->cfg.device));
-  std::vector<float> tmp((size_t)batch_size * kAP);
-  HIPCHK(hipMemcpyAsync(tmp.data(), net == DQNHIP_ACTOR ? h->aout16 : h->aout_t16, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  for (int r = 0; r < batch_size; ++r) memcpy(actor_out_host + (size_t)r * kNO, &tmp[(size_t)r * kAP], kNO * sizeof(float));
-  return 0;
-}
-
-// Sum the gradient arenas (4-float tails included) of n co-located learners of one data-parallel
-// group in rank order and leave the sum in every one of them: the exchange step of
-// dqnhip_update_phase for learners that share a device (multi-agent layouts, and the one-GPU parity
-// test of the dp_world > 1 code path).  Cross-device groups use dqnhip_dp_* (RCCL).
-int dqnhip_reduce_gradients_local(dqnhip_handle* hs, int32_t n, int32_t net) {
-  if (!hs || n < 1 || n > 8) return fail("reduce_gradients_local: 1..8 learners");
-  if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return fail("net must be ACTOR or CRITIC");
-  LocalReduce a{}; a.n = n;
-  for (int i = 0; i < n; ++i) {
-    if (!hs[i]) return fail("null handle");
-    if (hs[i]->cfg.device != hs[0]->cfg.device || !same_nets(hs[i], hs[0])) return fail("reduce_gradients_local: learners must share a device and a shape");
-    a.g[i] = hs[i]->g[net];
-  }
-  a.n4 = (layout_of(hs[0], net).arena + 4) / 4;
-  HIPCHK(hipSetDevice(hs[0]->cfg.device));
-  for (int i = 1; i < n; ++i) HIPCHK(hipStreamSynchronize(hs[i]->stream));   // their phase must be complete
-  hipLaunchKernelGGL(k_local_reduce, dim3(1024), dim3(256), 0, hs[0]->stream, a);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(hs[0]->stream));
-  return 0;
-}
-
-// ---- .replaymemory files (src/dqn.cpp:1146-1226) --------------------------------------------
-int dqnhip_snapshot_replay_memory(dqnhip_handle h, const char* filename) {
-  if (!h || !filename) return fail("null argument");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  // one RingUse for the whole file: with a shared ring another agent's AddTransitions must not
-  // move the head between chunks (the file would hold shifted / duplicated transitions)
-  RingUse ring_use(h);
-  RC(refresh_ring(h));
-  gzFile f = gzopen(filename, "wb");
-  if (!f) return fail("cannot open %s for writing", filename);
-  const int32_t n = (int32_t)RO(h)->h_size;
-  const size_t S = h->S;
-  bool ok = gzwrite(f, &n, sizeof n) == (int)sizeof n;
-  const int chunk = 65536;
-  std::vector<float> s((size_t)chunk * S), a((size_t)chunk * kNO), r(chunk), mc(chunk);
-  std::vector<uint8_t> term(chunk), rec;
-  for (int first = 0; first < n && ok; first += chunk) {
-    const int m = std::min(chunk, n - first);
-    if (read_memory_impl(h, first, m, s.data(), a.data(), r.data(), mc.data(), nullptr, term.data())) { gzclose(f); return 1; }
-    const size_t rb = S * 4 + kNO * 4 + 4 + 4 + 1;
-    rec.resize((size_t)m * rb);
-    for (int i = 0; i < m; ++i) {
-      uint8_t* p = &rec[(size_t)i * rb];
-      memcpy(p, &s[(size_t)i * S], S * 4); p += S * 4;
-      memcpy(p, &a[(size_t)i * kNO], kNO * 4); p += kNO * 4;     // sizeof(ActorOutput)
-      memcpy(p, &r[i], 4); p += 4;
-      memcpy(p, &mc[i], 4); p += 4;
-      *p = term[i] ? 1 : 0;                                       // sizeof(bool) == 1
-    }
-    ok = gzwrite(f, rec.data(), (unsigned)rec.size()) == (int)rec.size();
-  }
-  if (gzclose(f) != Z_OK || !ok) return fail("short write to %s", filename);
-  return 0;
-}
-
-int dqnhip_load_replay_memory(dqnhip_handle h, const char* filename) {
-  if (!h || !filename) return fail("null argument");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  gzFile f = gzopen(filename, "rb");
-  if (!f) return fail("Invalid file: %s", filename);              // CHECK(is_regular_file), src/dqn.cpp:1181
-  int32_t n = 0;
-  if (gzread(f, &n, sizeof n) != (int)sizeof n || n < 0) { gzclose(f); return fail("%s: bad header", filename); }
-  if (n > RO(h)->ring.cap) { gzclose(f); return fail("%s holds %d transitions, capacity is %d", filename, n, RO(h)->ring.cap); }
-  RC(dqnhip_clear_memory(h));
-  const size_t S = h->S, rb = S * 4 + kNO * 4 + 4 + 4 + 1;
-  const int chunk = 65536;
-  // one record of look-ahead: next state of the last row of a chunk is the first state of the next
-  std::vector<uint8_t> rec((size_t)(chunk + 1) * rb);
-  std::vector<float> s((size_t)chunk * S), nx((size_t)chunk * S), a((size_t)chunk * kNO), r(chunk), mc(chunk);
-  std::vector<uint8_t> term(chunk);
-  int have = 0;                       // records buffered in rec
-  int done = 0;
-  while (done < n) {
-    const int want = std::min(chunk + 1, n - done) - have;
-    if (want > 0) {
-      const int got = gzread(f, &rec[(size_t)have * rb], (unsigned)((size_t)want * rb));
-      if (got != (int)((size_t)want * rb)) { gzclose(f); return fail("%s: truncated", filename); }
-      have += want;
-    }
-    const int m = std::min(chunk, n - done);
-    for (int i = 0; i < m; ++i) {
-      const uint8_t* p = &rec[(size_t)i * rb];
-      memcpy(&s[(size_t)i * S], p, S * 4); p += S * 4;
-      memcpy(&a[(size_t)i * kNO], p, kNO * 4); p += kNO * 4;
-      memcpy(&r[i], p, 4); p += 4;
-      memcpy(&mc[i], p, 4); p += 4;
-      bool t = *p != 0;
-      const bool has_next = done + i + 1 < n;
-      if (!t && !has_next) t = true;                              // trailing non-terminal: next stays none
-      term[i] = t ? 1 : 0;
-      if (!t) memcpy(&nx[(size_t)i * S], &rec[(size_t)(i + 1) * rb], S * 4);
-      else memset(&nx[(size_t)i * S], 0, S * 4);
-    }
-    if (add_host(h, s.data(), a.data(), r.data(), mc.data(), nx.data(), term.data(), m, 2)) { gzclose(f); return 1; }
-    // keep the look-ahead record as the first record of the next chunk
-    if (have > m) memmove(&rec[0], &rec[(size_t)m * rb], rb);
-    have -= m;
-    done += m;
-  }
-  gzclose(f);
-  return 0;
-}
-
-// ---- parameters ----------------------------------------------------------------------
-
-static float* arena_ptr(H* h, int net, int kind) {
-  if (kind == DQNHIP_KIND_W) return (net >= 0 && net < 4) ? h->w[net] : nullptr;
-  if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return nullptr;
-  return kind == DQNHIP_KIND_M ? h->m[net] : kind == DQNHIP_KIND_V ? h->v[net] : kind == DQNHIP_KIND_G ? h->g[net] : nullptr;
-}
-
-int dqnhip_param_count(dqnhip_handle h, int32_t net, size_t* count) {
-  if (!h || !count) return fail("null argument");
-  if (net < 0 || net > 3) return fail("bad net %d", net);
-  *count = layout_of(h, net).dense;
-  return 0;
-}
-
-int dqnhip_get_params(dqnhip_handle h, int32_t net, int32_t kind, float* host, size_t count) {
-  if (!h || !host) return fail("null argument");
-  float* p = arena_ptr(h, net, kind);
-  if (!p) return fail("bad (net,kind) = (%d,%d)", net, kind);
-  const NetLayout& l = layout_of(h, net);
-  if (count != l.dense) return fail("count %zu != parameter count %zu", count, l.dense);
-  HIPCHK(hipSetDevice(h->cfg.device));
-  std::vector<float> arena(l.arena);
-  const size_t sh = kind == DQNHIP_KIND_W ? h->shared_fl[net & 1] : 0;   // shared first layers: the owner's storage
-  if (sh) HIPCHK(hipMemcpyAsync(arena.data(), h->w_owner->w[net], sh * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  if (sh < l.arena) HIPCHK(hipMemcpyAsync(arena.data() + sh, p + sh, (l.arena - sh) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  arena_to_dense(l, arena, host);
-  return 0;
-}
-
-int dqnhip_set_params(dqnhip_handle h, int32_t net, int32_t kind, const float* host, size_t count) {
-  if (!h || !host) return fail("null argument");
-  float* p = arena_ptr(h, net, kind);
-  if (!p) return fail("bad (net,kind) = (%d,%d)", net, kind);
-  const NetLayout& l = layout_of(h, net);
-  if (count != l.dense) return fail("count %zu != parameter count %zu", count, l.dense);
-  HIPCHK(hipSetDevice(h->cfg.device));
-  std::vector<float> arena;
-  dense_to_arena(l, host, arena);
-  const size_t sh = kind == DQNHIP_KIND_W ? h->shared_fl[net & 1] : 0;
-  if (sh) HIPCHK(hipMemcpyAsync(h->w_owner->w[net], arena.data(), sh * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  if (sh < l.arena) HIPCHK(hipMemcpyAsync(p + sh, arena.data() + sh, (l.arena - sh) * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (kind == DQNHIP_KIND_W) h->w16_dirty[net] = true;
-  return 0;
-}
-
-int dqnhip_clone_to_target(dqnhip_handle h, int32_t net) {
-  if (!h) return fail("null handle");
-  if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return fail("net must be ACTOR or CRITIC");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  const size_t sh = h->shared_fl[net], n = layout_of(h, net).arena;
-  if (sh) HIPCHK(hipMemcpyAsync(h->w_owner->w[net + 2], h->w_owner->w[net], sh * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-  if (sh < n) HIPCHK(hipMemcpyAsync(h->w[net + 2] + sh, h->w[net] + sh, (n - sh) * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-  h->w16_dirty[net + 2] = true;
-  return 0;
-}
-
-// ---- multi-agent sharing (src/dqn.cpp:1036-1083, src/dqn_main.cpp:305-323) ------------------
-
-static void drop_graphs(H* h) { drop_graphs_fwd(h); }
-
-static bool same_nets(const H* a, const H* b) {
-  if (a->S != b->S || a->L != b->L) return false;
-  for (int i = 0; i < a->L; ++i) if (a->cfg.hidden[i] != b->cfg.hidden[i]) return false;
-  return true;
-}
-
-// floats of the arena covered by the first `n` layers-with-blobs of a net (Caffe layer order:
-// ip1..ipL, then action_layer, actionpara_layer / q_values_layer)
-static int shared_prefix(const NetLayout& l, int n, size_t* fl) {
-  const int heads = l.NH == kNO ? 2 : 1;
-  if (n < 0 || n > l.L + heads) return fail("cannot share %d layers of a net with %d", n, l.L + heads);   // CHECK_LT, src/dqn.cpp:1060
-  if (n < l.L) *fl = l.w_off[n];
-  else if (n == l.L) *fl = l.hw_off;
-  else if (n == l.L + heads) *fl = l.arena;
-  else return fail("sharing action_layer without actionpara_layer is not supported (the two heads are one [10][H] matrix here)");
-  return 0;
-}
-
-int dqnhip_share_parameters(dqnhip_handle owner, dqnhip_handle other, int32_t num_actor_layers, int32_t num_critic_layers) {
-  if (!owner || !other || owner == other) return fail("ShareParameters needs two distinct learners");
-  if (owner->cfg.device != other->cfg.device) return fail("ShareParameters: both learners must live on the same device");
-  if (!same_nets(owner, other)) return fail("ShareParameters: net shapes differ");
-  if (owner->fp16 || other->fp16) return fail("ShareParameters is not supported in fp16 mode (each learner keeps private fp16 weight copies)");
-  if (owner->w_owner) return fail("ShareParameters: the owner itself shares another learner's layers; share from the root");
-  if (other->w_owner && other->w_owner != owner) return fail("ShareParameters: already sharing with a different owner");
-  size_t fa = 0, fc = 0;
-  RC(shared_prefix(owner->la, num_actor_layers, &fa));
-  RC(shared_prefix(owner->lc, num_critic_layers, &fc));
-  HIPCHK(hipSetDevice(owner->cfg.device));
-  HIPCHK(hipStreamSynchronize(owner->stream));
-  HIPCHK(hipStreamSynchronize(other->stream));
-  if (!other->w_owner && (fa || fc)) owner->sharers += 1;
-  if (other->w_owner && !(fa || fc)) owner->sharers -= 1;
-  other->w_owner = (fa || fc) ? owner : nullptr;
-  other->shared_fl[0] = fa; other->shared_fl[1] = fc;
-  drop_graphs(other);                      // captured launches hold the old weight pointers
-  return 0;
-}
-
-int dqnhip_share_replay_memory(dqnhip_handle owner, dqnhip_handle other) {
-  if (!owner || !other || owner == other) return fail("ShareReplayMemory needs two distinct learners");
-  if (owner->cfg.device != other->cfg.device) return fail("ShareReplayMemory: both learners must live on the same device");
-  if (owner->S != other->S) return fail("ShareReplayMemory: state sizes differ");
-  H* root = RO(owner);
-  if (RO(other) == root) return 0;
-  if (other->sharers && other->ring_shared) return fail("ShareReplayMemory: other learners already use this learner's memory");
-  HIPCHK(hipSetDevice(owner->cfg.device));
-  HIPCHK(hipStreamSynchronize(owner->stream));
-  HIPCHK(hipStreamSynchronize(other->stream));
-  if (other->ring_owner) other->ring_owner->sharers -= 1;
-  if (!root->ring_ev) HIPCHK(hipEventCreateWithFlags(&root->ring_ev, hipEventDisableTiming));
-  root->ring_shared = true;
-  root->sharers += 1;
-  other->ring_owner = root;                // other's deque is dropped: shared_ptr assignment, src/dqn.cpp:1081
-  drop_graphs(other);
-  return 0;
-}
-
-int dqnhip_get_iters(dqnhip_handle h, int32_t* actor_iter, int32_t* critic_iter) {
-  if (!h) return fail("null handle");
-  if (actor_iter) *actor_iter = h->h_actor_iter;
-  if (critic_iter) *critic_iter = h->h_critic_iter;
-  return 0;
-}
-
-int dqnhip_set_iters(dqnhip_handle h, int32_t actor_iter, int32_t critic_iter) {
-  if (!h) return fail("null handle");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  int v[2] = {actor_iter, critic_iter};
-  HIPCHK(hipMemcpy(&h->st->actor_iter, v, sizeof v, hipMemcpyHostToDevice));
-  h->h_actor_iter = actor_iter; h->h_critic_iter = critic_iter;
-  return 0;
-}
-
-// ---- introspection ----------------------------------------------------------------------
-
-int dqnhip_debug_read(dqnhip_handle h, const char* name, float* host, size_t count) {
-  if (!h || !name || !host) return fail("null argument");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  const size_t B = h->B;
-  const float* src = nullptr; size_t n = B; bool pad16 = false; bool is_int = false;
-  if (!strcmp(name, "q_target")) src = h->q_t;
-  else if (!strcmp(name, "y")) src = h->y;
-  else if (!strcmp(name, "q_train")) src = h->q1;
-  else if (!strcmp(name, "q_policy")) src = h->q2;
-  else if (!strcmp(name, "terminal")) src = h->mb_term;
-  else if (!strcmp(name, "actor_out")) { src = h->aout16; pad16 = true; n = B * kNO; }
-  else if (!strcmp(name, "dq_da")) { src = h->dA16; pad16 = true; n = B * kNO; }
-  else if (!strcmp(name, "idx")) { src = (const float*)h->mb_idx; is_int = true; }
-  else if (!strncmp(name, "act", 3) && name[3] >= '0' && name[3] <= '4' && name[4] == '_') {
-    // "act<p>_<i>": the stored (post-ReLU, in place: src/dqn.cpp:409-410) tower activations of the last update's pass p
-    // (0 actor_target(s'), 1 actor(s), 2 critic_target, 3 critic(s, a), 4 critic(s, mu(s))), layer i = 1 .. L, dense
-    // [B][width].  Parity tests compare their SIGNS with the oracle's: an fp32 evaluation may put a pre-activation that
-    // is within round-off of zero on the other side, which switches that unit's ReLU' between 1 and 0.01 for that row.
-    const int p = name[3] - '0', i = atoi(name + 5);
-    const NetLayout& l = layout_of(h, p >= 2);
-    if (i < 1 || i > h->L) return fail("debug buffer '%s': layer out of range", name);
-    const size_t W = l.dims[i];
-    if (count < B * W) return fail("buffer too small for '%s': %zu < %zu", name, count, B * W);
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->fp16) {
-      std::vector<h16> t16(B * W);
-      HIPCHK(hipMemcpy(t16.data(), h->act16[p][i], t16.size() * sizeof(h16), hipMemcpyDeviceToHost));
-      for (size_t e = 0; e < t16.size(); ++e) host[e] = (float)t16[e];
-    } else HIPCHK(hipMemcpy(host, h->act[p][i], B * W * sizeof(float), hipMemcpyDeviceToHost));
-    return 0;
-  }
-  else return fail("unknown debug buffer '%s'", name);
-  if (count < n) return fail("buffer too small for '%s': %zu < %zu", name, count, n);
-  std::vector<float> tmp(pad16 ? B * kAP : B);
-  HIPCHK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (pad16) { for (size_t r = 0; r < B; ++r) for (int c = 0; c < kNO; ++c) host[r * kNO + c] = tmp[r * kAP + c]; }
-  else if (is_int) { for (size_t r = 0; r < B; ++r) host[r] = (float)reinterpret_cast<const int*>(tmp.data())[r]; }
-  else memcpy(host, tmp.data(), B * sizeof(float));
-  return 0;
-}
-
-int dqnhip_get_stream(dqnhip_handle h, void** stream) {
-  if (!h || !stream) return fail("null argument");
-  *stream = (void*)h->stream;
-  return 0;
-}
-
-int dqnhip_set_kernel_timing(dqnhip_handle h, int32_t enable) {
-  if (!h) return fail("null handle");
-  h->timing = enable != 0;
-  return 0;
-}
-
-int dqnhip_get_kernel_timing(dqnhip_handle h, const char* family, float* avg_ms, int64_t* launches, int32_t reset) {
-  if (!h || !family) return fail("null argument");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  int fam = -1;
-  for (int i = 0; i < kNumFamily; ++i) if (!strcmp(family, kFamily[i])) fam = i;
-  if (fam < 0) return fail("unknown kernel family '%s' (gemm_fwd_lds_4x2|gemm_fwd_lds_2x2|gemm_fwd_direct|gemm_dgrad|gemm_wgrad|gemm_bwd_pair|adam|hgemm_fwd|hgemm_dgrad|hgemm_wgrad)", family);
-  HIPCHK(hipStreamSynchronize(h->stream));
-  double total = 0; int64_t cnt = 0;
-  for (auto& r : h->recs) {
-    if (r.family != fam) continue;
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
-    total += ms; cnt += 1;
-  }
-  if (avg_ms) *avg_ms = cnt ? (float)(total / cnt) : 0.0f;
-  if (launches) *launches = cnt;
-  if (reset) {
-    for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-    h->recs.clear();
-  }
-  return 0;
-}
-
-
-// ---- batched env front-end (include/dqnhip_env.h) -----------------------------------------
-}  // extern "C"
-
-struct dqnhip_env {
-  dqnhip_learner* h = nullptr;
-  dqnhip_env_config cfg{};
-  EnvDev d{};
-  int Npad = 0;
-  float* acts[kMaxL + 1] = {nullptr};
-  std::vector<void*> allocs;
-  float* eps_dev = nullptr;
-  int* commit_ticket = nullptr;
-  hipGraphExec_t graph[2] = {nullptr, nullptr};   // one batched step / kEnvUnroll steps, captured on first use
-  bool graph_failed = false;
-  // inside a sequence of batched steps the episode flush of step t (LabelTransitions + AddTransitions of the
-  // finished episodes) rides as extra workgroups of step t+1's first-layer launch: k_env_step resets the worker
-  // itself, so nothing before the next k_env_step depends on the flush
-  bool flush_deferred = false;
-};
-constexpr int kEnvUnroll = 16;
-
-namespace {
-template <typename T>
-int env_alloc(dqnhip_env* e, T** p, size_t n) {
-  HIPCHK(hipMalloc(p, n * sizeof(T)));
-  HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(T), e->h->stream));
-  e->allocs.push_back((void*)*p);
-  return 0;
-}
-}  // namespace
-
-extern "C" {
-
-static int env_create_impl(dqnhip_env* e);
-
-int dqnhip_env_create(dqnhip_handle h, const dqnhip_env_config* cfg, dqnhip_env_handle* out) {
-  if (!h || !cfg || !out) return fail("null argument");
-  *out = nullptr;
-  if (cfg->struct_size != (int32_t)sizeof(dqnhip_env_config)) return fail("dqnhip_env_config.struct_size mismatch");
-  if (cfg->workers < 1 || cfg->workers > (1 << 20)) return fail("workers out of range");
-  if (cfg->max_steps < 1 || cfg->max_steps > 4096) return fail("max_steps out of range");
-  if (h->S < 56) return fail("HFOGameState reads state indices up to 55: state_size must be >= 56 (src/hfo_game.cpp:130-152)");
-  if ((long long)cfg->workers * cfg->max_steps >= RO(h)->ring.cap)
-    return fail("replay capacity %d must exceed workers*max_steps = %lld", RO(h)->ring.cap, (long long)cfg->workers * cfg->max_steps);
-  HIPCHK(hipSetDevice(h->cfg.device));
-  dqnhip_env* e = new dqnhip_env();
-  e->h = h; e->cfg = *cfg;
-  const int rc = env_create_impl(e);
-  if (rc) { const std::string msg = g_err; dqnhip_env_destroy(e); g_err = msg; return rc; }
-  *out = e;
-  return 0;
-}
-
-static int env_create_impl(dqnhip_env* e) {
-  dqnhip_learner* h = e->h;
-  const dqnhip_env_config* cfg = &e->cfg;
-  EnvDev& d = e->d;
-  d.N = cfg->workers; d.S = h->S; d.SP = h->la.kp[0]; d.T = cfg->max_steps; d.unum = cfg->unum;
-  d.p_end = cfg->p_end; d.p_goal = cfg->p_goal; d.seed = cfg->seed;
-  e->Npad = round_up(d.N, 32);
-  const size_t N = d.N, Np = e->Npad;
-  RC(env_alloc(e, &d.cur, Np * d.SP)); RC(env_alloc(e, &d.out16, Np * kAP));
-  RC(env_alloc(e, &d.ep_s, N * d.T * d.SP)); RC(env_alloc(e, &d.ep_a, N * d.T * kAP)); RC(env_alloc(e, &d.ep_r, N * d.T));
-  RC(env_alloc(e, &d.game, N)); RC(env_alloc(e, &d.len, N)); RC(env_alloc(e, &d.done, N)); RC(env_alloc(e, &d.g, N));
-  RC(env_alloc(e, &d.act, N)); RC(env_alloc(e, &d.arg1, N)); RC(env_alloc(e, &d.arg2, N)); RC(env_alloc(e, &d.rew, N));
-  RC(env_alloc(e, &d.n_steps, N)); RC(env_alloc(e, &d.n_episodes, N)); RC(env_alloc(e, &d.n_goals, N)); RC(env_alloc(e, &d.reward_sum, N));
-  e->acts[0] = d.cur;
-  for (int i = 1; i <= h->L; ++i) RC(env_alloc(e, &e->acts[i], Np * h->la.kp[i]));
-  RC(env_alloc(e, &e->eps_dev, 16)); d.eps = e->eps_dev;
-  RC(env_alloc(e, &e->commit_ticket, 32));
-  hipLaunchKernelGGL(k_env_init, dim3(d.N), dim3(64), d.SP * sizeof(float), h->stream, d);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return 0;
-}
-
-int dqnhip_env_destroy(dqnhip_env_handle e) {
-  if (!e) return 0;
-  hipSetDevice(e->h->cfg.device);
-  hipStreamSynchronize(e->h->stream);
-  for (void* p : e->allocs) hipFree(p);
-  for (int i = 0; i < 2; ++i) if (e->graph[i]) hipGraphExecDestroy(e->graph[i]);
-  delete e;
-  return 0;
-}
-
-// First tower layer of batched step t+1 (the small-K direct kernel's 32x32 tiles) and the episode flush of step t
-// in ONE launch: blocks [0, tiles) are GEMM tiles, the next N blocks are k_env_flush's.  The two parts share no data
-// (the layer reads the state panel k_env_step(t) wrote, the flush reads done[] and the episode rows).  A side
-// stream was measured first (A/B in one call, 64 workers, S = 68): 48.0 us per step against 33.5 — every
-// cross-stream edge of a replayed graph costs more than the 7 us flush it would hide.
-__global__ __launch_bounds__(256) void k_env_l0_flush(const GemmBatch batch, EnvDev e, Ring ring, const DevState* st, double gamma) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if ((int)blockIdx.x < batch.total_tiles) {
-    int pi, tile_p, tile_q;
-    tile_of_block(batch, pi, tile_p, tile_q);
-    fwd_direct_body<2, 2>(batch.prob[pi], tile_p, tile_q, smem);
-    return;
-  }
-  env_flush_block(e, ring, st, gamma, (int)blockIdx.x - batch.total_tiles, (int)gridDim.x - batch.total_tiles, smem);
-}
-// one batched env step on the learner's stream: SelectActionGreedily for all workers, then the
-// per-worker epsilon draw / GetAction / reward / episode bookkeeping / AddTransitions
-static int env_one_step(dqnhip_env* e, bool more_follow) {
-  dqnhip_learner* h = e->h;
-  EnvDev d = e->d;
-  hipStream_t st = h->stream;
-  const NetLayout& la = h->la;
-  FwdPass fp{DQNHIP_ACTOR, &la, e->acts};
-  // 5 launches per batched step at L = 4 inside a sequence: the actor heads ride in k_env_step (the four waves of a
-  // worker's block compute its own 10 outputs), the ring bookkeeping in the flush's last block, and the flush itself
-  // in the NEXT step's first-layer launch.
-  // (beyond a few hundred workers the dedicated head kernel and a separate commit win: one block per head row is
-  // slower than the tiled head kernel there, and N arrivals on one counter serialise at ~12 ns each)
-  const bool fused = la.dims[la.L] % 4 == 0 && d.N <= 512;
-  if (fused) {
-    d.head_x = e->acts[la.L]; d.head_h = la.dims[la.L];
-    d.head_w = wat(h, DQNHIP_ACTOR, la.hw_off); d.head_b = wat(h, DQNHIP_ACTOR, la.hb_off);
-    d.commit_ticket = e->commit_ticket;
-  }
-  const bool l0_direct = !((la.kp[0] >= 512) && (la.kp[0] % 256 == 0)) && la.dims[1] % 32 == 0 && e->Npad % 32 == 0;
-  int first = 0;
-  if (e->flush_deferred) {
-    // the previous step's flush + this step's first layer (the deferral below is only made when this holds)
-    GemmBatch b{}; b.n = 1;
-    GemmProblem& p = b.prob[0];
-    p.P = wat(h, DQNHIP_ACTOR, la.w_off[0]); p.ldp = la.kp[0];
-    p.Q = e->acts[0]; p.ldq = la.kp[0];
-    p.C = e->acts[1]; p.ldc = la.kp[1];
-    p.Pdim = la.dims[1]; p.Qdim = e->Npad; p.Kred = la.kp[0];
-    p.bias = wat(h, DQNHIP_ACTOR, la.b_off[0]); p.relu = 1;
-    p.tiles_p = p.Pdim / 32; p.tiles_q = p.Qdim / 32; p.tile_base = 0;
-    b.total_tiles = p.tiles_p * p.tiles_q;
-    const size_t lds = std::max<size_t>(4 * 2 * 2 * 64 * 16, d.T * sizeof(float));
-    hipLaunchKernelGGL(k_env_l0_flush, dim3(b.total_tiles + d.N), dim3(256), lds, st, b, d, RO(h)->ring,
-                       (const DevState*)RO(h)->st, h->cfg.gamma);
-    HIPCHK(hipGetLastError());
-    e->flush_deferred = false;
-    first = 1;
-  }
-  for (int i = first; i < la.L; ++i) RC(layer_forward(h, st, &fp, 1, e->Npad, i));
-  if (!fused) {
-    HeadArgs a{}; a.X = e->acts[la.L]; a.ldx = la.dims[la.L]; a.H = la.dims[la.L]; a.rows = e->Npad;
-    a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.b = wat(h, DQNHIP_ACTOR, la.hb_off); a.out16 = d.out16;
-    RC((head_forward<kNO, HEAD_ACTOR>(h, st, a)));
-  }
-  hipLaunchKernelGGL(k_env_step, dim3(d.N), dim3(256), 2 * d.SP * sizeof(float), st, d);
-  HIPCHK(hipGetLastError());
-  if (more_follow && fused && l0_direct && !h->timing) { e->flush_deferred = true; return 0; }
-  hipLaunchKernelGGL(k_env_flush, dim3(d.N), dim3(256), d.T * sizeof(float), st, d, RO(h)->ring,
-                     (const DevState*)RO(h)->st, h->cfg.gamma);
-  HIPCHK(hipGetLastError());
-  if (d.commit_ticket == nullptr) {
-    hipLaunchKernelGGL(k_env_commit, dim3(1), dim3(256), 0, st, d, RO(h)->ring, RO(h)->st);
-    HIPCHK(hipGetLastError());
-  }
-  return 0;
-}
-
-static int env_capture(dqnhip_env* e, int which) {
-  dqnhip_learner* h = e->h;
-  hipGraph_t graph = nullptr;
-  HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-  int rc = 0;
-  const int n = which ? kEnvUnroll : 1;
-  for (int s = 0; s < n && !rc; ++s) rc = env_one_step(e, s + 1 < n);
-  e->flush_deferred = false;                     // (only left set if a launch failed: the sequence is abandoned)
-  hipError_t err = hipStreamEndCapture(h->stream, &graph);
-  if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-  if (err != hipSuccess) return fail("hipStreamEndCapture (env): %s", hipGetErrorString(err));
-  err = hipGraphInstantiate(&e->graph[which], graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
-  if (err != hipSuccess) return fail("hipGraphInstantiate (env): %s", hipGetErrorString(err));
-  return 0;
-}
-
-int dqnhip_env_step(dqnhip_env_handle e, float epsilon, int32_t n_steps) {
-  if (!e) return fail("null env");
-  if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return fail("Check failed: epsilon >= 0.0 && epsilon <= 1.0");   // src/dqn.cpp:698
-  if (n_steps < 1) return fail("n_steps must be >= 1");
-  dqnhip_learner* h = e->h;
-  HIPCHK(hipSetDevice(h->cfg.device));
-  hipStream_t st = h->stream;
-  RingUse ring_use(h);
-  hipLaunchKernelGGL(k_set_float<0>, dim3(1), dim3(1), 0, st, e->eps_dev, epsilon);
-  HIPCHK(hipGetLastError());
-  // the step is a fixed launch sequence (9 launches at L = 4, ~6 us each when launch-bound): replay it
-  // as a hipGraph unless the learner's layers may be re-pointed (sharing) or graphs are off
-  const bool use_graph = h->cfg.use_graph && !e->graph_failed && !h->timing && !h->w_owner && !h->ring_owner;
-  int s = 0;
-  if (use_graph) {
-    for (int which = 1; which >= 0; --which) {
-      const int n = which ? kEnvUnroll : 1;
-      while (n_steps - s >= n) {
-        if (!e->graph[which] && env_capture(e, which)) { e->graph_failed = true; break; }
-        HIPCHK(hipGraphLaunch(e->graph[which], st));
-        s += n;
-      }
-      if (e->graph_failed) break;
-    }
-  }
-  for (; s < n_steps; ++s) {
-    const int rc = env_one_step(e, s + 1 < n_steps);
-    if (rc) { e->flush_deferred = false; return rc; }
-  }
-  RO(h)->ring_stale = true;
-  return 0;
-}
-
-int dqnhip_env_stats(dqnhip_env_handle e, int64_t* env_steps, int64_t* episodes, double* reward_sum, int64_t* goals) {
-  if (!e) return fail("null env");
-  dqnhip_learner* h = e->h;
-  HIPCHK(hipSetDevice(h->cfg.device));
-  const size_t N = e->d.N;
-  std::vector<unsigned long long> a(N), b(N), c(N); std::vector<double> r(N);
-  HIPCHK(hipMemcpyAsync(a.data(), e->d.n_steps, N * 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(b.data(), e->d.n_episodes, N * 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(c.data(), e->d.n_goals, N * 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(r.data(), e->d.reward_sum, N * 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  long long s0 = 0, s1 = 0, s2 = 0; double s3 = 0;
-  for (size_t i = 0; i < N; ++i) { s0 += a[i]; s1 += b[i]; s2 += c[i]; s3 += r[i]; }
-  if (env_steps) *env_steps = s0; if (episodes) *episodes = s1; if (goals) *goals = s2; if (reward_sum) *reward_sum = s3;
-  RingUse ring_use(h);
-  return refresh_ring(h);
-}
-
-int dqnhip_env_debug_read(dqnhip_env_handle e, const char* name, float* host, size_t count) {
-  if (!e || !name || !host) return fail("null argument");
-  dqnhip_learner* h = e->h;
-  HIPCHK(hipSetDevice(h->cfg.device));
-  const size_t N = e->d.N;
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (!strcmp(name, "action") || !strcmp(name, "episode_len")) {
-    if (count < N) return fail("buffer too small");
-    std::vector<int> t(N);
-    HIPCHK(hipMemcpy(t.data(), !strcmp(name, "action") ? e->d.act : e->d.len, N * 4, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < N; ++i) host[i] = (float)t[i];
-    return 0;
-  }
-  const float* src = nullptr; size_t n = N;
-  if (!strcmp(name, "arg1")) src = e->d.arg1;
-  else if (!strcmp(name, "arg2")) src = e->d.arg2;
-  else if (!strcmp(name, "reward")) src = e->d.rew;
-  else if (!strcmp(name, "state")) {
-    if (count < N * h->S) return fail("buffer too small");
-    std::vector<float> t(N * e->d.SP);
-    HIPCHK(hipMemcpy(t.data(), e->d.cur, t.size() * 4, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < N; ++i) memcpy(host + i * h->S, &t[i * e->d.SP], h->S * 4);
-    return 0;
-  } else if (!strcmp(name, "actor_out")) {
-    // the ActorOutput chosen at the last step = last written row of the open episode, or (if the
-    // episode just ended) not available any more: report the greedy output instead
-    if (count < N * kNO) return fail("buffer too small");
-    std::vector<float> t(N * kAP);
-    HIPCHK(hipMemcpy(t.data(), e->d.out16, t.size() * 4, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < N; ++i) memcpy(host + i * kNO, &t[i * kAP], kNO * 4);
-    return 0;
-  } else return fail("unknown env debug buffer '%s'", name);
-  if (count < n) return fail("buffer too small");
-  HIPCHK(hipMemcpy(host, src, n * 4, hipMemcpyDeviceToHost));
-  return 0;
-}
 }  // extern "C"

@@ -83,7 +83,7 @@ struct Ring {
 // arithmetic runs on one thread and publishes (head,size); rows are scattered
 // by the rest of the grid from the values BEFORE the update (old_head/old_size
 // are recomputed identically by every block).
-__global__ void k_add_transitions(Ring ring, DevState* st, const float* __restrict__ s,
+static __global__ void k_add_transitions(Ring ring, DevState* st, const float* __restrict__ s,
                                   const float* __restrict__ a, const float* __restrict__ r,
                                   const float* __restrict__ mc, const float* __restrict__ nx,
                                   const uint8_t* __restrict__ term, int n, int single_mode,
@@ -123,7 +123,7 @@ __global__ void k_add_transitions(Ring ring, DevState* st, const float* __restri
   }
 }
 
-__global__ void k_read_memory(Ring ring, const DevState* st, int first, int n, float* s, float* a,
+static __global__ void k_read_memory(Ring ring, const DevState* st, int first, int n, float* s, float* a,
                               float* r, float* mc, float* nx, uint8_t* term) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -142,7 +142,7 @@ __global__ void k_read_memory(Ring ring, const DevState* st, int first, int n, f
 }
 
 // DQN::SampleStatesFromMemory (src/dqn.cpp:511-523): one wave per sampled transition, dense [n][S] out
-__global__ void k_sample_states(Ring ring, const DevState* rs, const int* __restrict__ idx_in, uint64_t key,
+static __global__ void k_sample_states(Ring ring, const DevState* rs, const int* __restrict__ idx_in, uint64_t key,
                                 unsigned long long counter, int n, float* __restrict__ out) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -259,7 +259,7 @@ __device__ __forceinline__ void gather_block(const GatherArgs& g, const int blk)
     o.term[row] = ring.term[slot] ? 1.0f : 0.0f; o.idx[row] = li;
   }
 }
-__global__ void k_gather(GatherArgs g) { gather_block(g, (int)blockIdx.x); }
+static __global__ void k_gather(GatherArgs g) { gather_block(g, (int)blockIdx.x); }
 
 
 // ---- skinny head layers ------------------------------------------------------
@@ -475,7 +475,7 @@ struct HeadTrainArgs {
   // critic's head-backward launch of Step(1) is gone.
   float* dZ;
 };
-__global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
+static __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
   __shared__ float s_part[4];
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void k_head_wred(HeadBwdBigArgs b, int chunks)
 // Sum of squares of a gradient arena -> per-block partials (used after an
 // all-reduce, where the GEMM-epilogue partials no longer describe the reduced
 // gradient).
-__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, size_t n4,
+static __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, size_t n4,
                                                float* __restrict__ partial) {
   __shared__ float s[4];
   float acc = 0.0f;
@@ -947,7 +947,7 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
   u += 0x7FFFu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-__global__ __launch_bounds__(256) void k_to_bf16(const float* __restrict__ g, size_t n4, uint16_t* __restrict__ out) {
+static __global__ __launch_bounds__(256) void k_to_bf16(const float* __restrict__ g, size_t n4, uint16_t* __restrict__ out) {
   typedef __attribute__((ext_vector_type(4))) uint16_t u16x4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void k_to_bf16(const float* __restrict__ g, si
   }
 }
 // bf16 image (after the all-reduce) -> fp32 arena + sum-of-squares partials (k_sumsq's layout and order)
-__global__ __launch_bounds__(256) void k_sumsq_bf16(const uint16_t* __restrict__ in, float* __restrict__ g, size_t n4,
+static __global__ __launch_bounds__(256) void k_sumsq_bf16(const uint16_t* __restrict__ in, float* __restrict__ g, size_t n4,
                                                     float* __restrict__ partial) {
   typedef __attribute__((ext_vector_type(4))) uint16_t u16x4;
   __shared__ float s[4];
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_adam_soft_t(AdamArgs a) {
 }
 __device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot, double* sq, bool skipped_now);   // below
 
-__global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
+static __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
   __shared__ float s[8];
   __shared__ double sq[4];
   adam_soft_body<1, 0>(a, blockIdx.x, gridDim.x, s);
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamArgs a) {
 // (nothing it reads or writes is touched by this optimiser pass: the minibatch panels are dead until that update's first
 // forward, its scalars go to the other DevState slot, its counters come from DevState::gbase), the rest is k_adam_soft.
 // Takes the gather (a ~5-us launch of two dependent HBM round trips) off the chain of all but the first update of such a graph.
-__global__ __launch_bounds__(256) void k_adam_soft_gather(AdamArgs a, GatherArgs g) {
+static __global__ __launch_bounds__(256) void k_adam_soft_gather(AdamArgs a, GatherArgs g) {
   __shared__ float s[8];
   __shared__ double sq[4];
   if ((int)blockIdx.x < g.blocks) { gather_block(g, (int)blockIdx.x); return; }
@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_adam_soft_gather(AdamArgs a, GatherArgs
 
 // Sum of up to 8 co-located gradient arenas in rank order, written back to all (dqnhip_reduce_gradients_local)
 struct LocalReduce { float* g[8]; int n; size_t n4; };
-__global__ __launch_bounds__(256) void k_local_reduce(LocalReduce a) {
+static __global__ __launch_bounds__(256) void k_local_reduce(LocalReduce a) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) {
     f32x4 s = reinterpret_cast<const f32x4*>(a.g[0])[i];
     for (int r = 1; r < a.n; ++r) { const f32x4 v = reinterpret_cast<const f32x4*>(a.g[r])[i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__(256) void k_local_reduce(LocalReduce a) {
 // Sharded optimiser (DQNHIP_DP_SHARD_OPT): the sum of squares of THIS rank's slice of the reduced gradient, folded from
 // k_sumsq's partials with the tree adam_scalars uses (strided sums, butterfly, fixed cross-wave order: a one-rank group
 // then derives the same bits as the replicated form) into tail[3]; the 4-float tail is what the ranks all-reduce.
-__global__ __launch_bounds__(256) void k_shard_scal(const float* __restrict__ partial, int n_partial, float* tail) {
+static __global__ __launch_bounds__(256) void k_shard_scal(const float* __restrict__ partial, int n_partial, float* tail) {
   __shared__ float s[4];
   float acc = 0.0f;
   for (int i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_shard_scal(const float* __restrict__ pa
   if (threadIdx.x == 0) tail[3] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 // dqnhip_apply_update_sharded (one process standing in for every rank of a group in turn): total += the slice's sum
-__global__ void k_shard_accumulate(float* total, const float* tail, int first) {
+static __global__ void k_shard_accumulate(float* total, const float* tail, int first) {
   total[0] = first ? tail[3] : total[0] + tail[3];
 }
 
@@ -1177,7 +1177,7 @@ __global__ void k_shard_accumulate(float* total, const float* tail, int first) {
 // ([loss_sum, q_sum, 0, 0]) so they ride in the gradient all-reduce.
 // tail[2] carries this rank's non-finite-target flag (0 / 1): the flag is raised from the rank's OWN replay shard,
 // so without it one rank would stop with "Target not finite!" while the others walk into the next collective.
-__global__ __launch_bounds__(256) void k_tails(const float* loss_partial, int n_loss, const double* q_partial, int n_q,
+static __global__ __launch_bounds__(256) void k_tails(const float* loss_partial, int n_loss, const double* q_partial, int n_q,
                                                float inv_batch, float* critic_tail, float* actor_tail, const DevState* st) {
   // one block, same reduction tree as k_tick (strided partials, butterfly, fixed cross-wave order)
   __shared__ float sdot[4];
@@ -1242,7 +1242,7 @@ __device__ __forceinline__ void tick_body(const TickArgs& a, float* sdot /*[4]*/
 // ++iter of one solver (dqnhip_apply_update: set_iter(iter() + 1), src/dqn.cpp:965)
 // It is also this path's "tick": an optimiser pass outside an update may have raised kFlagGradNorm (skipped step), and
 // dqnhip_read_stats only reads the host-mapped words — mirror the sticky flags there (loss / avg_q stay the last update's).
-__global__ void k_advance_iter(DevState* st, int which, float* host_stats) {
+static __global__ void k_advance_iter(DevState* st, int which, float* host_stats) {
   if (which == 0) st->actor_iter += 1; else st->critic_iter += 1;
   if (host_stats != nullptr) {
     const int fl = __hip_atomic_load(&st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1252,7 +1252,7 @@ __global__ void k_advance_iter(DevState* st, int which, float* host_stats) {
 
 // ---- acting-time helpers ---------------------------------------------------------
 // dense [n][S] -> padded panel [npad][SP] (pad rows/cols zero)
-__global__ void k_pack_rows(const float* __restrict__ src, int n, int S, float* __restrict__ dst,
+static __global__ void k_pack_rows(const float* __restrict__ src, int n, int S, float* __restrict__ dst,
                             int npad, int SP) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npad * SP) return;
@@ -1260,7 +1260,7 @@ __global__ void k_pack_rows(const float* __restrict__ src, int n, int S, float* 
   dst[i] = (r < n && c < S) ? src[(size_t)r * S + c] : 0.0f;
 }
 // critic input panel from dense states + dense actor outputs
-__global__ void k_pack_critic(const float* __restrict__ s, const float* __restrict__ a, int n, int S,
+static __global__ void k_pack_critic(const float* __restrict__ s, const float* __restrict__ a, int n, int S,
                               float* __restrict__ dst, int npad, int KP) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npad * KP) return;
@@ -1269,7 +1269,7 @@ __global__ void k_pack_critic(const float* __restrict__ s, const float* __restri
   if (r < n) { if (c < S) v = s[(size_t)r * S + c]; else if (c < S + kNO) v = a[(size_t)r * kNO + (c - S)]; }
   dst[i] = v;
 }
-__global__ void k_unpack_out(const float* __restrict__ out16, int n, float* __restrict__ dst) {
+static __global__ void k_unpack_out(const float* __restrict__ out16, int n, float* __restrict__ dst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * kNO) return;
   dst[i] = out16[(size_t)(i / kNO) * kAP + (i % kNO)];

@@ -120,6 +120,7 @@ class DQN:
         self.smoothed_actor_loss_ = 0.0
         self.last_snapshot_iter_ = 0
         self.snapshot_freq = 10000                      # FLAGS_snapshot_freq, src/dqn.cpp:28
+        self.select_actions_cap = 0                     # 0: the reference's cap (the minibatch, src/dqn.cpp:699); -1: none; n: n
 
     # -- plumbing -----------------------------------------------------------------
     @staticmethod
@@ -295,10 +296,15 @@ class DQN:
         return out
 
     def SelectActions(self, states_batch, epsilon):
-        """src/dqn.cpp:695-711: ONE epsilon draw for the whole batch."""
+        """src/dqn.cpp:695-711: ONE epsilon draw for the whole batch.  The reference's `CHECK_LE(states_batch.size(),
+        kMinibatchSize)` (:699) holds with this learner's minibatch; `select_actions_cap` widens it (-1: any batch — the
+        device path has no MemoryData layer whose width would bound it; n > 0: that many)."""
         if not (0.0 <= epsilon <= 1.0):
             raise DQNFatal("CHECK failed: epsilon >= 0.0 && epsilon <= 1.0")
         s = _f32(states_batch).reshape(-1, self.state_size_)
+        cap = self.kMinibatchSize if self.select_actions_cap == 0 else self.select_actions_cap
+        if cap >= 0 and s.shape[0] > cap:
+            raise DQNFatal("CHECK failed: states_batch.size() <= kMinibatchSize (%d vs. %d)" % (s.shape[0], cap))
         if self.random_engine.uniform(0.0, 1.0) < epsilon:
             return np.stack([self.GetRandomActorOutput() for _ in range(s.shape[0])])
         return self.SelectActionGreedily(s)
@@ -406,17 +412,28 @@ class DQN:
         return buf.raw
 
     @staticmethod
-    def _dp_flags(per_layer, half_grads, shard_opt=False):
+    def _dp_flags(per_layer, half_grads, shard_opt=False, unverified_ok=False):
         return ((capi.DP_PER_LAYER if per_layer else 0) | (capi.DP_HALF_GRADS if half_grads else 0) |
-                (capi.DP_SHARD_OPT if shard_opt else 0))
+                (capi.DP_SHARD_OPT if shard_opt else 0) | (capi.DP_UNVERIFIED_OK if unverified_ok else 0))
 
-    def dp_init(self, unique_id, per_layer=False, half_grads=False, shard_opt=False):
+    def dp_init(self, unique_id, per_layer=False, half_grads=False, shard_opt=False, unverified_ok=False):
+        """unverified_ok: per_layer / shard_opt have never run on more than one rank; a real group must ask for them explicitly."""
         assert len(unique_id) == capi.DP_ID_BYTES
         buf = C.create_string_buffer(bytes(unique_id), capi.DP_ID_BYTES)
-        self._ck(self.lib.dqnhip_dp_init(self.h, buf, capi.DP_ID_BYTES, self._dp_flags(per_layer, half_grads, shard_opt)))
+        self._ck(self.lib.dqnhip_dp_init(self.h, buf, capi.DP_ID_BYTES, self._dp_flags(per_layer, half_grads, shard_opt, unverified_ok)))
 
-    def dp_init_file(self, path, per_layer=False, timeout_s=120, half_grads=False, shard_opt=False):
-        self._ck(self.lib.dqnhip_dp_init_file(self.h, os.fsencode(path), self._dp_flags(per_layer, half_grads, shard_opt), int(timeout_s)))
+    def dp_init_file(self, path, per_layer=False, timeout_s=120, half_grads=False, shard_opt=False, unverified_ok=False):
+        self._ck(self.lib.dqnhip_dp_init_file(self.h, os.fsencode(path), self._dp_flags(per_layer, half_grads, shard_opt, unverified_ok), int(timeout_s)))
+
+    @staticmethod
+    def dp_info():
+        """(RCCL version, path of the librccl this process resolved): a group must not mix builds (dqnhip_dp_init checks)."""
+        lib = capi.load()
+        v = C.c_int32()
+        buf = C.create_string_buffer(4096)
+        if lib.dqnhip_dp_info(C.byref(v), buf, 4096) != 0:
+            raise DQNFatal(lib.dqnhip_last_error().decode())
+        return v.value, os.fsdecode(buf.value)
 
     def dp_gather_state(self):
         """sharded optimiser: all-gather of the Adam history (collective; no-op otherwise)"""

@@ -113,7 +113,7 @@ class NativeDataParallel:
 
 
 def make_native_data_parallel(pkg, state_size, rank, world, device, group=None, per_layer=False, half_grads=False,
-                              shard_opt=False, **dqn_kwargs):
+                              shard_opt=False, unverified_ok=False, **dqn_kwargs):
     """One learner per rank with an RCCL communicator inside the library.  Needs an initialised
     torch.distributed group only to ship the id when world > 1.  use_graph=True (a DQN keyword) makes
     dqnhip_dp_update replay the whole update, collectives included, as one captured hipGraph; shard_opt=True shards
@@ -122,5 +122,5 @@ def make_native_data_parallel(pkg, state_size, rank, world, device, group=None, 
     box = [pkg.DQN.dp_unique_id() if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(box, src=0, group=group)
-    dqn.dp_init(box[0], per_layer=per_layer, half_grads=half_grads, shard_opt=shard_opt)
+    dqn.dp_init(box[0], per_layer=per_layer, half_grads=half_grads, shard_opt=shard_opt, unverified_ok=unverified_ok)
     return dqn, NativeDataParallel(dqn)

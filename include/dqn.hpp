@@ -144,6 +144,8 @@ class DQN {
   int unum_;
   int minibatch_;
   bool dp_ = false;                                    // -dp_rendezvous given: UpdateActorCritic() is one rank's share of a data-parallel update
+  bool dp_sync_pending_ = false;                       // a Restore* / Load* ran since the group's last broadcast: re-sync at the next update
+  void SyncReplicasIfPending();
   dqnhip_handle h_;
 };
 

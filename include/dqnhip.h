@@ -250,6 +250,13 @@ int dqnhip_grad_buffer(dqnhip_handle h, int32_t net, void** dptr, size_t* nfloat
 #define DQNHIP_DP_PER_LAYER 1
 #define DQNHIP_DP_HALF_GRADS 2
 #define DQNHIP_DP_SHARD_OPT 4
+/* DQNHIP_DP_PER_LAYER and DQNHIP_DP_SHARD_OPT have only ever run on one-rank groups (no box with more than one GPU has been
+ * available): dqnhip_dp_init refuses them for dp_world > 1 unless this bit says the caller knows.  The replicated
+ * one-bucket exchange (flags 0, optionally DQNHIP_DP_HALF_GRADS) is the supported form. */
+#define DQNHIP_DP_UNVERIFIED_OK 256
+/* ncclGetVersion() and the shared object RCCL was resolved from in this process (a PyTorch host process resolves torch's
+ * bundled librccl, a bare host /opt/rocm's); dqnhip_dp_init cross-checks the version over the group and fails on a mix. */
+int dqnhip_dp_info(int32_t* rccl_version, char* path, size_t path_bytes);
 int dqnhip_dp_unique_id(void* id_out, size_t bytes);
 int dqnhip_dp_init(dqnhip_handle h, const void* id, size_t bytes, int32_t flags);
 int dqnhip_dp_init_file(dqnhip_handle h, const char* path, int32_t flags, int32_t timeout_s);

@@ -19,9 +19,14 @@ struct TestDQN : dqn::DQN {
   std::vector<dqn::InputStates> States(int n) { return SampleStatesFromMemory(n); }
 };
 
+// -check cpu_mode: construct under Caffe CPU mode (the driver's -gpu=false, src/dqn_main.cpp:208-212) -> the adaptor must stop with its
+//                  message before touching the device;  -check select_cap: SelectActions on minibatch + 1 states -> the reference's
+//                  CHECK_LE (src/dqn.cpp:699) unless -select_actions_cap widens it
+DEFINE_string(check, "", "run one boundary-behaviour check instead of the episode loop: cpu_mode | select_cap");
+
 int main(int argc, char** argv) {
   gflags::ParseCommandLineFlags(&argc, &argv, true);     // the learner flags are defined by dqn_dropin.cpp
-  caffe::Caffe::set_mode(caffe::Caffe::GPU);
+  caffe::Caffe::set_mode(FLAGS_check == "cpu_mode" ? caffe::Caffe::CPU : caffe::Caffe::GPU);
   const int num_features = 59;                      // NumStateFeatures(1), src/hfo_game.hpp:13-16
   caffe::SolverParameter actor_sp, critic_sp;
   // tower 128-64-64-64: what a user gets by editing <save>_actor.prototxt / _critic.prototxt
@@ -39,6 +44,14 @@ int main(int argc, char** argv) {
   TestDQN dqn(actor_sp, critic_sp, "/tmp/dqnhip_adaptor_smoke_run_agent0", num_features, 0);
   std::mt19937 env(1);
   std::uniform_real_distribution<float> U(-1.f, 1.f);
+  if (FLAGS_check == "cpu_mode") { std::fprintf(stderr, "the constructor accepted Caffe CPU mode\n"); return 20; }
+  if (FLAGS_check == "select_cap") {
+    std::vector<dqn::InputStates> batch(dqn.minibatch_size() + 1);
+    for (auto& in : batch) { in[0] = std::make_shared<dqn::StateData>(num_features); for (auto& v : *in[0]) v = U(env); }
+    const auto out = dqn.SelectActions(batch, 0.0);       // aborts here under the default cap
+    std::printf("select_cap: %zu actions\n", out.size());
+    return out.size() == batch.size() ? 0 : 21;
+  }
   int total_steps = 0;
   for (int episode = 0; episode < 6; ++episode) {
     std::vector<dqn::Transition> ep;

@@ -31,3 +31,23 @@ def test_adaptor_runs_episode_loop(pkg, gpu):
     r = subprocess.run([exe, "-seed", "7", "-memory", "5000", "-memory_threshold", "100"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "adaptor smoke OK" in r.stdout
+
+
+def test_cpu_mode_stops_with_the_adaptors_message(pkg):
+    """-gpu=false (Caffe CPU mode, src/dqn_main.cpp:208-212): no CPU backend exists by design; the adaptor says so through the
+    driver's logging path BEFORE touching the device (so this runs on a box without a GPU), instead of a bare CHECK."""
+    exe = _build(pkg)
+    r = subprocess.run([exe, "-check", "cpu_mode"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and r.returncode != 20, (r.returncode, r.stdout, r.stderr)
+    assert "-gpu=false" in r.stderr and "not provided by the MI355X drop-in" in r.stderr and "src/dqn_main.cpp:208-212" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_select_actions_keeps_the_references_batch_cap(pkg, gpu):
+    """src/dqn.cpp:699 CHECK_LE(states_batch.size(), kMinibatchSize): kept (with this learner's -minibatch); -select_actions_cap widens it."""
+    exe = _build(pkg)
+    r = subprocess.run([exe, "-check", "select_cap", "-memory", "5000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "select_cap:" not in r.stdout and "Check failed" in r.stderr, (r.returncode, r.stdout, r.stderr)
+    for cap in ("-1", "64"):
+        r = subprocess.run([exe, "-check", "select_cap", "-memory", "5000", "-select_actions_cap", cap], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "select_cap: 33 actions" in r.stdout, (cap, r.returncode, r.stdout, r.stderr)

@@ -68,7 +68,15 @@ def test_product_library_reads_no_environment_variable():
     """A/B switches are dqnhip_config.tuning_flags bits with parity tests, not getenv in the shipped code."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "dqn-hfo_amd", "csrc")
-    product = ["learner.hip", "snapshot.cpp", "dqn_dropin.cpp", "env.hip.h", "gemm_common.hip.h", "gemm_direct.hip.h",
+    product = ["learner.hip", "learner_dp.hip", "learner_io.hip", "learner_env.hip", "learner_internal.hip.h", "snapshot.cpp", "dqn_dropin.cpp", "env.hip.h", "gemm_common.hip.h", "gemm_direct.hip.h",
                "hgemm.hip.h", "small_kernels.hip.h"]
     hits = [f for f in product if "getenv" in open(os.path.join(csrc, f)).read()]
     assert hits == [], hits
+
+
+def test_rccl_build_is_reported_without_a_gpu(pkg):
+    """dqnhip_dp_info: which RCCL this process resolved (a PyTorch host process gets torch's bundled build, a bare host
+    /opt/rocm's); dqnhip_dp_init cross-checks the version over the group and fails loudly on a mix."""
+    ver, path = pkg.DQN.dp_info()
+    assert ver > 20000, ver
+    assert "rccl" in os.path.basename(path), path

@@ -175,3 +175,20 @@ def test_bench_two_ranks_flow_on_one_gpu(pkg, gpu):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 10 and d["config"]["parallelism"].startswith("dp2")
     assert d["config"]["global_minibatch"] == 512 and d["roofline"] is not None
+
+
+def test_unverified_exchange_forms_are_fenced_for_real_groups(pkg, gpu):
+    """DQNHIP_DP_PER_LAYER / DQNHIP_DP_SHARD_OPT have only ever run on one-rank groups: dqnhip_dp_init refuses them for
+    dp_world > 1 unless DQNHIP_DP_UNVERIFIED_OK is passed — before any communicator is created, so a rank of a 2-rank group
+    on this one-GPU box can show it without a peer.  One-rank groups (the launch-sequence tests) stay open."""
+    d = pkg.DQN(59, minibatch=32, hidden=(64, 64), memory=256, dp_world=2, dp_rank=0)
+    uid = pkg.DQN.dp_unique_id()
+    for kw in (dict(per_layer=True), dict(shard_opt=True), dict(shard_opt=True, half_grads=True)):
+        with pytest.raises(pkg.DQNFatal, match="never run on more than one rank"):
+            d.dp_init(uid, **kw)
+    d.close()
+    d1 = pkg.DQN(59, minibatch=32, hidden=(64, 64), memory=256)
+    d1.dp_init(pkg.DQN.dp_unique_id(), shard_opt=True)          # world 1: allowed
+    ver, path = pkg.DQN.dp_info()
+    assert ver > 20000 and "rccl" in path, (ver, path)
+    d1.dp_destroy(); d1.close()

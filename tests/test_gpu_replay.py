@@ -77,6 +77,17 @@ def test_select_actions_any_batch_and_epsilon(pkg, gpu):
     assert dqn.SelectAction(s[0], 0.0).shape == (10,)
     with pytest.raises(pkg.DQNFatal):
         dqn.SelectActions(s, 1.5)                               # CHECK(epsilon >= 0 && epsilon <= 1)
+    # CHECK_LE(states_batch.size(), kMinibatchSize), src/dqn.cpp:699 — kept; select_actions_cap widens it (-1: any batch)
+    s33 = synth_states(rng, 33, 59)
+    with pytest.raises(pkg.DQNFatal, match="kMinibatchSize"):
+        dqn.SelectActions(s33, 0.0)
+    assert dqn.SelectActions(s33[:32], 0.0).shape == (32, 10)
+    dqn.select_actions_cap = -1
+    np.testing.assert_allclose(dqn.SelectActions(s33, 0.0), orc.actor_forward(s33), atol=1e-4)
+    dqn.select_actions_cap = 40
+    assert dqn.SelectActions(s33, 1.0).shape == (33, 10)
+    with pytest.raises(pkg.DQNFatal):
+        dqn.SelectActions(synth_states(rng, 41, 59), 0.0)
     dqn.close(); orc.close()
 
 
