@@ -251,6 +251,63 @@ def live_pmc_traffic(kernel, extra_args):
         "%d + %d launches averaged); 2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md" % (len(acc), len(acc)))
 
 
+# kernel name (as rocprofv3 prints it, spaces removed) -> the learner's timing family
+TRACE_FAMILY = (("gemm_fwd_lds<4,2,true,1>", "gemm_fwd_lds_4x2"), ("gemm_fwd_lds<4,2,true>", "gemm_fwd_lds_4x2"), ("gemm_fwd_lds<2,2,true", "gemm_fwd_lds_2x2"),
+                ("gemm_fwd_lds<1,1,true", "gemm_fwd_lds_2x2"), ("gemm_fwd_direct", "gemm_fwd_direct"), ("gemm_bwd_seq", "gemm_bwd_pair"),
+                ("gemm_bwd_pair_direct", "gemm_bwd_pair"), ("gemm_dgrad_lds", "gemm_dgrad"), ("gemm_dgrad_direct", "gemm_dgrad"), ("gemm_dgrad_narrow", "gemm_dgrad"),
+                ("gemm_wgrad_tail", "gemm_wgrad"), ("gemm_wgrad_narrow", "gemm_wgrad"), ("k_adam_soft", "adam"))
+
+
+def live_kernel_trace(extra_args, updates=320):
+    """Per-kernel launch durations of the GRAPH-REPLAYED update, measured NOW on this box: one child run of this script under
+    `rocprofv3 --kernel-trace` (no counters, no other trace domain), the K steps enqueued exactly as the headline enqueues them
+    (dqnhip_update_async_n: sixteen updates per hipGraph launch).  Inside a replayed graph a kernel's reported duration runs up
+    to the next kernel's start (profiles/r04_graph_gap.txt), so these durations are what the wall clock is made of — the same
+    numbers `rocprofv3 --kernel-trace --stats` prints (profiles/rNN_fp32_b256_kernel_stats.md); eager HIP events around single
+    launches (the fallback) differ from them by a few per cent and from run to run.
+    Returns ({kernel: (mean_us, launches_per_update)}, source) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    d = tempfile.mkdtemp(prefix="dqnhip_kt_", dir="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+           "--steps", str(updates), "--warmup", "32", "--no-cpu-baseline", "--no-env", "--no-subrecords", "--no-live-pmc", "--no-live-trace", "--trace-child",
+           "--replay", "100000"] + list(extra_args)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+    except Exception as e:              # noqa: BLE001
+        shutil.rmtree(d, ignore_errors=True)
+        return None, "rocprofv3 --kernel-trace child failed: %r" % (e,)
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            n = row["Kernel_Name"].replace("void ", "").replace("dqnhip::", "")
+            n = (n[:n.index("(")] if "(" in n else n).replace(" ", "")
+            rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), n))
+    shutil.rmtree(d, ignore_errors=True)
+    if not rows:
+        return None, "rocprofv3 --kernel-trace child: no kernel rows (rc %d: %s)" % (r.returncode, (r.stderr or "")[-200:])
+    rows.sort()
+    # the timed region = the last `updates` updates: count them by the actor's optimiser pass, the last launch of every update
+    # (k_adam_soft_gather inside the sixteen-update graph, k_adam_soft with the tick otherwise: two k_adam_soft* per update)
+    adam = [i for i, x in enumerate(rows) if x[2].startswith("k_adam_soft")]
+    if len(adam) < 2 * updates:
+        return None, "rocprofv3 --kernel-trace child: %d optimiser launches < 2 x %d updates" % (len(adam), updates)
+    first = adam[len(adam) - 2 * updates - 1] + 1 if len(adam) > 2 * updates else 0
+    acc = {}
+    for s0, e0, n in rows[first:]:
+        a = acc.setdefault(n, [0.0, 0])
+        a[0] += (e0 - s0) / 1e3; a[1] += 1
+    span_us = (rows[-1][1] - rows[first][0]) / 1e3
+    out = {n: (v[0] / v[1], v[1] / float(updates)) for n, v in acc.items()}
+    return out, ("measured in this run: rocprofv3 --kernel-trace of a child pass of this bench.py (graph replay, %d updates, %.2f us per update "
+                 "inside the trace); a kernel's duration inside a replayed graph runs up to the next kernel's start" % (updates, span_us / updates))
+
+
 def probe_captured_dp(rank, world, local_rank, precision, half, per_layer, timeout_s=150):
     """Run tests/dp_native_worker.py --mode probe as a child of this rank (the children of all ranks form their own group).
     Returns {"ok": bool, ...}: ok = the child finished in time, its captured update was active and bit-identical to an
@@ -309,56 +366,74 @@ def prefill(dqn, n, seed, chunk=131072):
         done += m
 
 
-def cpu_baseline(budget_s=12.0):
-    """CPU stand-ins for 'the reference Caffe CPU solver' (which cannot be built here:
-    Caffe/HFO/boost/glog/gflags/protobuf are absent): (A) the C restatement
-    executing the reference's op sequence incl. its wasted work, OpenMP on all usable cores;
-    (B) the same sequence in PyTorch-CPU fp32 (MKL/oneDNN GEMMs).  Bounded sample."""
+REF_SHAPE = dict(B=32, S=59, hidden=(1024, 512, 256, 128))      # src/dqn.hpp:19, src/dqn.cpp:425: BASELINE configs[0]
+
+
+def cpu_baseline(budget_s=20.0):
+    """CPU stand-ins for 'the reference Caffe CPU solver' (which cannot be built here: Caffe / HFO / boost / glog / gflags /
+    protobuf are absent), SURVEY 8(d)'s matrix on this box's host cores, bounded to ~budget_s seconds:
+      shapes   BASE (B = 256, S = 58, 4 x 1024: the headline's) and REF (B = 32, S = 59, 1024-512-256-128: the reference's
+               compile-time defaults, BASELINE configs[0])
+      threads  1 and all usable cores
+      ports    (A) oracle/dqn_oracle.c executing the reference's op sequence INCLUDING its wasted work (the critic dW it computes
+               and discards, first-layer input gradients) — a checker first: every dot product is accumulated in double in a plain
+               loop, so it is NOT a BLAS-class proxy; (B) oracle/torch_ref.py in float32 (MKL / oneDNN GEMMs, autograd: necessary
+               work only) — the closest available stand-in for Caffe + an optimised BLAS.
+    `value` = the fastest BASE-shape, all-cores leg (what the headline is quoted beside)."""
     from oracle import c_oracle, torch_ref
     from synth import synth_replay
     import torch
     rng = np.random.default_rng(11)
     cores = c_oracle.usable_cores()          # affinity capped by the cgroup quota (16 on the GPU box)
-    c_oracle.set_threads(cores)
     n_rep = 8192
-    data = synth_replay(rng, n_rep, S)
-    wts = [torch_ref.init_params_np(rng, S, HIDDEN, a) for a in (True, False)]
-    res = {}
-    # (A) C port
-    orc = c_oracle.Oracle(B=B, S=S, hidden=HIDDEN, capacity=n_rep + 1, mirror_waste=1)
-    for net in (0, 1):
-        orc.set_params(net, wts[net]); orc.clone_to_target(net)
-    orc.add_transitions(*data)
-    orc.update(rng.integers(0, n_rep, size=B))      # warm-up
-    t0 = time.perf_counter(); n = 0
-    while n < 3 or time.perf_counter() - t0 < budget_s / 2:
-        orc.update(rng.integers(0, n_rep, size=B)); n += 1
-    res["c_port_openmp"] = n / (time.perf_counter() - t0)
-    orc.close()
-    # (B) torch fp32
-    torch.set_num_threads(cores)
-    t = torch_ref.TorchRef(B=B, S=S, hidden=HIDDEN, dtype=torch.float32)
-    for net in (0, 1):
-        t.set_params(net, wts[net]); t.set_params(net + 2, wts[net])
-    s, a, r, mc, nx, term = data
-    def one():
-        idx = rng.integers(0, n_rep, size=B)
-        t.update(s[idx], a[idx], r[idx], mc[idx], nx[idx], term[idx])
-    one()
-    t0 = time.perf_counter(); n = 0
-    while n < 3 or time.perf_counter() - t0 < budget_s / 2:
-        one(); n += 1
-    res["torch_cpu_fp32"] = n / (time.perf_counter() - t0)
-    best = max(res, key=res.get)
-    what = {"c_port_openmp": "C restatement (oracle/dqn_oracle.c), the reference's op sequence incl. the critic "
-                             "wgrad it computes and discards, OpenMP",
-            "torch_cpu_fp32": "PyTorch-CPU fp32 restatement (oracle/torch_ref.py, MKL/oneDNN GEMMs, autograd: "
-                              "necessary work only)"}
-    return {"value": round(res[best], 3), "unit": "updates/s", "cores": cores, "kind": "port",
-            "sample": "%s; ~%.0f s of B=256 4x1024 updates on an 8192-transition replay; faster of %s" % (
-                what[best], budget_s / 2, json.dumps({k: round(v, 3) for k, v in res.items()})),
-            "note": "stand-in: the reference's Caffe CPU solver cannot be built in this image; cores = CPU "
-                    "affinity capped by the cgroup quota"}
+    legs = [(shape, threads, port) for shape in ("base_b256", "ref_b32") for threads in (cores, 1) for port in ("c_port", "torch_fp32")]
+    per_leg = budget_s / len(legs)
+    res = {"base_b256": {"c_port": {}, "torch_fp32": {}}, "ref_b32": {"c_port": {}, "torch_fp32": {}}}
+    shapes = {"base_b256": dict(B=B, S=S, hidden=HIDDEN), "ref_b32": REF_SHAPE}
+    cache = {}
+    for shape, threads, port in legs:
+        sh = shapes[shape]
+        if shape not in cache:
+            cache[shape] = (synth_replay(rng, n_rep, sh["S"]), [torch_ref.init_params_np(rng, sh["S"], sh["hidden"], a) for a in (True, False)])
+        data, wts = cache[shape]
+        if port == "c_port":
+            c_oracle.set_threads(threads)
+            orc = c_oracle.Oracle(B=sh["B"], S=sh["S"], hidden=sh["hidden"], capacity=n_rep + 1, mirror_waste=1)
+            for net in (0, 1):
+                orc.set_params(net, wts[net]); orc.clone_to_target(net)
+            orc.add_transitions(*data)
+            one = lambda: orc.update(rng.integers(0, n_rep, size=sh["B"]))
+        else:
+            torch.set_num_threads(threads)
+            t = torch_ref.TorchRef(B=sh["B"], S=sh["S"], hidden=sh["hidden"], dtype=torch.float32)
+            for net in (0, 1):
+                t.set_params(net, wts[net]); t.set_params(net + 2, wts[net])
+            s_, a_, r_, mc_, nx_, term_ = data
+
+            def one():
+                idx = rng.integers(0, n_rep, size=sh["B"])
+                t.update(s_[idx], a_[idx], r_[idx], mc_[idx], nx_[idx], term_[idx])
+        one()                                   # warm-up
+        t0 = time.perf_counter(); n = 0
+        while n < 2 or time.perf_counter() - t0 < per_leg:
+            one(); n += 1
+        res[shape][port]["threads_1" if threads == 1 else "threads_all"] = round(n / (time.perf_counter() - t0), 3)
+        if port == "c_port":
+            orc.close()
+    c_oracle.set_threads(cores); torch.set_num_threads(cores)
+    base = {p_: res["base_b256"][p_].get("threads_all", res["base_b256"][p_].get("threads_1")) for p_ in ("c_port", "torch_fp32")}
+    best = max(base, key=base.get)
+    what = {"c_port": "C restatement (oracle/dqn_oracle.c): the reference's op sequence incl. the critic wgrad it computes and discards, OpenMP; "
+                      "double-accumulated dot products (a checker, not a BLAS proxy)",
+            "torch_fp32": "PyTorch-CPU fp32 restatement (oracle/torch_ref.py): MKL / oneDNN GEMMs, autograd, necessary work only"}
+    return {"value": base[best], "unit": "updates/s", "cores": cores, "threads": cores, "kind": "port",
+            "sample": "%s; ~%.0f s per leg of B=256 4x1024 updates on an 8192-transition replay; faster of the two ports at BASE shape, all cores" % (what[best], per_leg),
+            "updates_per_s": res,
+            "ref_shape": {"B": 32, "S": 59, "hidden": [1024, 512, 256, 128], "what": "BASELINE configs[0] / SURVEY 8(d): the reference's compile-time defaults (src/dqn.hpp:19, src/dqn.cpp:425)",
+                          "threads_1": {p_: res["ref_b32"][p_].get("threads_1") for p_ in res["ref_b32"]},
+                          "threads_all": {p_: res["ref_b32"][p_].get("threads_all") for p_ in res["ref_b32"]}},
+            "note": "stand-in: the reference's Caffe CPU solver cannot be built in this image; cores = CPU affinity capped by the cgroup quota; "
+                    "of the two ports only torch_fp32 (optimised GEMMs) is a Caffe+BLAS-class proxy"}
 
 
 def timed(step, sync, n, warm):
@@ -430,6 +505,18 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
                                                "note": "independent streams overlap each other's launch floors; dqnhip_update_async_n per agent"}
         for d in agents:
             d.read_stats(); d.close()
+        # What launches GROUPED across the two agents (both learners' layer i in one launch) could reach at most:
+        # ONE learner with a 512-row minibatch runs exactly those launches — every GEMM launch with twice the rows — and is kinder
+        # than the grouped form could be (one weight set instead of two, 64 x 32 tiles over shared weight panels).  Its rate in
+        # 256-row updates is the bound; two independent streams (above) already deliver more, so the grouped call is not built.
+        d = pkg.DQN(S, minibatch=2 * B, hidden=HIDDEN, memory=100000, seed=11, device=local_rank, use_graph=True)
+        prefill(d, 60000, seed=21)
+        dt512 = timed_n(d, torch.cuda.synchronize, 512, 64)
+        d.read_stats(); d.close()
+        out["two_agents_one_gpu_b256_fp32"]["grouped_launch_upper_bound"] = {
+            "aggregate_updates_per_s": round(2 / dt512, 1), "ms_per_512_row_update": round(dt512 * 1e3, 5),
+            "what": "one learner at minibatch 512 = the launches a two-agent grouped update would make, with ONE weight set: a bound on "
+                    "dqnhip_update_group-style grouping (not built: two streams deliver more)"}
         # configs[0]'s workload (the reference's compile-time defaults: minibatch 32, S = 59, tower 1024-512-256-128,
         # src/dqn.hpp:19, src/dqn.cpp:425) — on the GPU, since there is no CPU backend here; async and the drop-in's blocking form
         d = pkg.DQN(59, minibatch=32, hidden=(1024, 512, 256, 128), memory=100000, seed=1, device=local_rank, use_graph=True)
@@ -632,6 +719,8 @@ def main():
     ap.add_argument("--dp-timeout", type=int, default=600, help="N > 1: seconds the headline measurement may take before every rank gives up")
     ap.add_argument("--tuning", type=int, default=0, help="dqnhip_config.tuning_flags (A/B switches, include/dqnhip.h DQNHIP_TUNE_*)")
     ap.add_argument("--test-strong-record", action="store_true", help="testing: also run the N > 1 strong-scaling record with the ranks there are")
+    ap.add_argument("--trace-child", action="store_true", help="internal (live_kernel_trace): leave right after the K timed steps, so that they are the last updates in the kernel trace")
+    ap.add_argument("--no-live-trace", action="store_true", help="roofline durations from eager HIP events around single launches instead of a live rocprofv3 --kernel-trace child pass (graph replay)")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC summary instead of two live rocprofv3 --pmc child passes")
     ap.add_argument("--no-subrecords", action="store_true", help="skip the per-config sub-records (configs #3, #5; strong scaling under N > 1)")
     ap.add_argument("--mode", default="dp", choices=["dp", "replicas"],
@@ -797,6 +886,10 @@ def main():
     steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.trace_child:
+        print(json.dumps({"trace_child": True, "ms_per_step": elapsed / args.steps * 1e3}), flush=True)
+        dqn.close()
+        return                               # (a normal exit: the profiler writes its trace from its exit handlers)
     one_per_launch_ms = None
     if batched_enqueue and not args.no_graph:
         # the same K updates as K calls of dqnhip_update_async (one update per hipGraph launch), for the record
@@ -835,6 +928,29 @@ def main():
             stats[fam] = (ms, cnt)
         dqn.kernel_timing("adam", reset=True)
         dqn.set_kernel_timing(False)
+        events_stats = dict(stats)
+        dur_src = "HIP events (hipExtLaunchKernelGGL start / stop) around each launch of %d eager updates after the timed region" % n_t
+        trace = None
+        extra = ["--minibatch", str(B), "--precision", args.precision, "--tuning", str(args.tuning)]
+        if world == 1 and not args.no_live_trace and not args.no_graph:
+            trace, why = live_kernel_trace(extra)
+            if trace is None:
+                dur_src += " [live kernel trace unavailable: %s]" % why
+            else:
+                # fold the traced kernels into the timing families: (mean ms per launch, launches in n_t updates)
+                fam_acc = {}
+                for kname, (us, per_upd) in trace.items():
+                    fam = next((f for pre, f in TRACE_FAMILY if kname.startswith(pre)), None)
+                    if fam is None:
+                        continue
+                    a = fam_acc.setdefault(fam, [0.0, 0.0])
+                    a[0] += us * per_upd; a[1] += per_upd
+                if all(f in fam_acc for f in fam_flops):
+                    stats = {f: ((fam_acc[f][0] / fam_acc[f][1]) * 1e-3, fam_acc[f][1] * n_t) for f in fam_acc}
+                    dur_src = why
+                else:
+                    dur_src += " [live kernel trace lacks families: %s]" % sorted(set(fam_flops) - set(fam_acc))
+                    trace = None
         dom = max(fam_flops, key=lambda f: stats[f][0] * stats[f][1])
         ms, cnt = stats[dom]
         per_update_launches = cnt / n_t
@@ -842,7 +958,6 @@ def main():
         ach = flops_per_launch / (ms * 1e-3) / 1e12
         traffic, traffic_src = (None, None)
         if world == 1 and not args.no_live_pmc:
-            extra = ["--minibatch", str(B), "--precision", args.precision, "--tuning", str(args.tuning)]
             traffic, traffic_src = live_pmc_traffic(KERNEL_NAMES[dom], extra)
         if traffic is None:
             why = traffic_src
@@ -854,7 +969,11 @@ def main():
                 "traffic_source": traffic_src,
                 "avg_launch_us": round(ms * 1e3, 2), "launches_per_update": per_update_launches,
                 "flops_per_launch": flops_per_launch,
-                "families_us": {f: [round(stats[f][0] * 1e3, 2), stats[f][1] / n_t] for f in stats},
+                "duration_source": dur_src,
+                "families_us": {f: [round(stats[f][0] * 1e3, 2), round(stats[f][1] / n_t, 3)] for f in stats},
+                # the same families timed with eager HIP events in this process (a cross-check; differs by a few per cent run to run)
+                "families_us_eager_events": {f: [round(events_stats[f][0] * 1e3, 2), events_stats[f][1] / n_t] for f in events_stats},
+                **({"kernel_trace_us": {k: [round(v[0], 2), round(v[1], 3)] for k, v in sorted(trace.items()) if v[1] >= 0.5}} if trace else {}),
                 # every GEMM family's own fraction of the peak (algorithmic FLOPs of its launches / their summed duration)
                 "families_frac": {f: round(fam_flops[f] * n_t / (stats[f][0] * 1e-3 * stats[f][1]) / 1e12 / peak, 4) for f in fam_flops if stats[f][1]}}
     torch.cuda.synchronize()
@@ -923,9 +1042,9 @@ def main():
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f16 operands, f32 accumulate (master weights / Adam / heads f32)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: 1v0 HFO, 1 MI355X, 4x1024 actor-critic MLP, "
-                                   "minibatch %d per GPU, device-resident replay %d transitions, 58-dim synthetic states"
-                                   % (B, args.replay),
+            # (the driver keeps 120 characters of `workload`: the sizes it cut off last round are keys of their own)
+            "config": {"workload": "BASELINE configs[1]: 1v0 HFO, 1 MI355X, 4x1024 actor-critic, minibatch %d, %s-transition device replay" % (B, ("%dM" % (args.replay // 1000000)) if args.replay % 1000000 == 0 else str(args.replay)),
+                       "replay_transitions": args.replay, "state_size": S, "hidden": list(HIDDEN), "minibatch": B,
                        "minibatch_per_gpu": B, "global_minibatch": B * (world if use_dp else 1),
                        "parallelism": ("dp%d (%s all-reduce of critic then actor gradients); value counts %s"
                                        % (world, "RCCL inside libdqnhip.so (dqnhip_dp_update)" if native else args.backend + " via torch.distributed",
