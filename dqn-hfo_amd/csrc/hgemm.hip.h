@@ -139,9 +139,8 @@ typedef __attribute__((__vector_size__(4 * sizeof(short)))) short hg_s16x4;
 typedef __attribute__((address_space(3))) hg_s16x4* hg_lds_s16x4_ptr;
 
 // MODE = ta | tb << 1 of the problem (compile time: the fragment loads of the main loop differ)
-// tile_t >= 0: the caller's own block -> tile map (hgemm_group_db's XCD-aware one): row-major tile tile_t, sum-of-squares slot tile_t
 template <int WM, int WN, int MODE, int TM = 1>
-__device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid, const int tile_t = -1) {
+__device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid) {
   using Cfg = HGCfg<WM, WN, TM>;
   constexpr int NW = Cfg::NW, NT = Cfg::NT;
   constexpr int MI = 2 * TM;                 // 32-row MFMA blocks per wave in M
@@ -158,8 +157,7 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid, const 
   const int wm = (WK == 1) ? (w >> 1) : 0, wn = (WK == 1) ? (w & 1) : 0;
   const int tiles_n = g.N / BN, tiles_m = g.M / BM;
   int tm, tn;
-  if (tile_t >= 0) { tm = tile_t / tiles_n; tn = tile_t % tiles_n; }
-  else if (!(TA && TB && hg_tile_2d(bid, tiles_m, tiles_n, tm, tn))) {
+  if (!(TA && TB && hg_tile_2d(bid, tiles_m, tiles_n, tm, tn))) {
     const int T = hg_tile_of_block(bid, tiles_m * tiles_n);
     tm = T / tiles_n; tn = T % tiles_n;
   }
@@ -482,7 +480,7 @@ __device__ __forceinline__ void hgemm_body(const HGemm& g, const int bid, const 
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < NW; ++i) t += s_sq[i];
-      g.sumsq_partial[tile_t >= 0 ? tile_t : bid] = t;
+      g.sumsq_partial[bid] = t;
     }
   }
 #ifdef HG_WITH_CT16
@@ -750,86 +748,15 @@ __global__ __launch_bounds__(256) void k_db16_cols(Db16Batch b) {
 // of the chip — or 256 of 64 x 64 at four times the operand bytes per FLOP (455 TF at 4096 rows, r02 profile);
 // once the dgrad chain has produced every dZ panel the L wgrads are independent, and together they are
 // 3 x 64 + 8 = 200 tiles of 128 x 128 (+ 48 column-sum workgroups) at 4 x 1024: one round on 256 CUs.
-//
-// Which XCD computes which tile (round 5).  A wgrad's operand panels are LONG — a 128-column strip of dY or X over the
-// whole minibatch, 1 MiB at 4096 rows — and the eight XCD L2s are not coherent: a panel is fetched once by every XCD that
-// owns a tile of its tile row / column.  Spreading one layer's 8 x 8 tiles over all eight XCDs (hg_tile_2d: a 2 x 4 block
-// each) costs 8 x (2 + 4) = 48 panel fetches per layer for 16 unique panels; PMC (profiles/r04_pmc_summary.json): 212.6 MB
-// per launch for ~73 MB of operands, 4.7 TB/s over its 45 us — the launch ran at the fabric rate.  An XCD has 32 CUs and a
-// tile needs a whole CU (128 KiB of LDS), so a layer's 64 tiles fit on TWO XCDs in one round just as well: 2 x (4 + 8) = 24
-// fetches.  HGroupMap gives every problem of the launch (and the column-sum blocks) a run of XCDs and a run of slots on
-// them; block b = (XCD b % 8, slot b / 8) — dispatch order, observed, for speed only: the map is a bijection onto the tiles
-// whatever the placement really is.
-struct HGroupMap {
-  int n;                                   // entries: the batch's problems in order, then (if any) the column-sum blocks
-  unsigned char xcd0[kHGemmMax + 1], nxcd[kHGemmMax + 1];
-  unsigned short slot0[kHGemmMax + 1], per_xcd[kHGemmMax + 1], tiles[kHGemmMax + 1];
-};
-__device__ __forceinline__ bool hg_group_lookup(const HGroupMap& m, int blk, int& sel, int& t) {
-  const int x = blk & 7, j = blk >> 3;
-  bool hit = false;
-#pragma unroll
-  for (int i = 0; i <= kHGemmMax; ++i) {
-    if (i < m.n && !hit) {
-      const int dx = x - (int)m.xcd0[i], dj = j - (int)m.slot0[i];
-      if (dx >= 0 && dx < (int)m.nxcd[i] && dj >= 0 && dj < (int)m.per_xcd[i]) {
-        const int tt = dx * (int)m.per_xcd[i] + dj;
-        if (tt < (int)m.tiles[i]) { sel = i; t = tt; hit = true; }
-      }
-    }
-  }
-  return hit;
-}
 template <int WM, int WN>
-__global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_group_db(HGemmBatch batch, Db16Batch db, HGroupMap map) {
+__global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_group_db(HGemmBatch batch, Db16Batch db) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char hg_smem[];
-  if (map.n > 0) {
-    int sel = 0, t = 0;
-    if (!hg_group_lookup(map, (int)blockIdx.x, sel, t)) return;          // a slot nothing was assigned to
-    if (sel < batch.n) hgemm_body<WM, WN, 3>(batch.g[sel], t, t);
-    else db16_cols_block(db, t, reinterpret_cast<float*>(hg_smem));
-    return;
-  }
   const int nt = batch.tile_end[batch.n - 1];
   if ((int)blockIdx.x < nt) {
     int bid;
     const int sel = hg_select(batch, (int)blockIdx.x, bid);
     hgemm_body<WM, WN, 3>(batch.g[sel], bid);
   } else db16_cols_block(db, (int)blockIdx.x - nt, reinterpret_cast<float*>(hg_smem));
-}
-// Host side of the map.  Problems with at least 32 tiles ("big") get floor(8 / #big) XCDs each — whole tile rows per XCD, so
-// an XCD's run is a (rows x all columns) block of the tile grid — everything else (narrow first layers, the column sums)
-// goes to the XCDs left over, or behind the big tiles when none is.  Returns the grid (0: no useful map — use the flat one).
-inline unsigned hgemm_group_map(const HGemmBatch& b, int bm, int bn, int db_blocks, HGroupMap& m) {
-  m = HGroupMap{};
-  int tiles[kHGemmMax + 1], tn[kHGemmMax + 1], n_big = 0;
-  for (int i = 0; i < b.n; ++i) { tn[i] = b.g[i].N / bn; tiles[i] = (b.g[i].M / bm) * tn[i]; if (tiles[i] >= 32) ++n_big; }
-  if (n_big < 2 || n_big > 8) return 0;              // one big problem spread over all XCDs is what the 2-D map already does
-  const int nx = 8 / n_big;
-  int next_xcd = 0, max_slots = 0;
-  for (int i = 0; i < b.n; ++i) {
-    if (tiles[i] < 32) continue;
-    const int rows = b.g[i].M / bm, rows_x = (rows + nx - 1) / nx;      // tile rows per XCD
-    m.xcd0[i] = (unsigned char)next_xcd; m.nxcd[i] = (unsigned char)nx; m.slot0[i] = 0;
-    m.per_xcd[i] = (unsigned short)(rows_x * tn[i]); m.tiles[i] = (unsigned short)tiles[i];
-    if (rows_x * tn[i] > 0xffff || tiles[i] > 0xffff) return 0;
-    next_xcd += nx;
-    max_slots = rows_x * tn[i] > max_slots ? rows_x * tn[i] : max_slots;
-  }
-  const int rest = 8 - next_xcd;                       // XCDs without a big problem
-  int slot = rest > 0 ? 0 : max_slots;                 // next free slot on the XCDs the small work goes to
-  const int sx0 = rest > 0 ? next_xcd : 0, snx = rest > 0 ? rest : 8;
-  auto place_small = [&](int i, int count) {
-    const int per = (count + snx - 1) / snx;
-    m.xcd0[i] = (unsigned char)sx0; m.nxcd[i] = (unsigned char)snx; m.slot0[i] = (unsigned short)slot;
-    m.per_xcd[i] = (unsigned short)per; m.tiles[i] = (unsigned short)count;
-    slot += per;
-  };
-  for (int i = 0; i < b.n; ++i) if (tiles[i] < 32) place_small(i, tiles[i]);
-  m.n = b.n;
-  if (db_blocks > 0) { if (db_blocks > 0xffff) return 0; place_small(b.n, db_blocks); m.n = b.n + 1; }
-  max_slots = slot > max_slots ? slot : max_slots;
-  return (unsigned)(8 * max_slots);
 }
 inline hipError_t hgemm_group_db_prepare() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_group_db<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, HGCfg<1, 1>::LDS_BYTES);
@@ -838,25 +765,19 @@ inline hipError_t hgemm_group_db_prepare() {
 }
 // gs: n reduction-major wgrads (mode 3); db_blocks = 64-column blocks of db (0: none).  big: 128 x 128 tiles
 // (every M, N a multiple of 128), else 64 x 64 split-K tiles.
-// xcd_map: big tiles only — give every problem its own XCDs (HGroupMap) instead of spreading each over all eight
 inline hipError_t hgemm_group_db_launch(const HGemm* gs, int n, bool big, const Db16Batch& db, int db_blocks, hipStream_t st,
-                                        hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, bool xcd_map = false) {
+                                        hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
   for (int i = 0; i < n; ++i) if (hgemm_mode(gs[i]) != 3) return hipErrorInvalidValue;
   HGemmBatch b; int wm, wn; long blocks;
   hipError_t e = hgemm_plan(gs, n, big ? 1 : 2, b, wm, wn, blocks);
   if (e != hipSuccess) return e;
-  unsigned grid = (unsigned)(blocks + db_blocks);
-  HGroupMap map{};
-  if (big && xcd_map) {
-    const unsigned g2 = hgemm_group_map(b, 128, 128, db_blocks, map);
-    if (g2) grid = g2; else map = HGroupMap{};
-  }
+  const unsigned grid = (unsigned)(blocks + db_blocks);
   if (big) {
-    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, b, db, map);
-    else hipLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, b, db, map);
+    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, b, db);
+    else hipLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, b, db);
   } else {
-    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, b, db, map);
-    else hipLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, b, db, map);
+    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, b, db);
+    else hipLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, b, db);
   }
   return hipGetLastError();
 }

@@ -514,7 +514,7 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
   if (grouped) {
     // 128x128 tiles: a quarter of the operand bytes per FLOP of the 64x64 split-K tile (fp16 mode guarantees
     // hidden % 128 == 0, minibatch % 128 == 0 and a 128-wide first panel, so every wgrad tiles)
-    HIPCHK(hgemm_group_db_launch(gws, l.L, true, db, db_blocks, st, e0, e1, !(h->cfg.tuning_flags & DQNHIP_TUNE_FP16_WGRAD_FLAT_MAP)));
+    HIPCHK(hgemm_group_db_launch(gws, l.L, true, db, db_blocks, st, e0, e1));
   } else if (!input_grad && hgemm_uses_small_tile(gws[0]) && gws[0].K % 128 == 0) {
     // per-layer form: the first layer's wgrad (few tiles, long reduction) carries the column sums
     HIPCHK(hgemm_group_db_launch(gws, 1, false, db, db_blocks, st, e0, e1));

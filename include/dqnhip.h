@@ -119,9 +119,6 @@ typedef struct dqnhip_config {
 /* fp32 learner: a tower's backward as wgrad(i) + dgrad(i) per layer and a last launch with the first layer's wgrad alone,
  * instead of the shifted schedule dgrad(L-1) | wgrad(i+1) + dgrad(i) ... | wgrad(1) + wgrad(0) (same launch count). */
 #define DQNHIP_TUNE_BWD_UNSHIFTED 4
-/* fp16 learner, grouped wgrad launch: every layer's tiles spread over all eight XCDs (round 3's 2 x 4 blocks) instead of each
- * layer on its own XCDs (round 5: a quarter of the panel fetches through the non-coherent L2s). */
-#define DQNHIP_TUNE_FP16_WGRAD_FLAT_MAP 8
 
 typedef struct dqnhip_learner* dqnhip_handle;
 

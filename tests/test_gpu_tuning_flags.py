@@ -144,26 +144,3 @@ def test_fp16_fused_head_seed_equals_separate_launch(pkg, gpu, B, hidden):
     for x, y in zip(a[2], b[2]):
         np.testing.assert_array_equal(x, y)
 
-
-@pytest.mark.parametrize("B,hidden", [
-    (512, (256, 128, 128)),                    # fewer than two problems of >= 32 tiles: the map declines, both sides run the flat one
-    (512, (1024, 1024, 1024, 1024)),           # 3 x 64 tiles -> two XCDs per layer, first layer + column sums on the other two
-    (2048, (1024, 1024, 1024, 1024)),
-    (1024, (1024, 1024)),                      # 2 layers: one big problem only (first layer has 8 tiles) -> flat
-    (512, (1024, 1024, 1024)),                 # two big problems: four XCDs each, nothing left over -> small work behind the big tiles
-    (512, (2048, 1024, 512)),                  # big problems of different tile grids (8 x 16, 4 x 8)
-])
-def test_fp16_grouped_wgrad_xcd_map_equals_flat_map(pkg, gpu, B, hidden):
-    """Grouped wgrad launch: every problem on its own XCDs (HGroupMap, default) against every problem spread over all eight
-    (DQNHIP_TUNE_FP16_WGRAD_FLAT_MAP).  Which workgroup computes which tile changes, nothing else: every gradient element
-    bit-identical (so the map is a bijection onto the tiles and the column-sum blocks), the per-update scalars equal; only the
-    ORDER of the sum-of-squares partials differs, i.e. the clip norm's last bits when the clip is active."""
-    a = _run(pkg, 0, B, hidden)
-    b = _run(pkg, pkg.capi.TUNE_FP16_WGRAD_FLAT_MAP, B, hidden)
-    (ga, gc), (gb_a, gb_c) = a[1][0], b[1][0]                  # first update: identical weights on both sides
-    np.testing.assert_array_equal(ga, gb_a); np.testing.assert_array_equal(gc, gb_c)
-    assert np.allclose(a[0], b[0], rtol=1e-5, atol=1e-7), (a[0], b[0])
-    lr = {0: 1e-5, 1: 1e-3, 2: 1e-5 * 1e-3, 3: 1e-3 * 1e-3}
-    for net, (wa, wb) in enumerate(zip(a[2], b[2])):
-        dd = np.abs(wa - wb)
-        assert dd.max() <= 2 * 3 * lr[net] + 1e-7 and dd.mean() <= 0.01 * lr[net] + 1e-9, (net, dd.max(), dd.mean())
