@@ -110,11 +110,17 @@ def _check_update(dqn, orc, idx, t64=None, data=None):
     # explodes to 5e4 after one lr=1e-3 Adam step and HIP, the C oracle and a float64 reference
     # then differ from each other by ReLU-mask flips in different rows (all three measured).
     dict(B=256, S=58, hidden=(1024, 1024, 1024, 1024), wscale=2.0, f64=True),
+    # minibatches above 256 rows on seeds for which learner and oracle take the same ReLU branch in every unit of every pass
+    # of every update (scanned on the MI355X, scripts/_scratch: 6 of 8 seeds at 1024 x 256-256, 4 of 8 at 512 x 1024-1024):
+    # the 1e-5 gradient bound applies throughout and nothing is ever re-synchronised
+    dict(B=1024, S=58, hidden=(256, 256), wscale=3.0, seed=2, no_flips=True),
+    dict(B=512, S=58, hidden=(1024, 1024), wscale=2.0, seed=2, no_flips=True, f64=True),
 ])
 def test_update_matches_oracle(pkg, gpu, shape):
     shape = dict(shape)
     shape.setdefault("wscale", 5.0)
     use64 = shape.pop("f64", False)
+    no_flips = shape.pop("no_flips", False)
     dqn, orc, data, rng = make_pair(pkg, n_replay=2048, **shape)
     B = shape["B"]
     t64 = None
@@ -137,7 +143,7 @@ def test_update_matches_oracle(pkg, gpu, shape):
                 for kind in (1, 2):
                     for net in (0, 1):
                         ref.set_params(net, dqn.get_params(net, kind), kind)
-    if B <= 256:
+    if B <= 256 or no_flips:
         assert flips == 0, flips          # (so the 1e-5 bound was the one applied at BASELINE's and the reference's shapes)
     # Adam's normalised step m/(sqrt(v)+eps) is O(1) whatever |g| is, so an element whose gradient
     # is at fp32-roundoff level may legitimately move differently by up to lr per update; on
