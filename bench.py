@@ -106,7 +106,7 @@ KERNEL_NAMES = {"hgemm_fwd": "hgemm_nt<2,2>/<1,1> (forward epilogue)", "hgemm_dg
                 "gemm_dgrad": "gemm_dgrad_lds<1,1>", "gemm_wgrad": "gemm_wgrad_tail<1>"}
 
 
-PMC_SUMMARY = "profiles/r04_pmc_summary.json"
+PMC_SUMMARY = "profiles/r05_pmc_summary.json"
 
 # xGMI (MI355X, 8 GPUs fully connected): 7 links per GPU, 153.6 GB/s per link counting both directions = 76.8 GB/s
 # each way.  Two bounds for a sum all-reduce of S bytes over N ranks: ONE ring = every byte crosses one

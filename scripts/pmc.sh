@@ -4,11 +4,11 @@
 # FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 #   workloads: the fp32 headline (B = 256) and the fp16 learner at minibatch 4096 (configs[4] on one GPU), eager launches
 export TMPDIR=/tmp
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 export R
 O=gpurun_out/${R}prof; mkdir -p $O
 rm -rf /tmp/pmc3; mkdir -p /tmp/pmc3
-C="--no-graph --no-cpu-baseline --no-env --no-subrecords --replay 200000"
+C="--no-graph --no-cpu-baseline --no-env --no-subrecords --no-live-pmc --no-live-trace --replay 200000"
 i=0
 for wl in "fp32_b256:--steps 60 --warmup 10" "fp16_b4096:--precision fp16 --minibatch 4096 --steps 30 --warmup 5"; do
   tag=${wl%%:*}; args=${wl#*:}

@@ -4,7 +4,7 @@
 #   usage: ROUND=r04 scripts/profiles.sh [stats|pmc|all]        (then copy gpurun_out/$ROUND"prof"/$ROUND_* into profiles/)
 export TMPDIR=/tmp
 what=${1:-all}
-R=${ROUND:-r04}; N=${R#r}; N=$((10#$N))
+R=${ROUND:-r05}; N=${R#r}; N=$((10#$N))
 O=gpurun_out/${R}prof; mkdir -p $O
 HEAD=$(cat .git_head 2>/dev/null || echo unknown)
 rc=0
@@ -18,7 +18,7 @@ stats() {  # tag n_updates title -- command...
   python scripts/stats_to_md.py "$f" $nup "$title" "rocprofv3 --kernel-trace --stats --output-format csv -- $*" > $O/${tag}_kernel_stats.md
   if [ $(grep -c '^| `' $O/${tag}_kernel_stats.md) -lt 3 ]; then echo "EMPTY table for $tag"; rc=1; fi
 }
-C="--no-cpu-baseline --no-env --no-subrecords"
+C="--no-cpu-baseline --no-env --no-subrecords --no-live-pmc --no-live-trace"
 if [ "$what" != pmc ]; then
 stats ${R}_fp32_b256 0 "rocprofv3 --kernel-trace --stats — round $N, fp32, B=256 (headline; hipGraph replay)" python bench.py --steps 500 --warmup 50 $C
 stats ${R}_fp16_b4096 0 "rocprofv3 --kernel-trace --stats — round $N, fp16 learner, minibatch 4096, 4x1024 (BASELINE configs[4] on one GPU)" python bench.py --precision fp16 --minibatch 4096 --steps 200 --warmup 20 --replay 200000 $C

@@ -604,6 +604,138 @@ __global__ __launch_bounds__(256) void k_fwd_lds_wt(const GemmBatch batch) {
   tile_of_block(batch, pi, tile_p, tile_q);
   fwd_lds_body<2, 2, true, 2, true>(batch.prob[pi], tile_p, tile_q, smem);
 }
+// ---- round 5: the cheapest in-launch seam this chip offers, for the record ----------------------------------------------
+// k_fwd_chain pays, per layer, an agent-scope ACQUIRE on the consumer (~1.7 us: it invalidates the CU's L1) and starts BOTH
+// operand streams only after the wait.  Weights do not depend on the chain and an L2 line does not survive a kernel boundary
+// (profiles/r05_weight_prefetch.txt) — but it does survive INSIDE a launch.  So (map bit 3): the consumer requests the first
+// two 32-k steps of its WEIGHT tile before it polls, takes the activations through device-scope (sc1) buffer loads — which the
+// guide allows in place of the acquire when the producer stored sc1 (write-through; map bit 1 is implied) — and no fence
+// executes on either side.  Same tile map, same arithmetic, same reduction order as fwd_lds_body<2,2,true,2> (bit-identical).
+typedef unsigned chain_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 chain_ld_sc1(const __amdgpu_buffer_rsrc_t rs, int byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16 /* sc1 */));
+}
+__device__ __forceinline__ void fwd_chain_body_ra(const GemmProblem& pr, int tile_p, int tile_q, float* smem, const int* flag, int target,
+                                                  int* err, int* s_fail) {
+  constexpr int TP = 2, TQ = 2, NB = TP + TQ, NACC = TP * TQ, SLOT = NB * 512, NSLOT = 2;
+  constexpr int WSTR = (NSLOT * SLOT > NACC * 256) ? NSLOT * SLOT : NACC * 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4, lr = lane >> 3, lc = lane & 7;
+  const int p0 = tile_p * 16 * TP, q0 = tile_q * 16 * TQ;
+  const int Kw = pr.Kred >> 2, T = Kw >> 5;
+  float* wsm = smem + wave * WSTR;
+  const float* gp[TP]; int qoff[TQ];
+  const size_t ldp8 = (size_t)8 * pr.ldp; const int ldq8b = 8 * pr.ldq * 4;
+#pragma unroll
+  for (int b = 0; b < TP; ++b) gp[b] = pr.P + (size_t)(p0 + b * 16 + lr) * pr.ldp + wave * Kw + lc * 4;
+#pragma unroll
+  for (int a = 0; a < TQ; ++a) qoff[a] = ((q0 + a * 16 + lr) * pr.ldq + wave * Kw + lc * 4) * 4;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.Q), 0, pr.Qdim * pr.ldq * 4, 0x00020000);
+  const int woff = lr * 32 + ((lc ^ lr) << 2);
+  int roff[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) roff[kb] = li * 32 + ((((kb << 2) + lg) ^ (li & 7)) << 2);
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 G0[NB][2], G1[NB][2], F[NB][2], Fn[NB][2];
+#define C_GLOADP(G, t) { _Pragma("unroll") for (int b = 0; b < TP; ++b) { \
+      G[b][0] = *reinterpret_cast<const f32x4*>(gp[b] + ((t) << 5)); G[b][1] = *reinterpret_cast<const f32x4*>(gp[b] + ldp8 + ((t) << 5)); } }
+#define C_GLOADQ(G, t) { _Pragma("unroll") for (int a = 0; a < TQ; ++a) { \
+      G[TP + a][0] = chain_ld_sc1(rq, qoff[a] + ((t) << 7)); G[TP + a][1] = chain_ld_sc1(rq, qoff[a] + ldq8b + ((t) << 7)); } }
+#define C_GLOAD(G, t) { C_GLOADP(G, t) C_GLOADQ(G, t) }
+#define C_SWRITE(slot, G) { _Pragma("unroll") for (int b = 0; b < NB; ++b) { \
+      *reinterpret_cast<f32x4*>(wsm + ((slot) % NSLOT) * SLOT + b * 512 + woff) = G[b][0]; \
+      *reinterpret_cast<f32x4*>(wsm + ((slot) % NSLOT) * SLOT + b * 512 + 256 + woff) = G[b][1]; } }
+#define C_SREAD(FF, slot) { _Pragma("unroll") for (int b = 0; b < NB; ++b) { \
+      FF[b][0] = *reinterpret_cast<const f32x4*>(wsm + ((slot) % NSLOT) * SLOT + b * 512 + roff[0]); \
+      FF[b][1] = *reinterpret_cast<const f32x4*>(wsm + ((slot) % NSLOT) * SLOT + b * 512 + roff[1]); } }
+#define C_MFMA(FF) { _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) _Pragma("unroll") for (int s = 0; s < 4; ++s) \
+    _Pragma("unroll") for (int a = 0; a < TQ; ++a) _Pragma("unroll") for (int c = 0; c < TP; ++c) \
+        acc[a * TP + c] = DQN_MFMA(FF[c][kb][s], FF[TP + a][kb][s], acc[a * TP + c]); }
+  // the weight stream runs ahead of the dependency
+  C_GLOADP(G0, 0) DQN_PIN(); C_GLOADP(G1, 1) DQN_PIN();
+  if (flag != nullptr) {
+    if (threadIdx.x == 0) {
+      int spins = 0, fail = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 400000) { fail = 1; break; }
+      }
+      *s_fail = fail;
+      if (fail) *err = 1;
+    }
+    __syncthreads();
+  }
+  C_GLOADQ(G0, 0) DQN_PIN(); C_GLOADQ(G1, 1) DQN_PIN();
+  C_SWRITE(0, G0) DQN_PIN(); C_GLOAD(G0, 2) DQN_PIN(); C_SREAD(F, 0) DQN_PIN();
+  int t = 0;
+  for (; t + 4 < T; t += 2) {
+    C_SWRITE(1, G1) DQN_PIN(); C_GLOAD(G1, t + 3) DQN_PIN(); C_SREAD(Fn, 1) DQN_PIN();
+    C_MFMA(F) DQN_PIN();
+    C_SWRITE(0, G0) DQN_PIN(); C_GLOAD(G0, t + 4) DQN_PIN(); C_SREAD(F, 0) DQN_PIN();
+    C_MFMA(Fn) DQN_PIN();
+  }
+  C_SWRITE(1, G1) C_GLOAD(G1, T - 1) C_SREAD(Fn, 1) DQN_PIN();
+  C_MFMA(F) DQN_PIN();
+  C_SWRITE(0, G0) C_SREAD(F, 0) DQN_PIN();
+  C_MFMA(Fn) DQN_PIN();
+  C_SWRITE(1, G1) C_SREAD(Fn, 1) DQN_PIN();
+  C_MFMA(F) DQN_PIN();
+  C_MFMA(Fn)
+#undef C_GLOADP
+#undef C_GLOADQ
+#undef C_GLOAD
+#undef C_SWRITE
+#undef C_SREAD
+#undef C_MFMA
+  constexpr int NBV = (NACC + 3) / 4;
+  f32x4 bvp[NBV];
+#pragma unroll
+  for (int j = 0; j < NBV; ++j) { const int e = j * 4 + wave; if (e < NACC) bvp[j] = *reinterpret_cast<const f32x4*>(pr.bias + p0 + (e % TP) * 16 + (lg << 2)); }
+  f32x4* park = reinterpret_cast<f32x4*>(wsm);
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) park[e * 64 + lane] = acc[e];
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, pr.Qdim * pr.ldc * 4, 0x00020000);
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) {
+    if ((e & 3) == wave) {
+      const int a = e / TP, c = e % TP;
+      const f32x4 a0 = reinterpret_cast<const f32x4*>(smem + 0 * WSTR)[e * 64 + lane], a1 = reinterpret_cast<const f32x4*>(smem + 1 * WSTR)[e * 64 + lane];
+      const f32x4 a2 = reinterpret_cast<const f32x4*>(smem + 2 * WSTR)[e * 64 + lane], a3 = reinterpret_cast<const f32x4*>(smem + 3 * WSTR)[e * 64 + lane];
+      f32x4 v;
+      v.x = (a0.x + a1.x) + (a2.x + a3.x); v.y = (a0.y + a1.y) + (a2.y + a3.y);
+      v.z = (a0.z + a1.z) + (a2.z + a3.z); v.w = (a0.w + a1.w) + (a2.w + a3.w);
+      const int q = q0 + a * 16 + li, p = p0 + c * 16 + (lg << 2);
+      const f32x4 bv = bvp[e >> 2];
+      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      v.x = lrelu_fwd(v.x); v.y = lrelu_fwd(v.y); v.z = lrelu_fwd(v.z); v.w = lrelu_fwd(v.w);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, v), rs, (int)(((size_t)q * pr.ldc + p) * 4), 0, 16 /* sc1 */);
+    }
+  }
+  __syncthreads();             // the parked tiles are read: the next layer's staging may overwrite them
+}
+__global__ __launch_bounds__(256) void k_fwd_chain_ra(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_fail;
+  const int slabs = a.rows / 32, ctiles = a.width / 32;
+  int tile_p, tile_q;
+  if (a.map == 0) { const int b = blockIdx.x, xcd = b & 7, j = b >> 3; tile_q = j % slabs; tile_p = (j / slabs) * 8 + xcd; }
+  else { const int b = blockIdx.x; tile_q = b & 7; tile_p = b >> 3; }
+  if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  for (int l = 0; l < a.L; ++l) {
+    GemmProblem pr{};
+    pr.P = a.W[l]; pr.ldp = a.width; pr.Q = a.act[l]; pr.ldq = a.width; pr.C = a.act[l + 1]; pr.ldc = a.width;
+    pr.Pdim = a.width; pr.Qdim = a.rows; pr.Kred = a.width; pr.bias = a.bias[l]; pr.relu = 1;
+    fwd_chain_body_ra(pr, tile_p, tile_q, smem, l > 0 ? a.counters + (l - 1) * slabs + tile_q : nullptr, ctiles * a.epoch, a.err, &s_fail);
+    if (l + 1 < a.L) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its write-through stores
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(a.counters + l * slabs + tile_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 __global__ __launch_bounds__(256) void k_fwd_chain(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_fail;
@@ -652,7 +784,7 @@ __global__ __launch_bounds__(256) void k_fwd_chain(ChainArgs a) {
 extern "C" int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, float* us_launches, float* us_persistent,
                                  float* max_abs_diff, int32_t* gave_up) {
   // map bit 0: tile -> XCD map (0 learner's, 1 slab per XCD); bit 1: write-through (sc1) hand-off without a release fence
-  const int wt = (map >> 1) & 1, wt_launches = (map >> 2) & 1; map &= 1;
+  const int wt = (map >> 1) & 1, wt_launches = (map >> 2) & 1, run_ahead = (map >> 3) & 1; map &= 1;
   if (layers < 1 || layers > 8 || iters < 1) return 1;
   const int rows = 256, width = 1024;
   hipStream_t s; CK(hipStreamCreate(&s));
@@ -672,6 +804,7 @@ extern "C" int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, flo
   CK(hipMalloc(&a.err, sizeof(int))); CK(hipMemsetAsync(a.err, 0, sizeof(int), s));
   const int lds = fwd_lds_bytes<2, 2, true>();
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_chain), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_chain_ra), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_lds_wt), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   auto run_launches = [&]() -> hipError_t {
     for (int l = 0; l < layers; ++l) {
@@ -687,7 +820,8 @@ extern "C" int dqnhip_test_chain(int32_t layers, int32_t map, int32_t iters, flo
   int epoch = 0;
   auto run_persistent = [&]() -> hipError_t {
     a.epoch = ++epoch;
-    hipLaunchKernelGGL(k_fwd_chain, dim3(256), dim3(256), lds, s, a);
+    if (run_ahead) hipLaunchKernelGGL(k_fwd_chain_ra, dim3(256), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_fwd_chain, dim3(256), dim3(256), lds, s, a);
     return hipGetLastError();
   };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
