@@ -372,3 +372,53 @@ def test_applied_gradient_is_clipped(pkg, gpu, clip):
         np.testing.assert_allclose(step, -lr * applied / (np.abs(applied) + 1e-8 / np.sqrt(1 - b2)), rtol=2e-3, atol=2e-8)
         assert np.all(step[applied == 0] == 0)
     dqn.close()
+
+
+# =========================================== the fp16-MFMA learner behaves the same way ========================================
+@pytest.mark.parametrize("k", [+0.5, -0.5])
+def test_fp16_learner_moves_up_the_critics_gradient(pkg, gpu, k):
+    """BASELINE configs[4]'s precision (fp16 MFMA operands, fp32 accumulate; master weights, heads, Adam in fp32): against the
+    fp32 oracle its gradients are only 1-2 % tight (tests/test_gpu_fp16.py), so the direction test matters more here.  Hand-built
+    frozen critic Q = k * dash_power: mu(s)[4] must move with the sign of k and avg_q must rise."""
+    rng = np.random.default_rng(6)
+    B, hid, col = 128, (128, 128), 4
+    dqn = pkg.DQN(S, minibatch=B, hidden=hid, memory=4096, precision="fp16", critic_lr=0.0, actor_lr=5e-3, tau=0.0, clip_grad=1e9,
+                  gamma=0.0, beta=0.0)
+    bias = np.zeros(10, np.float32); bias[col] = 30.0
+    dqn.set_params(ACTOR, actor_with_bias(rng, S, hid, bias)); dqn.CloneNet(ACTOR)
+    dqn.set_params(CRITIC, linear_critic(S, hid, col, k)); dqn.CloneNet(CRITIC)
+    states = fill_replay(dqn, rng, 1024, S)[0]
+    probe = states[:64]
+    mu0 = dqn.SelectActionGreedily(probe)[:, col].mean()
+    avg_q = [dqn.UpdateActorCritic(rng.integers(0, 1024, B))[1] for _ in range(60)]
+    mu1 = dqn.SelectActionGreedily(probe)[:, col].mean()
+    assert np.sign(mu1 - mu0) == np.sign(k) and abs(mu1 - mu0) > 0.05, (mu0, mu1)
+    assert np.mean(avg_q[-10:]) > np.mean(avg_q[:10]), (avg_q[:3], avg_q[-3:])
+    dqn.close()
+
+
+def test_fp16_learner_bandit(pkg, gpu):
+    """The one-step bandit of test_bandit_actor_finds_the_rewarded_parameter on the fp16 learner."""
+    rng = np.random.default_rng(12)
+    B, N, col, opt, hid = 128, 2048, 8, 60.0, (128, 128)
+    dqn = pkg.DQN(S, minibatch=B, hidden=hid, memory=4096, precision="fp16", critic_lr=2e-3, actor_lr=2e-3, tau=1.0, clip_grad=10.0,
+                  gamma=0.0, beta=0.0)
+    bias = np.zeros(10, np.float32); bias[col] = 20.0
+    dqn.set_params(ACTOR, actor_with_bias(rng, S, hid, bias, scale=0.02)); dqn.CloneNet(ACTOR)
+    sl, count = layer_slices(S + 10, hid, (1,))
+    wc = small_random(rng, count, 0.05)
+    a0, b0, n0, k0 = sl[0]
+    wc[a0:b0].reshape(n0, k0)[:, S + 4:] *= 0.02
+    dqn.set_params(CRITIC, wc); dqn.CloneNet(CRITIC)
+    acts = synth_actions(rng, N); acts[:, col] = rng.uniform(0, 100, N)
+    states = fill_replay(dqn, rng, N, S, reward_fn=lambda s, a: 1.0 - ((a[:, col] - opt) / 40.0) ** 2, actions=acts)[0]
+    probe = states[:128]
+    mu0 = dqn.SelectActionGreedily(probe)[:, col].mean()
+    loss, avg_q = [], []
+    for u in range(400):
+        l, aq = dqn.UpdateActorCritic(rng.integers(0, N, B)); loss.append(l); avg_q.append(aq)
+    mu1 = dqn.SelectActionGreedily(probe)[:, col].mean()
+    assert np.mean(loss[-50:]) < 0.3 * np.mean(loss[:20]), (np.mean(loss[:20]), np.mean(loss[-50:]))
+    assert abs(mu1 - opt) < abs(mu0 - opt) - 5.0 and mu1 > mu0, (mu0, mu1)
+    assert np.mean(avg_q[-50:]) > np.mean(avg_q[60:110]), (np.mean(avg_q[60:110]), np.mean(avg_q[-50:]))
+    dqn.close()
