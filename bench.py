@@ -908,6 +908,19 @@ def main():
         elapsed = float(tt.item())
     loss, avgq = dqn.read_stats()
     final_line = None
+    # N > 1: the one-GPU rate measured in THIS job (a plain learner per rank, no communicator, all ranks at once so that they
+    # stay in step), so that a SCALE record can be cross-checked against the BENCH record of the same round without trusting
+    # that two boxes clock alike
+    n1_same_job = None
+    if dist_on and world > 1 and not args.strong:
+        d1 = pkg.DQN(S, minibatch=B, hidden=HIDDEN, memory=100000, seed=1, device=local_rank, use_graph=not args.no_graph,
+                     precision=args.precision, tuning=args.tuning)
+        prefill(d1, 60000, seed=5 + rank)
+        dt1 = timed_n(d1, torch.cuda.synchronize, 320, 64)
+        d1.read_stats(); d1.close()
+        barrier()
+        n1_same_job = {"updates_per_s": round(1 / dt1, 1), "ms_per_step": round(dt1 * 1e3, 5),
+                       "what": "rank 0's plain single learner (dqnhip_update_async_n, 320 updates, 60 000-transition replay) while every other rank runs its own: the N = 1 point of the same job"}
 
     # roofline of the dominant kernel family, timed live with HIP events on the learner's stream
     roof = None
@@ -1056,6 +1069,7 @@ def main():
                                    else "one call (one hipGraph launch) per update"),
                        **({"ms_per_step_one_update_per_graph_launch": round(one_per_launch_ms, 5)} if one_per_launch_ms else {}),
                        "tuning_flags": args.tuning,
+                       **({"n1_same_job": n1_same_job} if n1_same_job else {}),
                        **({"native_dp_error": native_error} if native_error else {}),
                        **({"captured_dp_probe": dp_probe} if use_dp and dp_probe is not None else {}),
                        "sampling": "on-device Philox, uniform with replacement"},

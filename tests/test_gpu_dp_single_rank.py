@@ -175,6 +175,9 @@ def test_bench_two_ranks_flow_on_one_gpu(pkg, gpu):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 10 and d["config"]["parallelism"].startswith("dp2")
     assert d["config"]["global_minibatch"] == 512 and d["roofline"] is not None
+    # the N = 1 point measured in the same job (two plain learners share GPU 0 here, so only its presence and sanity are checked)
+    n1 = d["config"]["n1_same_job"]
+    assert n1["updates_per_s"] > 100 and abs(n1["ms_per_step"] * n1["updates_per_s"] - 1e3) < 1.0
 
 
 def test_unverified_exchange_forms_are_fenced_for_real_groups(pkg, gpu):
