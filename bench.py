@@ -33,279 +33,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from __graft_entry__ import load_package  # noqa: E402
+from benchlib.flops import (HBM_PEAK_GBS, MFMA_F32_PEAK_TF, MFMA_F16_PEAK_TF, KERNEL_NAMES, TRACE_FAMILY, tower_weights, family_flops,  # noqa: E402,F401
+                            family_flops16)
+from benchlib.scaling_model import (XGMI_LINK_GBS_ONE_WAY, COLLECTIVE_LATENCY_US, ADAM_SLICE_US, collective_us, allreduce_projection_us,  # noqa: E402,F401
+                                    exposed_exchange_us, dp_projection, grad_bytes)
+from benchlib.profiling import PMC_SUMMARY, pmc_traffic, live_pmc_traffic, live_kernel_trace  # noqa: E402,F401
 
 HIDDEN = (1024, 1024, 1024, 1024)
 B = 256
 S = 58
 REPLAY = 1_000_000
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA dense peak
-
-
-def tower_weights(in_dim, hidden):
-    dims = (in_dim,) + tuple(hidden)
-    return [dims[i] * dims[i + 1] for i in range(len(hidden))]
-
-
-def family_flops(B, S, hidden, shifted=True):
-    """Algorithmic GEMM FLOPs per update, per kernel (tower layers only; the skinny heads are
-    separate kernels).  See DESIGN.md §5.  Keys are the learner's timing families.
-    shifted: the backward schedule of learner.hip tower_backward (default for >= 2 tower layers at minibatches whose layers
-    take the one-workgroup-type form): dgrad(L-1) | wgrad(i+1) + dgrad(i) ... | wgrad(1) + wgrad(0); else wgrad(i) + dgrad(i)
-    per layer and the first layer's wgrad alone (DQNHIP_TUNE_BWD_UNSHIFTED, or the side-by-side pair launches of small shapes)."""
-    wa = tower_weights(S, hidden)
-    wc = tower_weights(S + 10, hidden)
-    h1 = hidden[0]
-    L = len(hidden)
-    if shifted and L >= 2:
-        pair = lambda w: sum(w[j + 1] + w[j] for j in range(1, L - 1))
-        return {
-            "gemm_fwd_lds_4x2": 2 * B * (2 * sum(wa[1:]) + 2 * sum(wc[1:])),
-            "gemm_fwd_lds_2x2": 2 * B * sum(wc[1:]),
-            "gemm_fwd_direct": 2 * B * (2 * wa[0] + 3 * wc[0]),
-            # wgrad(i+1) + dgrad(i), i = L-2 .. 1: critic train + actor
-            "gemm_bwd_pair": 2 * B * (pair(wc) + pair(wa)),
-            # critic dQ/da chain (layers 2..L + the 10 action columns of layer 1) + the top layer's dgrad of both backward passes
-            "gemm_dgrad": 2 * B * (sum(wc[1:]) + 10 * h1 + wc[L - 1] + wa[L - 1]),
-            # the tails: wgrad(1) + wgrad(0), critic + actor
-            "gemm_wgrad": 2 * B * (wc[1] + wc[0] + wa[1] + wa[0]),
-        }
-    return {
-        # {actor_target, actor} and {critic_target, critic} layers 2..L, two layers per launch
-        "gemm_fwd_lds_4x2": 2 * B * (2 * sum(wa[1:]) + 2 * sum(wc[1:])),
-        # critic(s, mu(s)) layers 2..L
-        "gemm_fwd_lds_2x2": 2 * B * sum(wc[1:]),
-        # first layers (K = 58 / 68): 2 actor + 3 critic passes
-        "gemm_fwd_direct": 2 * B * (2 * wa[0] + 3 * wc[0]),
-        # dgrad+wgrad of layers 2..L: critic train + actor
-        "gemm_bwd_pair": 2 * B * (2 * sum(wc[1:]) + 2 * sum(wa[1:])),
-        # critic dQ/da chain: layers 2..L plus the 10 action columns of layer 1
-        "gemm_dgrad": 2 * B * (sum(wc[1:]) + 10 * h1),
-        # first-layer wgrads: critic + actor
-        "gemm_wgrad": 2 * B * (wc[0] + wa[0]),
-    }
-
-
-def family_flops16(B, S, hidden):
-    """Same algorithmic FLOPs, grouped by the fp16 learner's timing families (hgemm_nt launches)."""
-    wa = tower_weights(S, hidden)
-    wc = tower_weights(S + 10, hidden)
-    h1 = hidden[0]
-    return {
-        "hgemm_fwd": 2 * B * (2 * sum(wa) + 3 * sum(wc)),
-        "hgemm_dgrad": 2 * B * (sum(wc[1:]) + sum(wa[1:]) + sum(wc[1:]) + 10 * h1),
-        "hgemm_wgrad": 2 * B * (sum(wc) + sum(wa)),
-    }
-
-
-MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: fp16/bf16 dense MFMA peak
-
-KERNEL_NAMES = {"hgemm_fwd": "hgemm_nt<2,2>/<1,1> (forward epilogue)", "hgemm_dgrad": "hgemm_nt (dgrad epilogue)",
-                "hgemm_wgrad": "hgemm_nt (wgrad epilogue)","gemm_fwd_lds_4x2": "gemm_fwd_lds<4,2,true,1>", "gemm_fwd_lds_2x2": "gemm_fwd_lds<2,2,true,2>",
-                "gemm_fwd_direct": "gemm_fwd_direct<4,2>", "gemm_bwd_pair": "gemm_bwd_seq<true>",
-                "gemm_dgrad": "gemm_dgrad_lds<1,1>", "gemm_wgrad": "gemm_wgrad_tail<1>"}
-
-
-PMC_SUMMARY = "profiles/r05_pmc_summary.json"
-
-# xGMI (MI355X, 8 GPUs fully connected): 7 links per GPU, 153.6 GB/s per link counting both directions = 76.8 GB/s
-# each way.  Two bounds for a sum all-reduce of S bytes over N ranks (DESIGN.md 6): ONE ring = every byte crosses one
-# link per step, 2 (N-1)/N S / b; ALL links busy (N-1 edge-disjoint rings, or direct reduce-scatter + all-gather) =
-# that divided by N-1.  Per-collective latency floor on top (launch + 2 (N-1) hops).
-XGMI_LINK_GBS_ONE_WAY = 76.8
-COLLECTIVE_LATENCY_US = 20.0
-
-
-def collective_us(nbytes, world, links, factor=2.0):
-    """One collective of `nbytes` over `world` ranks: factor 2 = all-reduce (reduce-scatter + all-gather volume),
-    1 = a reduce-scatter or an all-gather alone; links = 1 (ONE ring: every byte crosses one link per step) or world - 1
-    (all links busy: edge-disjoint rings / direct exchange on the full mesh)."""
-    if world < 2:
-        return 0.0
-    vol = factor * (world - 1) / world * nbytes
-    return COLLECTIVE_LATENCY_US + vol / (XGMI_LINK_GBS_ONE_WAY * 1e9 * links) * 1e6
-
-
-def allreduce_projection_us(nbytes, world):
-    if world < 2:
-        return {"one_ring_us": 0.0, "all_links_us": 0.0}
-    return {"one_ring_us": round(collective_us(nbytes, world, 1), 1), "all_links_us": round(collective_us(nbytes, world, world - 1), 1)}
-
-
-def exposed_exchange_us(buckets, compute_end_us, world, links):
-    """Overlap-aware price of one net's gradient exchange.  buckets = [(ready_us, nbytes), ...] in
-    issue order: bucket i may start once its producing launch has ended (ready_us, measured from the start of the net's
-    backward chain) AND the previous collective has finished (one communication stream: collectives do not overlap each
-    other); the phase's own launches end at compute_end_us.  Returns the microseconds the main stream WAITS at the join."""
-    t = 0.0
-    for ready, nbytes in buckets:
-        t = max(t, ready) + collective_us(nbytes, world, links)
-    return max(0.0, t - compute_end_us)
-
-
-# k_adam_soft on 1/N of a 4x1024 net's arena, Infinity-Cache-resident / evicted (profiles/r04_adam_slice_probe.txt, MI355X):
-ADAM_SLICE_US = {1: (19.6, 28.2), 2: (9.2, 18.7), 4: (6.8, 12.0), 8: (5.0, 8.7)}
-
-
-def dp_projection(world, half, net_bytes, t_rank_ms, t_1gpu_ms, bwd_launch_us, narrow_launch_us, per_layer_slices):
-    """What N ranks of this rank shape would take per update, from what ONE GPU can measure + the link model
-    (76.8 GB/s one way per link, 7 links per GPU, 20 us per collective).  Four exchange forms per link model:
-      single      one all-reduce per net after its backward chain (nothing overlaps: the optimiser needs the clip norm of the
-                  WHOLE reduced gradient)
-      per_layer   one bucket per tower layer on a communication stream, started when that layer's backward launch has ended;
-                  the chain's remaining launches run beside it (exposed_exchange_us) — only the part the chain does not
-                  cover is paid, but every bucket pays the per-collective latency
-      sharded     ZeRO-1 style: reduce-scatter, a 4-float all-reduce for the clip norm + tails, clip+Adam+soft update on this
-                  rank's 1/N slice, all-gather of the updated online AND target weights (the target nets move every update:
-                  src/dqn.cpp:967-970 — twice an ordinary model's all-gather volume)
-    Returns {form: {"one_ring": ms, "all_links": ms, "speedup_one_ring": x, "speedup_all_links": x}}."""
-    out = {}
-    adam_full, adam_slice = ADAM_SLICE_US[1][0], ADAM_SLICE_US.get(world, ADAM_SLICE_US[8])[0]
-    for form in ("single", "per_layer", "sharded"):
-        r = {}
-        for name, links in (("one_ring", 1), ("all_links", max(1, world - 1))):
-            extra = 0.0
-            for nb, slices in zip(net_bytes, per_layer_slices):
-                if form == "single" or (form == "per_layer" and half):
-                    extra += collective_us(nb, world, links)
-                elif form == "per_layer":
-                    # backward order: top tower layer first; its bucket is ready when its own launch ends
-                    ready, t, bk = [], 0.0, []
-                    n_big = len(slices) - 2                    # slices = [layer L-1, ..., layer 1, layer 0, head + tail] in bytes
-                    for i, sb in enumerate(slices):
-                        t += bwd_launch_us if i < n_big else (narrow_launch_us if i == n_big else 5.0)
-                        bk.append((t, sb))
-                    extra += exposed_exchange_us(bk, t, world, links)
-                else:
-                    # all-gather, as built: the updated online weights AND the targets in fp32 (2 x 4 B/param) and, for the fp16
-                    # learner, their two fp16 mirrors as well (2 x 2 B/param) — against gradient bytes nb of 4 B/param (fp32
-                    # exchange) or 2 B/param (bf16 exchange): 2 x nb resp. 6 x nb.  (A leaner fp16 form — mirrors + the fp32
-                    # bias / head slices only — would move 2 x nb; it still loses to the single all-reduce, DESIGN 6.)
-                    extra += (collective_us(nb, world, links, 1.0) + collective_us(16, world, links)
-                              + collective_us((6 if half else 2) * nb, world, links, 1.0) - (adam_full - adam_slice))
-            ms = (t_rank_ms[form] if isinstance(t_rank_ms, dict) else t_rank_ms) + extra * 1e-3
-            r[name] = round(ms, 4); r["speedup_" + name] = round(t_1gpu_ms / ms, 2)
-        out[form] = r
-    return out
-
-
-def grad_bytes(S_, hidden, half):
-    """bytes per update that cross the links: both gradient arenas (critic, then actor) + the fp32 tails"""
-    na = sum(tower_weights(S_, hidden)) + sum(hidden) + 10 * hidden[-1] + 10
-    nc = sum(tower_weights(S_ + 10, hidden)) + sum(hidden) + hidden[-1] + 1
-    per = 2 if half else 4
-    return [nc * per + 16, na * per + 16]
-
-
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel`.  PMC counters cannot be read from inside this process
-    (rocprofv3 wraps the command), so the figure comes from the committed PMC passes of the SAME
-    kernels (scripts/pmc.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    bench.py; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads on
-    gfx950) and is labelled with its source.  (None, None) if that kernel is not in the file."""
-    try:
-        j = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
-        d = j["kernels"][kernel.replace(" ", "")]
-        return int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024), "%s (%s)" % (PMC_SUMMARY, j.get("kernels_version", "kernel version not recorded"))
-    except Exception:
-        return None, None
-
-
-def live_pmc_traffic(kernel, extra_args):
-    """HBM-side bytes per launch of `kernel`, measured NOW on this box: two child runs of this script under
-    `rocprofv3 --kernel-trace --pmc <one counter>` (FETCH_SIZE, then WRITE_SIZE: separate passes, no other trace domain, as
-    MI355X_MICROARCH.md prescribes), eager launches, a small replay.  2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950
-    correction for wide coalesced reads).  Returns (bytes, source) or (None, reason)."""
-    import csv
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
-    if shutil.which("rocprofv3") is None:
-        return None, "rocprofv3 not on PATH"
-    want = kernel.replace(" ", "")
-    vals = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="dqnhip_pmc_", dir="/tmp")
-        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
-               os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--prewarm-ms", "0", "--no-graph", "--no-cpu-baseline",
-               "--no-env", "--no-subrecords", "--no-live-pmc", "--replay", "100000"] + list(extra_args)
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
-        except Exception as e:          # noqa: BLE001
-            shutil.rmtree(d, ignore_errors=True)
-            return None, "rocprofv3 pass %s failed: %r" % (counter, e)
-        acc = []
-        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-            for row in csv.DictReader(open(f)):
-                n = row["Kernel_Name"].replace("void ", "").replace("dqnhip::", "")
-                n = (n[:n.index("(")] if "(" in n else n).replace(" ", "")
-                if n == want and row["Counter_Name"] == counter:
-                    acc.append(float(row["Counter_Value"]))
-        shutil.rmtree(d, ignore_errors=True)
-        if not acc:
-            return None, "rocprofv3 pass %s: no rows for %s (rc %d)" % (counter, want, r.returncode)
-        vals[counter] = sum(acc) / len(acc)
-    return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
-        "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes of this bench.py, eager, "
-        "%d + %d launches averaged); 2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md" % (len(acc), len(acc)))
-
-
-# kernel name (as rocprofv3 prints it, spaces removed) -> the learner's timing family
-TRACE_FAMILY = (("gemm_fwd_lds<4,2,true,1>", "gemm_fwd_lds_4x2"), ("gemm_fwd_lds<4,2,true>", "gemm_fwd_lds_4x2"), ("gemm_fwd_lds<2,2,true", "gemm_fwd_lds_2x2"),
-                ("gemm_fwd_lds<1,1,true", "gemm_fwd_lds_2x2"), ("gemm_fwd_direct", "gemm_fwd_direct"), ("gemm_bwd_seq", "gemm_bwd_pair"),
-                ("gemm_bwd_pair_direct", "gemm_bwd_pair"), ("gemm_dgrad_lds", "gemm_dgrad"), ("gemm_dgrad_direct", "gemm_dgrad"), ("gemm_dgrad_narrow", "gemm_dgrad"),
-                ("gemm_wgrad_tail", "gemm_wgrad"), ("gemm_wgrad_narrow", "gemm_wgrad"), ("k_adam_soft", "adam"))
-
-
-def live_kernel_trace(extra_args, updates=320):
-    """Per-kernel launch durations of the GRAPH-REPLAYED update, measured NOW on this box: one child run of this script under
-    `rocprofv3 --kernel-trace` (no counters, no other trace domain), the K steps enqueued exactly as the headline enqueues them
-    (dqnhip_update_async_n: sixteen updates per hipGraph launch).  Inside a replayed graph a kernel's reported duration runs up
-    to the next kernel's start (profiles/r04_graph_gap.txt), so these durations are what the wall clock is made of — the same
-    numbers `rocprofv3 --kernel-trace --stats` prints (profiles/rNN_fp32_b256_kernel_stats.md); eager HIP events around single
-    launches (the fallback) differ from them by a few per cent and from run to run.
-    Returns ({kernel: (mean_us, launches_per_update)}, source) or (None, reason)."""
-    import csv
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
-    if shutil.which("rocprofv3") is None:
-        return None, "rocprofv3 not on PATH"
-    d = tempfile.mkdtemp(prefix="dqnhip_kt_", dir="/tmp")
-    cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-           "--steps", str(updates), "--warmup", "32", "--no-cpu-baseline", "--no-env", "--no-subrecords", "--no-live-pmc", "--no-live-trace", "--trace-child",
-           "--replay", "100000"] + list(extra_args)
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
-    except Exception as e:              # noqa: BLE001
-        shutil.rmtree(d, ignore_errors=True)
-        return None, "rocprofv3 --kernel-trace child failed: %r" % (e,)
-    rows = []
-    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
-        for row in csv.DictReader(open(f)):
-            n = row["Kernel_Name"].replace("void ", "").replace("dqnhip::", "")
-            n = (n[:n.index("(")] if "(" in n else n).replace(" ", "")
-            rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), n))
-    shutil.rmtree(d, ignore_errors=True)
-    if not rows:
-        return None, "rocprofv3 --kernel-trace child: no kernel rows (rc %d: %s)" % (r.returncode, (r.stderr or "")[-200:])
-    rows.sort()
-    # the timed region = the last `updates` updates: count them by the actor's optimiser pass, the last launch of every update
-    # (k_adam_soft_gather inside the sixteen-update graph, k_adam_soft with the tick otherwise: two k_adam_soft* per update)
-    adam = [i for i, x in enumerate(rows) if x[2].startswith("k_adam_soft")]
-    if len(adam) < 2 * updates:
-        return None, "rocprofv3 --kernel-trace child: %d optimiser launches < 2 x %d updates" % (len(adam), updates)
-    first = adam[len(adam) - 2 * updates - 1] + 1 if len(adam) > 2 * updates else 0
-    acc = {}
-    for s0, e0, n in rows[first:]:
-        a = acc.setdefault(n, [0.0, 0])
-        a[0] += (e0 - s0) / 1e3; a[1] += 1
-    span_us = (rows[-1][1] - rows[first][0]) / 1e3
-    out = {n: (v[0] / v[1], v[1] / float(updates)) for n, v in acc.items()}
-    return out, ("measured in this run: rocprofv3 --kernel-trace of a child pass of this bench.py (graph replay, %d updates, %.2f us per update "
-                 "inside the trace); a kernel's duration inside a replayed graph runs up to the next kernel's start" % (updates, span_us / updates))
 
 
 def probe_captured_dp(rank, world, local_rank, precision, half, per_layer, timeout_s=150):
@@ -366,10 +103,11 @@ def prefill(dqn, n, seed, chunk=131072):
         done += m
 
 
+# (the cpu_baseline leg stays in this file: bench.py is the one place outside tests/ and smoke() that may execute oracle/ code)
 REF_SHAPE = dict(B=32, S=59, hidden=(1024, 512, 256, 128))      # src/dqn.hpp:19, src/dqn.cpp:425: BASELINE configs[0]
 
 
-def cpu_baseline(budget_s=20.0):
+def cpu_baseline(B, S, HIDDEN, budget_s=20.0):
     """CPU stand-ins for 'the reference Caffe CPU solver' (which cannot be built here: Caffe / HFO / boost / glog / gflags /
     protobuf are absent), SURVEY 8(d)'s matrix on this box's host cores, bounded to ~budget_s seconds:
       shapes   BASE (B = 256, S = 58, 4 x 1024: the headline's) and REF (B = 32, S = 59, 1024-512-256-128: the reference's
@@ -1081,7 +819,7 @@ def main():
             "sub_records": None,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(B, S, HIDDEN)
         else:
             out["cpu_baseline"] = None
 
