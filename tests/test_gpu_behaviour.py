@@ -422,3 +422,39 @@ def test_fp16_learner_bandit(pkg, gpu):
     assert abs(mu1 - opt) < abs(mu0 - opt) - 5.0 and mu1 > mu0, (mu0, mu1)
     assert np.mean(avg_q[-50:]) > np.mean(avg_q[60:110]), (np.mean(avg_q[60:110]), np.mean(avg_q[-50:]))
     dqn.close()
+
+
+# =========================================== normalisers and ordering =================================
+def test_gradient_normalisers_and_the_order_of_the_two_steps(pkg, gpu):
+    """From the library's own per-row outputs, no oracle: (5) the critic's loss gradient is AVERAGED over the minibatch
+    (EuclideanLoss: d loss / d q_m = (q_m - y_m) / B, so the q head's bias gradient is mean(q - y)) while the actor's gradient is
+    a SUM over rows (q diff = -1 per row, src/dqn.cpp:918-921: the head bias gradients are the column sums of the post-invert
+    diffs); (6) avg_q is evaluated with the critic AFTER its step and the policy BEFORE the actor's (src/dqn.cpp:904-916)."""
+    rng = np.random.default_rng(13)
+    B, N = 32, 512
+    dqn = make(pkg, B=B, critic_lr=5e-3, actor_lr=5e-3, tau=0.5, clip_grad=1e9)
+    for net, sz in ((ACTOR, S), (CRITIC, S + 10)):
+        sl, count = layer_slices(sz, HID, (4, 6) if net == ACTOR else (1,))
+        w = small_random(rng, count, 0.2)
+        if net == CRITIC: w[sl[0][0]:sl[0][1]].reshape(HID[0], S + 10)[:, S + 4:] *= 0.02
+        dqn.set_params(net, w); dqn.CloneNet(net)
+    s, a, r, mc, nx, term = fill_replay(dqn, rng, N, S, terminal_every=7)
+    rows = head_rows(S, HID)
+    slc, _ = layer_slices(S + 10, HID, (1,))
+    q_bias = slc[2 * len(HID) + 1][0]
+    for u in range(3):
+        idx = rng.integers(0, N, B)
+        mu_before = dqn.SelectActionGreedily(s[idx])                       # the policy this update's avg_q must use
+        loss, avg_q = dqn.UpdateActorCritic(idx)
+        q, y = dqn.debug_read("q_train").astype(np.float64), dqn.debug_read("y").astype(np.float64)
+        gc, ga = dqn.get_params(CRITIC, KIND_G).astype(np.float64), dqn.get_params(ACTOR, KIND_G).astype(np.float64)
+        np.testing.assert_allclose(gc[q_bias], np.mean(q - y), rtol=1e-5, atol=1e-7)          # averaged over B
+        dq = dqn.debug_read("dq_da").astype(np.float64)
+        for j in range(10):
+            np.testing.assert_allclose(ga[rows[j][1]], dq[:, j].sum(), rtol=1e-5, atol=1e-6)    # summed over B
+        np.testing.assert_allclose(dqn.debug_read("actor_out"), mu_before, rtol=1e-5, atol=1e-5)
+        q_after = dqn.CriticForward(s[idx], mu_before)                      # the critic has taken its step, the policy is the old one
+        np.testing.assert_allclose(avg_q, q_after.astype(np.float64).mean(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(dqn.debug_read("q_policy"), q_after, rtol=1e-5, atol=1e-6)
+        assert not np.allclose(dqn.CriticForward(s[idx], dqn.SelectActionGreedily(s[idx])), q_after, rtol=1e-5, atol=1e-6), "the actor did move"
+    dqn.close()
