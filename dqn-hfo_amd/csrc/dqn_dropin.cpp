@@ -386,7 +386,7 @@ void DQN::AddTransition(const Transition& t) {
 
 void DQN::AddTransitions(const std::vector<Transition>& ts) {
   const size_t n = ts.size(), S = (size_t)state_size_;
-  if (n == 0) return;
+  if (n == 0) { DQNHIP_CK(dqnhip_add_transitions(h_, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0)); return; }   // (:776 still evicts one from a full deque)
   std::vector<float> s(n * S), nx(n * S, 0.f), a(n * (kActionSize + kActionParamSize)), r(n), mc(n);
   std::vector<uint8_t> term(n);
   for (size_t i = 0; i < n; ++i) {

@@ -93,13 +93,15 @@ int dqnhip_critic_forward(dqnhip_handle h, int32_t net, const float* states_host
 
 static int add_dev(H* h, const float* s, const float* a, const float* r, const float* mc, const float* nx,
                    const uint8_t* term, int n, int single) {
-  if (n < 1) return fail("n must be >= 1");
+  // n == 0 is AddTransitions of an empty vector: `while (size() + 0 >= capacity) pop_front()` (src/dqn.cpp:776) still evicts
+  // one transition from a full deque — only the bookkeeping runs
+  if (n < 0 || (n == 0 && single != 0)) return fail("n must be >= 1");
   RingUse ring_use(h);
   RC(refresh_ring(h));
   const long long cap = RO(h)->ring.cap;
   if (single == 0 && n >= cap) return fail("AddTransitions: batch of %d does not fit capacity %lld (the reference would pop an empty deque)", n, cap);
   if (single == 2 && RO(h)->h_size + n > cap) return fail("LoadReplayMemory: %lld transitions exceed the capacity %lld", RO(h)->h_size + n, cap);
-  hipLaunchKernelGGL(k_add_transitions, dim3((n + 3) / 4), dim3(256), 0, h->stream, RO(h)->ring, RO(h)->st, s, a, r, mc, nx,
+  hipLaunchKernelGGL(k_add_transitions, dim3(std::max(1, (n + 3) / 4)), dim3(256), 0, h->stream, RO(h)->ring, RO(h)->st, s, a, r, mc, nx,
                      term, n, single, RO(h)->done_counter);
   HIPCHK(hipGetLastError());
   // host mirror of the same deque arithmetic (src/dqn.cpp:768-781)
@@ -125,9 +127,10 @@ int dqnhip_add_transitions_device(dqnhip_handle h, const float* states, const fl
 static int add_host(H* h, const float* s, const float* a, const float* r, const float* mc, const float* nx,
                     const uint8_t* term, int n, int single) {
   if (!h) return fail("null handle");
-  if (n < 1) return fail("n must be >= 1");
-  if (!s || !a || !r || !mc || !term) return fail("null input array");
+  if (n < 0 || (n == 0 && single != 0)) return fail("n must be >= 1");
   HIPCHK(hipSetDevice(h->cfg.device));
+  if (n == 0) return add_dev(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0);      // empty AddTransitions: eviction only
+  if (!s || !a || !r || !mc || !term) return fail("null input array");
   const size_t sb = round_up_z((size_t)n * h->S * 4, 256), ab = round_up_z((size_t)n * kNO * 4, 256), vb = round_up_z((size_t)n * 4, 256);
   // staging is reused: wait for the previous scatter to drain before overwriting
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -38,7 +38,17 @@ def test_ring_eviction_matches_deque(pkg, gpu):
     a, b = dqn.read_memory(0, cap), orc.read_memory(0, cap)
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
+    # AddTransitions of an EMPTY vector on a full deque: `while (size() + 0 >= capacity) pop_front()` (src/dqn.cpp:776) evicts the
+    # oldest transition and appends nothing; on a deque below capacity it is a no-op
+    dqn.AddTransitions([])
+    assert dqn.memory_size() == cap - 1
+    a2 = dqn.read_memory(0, cap - 1)
+    for x, y in zip(a2, a):
+        np.testing.assert_array_equal(x, y[1:])
+    dqn.AddTransitions([])
+    assert dqn.memory_size() == cap - 1
     dqn.ClearReplayMemory(); assert dqn.memory_size() == 0
+    dqn.AddTransitions([]); assert dqn.memory_size() == 0
     dqn.close(); orc.close()
 
 
