@@ -262,6 +262,9 @@ DQN::DQN(caffe::SolverParameter& actor_solver_param, caffe::SolverParameter& cri
     const std::string rv = FLAGS_dp_rendezvous + "_agent" + std::to_string(tid);
     LOG(INFO) << "[Agent" << tid << "] data-parallel rank " << FLAGS_dp_rank << " of " << FLAGS_dp_world << " (rendezvous " << rv << ")";
     DQNHIP_CK(dqnhip_dp_init_file(h_, rv.c_str(), FLAGS_dp_half_grads ? DQNHIP_DP_HALF_GRADS : 0, 300));
+    // every rank re-synchronises at its first Update(), whether or not IT restored anything: a rank that found a snapshot under
+    // its own -save prefix and a rank that did not must still enter the same collective (see SyncReplicasIfPending)
+    dp_sync_pending_ = true;
     int32_t ver = 0; char path[1024] = {0};
     if (dqnhip_dp_info(&ver, path, sizeof path) == 0) LOG(INFO) << "[Agent" << tid << "] RCCL " << ver << " from " << path;
   }
@@ -272,7 +275,8 @@ DQN::DQN(caffe::SolverParameter& actor_solver_param, caffe::SolverParameter& cri
 // train diverged replicas on summed gradients, and ranks whose iteration counters differ would leave the max_iter gate of
 // Update() at different updates — one of them waiting in a collective for ever.  So every such call re-arms a broadcast of
 // rank 0's weights, Adam history and iterations, taken at the next Update() / UpdateActorCritic(): the first point every rank
-// passes in the same order.
+// passes in the same order.  The flag is also set by the constructor, so the FIRST update of every rank broadcasts whether or not
+// that rank restored anything (symmetric: one rank with a snapshot and one without still meet in the same collective).
 void DQN::SyncReplicasIfPending() {
   if (!dp_ || !dp_sync_pending_) return;
   LOG(INFO) << "[Agent" << tid_ << "] data-parallel: re-synchronising the replicas from rank 0 (weights, Adam history, iterations)";
