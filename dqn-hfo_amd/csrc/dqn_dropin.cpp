@@ -236,6 +236,10 @@ DQN::DQN(caffe::SolverParameter& actor_solver_param, caffe::SolverParameter& cri
       << "actor and critic solvers must share momentum / momentum2 / delta / clip_gradients";
   c.momentum = critic_solver_param_.momentum(); c.momentum2 = critic_solver_param_.momentum2();
   c.delta = critic_solver_param_.delta(); c.clip_gradients = critic_solver_param_.clip_gradients();
+  // -lr_policy (src/dqn_main.cpp:36, 255-256): the fused optimiser pass applies base_lr as it stands, i.e. Caffe's "fixed" policy
+  // (the reference's default); anything else would silently train with a different schedule than the user asked for
+  for (const caffe::SolverParameter* sp : {&actor_solver_param_, &critic_solver_param_})
+    CHECK(sp->lr_policy().empty() || sp->lr_policy() == "fixed") << "only -lr_policy fixed is implemented (got '" << sp->lr_policy() << "')";
   CHECK(actor_solver_param_.type() == "Adam" && critic_solver_param_.type() == "Adam") << "only the Adam solver is implemented (-solver Adam, the reference's default)";
   c.device = FLAGS_hip_device + tid * FLAGS_hip_agent_device_stride;
   c.use_graph = FLAGS_hip_graph ? 1 : 0;
