@@ -220,6 +220,13 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
             out["configs4_1gpu_b4096_%s" % prec] = {"ms_per_update": round(dt * 1e3, 4), "updates_per_s": round(1 / dt, 1),
                                                     "samples_per_s": round(GB / dt), "update_mfma_frac": round(fl / dt / 1e12 / peak, 4)}
             d.read_stats(); d.close()
+        # the headline's own shape on the fp16-MFMA learner (configs[4]'s precision at configs[1]'s sizes): not the parity path, for the record
+        d = pkg.DQN(S, minibatch=B, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, use_graph=True, precision="fp16")
+        prefill(d, 150000, seed=7)
+        dt = timed_n(d, torch.cuda.synchronize, 512, 64)
+        out["configs1_shape_b256_fp16"] = {"ms_per_update": round(dt * 1e3, 5), "updates_per_s": round(1 / dt, 1),
+                                           "note": "fp16 MFMA operands, fp32 accumulate / master weights / Adam / heads; launch-bound (22 GEMM launches of ~6.3 us)"}
+        d.read_stats(); d.close()
         # two independent agents (learners) on this one GPU, each on its own stream with its own captured update —
         # how the reference packs a multi-agent team onto one device (one DQN per agent thread, src/dqn_main.cpp:62, 264)
         agents = [pkg.DQN(S, minibatch=B, hidden=HIDDEN, memory=100000, seed=11 + i, device=local_rank, use_graph=True) for i in range(2)]
