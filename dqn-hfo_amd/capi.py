@@ -11,6 +11,7 @@ DP_UNVERIFIED_OK = 256   # lets DP_PER_LAYER / DP_SHARD_OPT through for dp_world
 TUNE_FP16_WGRAD_PER_LAYER = 1                       # dqnhip_config.tuning_flags bits
 TUNE_SEPARATE_HEAD_SEED = 2
 TUNE_BWD_UNSHIFTED = 4
+TUNE_SEPARATE_ACTOR_HEAD_BWD = 8
 ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET = 0, 1, 2, 3
 KIND_W, KIND_M, KIND_V, KIND_G = 0, 1, 2, 3
 

@@ -293,7 +293,9 @@ __device__ __forceinline__ void dgrad_direct_body(const GemmProblem& pr, int til
 // workgroups, 4.2 us of MFMA per wave) only the 16-column tiles that contain those columns are
 // computed, a quarter of the MFMA chain per wave.  P = W (one column per lane, scalar loads),
 // Q = dY (16 rows).  Same K split over the 4 waves, same fixed-order reduction.
-__device__ __forceinline__ void dgrad_narrow_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
+// dgrad_narrow_tile: the reduced (and masked) 16 x 16 tile in wave 0's lanes — lane (li, lg), register r = dX[row q0 + li][column
+// p0 + 4 lg + r]; the other waves return zeros.  dgrad_narrow_body stores it.
+__device__ __forceinline__ f32x4 dgrad_narrow_tile(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
   constexpr int NACC = 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -333,13 +335,21 @@ __device__ __forceinline__ void dgrad_narrow_body(const GemmProblem& pr, int til
   if (wave == 0 && pr.mask != nullptr) mv = *reinterpret_cast<const f32x4*>(pr.mask + (size_t)(q0 + li) * pr.ldm + p0 + (lg << 2));
   park_accumulators<NACC>(smem, acc, wave, lane);
   __syncthreads();
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
   if (wave == 0) {
     // C/D map: lane (li, lg) register r = C[i = 4 lg + r][j = li] = dX[row q0 + li][column p0 + 4 lg + r]
-    f32x4 v = reduce_accumulator<NACC>(smem, 0, lane);
-    const int q = q0 + li, p = p0 + (lg << 2);
+    v = reduce_accumulator<NACC>(smem, 0, lane);
     if (pr.mask != nullptr) {
       v.x *= lrelu_mask(mv.x); v.y *= lrelu_mask(mv.y); v.z *= lrelu_mask(mv.z); v.w *= lrelu_mask(mv.w);
     }
+  }
+  return v;
+}
+__device__ __forceinline__ void dgrad_narrow_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
+  const f32x4 v = dgrad_narrow_tile(pr, tile_p, tile_q, smem);
+  if ((threadIdx.x >> 6) == 0) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const int q = tile_q * 16 + li, p = tile_p * 16 + (lg << 2);
     *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
   }
 }

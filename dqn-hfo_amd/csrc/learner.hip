@@ -172,9 +172,11 @@ inline bool head_wgrad_can_ride(const NetLayout& l, int rows) {
   const int NH = l.NH, H = l.dims[l.L];
   return H % kRiderCW == 0 && (size_t)(rows * NH + 256 * NH) * sizeof(float) <= (size_t)64 * 1024;
 }
+// fuse: the critic's dQ/da pass — the first layer's action-column tiles, the inverting gradients and the actor heads' backward in
+// ONE launch (k_dqda_head_bwd) instead of the narrow dgrad launch here and a head-backward launch after it; carries the q rider
 int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* garena, float* partial,
                    float** act, float** dZ, int rows, bool want_w, bool input_grad, int in_lo = 0, int in_hi = -1,
-                   const HeadWgradRider* rider = nullptr, const QHeadRider* qrider = nullptr) {
+                   const HeadWgradRider* rider = nullptr, const QHeadRider* qrider = nullptr, DqdaHeadArgs* fuse = nullptr) {
   auto dgrad_of = [&](int i) {             // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
     GemmProblem p{};
     p.mode = GEMM_DGRAD;
@@ -243,6 +245,14 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
         if (lds_ok) HIPCHK((bwd_pair_direct_launch<1, true>(b, st))); else HIPCHK((bwd_pair_direct_launch<1, false>(b, st)));
       } else if (lds_ok) HIPCHK((bwd_seq_launch<true>(b, st)));
       else HIPCHK((bwd_seq_launch<false>(b, st)));
+    } else if (need_dx && i == 0 && fuse != nullptr) {
+      GemmProblem p = bd.prob[0];
+      p.P += in_lo; p.C = nullptr; p.Pdim = 16; p.mask = nullptr;
+      fuse->pr = p;
+      const QHeadRider none{};
+      ScopedTiming t(h, 1, st);
+      HIPCHK(dqda_head_bwd_launch(*fuse, qrider ? *qrider : none, st));
+      qrider = nullptr;
     } else if (need_dx && i == 0 && in_hi > in_lo && rows % 16 == 0) {
       GemmProblem& p = bd.prob[0];
       const int c0 = (in_lo / 16) * 16, c1 = std::min(l.kp[0], (in_hi + 15) / 16 * 16);
@@ -751,16 +761,26 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       a.q_bias = wat(h, DQNHIP_CRITIC, lc.hb_off); a.q_out = h->q2; a.qsum_partial = h->q_partial;
       RC(head_backward<1>(h, st, a));
     }
-    RC(tower_backward(h, st, lc, DQNHIP_CRITIC, nullptr, nullptr, h->act[4], h->dZc, B, false, true, h->S, h->S + kNO, nullptr, fused_seed ? &qr : nullptr));
+    // dQ/da's last step, the inverting gradients (src/dqn.cpp:924-957) and the actor heads' backward (src/dqn.cpp:960-963) share
+    // ONE launch (k_dqda_head_bwd) when the actor head's own gradients ride in the actor's last backward launch and the shapes
+    // allow it (16 columns from the first action column inside the panel row, H a multiple of 256, fewer than 1024 rows);
+    // DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD: the narrow dgrad launch + k_head_bwd<10> (same arithmetic, one launch more)
+    const bool ride_a = !head_big_ok(h, B, Hh) && head_wgrad_can_ride(la, B);
+    const bool fuse_head = ride_a && !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) && B % 16 == 0 && Hh % 256 == 0 &&
+                           h->S + 16 <= lc.kp[0] && L >= 1 && lc.dims[1] % 64 == 0;
+    DqdaHeadArgs fz{};
+    fz.aout16 = h->aout16; fz.dA16 = h->dA16; fz.W = wat(h, DQNHIP_ACTOR, la.hw_off); fz.X4 = h->act[1][L]; fz.dZ = h->dZa[L]; fz.H = Hh; fz.rows = B;
+    RC(tower_backward(h, st, lc, DQNHIP_CRITIC, nullptr, nullptr, h->act[4], h->dZc, B, false, true, h->S, h->S + kNO, nullptr, fused_seed ? &qr : nullptr,
+                      fuse_head ? &fz : nullptr));
     // inverting gradients (src/dqn.cpp:924-957) + actor heads backward (src/dqn.cpp:960-963)
     {
       HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;
       a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.X4 = h->act[1][L]; a.H = Hh; a.rows = B; a.dZ = h->dZa[L];
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
-      const bool ride = !head_big_ok(h, B, Hh) && head_wgrad_can_ride(la, B);
+      const bool ride = ride_a;
       HeadWgradRider r{h->dA16, kAP, h->act[1][L], Hh, B, a.dW, a.db, a.partial, Hh / kRiderCW};   // dA16: the post-invert diffs this launch leaves
       if (ride) { a.dW = nullptr; a.db = nullptr; a.partial = nullptr; }
-      RC(head_backward<kNO>(h, st, a));
+      if (!fuse_head) RC(head_backward<kNO>(h, st, a));
       RC(tower_backward(h, st, la, DQNHIP_ACTOR, h->g[0], h->part[0], h->act[1], h->dZa, B, true, false, 0, -1, ride ? &r : nullptr));
     }
     if (dp) {

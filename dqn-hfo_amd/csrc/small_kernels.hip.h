@@ -722,6 +722,82 @@ __global__ __launch_bounds__(1024) void k_head_bwd(HeadBwdArgs a) {
   }
 }
 
+// ---- critic dQ/da + inverting gradients + actor heads' backward in ONE launch (round 5) ----------------------------------------
+// The critic's BackwardFrom(q_values) chain (src/dqn.cpp:918-923) ends in the first layer's input gradient, of which only the ten
+// action columns are consumed; the inverting-gradients pass (:924-957) and the actor heads' backward (BackwardFrom(actionpara_layer),
+// :960-963: head dgrad + the tower top's ReLU') follow.  They used to be two launch-floor launches (gemm_dgrad_narrow_qrider:
+// 32 tiles of 16 x 16 + the q riders, 6.2 us; k_head_bwd<10>: 4.8 us).  Here workgroup (row tile t, column chunk c) recomputes
+// the 16 x 16 tile of dQ/da for its 16 rows — a 1024-deep reduction on four waves, 0.1 us of MFMA: recomputing it in each of the
+// H / 256 column chunks costs less than handing it across a kernel boundary — inverts it, and writes its 16 x 256 piece of the
+// actor's tower-top gradient.  Same arithmetic in the same order as the two kernels it replaces (bit-identical: the narrow
+// tile's values do not depend on which columns a workgroup owns, the head part is k_head_bwd's loop).  The q(s, mu(s)) riders
+// come last in the grid, as before.  The head's own dW / db are the wgrad-tail launch's riders (HeadWgradRider).
+struct DqdaHeadArgs {
+  GemmProblem pr;                          // critic first layer's narrow dgrad: P = W_0 + S (16 columns from the first action column), Q = dZ_1, Kred = width of layer 1
+  const float* aout16; float* dA16;        // mu(s) [rows][16]; post-invert diffs [rows][16] (column chunk 0 writes them)
+  const float* W; const float* X4;         // actor head weights [10][H], actor tower top [rows][H]
+  float* dZ;                               // actor tower-top gradient [rows][H]
+  int H, rows, row_tiles;                  // row_tiles = rows / 16
+};
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_dqda_head_bwd(const DqdaHeadArgs a, const QHeadRider rider) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // the narrow dgrad's parking area (4 waves x 64 lanes x 16 B)
+  __shared__ float s_d[16][17];
+  __shared__ float s_dy[16 * kNO];
+  const int tiles = a.row_tiles * (a.H >> 8);
+  if ((int)blockIdx.x >= tiles) { q_head_rider(rider, (int)blockIdx.x - tiles); return; }
+  const int rt = (int)blockIdx.x % a.row_tiles, cc = (int)blockIdx.x / a.row_tiles;
+  const int tid = threadIdx.x, q0 = rt * 16, k = (cc << 8) + tid;
+  // everything the head part needs that does not depend on dQ/da goes out first: this thread's ten head weights, its column of
+  // the 16 tower-top rows, and (160 threads) one output of mu(s)
+  float wh[kNO], xv[16];
+#pragma unroll
+  for (int j = 0; j < kNO; ++j) wh[j] = a.W[(size_t)j * a.H + k];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xv[r] = a.X4[(size_t)(q0 + r) * a.H + k];
+  float out = 0.0f;
+  if (tid < 16 * kNO) out = a.aout16[(size_t)(q0 + tid / kNO) * kAP + tid % kNO];
+  const f32x4 v = dgrad_narrow_tile(a.pr, 0, rt, smem);
+  if (tid < 64) {                          // wave 0 holds the tile: lane (li, lg), register r = dX[row q0 + li][column 4 lg + r]
+    const int li = tid & 15, lg = tid >> 4;
+    s_d[li][(lg << 2) + 0] = v.x; s_d[li][(lg << 2) + 1] = v.y; s_d[li][(lg << 2) + 2] = v.z; s_d[li][(lg << 2) + 3] = v.w;
+  }
+  __syncthreads();
+  if (tid < 16 * kNO) {                    // inverting gradients (k_head_bwd<10>'s staging loop)
+    const int r = tid / kNO, j = tid % kNO;
+    float d = s_d[r][j];
+    float mn, mx;
+    if (j < kNA) { mn = -1.0f; mx = 1.0f; }
+    else { const int p = j - kNA; if (p == 0 || p == 4) { mn = 0.0f; mx = 100.0f; } else { mn = -180.0f; mx = 180.0f; } }
+    if (d < 0) d *= (mx - out) / (mx - mn);
+    else if (d > 0) d *= (out - mn) / (mx - mn);
+    if (cc == 0) a.dA16[(size_t)(q0 + r) * kAP + j] = d;
+    s_dy[tid] = d;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kNO; ++j) {
+      const float d = s_dy[r * kNO + j];
+      // Split layer: action_layer's and actionpara_layer's bottom diffs are formed separately and added
+      if (j >= kNA) s1 = fmaf(d, wh[j], s1); else s0 = fmaf(d, wh[j], s0);
+    }
+    s0 += s1;
+    a.dZ[(size_t)(q0 + r) * a.H + k] = s0 * lrelu_mask(xv[r]);
+  }
+}
+inline hipError_t dqda_head_bwd_launch(DqdaHeadArgs& a, const QHeadRider& rider, hipStream_t stream) {
+  a.row_tiles = a.rows / 16;
+  a.pr.tiles_p = 1; a.pr.tiles_q = a.row_tiles; a.pr.tile_base = 0;
+  const int grid = a.row_tiles * (a.H / 256) + rider.blocks;
+  LaunchTimer& lt = launch_timer();
+  if (lt.start) { hipExtLaunchKernelGGL(k_dqda_head_bwd<0>, dim3(grid), dim3(256), 4 * 64 * 16, stream, lt.start, lt.stop, 0, a, rider); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL(k_dqda_head_bwd<0>, dim3(grid), dim3(256), 4 * 64 * 16, stream, a, rider);
+  return hipGetLastError();
+}
+
 // ---- head backward for large minibatches (rows >= 1024) -------------------------------------
 // Same arithmetic as k_head_bwd, re-tiled for bandwidth: block = 64 rows x 256 columns, wave = 16
 // rows, lane = 4 consecutive columns (16-B loads / stores of X4 and dZ).  Per-chunk partial head

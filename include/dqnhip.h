@@ -119,6 +119,9 @@ typedef struct dqnhip_config {
 /* fp32 learner: a tower's backward as wgrad(i) + dgrad(i) per layer and a last launch with the first layer's wgrad alone,
  * instead of the shifted schedule dgrad(L-1) | wgrad(i+1) + dgrad(i) ... | wgrad(1) + wgrad(0) (same launch count). */
 #define DQNHIP_TUNE_BWD_UNSHIFTED 4
+/* fp32 learner: the critic's first-layer action-column input gradient in a launch of its own (+ the q riders) and the inverting
+ * gradients + actor heads' backward in another (k_head_bwd<10>), instead of all three in one launch (k_dqda_head_bwd, round 5). */
+#define DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD 8
 
 typedef struct dqnhip_learner* dqnhip_handle;
 

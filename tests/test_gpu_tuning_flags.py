@@ -144,3 +144,29 @@ def test_fp16_fused_head_seed_equals_separate_launch(pkg, gpu, B, hidden):
     for x, y in zip(a[2], b[2]):
         np.testing.assert_array_equal(x, y)
 
+
+
+@pytest.mark.parametrize("B,hidden,S", [
+    (256, (1024, 1024, 1024, 1024), 58),       # BASELINE configs[1]: 16 row tiles x 4 column chunks + 64 q-rider blocks
+    (32, (1024, 512, 256, 256), 59),           # 2 row tiles, one column chunk
+    (64, (256, 128, 64, 64), 59),              # H = 64: not a multiple of 256 -> both sides take the separate launches
+    (512, (1024, 1024), 68),                   # 1v1 state size: the action columns start at 68 (panel 128 wide)
+    (128, (512,), 58),                         # one tower layer: the fused launch reads the seed the forward epilogue left
+    (96, (256, 256, 256), 77),                 # 2v1 state size, a row count that is not a multiple of 64
+])
+def test_fused_dqda_and_actor_head_backward_equals_separate_launches(pkg, gpu, B, hidden, S):
+    """fp32 learner: the critic's first-layer action-column input gradient, the inverting gradients and the actor heads'
+    backward in ONE launch (k_dqda_head_bwd, default) against the narrow dgrad launch + k_head_bwd<10>
+    (DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD).  The fused workgroups recompute the same 16 x 16 tile values and run the same head
+    loop: every result bit-identical, eager and graph-replayed."""
+    a = _run32(pkg, 0, B, hidden, S)
+    b = _run32(pkg, pkg.capi.TUNE_SEPARATE_ACTOR_HEAD_BWD, B, hidden, S)
+    assert a[0] == b[0], (a[0], b[0])
+    for (qa, da), (qb, db) in zip(a[1], b[1]):
+        np.testing.assert_array_equal(qa, qb); np.testing.assert_array_equal(da, db)
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
+    g = _run32(pkg, 0, B, hidden, S, use_graph=True)
+    assert a[0] == g[0]
+    for x, y in zip(a[2], g[2]):
+        np.testing.assert_array_equal(x, y)
