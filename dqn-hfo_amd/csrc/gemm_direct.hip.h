@@ -295,6 +295,9 @@ __device__ __forceinline__ void dgrad_direct_body(const GemmProblem& pr, int til
 // Q = dY (16 rows).  Same K split over the 4 waves, same fixed-order reduction.
 // dgrad_narrow_tile: the reduced (and masked) 16 x 16 tile in wave 0's lanes — lane (li, lg), register r = dX[row q0 + li][column
 // p0 + 4 lg + r]; the other waves return zeros.  dgrad_narrow_body stores it.
+// NS: register ring depth in 16-k steps (a wave's quarter of a 1024-deep reduction is 16 steps: NS = 8 -> two load round trips
+// instead of four; the order in which the MFMAs accumulate does not depend on it)
+template <int NS = 4>
 __device__ __forceinline__ f32x4 dgrad_narrow_tile(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
   constexpr int NACC = 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -307,7 +310,6 @@ __device__ __forceinline__ f32x4 dgrad_narrow_tile(const GemmProblem& pr, int ti
   const size_t ldp = pr.ldp;
   f32x4 acc[NACC];
   acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int NS = 4;
   float rp[NS][4]; f32x4 rq[NS];
 #define DN_LOAD(slot, kb)                                                               \
   {                                                                                     \
@@ -316,19 +318,19 @@ __device__ __forceinline__ f32x4 dgrad_narrow_tile(const GemmProblem& pr, int ti
   }
 #define DN_COMPUTE(slot)                                                                \
   { _Pragma("unroll") for (int s = 0; s < 4; ++s) acc[0] = DQN_MFMA(rp[slot][s], rq[slot][s], acc[0]); }
-  const int nkb4 = nkb & ~3;
-  if (nkb4 > 0) {
-    DN_LOAD(0, 0) DQN_PIN(); DN_LOAD(1, 1) DQN_PIN(); DN_LOAD(2, 2) DQN_PIN(); DN_LOAD(3, 3) DQN_PIN();
+  const int nkbN = nkb - nkb % NS;
+  if (nkbN > 0) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { DN_LOAD(i, i) DQN_PIN(); }
     int kb = 0;
-    for (; kb + 4 < nkb4; kb += 4) {
-      DN_COMPUTE(0) DQN_PIN(); DN_LOAD(0, kb + 4) DQN_PIN();
-      DN_COMPUTE(1) DQN_PIN(); DN_LOAD(1, kb + 5) DQN_PIN();
-      DN_COMPUTE(2) DQN_PIN(); DN_LOAD(2, kb + 6) DQN_PIN();
-      DN_COMPUTE(3) DQN_PIN(); DN_LOAD(3, kb + 7) DQN_PIN();
+    for (; kb + NS < nkbN; kb += NS) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) { DN_COMPUTE(i) DQN_PIN(); DN_LOAD(i, kb + NS + i) DQN_PIN(); }
     }
-    DN_COMPUTE(0) DN_COMPUTE(1) DN_COMPUTE(2) DN_COMPUTE(3)
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { DN_COMPUTE(i) }
   }
-  for (int kb = nkb4; kb < nkb; ++kb) { DN_LOAD(0, kb) DN_COMPUTE(0) }
+  for (int kb = nkbN; kb < nkb; ++kb) { DN_LOAD(0, kb) DN_COMPUTE(0) }
 #undef DN_LOAD
 #undef DN_COMPUTE
   f32x4 mv = f32x4{0.f, 0.f, 0.f, 0.f};          // requested ahead of the cross-wave reduction
@@ -346,7 +348,7 @@ __device__ __forceinline__ f32x4 dgrad_narrow_tile(const GemmProblem& pr, int ti
   return v;
 }
 __device__ __forceinline__ void dgrad_narrow_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
-  const f32x4 v = dgrad_narrow_tile(pr, tile_p, tile_q, smem);
+  const f32x4 v = dgrad_narrow_tile<4>(pr, tile_p, tile_q, smem);
   if ((threadIdx.x >> 6) == 0) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     const int q = tile_q * 16 + li, p = tile_p * 16 + (lg << 2);

@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void k_dqda_head_bwd(const DqdaHeadArgs a, con
   for (int r = 0; r < 16; ++r) xv[r] = a.X4[(size_t)(q0 + r) * a.H + k];
   float out = 0.0f;
   if (tid < 16 * kNO) out = a.aout16[(size_t)(q0 + tid / kNO) * kAP + tid % kNO];
-  const f32x4 v = dgrad_narrow_tile(a.pr, 0, rt, smem);
+  const f32x4 v = dgrad_narrow_tile<8>(a.pr, 0, rt, smem);
   if (tid < 64) {                          // wave 0 holds the tile: lane (li, lg), register r = dX[row q0 + li][column 4 lg + r]
     const int li = tid & 15, lg = tid >> 4;
     s_d[li][(lg << 2) + 0] = v.x; s_d[li][(lg << 2) + 1] = v.y; s_d[li][(lg << 2) + 2] = v.z; s_d[li][(lg << 2) + 3] = v.w;
