@@ -75,5 +75,5 @@ KERNEL_NAMES = {"hgemm_fwd": "hgemm_nt<2,2>/<1,1> (forward epilogue)", "hgemm_dg
 # kernel name (as rocprofv3 prints it, spaces removed) -> the learner's timing family
 TRACE_FAMILY = (("gemm_fwd_lds<4,2,true,1>", "gemm_fwd_lds_4x2"), ("gemm_fwd_lds<4,2,true>", "gemm_fwd_lds_4x2"), ("gemm_fwd_lds<2,2,true", "gemm_fwd_lds_2x2"),
                 ("gemm_fwd_lds<1,1,true", "gemm_fwd_lds_2x2"), ("gemm_fwd_direct", "gemm_fwd_direct"), ("gemm_bwd_seq", "gemm_bwd_pair"),
-                ("gemm_bwd_pair_direct", "gemm_bwd_pair"), ("gemm_dgrad_lds", "gemm_dgrad"), ("gemm_dgrad_direct", "gemm_dgrad"), ("gemm_dgrad_narrow", "gemm_dgrad"), ("k_dqda_head_bwd", "gemm_dgrad"),
+                ("gemm_bwd_pair_direct", "gemm_bwd_pair"), ("gemm_dgrad_lds", "gemm_dgrad"), ("gemm_dgrad_direct", "gemm_dgrad"), ("gemm_dgrad_narrow", "gemm_dgrad"), ("k_dqda_head_bwd", "gemm_dgrad"), ("k_dgrad_qtrain", "gemm_dgrad"),
                 ("gemm_wgrad_tail", "gemm_wgrad"), ("gemm_wgrad_narrow", "gemm_wgrad"), ("k_adam_soft", "adam"))

@@ -12,6 +12,7 @@ TUNE_FP16_WGRAD_PER_LAYER = 1                       # dqnhip_config.tuning_flags
 TUNE_SEPARATE_HEAD_SEED = 2
 TUNE_BWD_UNSHIFTED = 4
 TUNE_SEPARATE_ACTOR_HEAD_BWD = 8
+TUNE_SEPARATE_Q_TRAIN = 16
 ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET = 0, 1, 2, 3
 KIND_W, KIND_M, KIND_V, KIND_G = 0, 1, 2, 3
 

@@ -37,6 +37,10 @@ struct GemmProblem {
   // (src/dqn.cpp:918-923: q diff = -1 per row) taken through the head and this layer's ReLU,
   // C2[q][p] = (-seed_w[p]) * lrelu'(C[q][p]) — what a head-backward launch of its own used to compute from C (null: none)
   const float* seed_w; float* C2;
+  // FWD, top tower layer of a critic pass of Step(1): the epilogue also leaves the head's dot product in pieces,
+  // dot_out[q][p / 16] = sum over the 16 finished activations C[q][p .. p+15] of C * dot_w (fixed order: a lane's four columns
+  // as an fma chain from 0, then (g0 + g1) + (g2 + g3) over the four lane groups) — k_dgrad_qtrain sums the Pdim / 16 pieces of a row
+  const float* dot_w; float* dot_out;
   int mode;                  // mixed-mode launches (gemm_bwd_pair_direct): GEMM_DGRAD / GEMM_WGRAD
   int tiles_p, tiles_q, tile_base;
 };

@@ -90,6 +90,15 @@ __device__ __forceinline__ void store_head_seed(const GemmProblem& pr, int q, in
   *reinterpret_cast<f32x4*>(pr.C2 + (size_t)q * pr.ldc + p) = dz;
 }
 
+// GemmProblem::dot_w: this lane's four finished activations v against the head weights dw, summed over the four lane groups
+// (16 columns), written by lane group 0
+__device__ __forceinline__ void store_head_dot(const GemmProblem& pr, int q, int p, int lg, const f32x4& v, const f32x4& dw) {
+  float d = fmaf(v.x, dw.x, 0.0f); d = fmaf(v.y, dw.y, d); d = fmaf(v.z, dw.z, d); d = fmaf(v.w, dw.w, d);
+  d += __shfl_xor(d, 16, 64);
+  d += __shfl_xor(d, 32, 64);
+  if (lg == 0) pr.dot_out[(size_t)q * (pr.Pdim >> 4) + (p >> 4)] = d;
+}
+
 // ================================ FWD ================================================
 // Y[m][n] = lrelu(sum_k X[m][k] W[n][k] + b[n]).  P = W (KC, 16-row blocks), Q = X (KC).
 // Tile = (16*TP) x (16*TQ).  Kred % 64 == 0.
@@ -156,7 +165,7 @@ __device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_
 
   // this wave's bias (and head-seed) pieces, requested ahead of the cross-wave reduction
   constexpr int NBV = (NACC + 3) / 4;
-  f32x4 bvp[NBV], swp[NBV];
+  f32x4 bvp[NBV], swp[NBV], dwp[NBV];
   if (pr.bias != nullptr) {
 #pragma unroll
     for (int j = 0; j < NBV; ++j) {
@@ -169,6 +178,13 @@ __device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_
     for (int j = 0; j < NBV; ++j) {
       const int e = j * 4 + wave;
       if (e < NACC) swp[j] = *reinterpret_cast<const f32x4*>(pr.seed_w + p0 + (e % TP) * 16 + (lg << 2));
+    }
+  }
+  if (pr.dot_w != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) {
+      const int e = j * 4 + wave;
+      if (e < NACC) dwp[j] = *reinterpret_cast<const f32x4*>(pr.dot_w + p0 + (e % TP) * 16 + (lg << 2));
     }
   }
   park_accumulators<NACC>(smem, acc, wave, lane);
@@ -186,6 +202,7 @@ __device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_
       if (pr.relu) { v.x = lrelu_fwd(v.x); v.y = lrelu_fwd(v.y); v.z = lrelu_fwd(v.z); v.w = lrelu_fwd(v.w); }
       *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
       if (pr.seed_w != nullptr) store_head_seed(pr, q, p, v, swp[e >> 2]);
+      if (pr.dot_w != nullptr) store_head_dot(pr, q, p, lg, v, dwp[e >> 2]);
     }
   }
 }
@@ -700,7 +717,7 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
 
   // this wave's bias pieces, requested ahead of the cross-wave reduction
   constexpr int NBV = (NACC + 3) / 4;
-  f32x4 bvp[NBV], swp[NBV];
+  f32x4 bvp[NBV], swp[NBV], dwp[NBV];
   if (pr.bias != nullptr) {
 #pragma unroll
     for (int j = 0; j < NBV; ++j) {
@@ -713,6 +730,13 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
     for (int j = 0; j < NBV; ++j) {
       const int e = j * 4 + wave;
       if (e < NACC) swp[j] = *reinterpret_cast<const f32x4*>(pr.seed_w + p0 + (e % TP) * 16 + (lg << 2));
+    }
+  }
+  if (pr.dot_w != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) {
+      const int e = j * 4 + wave;
+      if (e < NACC) dwp[j] = *reinterpret_cast<const f32x4*>(pr.dot_w + p0 + (e % TP) * 16 + (lg << 2));
     }
   }
   // park into this wave's own (now idle) staging region, reduce across waves in fixed order
@@ -745,6 +769,7 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
         *reinterpret_cast<f32x4*>(pr.C + (size_t)q * pr.ldc + p) = v;
       }
       if (pr.seed_w != nullptr) store_head_seed(pr, q, p, v, swp[e >> 2]);
+      if (pr.dot_w != nullptr) store_head_dot(pr, q, p, lg, v, dwp[e >> 2]);
     }
   }
 }
@@ -753,8 +778,13 @@ __device__ __forceinline__ void fwd_lds_body(const GemmProblem& pr, int tile_p, 
 // dgrad_direct_body with the k-contiguous operand (dY, 16-row blocks) fetched as whole 128-B
 // lines through the wave-private LDS transpose of fwd_lds_body; the weight operand (k-strided)
 // stays a direct full-line load.  Requires Kred % 256 == 0 and Kred >= 512.
-template <int TPB, int TQ, bool SCH = true>
-__device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
+// s_rowscale (LDS, [16 TQ] floats, published before this body's barrier by a wave that does not run it — k_dgrad_qtrain): the
+// reduced sums of row r are multiplied by s_rowscale[r] before the ReLU' mask (a dY panel whose rows share a late-known scalar factor)
+// hook (k_dgrad_qtrain): after_prologue() runs once the operand pipeline is primed (a place to REQUEST data whose latency the
+// main loop then hides), before_park() after the last MFMA and before this body's only barrier (a place to publish s_rowscale).
+struct DgradNoHook { __device__ __forceinline__ void after_prologue() {} __device__ __forceinline__ void before_park() {} };
+template <int TPB, int TQ, bool SCH = true, typename Hook = DgradNoHook>
+__device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem, const float* s_rowscale, Hook& hook) {
   constexpr int NACC = TPB * 4 * TQ;
   constexpr int SLOT = TQ * 512;
   constexpr int WAVE_FLOATS = (2 * SLOT > NACC * 256) ? 2 * SLOT : NACC * 256;   // staging, later the parked tile
@@ -837,6 +867,7 @@ __device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p
     DQN_PIN(); }
 
   D_GLOADQ(G0, 0) D_PIN() D_GLOADQ(G1, 1) D_PIN() D_GLOADP(P0, 0) D_PIN()
+  hook.after_prologue(); D_PIN()      // (with the first, cold round of operand requests: later, its cold misses hold up the in-order vmcnt of the loop's loads)
   D_SWRITE(0, G0) D_PIN() D_GLOADQ(G0, 2) D_PIN() D_SREAD(F, 0) D_PIN() D_GLOADP(P1, 1) D_PIN()
   int t = 0;
   for (; t + 4 < T; t += 2) {
@@ -848,6 +879,7 @@ __device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p
   D_SWRITE(0, G0) D_SREAD(F, 0) D_MFMA(Fn, P1) D_GLOADP(P1, T - 1) D_SCHED_(false, true)
   D_SWRITE(1, G1) D_SREAD(Fn, 1) D_MFMA(F, P0) D_SCHED_(false, false)
   D_MFMA(Fn, P1)
+  D_PIN() hook.before_park();
 #undef D_SCHED_
 #undef D_PIN
 #undef D_GLOADQ
@@ -881,6 +913,7 @@ __device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p
       if (((ab + r) & 3) == wave) {
         const int p = p0 + b * 64 + (lg << 4) + (r << 2);
         f32x4 v = f32x4{r0[r], r1[r], r2[r], r3[r]};
+        if (s_rowscale != nullptr) { const float sc = s_rowscale[a * 16 + li]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
         if (pr.mask != nullptr) {
           const f32x4 mv = mk[ab];
           v.x *= lrelu_mask(mv.x); v.y *= lrelu_mask(mv.y); v.z *= lrelu_mask(mv.z); v.w *= lrelu_mask(mv.w);
@@ -912,6 +945,11 @@ __global__ __launch_bounds__(256) void gemm_dgrad_direct(const GemmBatch batch) 
   int pi, tile_p, tile_q;
   tile_of_block(batch, pi, tile_p, tile_q);
   dgrad_direct_body<TPB, TQ>(batch.prob[pi], tile_p, tile_q, smem);
+}
+template <int TPB, int TQ, bool SCH = true>
+__device__ __forceinline__ void dgrad_lds_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
+  DgradNoHook none;
+  dgrad_lds_body<TPB, TQ, SCH, DgradNoHook>(pr, tile_p, tile_q, smem, nullptr, none);
 }
 template <int TPB, int TQ>
 __global__ __launch_bounds__(256) void gemm_dgrad_lds(const GemmBatch batch) {

@@ -122,6 +122,7 @@ int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, 
     p.Pdim = l.dims[i + 1]; p.Qdim = rows; p.Kred = l.kp[i];
     p.bias = wat(h, passes[j].net, l.b_off[i]); p.relu = 1;
     if (i == l.L - 1 && passes[j].seed_w != nullptr) { p.seed_w = passes[j].seed_w; p.C2 = passes[j].seed_out; }
+    if (i == l.L - 1 && passes[j].dot_w != nullptr) { p.dot_w = passes[j].dot_w; p.dot_out = passes[j].dot_out; }
   }
   // K >= 512 and K % 256 == 0: full-line loads + wave-private LDS transpose; else (first
   // layer, narrow towers) the plain direct kernel.  One problem: 32x32 tiles (256 workgroups
@@ -172,11 +173,20 @@ inline bool head_wgrad_can_ride(const NetLayout& l, int rows) {
   const int NH = l.NH, H = l.dims[l.L];
   return H % kRiderCW == 0 && (size_t)(rows * NH + 256 * NH) * sizeof(float) <= (size_t)64 * 1024;
 }
+// does a weights-wanted, no-input-gradient backward of this tower take the SHIFTED schedule (see tower_backward)?
+inline bool bwd_is_shifted(const H* h, const NetLayout& l, int rows) {
+  bool shifted = l.L >= 2 && rows % 16 == 0 && !(h->cfg.tuning_flags & DQNHIP_TUNE_BWD_UNSHIFTED);
+  for (int i = 1; i < l.L && shifted; ++i) shifted = !bwd_layer_is_pair(l, i, rows) && l.kp[i] % 64 == 0 && l.dims[i + 1] % 64 == 0;
+  return shifted;
+}
 // fuse: the critic's dQ/da pass — the first layer's action-column tiles, the inverting gradients and the actor heads' backward in
-// ONE launch (k_dqda_head_bwd) instead of the narrow dgrad launch here and a head-backward launch after it; carries the q rider
+// ONE launch (k_dqda_head_bwd) instead of the narrow dgrad launch here and a head-backward launch after it; carries the q rider.
+// qtrain (Step(1)'s backward, shifted schedule): the top layer's dgrad launch also does k_head_q_train's work (k_dgrad_qtrain);
+// qtrain_seed = the panel U = (-w_h) lrelu'(x_L) the online critic's top forward layer left (the dgrad's dY operand)
 int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* garena, float* partial,
                    float** act, float** dZ, int rows, bool want_w, bool input_grad, int in_lo = 0, int in_hi = -1,
-                   const HeadWgradRider* rider = nullptr, const QHeadRider* qrider = nullptr, DqdaHeadArgs* fuse = nullptr) {
+                   const HeadWgradRider* rider = nullptr, const QHeadRider* qrider = nullptr, DqdaHeadArgs* fuse = nullptr,
+                   const HeadTrainArgs* qtrain = nullptr, const float* qtrain_seed = nullptr) {
   auto dgrad_of = [&](int i) {             // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
     GemmProblem p{};
     p.mode = GEMM_DGRAD;
@@ -206,13 +216,14 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
   // instead of  wgrad(i) + dgrad(i) per layer and a last launch with the first layer's narrow wgrad alone.  Same launch
   // count, same workgroups, same arithmetic: the chain's last launch — 64-128 short workgroups, 6 us of launch floor —
   // is absorbed into a full wgrad launch (+~1 us), at the price of splitting one pair (8.3 + 7.9 instead of 14.5 us).
-  bool shifted = want_w && !input_grad && l.L >= 2 && rows % 16 == 0 && !(h->cfg.tuning_flags & DQNHIP_TUNE_BWD_UNSHIFTED);
-  for (int i = 1; i < l.L && shifted; ++i) shifted = !bwd_layer_is_pair(l, i, rows) && l.kp[i] % 64 == 0 && l.dims[i + 1] % 64 == 0;
+  const bool shifted = want_w && !input_grad && bwd_is_shifted(h, l, rows);
+  if (qtrain != nullptr && !(shifted && lds_ok_of(l.L - 1))) return fail("internal: k_dgrad_qtrain needs the shifted schedule and an LDS-staged top layer");
   if (shifted) {
     {
       GemmBatch bd{}; bd.n = 1; bd.prob[0] = dgrad_of(l.L - 1);
       ScopedTiming t(h, 1, st);
-      if (lds_ok_of(l.L - 1)) HIPCHK((dgrad_lds_launch<1, 1>(bd, st))); else HIPCHK((dgrad_direct_launch<1, 1>(bd, st)));
+      if (qtrain != nullptr) { bd.prob[0].Q = qtrain_seed; HIPCHK(dgrad_qtrain_launch(bd, *qtrain, st)); }
+      else if (lds_ok_of(l.L - 1)) HIPCHK((dgrad_lds_launch<1, 1>(bd, st))); else HIPCHK((dgrad_direct_launch<1, 1>(bd, st)));
     }
     for (int i = l.L - 2; i >= 1; --i) {
       GemmBatch b{}; b.n = 2; b.prob[0] = dgrad_of(i); b.prob[1] = wgrad_of(i + 1);
@@ -695,6 +706,15 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     HeadArgs hA{}; hA.X = h->act[1][L]; hA.ldx = Hh; hA.H = Hh; hA.rows = B;
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
     hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
+    // Step(1)'s head arithmetic (q', q, TD target, loss, dq, dZ_L) inside the critic's top-layer dgrad launch (k_dgrad_qtrain)
+    // instead of a launch of its own: the online critic's top forward layer then also leaves U = (-w_h) lrelu'(x_L)
+    const bool fuse_q = h->U3 != nullptr && !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_Q_TRAIN) && !head_big_ok(h, B, Hc) && head_wgrad_can_ride(lc, B) &&
+                        bwd_is_shifted(h, lc, B) && lc.dims[L] >= 512 && lc.dims[L] <= 1024 && lc.dims[L] % 256 == 0;   // (one 16-column piece per lane: H / 16 <= 64)
+    if (fuse_q) {
+      pC1.seed_w = wat(h, DQNHIP_CRITIC, lc.hw_off); pC1.seed_out = h->U3;
+      pC1.dot_w = pC1.seed_w; pC1.dot_out = h->qdot[1];
+      pCT.dot_w = wat(h, DQNHIP_CRITIC_TARGET, lc.hw_off); pCT.dot_out = h->qdot[0];
+    }
     FwdPass cp[2] = {pCT, pC1};
     if (split) {
       // data-parallel overlap form: the online actor's forward (phase 11) is left out so that it can
@@ -709,6 +729,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));     // both actors' heads in one launch
     }
     RC(tower_forward(h, st, cp, 2, B));
+    HeadTrainArgs qt_args{};
     {
       HeadTrainArgs t{};
       t.Xt = h->act[2][L]; t.Wt = wat(h, DQNHIP_CRITIC_TARGET, lc.hw_off); t.bt = wat(h, DQNHIP_CRITIC_TARGET, lc.hb_off);
@@ -718,8 +739,12 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch; t.st = h->st;
       // with the head's dW / db riding in the net's last backward launch, the head's dZ comes out of this launch too
       if (!head_big_ok(h, B, Hc) && head_wgrad_can_ride(lc, B)) t.dZ = h->dZc[L];
-      hipLaunchKernelGGL(k_head_q_train, dim3((B + 3) / 4), dim3(256), 0, st, t);
-      HIPCHK(hipGetLastError());
+      t.pdt = h->qdot[0]; t.pd = h->qdot[1];
+      qt_args = t;
+      if (!fuse_q) {
+        hipLaunchKernelGGL(k_head_q_train, dim3((B + 3) / 4), dim3(256), 0, st, t);
+        HIPCHK(hipGetLastError());
+      }
     }
     // critic backward (rest of Step(1)): head (dgrad + ReLU' + wgrad fused), then tower; wgrad
     // writes (beta=0) so ClearParamDiffs/ZeroGradParameters (src/dqn.cpp:63-78, 908-909) vanish
@@ -731,7 +756,8 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       const bool ride = !head_big_ok(h, B, Hc) && head_wgrad_can_ride(lc, B);
       HeadWgradRider r{h->dq, 1, h->act[3][L], Hc, B, a.dW, a.db, a.partial, Hc / kRiderCW};
       if (!ride) RC(head_backward<1>(h, st, a));          // (riding: dZ came out of k_head_q_train, dW / db come from the rider)
-      RC(tower_backward(h, st, lc, DQNHIP_CRITIC, h->g[1], h->part[1], h->act[3], h->dZc, B, true, false, 0, -1, ride ? &r : nullptr));
+      RC(tower_backward(h, st, lc, DQNHIP_CRITIC, h->g[1], h->part[1], h->act[3], h->dZc, B, true, false, 0, -1, ride ? &r : nullptr, nullptr, nullptr,
+                        fuse_q ? &qt_args : nullptr, fuse_q ? h->U3 : nullptr));
     }
     if (dp) {
       hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)h->loss_partial,
@@ -968,6 +994,8 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
   for (int p = 0; p < 5; ++p)
     for (int i = 1; i <= L; ++i) RC(dalloc(&h->act[p][i], (size_t)B * layout_of(h, p >= 2).kp[i]));
   for (int i = 0; i <= L; ++i) { RC(dalloc(&h->dZa[i], (size_t)B * h->la.kp[i])); RC(dalloc(&h->dZc[i], (size_t)B * h->lc.kp[i])); }
+  RC(dalloc(&h->U3, (size_t)B * h->lc.kp[L]));
+  for (int j = 0; j < 2; ++j) RC(dalloc(&h->qdot[j], (size_t)B * (h->lc.kp[L] / 16)));        // the training pass's head-seed panel (k_dgrad_qtrain)
   RC(dalloc(&h->mb_reward, B)); RC(dalloc(&h->mb_mc, B)); RC(dalloc(&h->mb_term, B));
   HIPCHK(hipMalloc(&h->mb_idx, B * sizeof(int)));
   HIPCHK(hipHostMalloc((void**)&h->idx_pinned, B * sizeof(int), hipHostMallocMapped));
@@ -1083,7 +1111,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   hipFree(h->Xa_s); hipFree(h->Xa_n); hipFree(h->Xc_tr); hipFree(h->Xc_pl); hipFree(h->Xc_nx);
   for (int p = 0; p < 5; ++p) for (int i = 1; i <= h->L; ++i) hipFree(h->act[p][i]);
   for (int i = 0; i <= h->L; ++i) { hipFree(h->dZa[i]); hipFree(h->dZc[i]); }
-  hipFree(h->mb_reward); hipFree(h->mb_mc); hipFree(h->mb_term); hipFree(h->mb_idx);
+  hipFree(h->mb_reward); hipFree(h->mb_mc); hipFree(h->mb_term); hipFree(h->mb_idx); hipFree(h->U3); hipFree(h->qdot[0]); hipFree(h->qdot[1]);
   hipHostFree(h->idx_pinned); hipHostFree(h->pinned_stats);
   hipFree(h->aout_t16); hipFree(h->aout16); hipFree(h->dA16);
   hipFree(h->q_t); hipFree(h->q1); hipFree(h->q2); hipFree(h->y); hipFree(h->dq);

@@ -142,6 +142,8 @@ struct dqnhip_learner {
   float* dZa[kMaxL + 1] = {nullptr};
   float* dZc[kMaxL + 1] = {nullptr};
   float *mb_reward = nullptr, *mb_mc = nullptr, *mb_term = nullptr;
+  float* qdot[2] = {nullptr, nullptr};   // [B][kp[L] / 16]: the head dot products of critic_target(s', .) / critic(s, a) in 16-column pieces (GemmProblem::dot_w)
+  float* U3 = nullptr;                  // [B][kp[L]]: (-w_h) lrelu'(x_L) of the critic(s, a) training pass (left by its top forward layer for k_dgrad_qtrain)
   int* mb_idx = nullptr;
   int* idx_pinned = nullptr;
   const int* idx_pinned_dev = nullptr;  // device alias of idx_pinned: the gather reads explicit indices straight from host memory (no H2D copy)
@@ -235,7 +237,8 @@ inline size_t grad_arena_floats(const NetLayout& la, const NetLayout& lc) { retu
 
 // ---- building blocks defined in learner.hip, used by the other translation units ---------------------------------
 // seed_w / seed_out: the TOP layer's launch also writes the dq = -1 pass's tower-top gradient (GemmProblem::seed_w)
-struct FwdPass { int net; const NetLayout* l; float** act; const float* seed_w = nullptr; float* seed_out = nullptr; };
+struct FwdPass { int net; const NetLayout* l; float** act; const float* seed_w = nullptr; float* seed_out = nullptr;
+                 const float* dot_w = nullptr; float* dot_out = nullptr; };   // dot_w / dot_out: GemmProblem::dot_w, same layer
 
 int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, int i);
 int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows);

@@ -474,6 +474,8 @@ struct HeadTrainArgs {
   // row of X and W through its registers; the head's own dW / db ride elsewhere (head_wgrad_rider), so with this the
   // critic's head-backward launch of Step(1) is gone.
   float* dZ;
+  // k_dgrad_qtrain: the two head dot products in 16-column pieces, [rows][H / 16], left by the top forward layers (GemmProblem::dot_w)
+  const float* pdt; const float* pd;
 };
 static __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -524,6 +526,108 @@ static __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
   if (lane == 0) s_part[wave] = d2;
   __syncthreads();
   if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+}
+
+// ---- Step(1)'s head arithmetic inside the critic's first backward launch (round 5) -------------------------------------------
+// k_head_q_train sits between the critics' last forward launch and the critic's top-layer dgrad: a 4.9-us launch-floor link
+// whose output the dgrad needs only as a PER-ROW SCALAR.  dZ_L[r][n] = (dq_r w_n) lrelu'(x_rn) = (-dq_r) U[r][n] with
+// U = (-w) lrelu'(x), which does not depend on q: the online critic's top forward layer leaves U in its epilogue
+// (GemmProblem::seed_w, as the dq = -1 pass already does), the dgrad runs on U, and
+//     dZ_{L-1}[r][j] = ((sum_n U[r][n] W[n][j]) * (-dq_r)) * lrelu'(x_{L-1}[r][j])
+// takes the scalar in its epilogue.  The two head dot products arrive in 16-column pieces from the critics' top forward layers
+// (GemmProblem::dot_w: the finished activations are in that epilogue's registers anyway).  Each of the workgroup's four waves
+// requests the pieces of four of the tile's 16 rows once its operand pipeline is primed (2 KB per workgroup), and after its last
+// MFMA sums them, forms q', q, the TD target and dq (k_head_q_train's arithmetic from there on), publishes -dq_r in LDS before
+// the body's barrier; afterwards the workgroup writes its 64-column slices of dZ_L (the next launch's wgrad reads them).  The
+// workgroups of tile column 0 write the per-row outputs.  q', q and dZ_{L-1} differ from the two-launch form by fp32 round-off
+// only (the dot product is summed in another fixed order; the scalar is applied after the reduction instead of before):
+// DQNHIP_TUNE_SEPARATE_Q_TRAIN restores the two launches.
+// Measured on the way (profiles/r05_dgrad_qtrain.txt): a FIFTH wave per workgroup reading the tower tops itself — 17.4 us against
+// 8.3 + 4.8 for the two launches (it shares a SIMD and the CU's load path with an MFMA wave); the four MFMA waves reading their
+// rows of the tower tops — 12.1 us (the 16 workgroups of a tile row each re-read the same 128 KB: +50% on an L2-bound kernel).
+struct QTrainHook {
+  const HeadTrainArgs& a; float* s_scale; float* s_dq; int q0; bool owner;
+  float v0[4], v1[4];        // rows 4 wave + j: piece `lane` of the target / online head dot product (H / 16 <= 64 pieces)
+  float rw[4], mcv[4], tm[4], bt0, b0;
+  f32x4 xv, wv;              // this thread's piece of the workgroup's first dZ_L slice (row threadIdx.x / 16, 4 columns)
+  int c_first;
+  __device__ __forceinline__ QTrainHook(const HeadTrainArgs& a_, float* sc, float* sd, int q0_, int tile_p) : a(a_), s_scale(sc), s_dq(sd), q0(q0_), owner(tile_p == 0), c_first(tile_p * 64) {}
+  __device__ __forceinline__ void after_prologue() {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int np = a.H >> 4;
+    const int pc = lane < np ? lane : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t x0 = (size_t)(q0 + wave * 4 + j) * np + pc;
+      v0[j] = a.pdt[x0]; v1[j] = a.pd[x0];
+      const int row = q0 + wave * 4 + j;
+      rw[j] = a.reward[row]; mcv[j] = a.mc[row]; tm[j] = a.term[row];
+    }
+    bt0 = a.bt[0]; b0 = a.b[0];
+    if (c_first < a.H) {
+      const int rr = threadIdx.x >> 4, c = c_first + ((threadIdx.x & 15) << 2);
+      xv = *reinterpret_cast<const f32x4*>(a.X + (size_t)(q0 + rr) * a.H + c); wv = *reinterpret_cast<const f32x4*>(a.W + c);
+    }
+  }
+  __device__ __forceinline__ void before_park() {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in = lane < (a.H >> 4);
+    float d2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rr = wave * 4 + j, row = q0 + rr;
+      const float at = wave_sum64(in ? v0[j] : 0.0f), ao = wave_sum64(in ? v1[j] : 0.0f);
+      const float r = rw[j];
+      const float qt = at + bt0, q = ao + b0;
+      const float off_policy = tm[j] != 0.0f ? r : (float)((double)r + a.gamma * (double)qt);      // src/dqn.cpp:893-900
+      const float target = (float)(a.beta * (double)mcv[j] + (1 - a.beta) * (double)off_policy);
+      const float d = q - target;
+      const float dq_row = a.inv_batch * d;
+      d2[j] = d * d;
+      if (lane == 0) {
+        s_scale[rr] = -dq_row; s_dq[rr] = dq_row;
+        if (owner) {
+          a.q_target[row] = qt; a.q[row] = q; a.y[row] = target; a.dq[row] = dq_row;
+          if (!isfinite(target)) atomicOr(&a.st->flags, kFlagTarget);   // CHECK(std::isfinite(target)), src/dqn.cpp:898
+        }
+      }
+    }
+    // k_head_q_train's partial of its block of four rows (one row per wave there: ((w0 + w1) + w2) + w3)
+    if (owner && lane == 0) a.loss_partial[(q0 >> 2) + wave] = ((d2[0] + d2[1]) + d2[2]) + d2[3];
+  }
+};
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dgrad_qtrain(const GemmBatch batch, const HeadTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float s_scale[16], s_dq[16];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  const GemmProblem& pr = batch.prob[0];
+  const int q0 = tile_q * 16;
+  QTrainHook hook(a, s_scale, s_dq, q0, tile_p);
+  dgrad_lds_body<1, 1, true, QTrainHook>(pr, tile_p, tile_q, smem, s_scale, hook);
+  // this workgroup's slices of dZ_L: columns [64 tile_p, +64) and every tiles_p-th slice after it, 16 rows (one float4 per thread);
+  // s_dq was published before the body's barrier
+  for (int c0 = tile_p * 64; c0 < a.H; c0 += pr.tiles_p * 64) {
+    const int rr = threadIdx.x >> 4, c = c0 + ((threadIdx.x & 15) << 2);
+    const size_t x0 = (size_t)(q0 + rr) * a.H + c;
+    f32x4 xv = hook.xv, wv = hook.wv;       // (the first slice's operands were requested under the main loop)
+    if (c0 != tile_p * 64) { xv = *reinterpret_cast<const f32x4*>(a.X + x0); wv = *reinterpret_cast<const f32x4*>(a.W + c); }
+    const float dqv = s_dq[rr];
+    f32x4 dz;
+    dz.x = (dqv * wv.x) * lrelu_mask(xv.x); dz.y = (dqv * wv.y) * lrelu_mask(xv.y);
+    dz.z = (dqv * wv.z) * lrelu_mask(xv.z); dz.w = (dqv * wv.w) * lrelu_mask(xv.w);
+    *reinterpret_cast<f32x4*>(a.dZ + x0) = dz;
+  }
+}
+inline hipError_t dgrad_qtrain_launch(GemmBatch& batch, const HeadTrainArgs& a, hipStream_t stream) {
+  GemmProblem& p = batch.prob[0];
+  p.tiles_p = p.Pdim / 64; p.tiles_q = p.Qdim / 16; p.tile_base = 0;
+  batch.n = 1; batch.total_tiles = p.tiles_p * p.tiles_q;
+  LaunchTimer& lt = launch_timer();
+  if (lt.start) { hipExtLaunchKernelGGL(k_dgrad_qtrain<0>, dim3(batch.total_tiles), dim3(256), (dgrad_lds_bytes<1, 1>()), stream, lt.start, lt.stop, 0, batch, a); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL(k_dgrad_qtrain<0>, dim3(batch.total_tiles), dim3(256), (dgrad_lds_bytes<1, 1>()), stream, batch, a);
+  return hipGetLastError();
 }
 
 // Fused head backward: in one pass over the tower top X4[rows][H]

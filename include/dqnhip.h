@@ -122,6 +122,11 @@ typedef struct dqnhip_config {
 /* fp32 learner: the critic's first-layer action-column input gradient in a launch of its own (+ the q riders) and the inverting
  * gradients + actor heads' backward in another (k_head_bwd<10>), instead of all three in one launch (k_dqda_head_bwd, round 5). */
 #define DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD 8
+/* fp32 learner: Step(1)'s head arithmetic (q', q, TD target, loss, dq, the tower-top gradient) in a launch of its own
+ * (k_head_q_train) instead of inside the critic's top-layer dgrad launch (k_dgrad_qtrain, round 5: the two head dot products
+ * arrive in 16-column pieces from the critics' top forward layers).  The two forms differ by fp32 round-off only (another fixed
+ * summation order for q', q; the per-row scalar dq applied after the dgrad's reduction instead of before). */
+#define DQNHIP_TUNE_SEPARATE_Q_TRAIN 16
 
 typedef struct dqnhip_learner* dqnhip_handle;
 

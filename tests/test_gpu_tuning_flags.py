@@ -118,9 +118,11 @@ def test_fused_head_seed_under_graph_replay(pkg, gpu):
 def test_shifted_backward_schedule_equals_per_layer_launches(pkg, gpu, B, hidden, S):
     """fp32 learner: dgrad(L-1) | wgrad(i+1) + dgrad(i) | ... | wgrad(1) + wgrad(0) + head riders (default) against
     wgrad(i) + dgrad(i) per layer + a last launch with the first layer's wgrad alone (DQNHIP_TUNE_BWD_UNSHIFTED): the same
-    workgroups doing the same arithmetic in different launches — every result bit-identical."""
-    a = _run32(pkg, 0, B, hidden, S)
-    b = _run32(pkg, pkg.capi.TUNE_BWD_UNSHIFTED, B, hidden, S)
+    workgroups doing the same arithmetic in different launches — every result bit-identical.  (Both sides with k_head_q_train
+    in a launch of its own: k_dgrad_qtrain exists in the shifted schedule only and has its own test below.)"""
+    sep = pkg.capi.TUNE_SEPARATE_Q_TRAIN
+    a = _run32(pkg, sep, B, hidden, S)
+    b = _run32(pkg, sep | pkg.capi.TUNE_BWD_UNSHIFTED, B, hidden, S)
     assert a[0] == b[0], (a[0], b[0])
     for x, y in zip(a[2], b[2]):
         np.testing.assert_array_equal(x, y)
@@ -170,3 +172,48 @@ def test_fused_dqda_and_actor_head_backward_equals_separate_launches(pkg, gpu, B
     assert a[0] == g[0]
     for x, y in zip(a[2], g[2]):
         np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("B,hidden,S", [
+    (256, (1024, 1024, 1024, 1024), 58),       # BASELINE configs[1]
+    (512, (1024, 1024), 68),                   # two layers: the fused launch is the whole dgrad chain of Step(1)
+    (256, (512, 1024, 512), 59),               # layers of different widths: 8 column tiles write 8 slices of a 512-wide dZ_L
+    (64, (1024, 512), 59),                     # 32 tiles of 64 x 16 at 64 rows
+    (32, (1024, 512, 256, 128), 59),           # the reference's defaults: pair launches, top layer 128 wide -> both sides separate (identical)
+])
+def test_q_train_inside_the_top_dgrad_equals_its_own_launch(pkg, gpu, B, hidden, S):
+    """fp32 learner, Step(1): q', q, the TD target, the loss, dq and the tower-top gradient inside the critic's top-layer dgrad
+    launch (k_dgrad_qtrain, default: the head dot products arrive in 16-column pieces from the top forward layers' epilogues)
+    against k_head_q_train in a launch of its own (DQNHIP_TUNE_SEPARATE_Q_TRAIN).  The dot product is summed in another fixed
+    order and the top layer's input gradient takes dq_r after the reduction instead of before: fp32 round-off, so the per-row
+    outputs agree to a few ulp of the row's |x||w|, the gradients to ~1e-6 of their norm and the parameters to the usual
+    Adam-step bound."""
+    out = {}
+    for tuning in (0, pkg.capi.TUNE_SEPARATE_Q_TRAIN):
+        d = pkg.DQN(S, minibatch=B, hidden=hidden, memory=4096, seed=3, tuning=tuning)
+        d.add_transitions_arrays(*synth_replay(np.random.default_rng(5), 2000, S))
+        rng = np.random.default_rng(7)
+        rec = []
+        for u in range(3):
+            idx = rng.integers(0, 2000, B).astype(np.int32)
+            d.update_phase(0, idx)
+            first = {k: d.debug_read(k) for k in ("q_target", "q_train", "y")}
+            first["gc"] = d.get_params(1, pkg.KIND_G)
+            d.update_phase(1); d.update_phase(2)
+            first["stats"] = d.read_stats()
+            rec.append(first)
+        out[tuning] = (rec, [d.get_params(n).astype(np.float64) for n in range(4)])
+        d.close()
+    (ra, wa), (rb, wb) = out[0], out[pkg.capi.TUNE_SEPARATE_Q_TRAIN]
+    for k in ("q_target", "q_train", "y"):                           # first update: same weights
+        scale = max(1.0, float(np.abs(rb[0][k]).max()))
+        np.testing.assert_allclose(ra[0][k], rb[0][k], rtol=0, atol=4e-6 * scale)
+    assert abs(ra[0]["stats"][0] - rb[0]["stats"][0]) <= 1e-5 * max(1.0, abs(rb[0]["stats"][0]))     # the reported (pre-update) loss
+    rel = np.linalg.norm(ra[0]["gc"].astype(np.float64) - rb[0]["gc"]) / np.linalg.norm(rb[0]["gc"])
+    assert rel <= 2e-5, rel
+    for a, b in zip(ra, rb):
+        assert np.allclose(a["stats"], b["stats"], rtol=1e-4, atol=1e-6), (a["stats"], b["stats"])
+    lr = {0: 1e-5, 1: 1e-3, 2: 1e-5 * 1e-3, 3: 1e-3 * 1e-3}
+    for net, (x, y) in enumerate(zip(wa, wb)):
+        dd = np.abs(x - y)
+        assert dd.max() <= 2 * 3 * lr[net] + 1e-7 and dd.mean() <= 0.01 * lr[net] + 1e-9, (net, dd.max(), dd.mean())
