@@ -151,8 +151,8 @@ int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, 
   }
   return 0;
 }
-int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows) {
-  for (int i = 0; i < passes[0].l->L; ++i) RC(layer_forward(h, st, passes, n, rows, i));
+int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, int first_layer) {
+  for (int i = first_layer; i < passes[0].l->L; ++i) RC(layer_forward(h, st, passes, n, rows, i));
   return 0;
 }
 
@@ -350,7 +350,7 @@ GatherArgs gather_args(H* h, const int* idx_dev, int pos) {
 // clip + Adam + Net::Update + soft target update over arena floats [begin, end)
 // corr_pre: the update's first launch (k_gather) has left this step's bias correction in DevState::adam_corr
 int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick,
-                bool corr_pre) {
+                bool corr_pre, const FirstLayerRider* fl) {
   AdamArgs a{};
   const int slot = h->cap_u > 0 ? (h->cap_u & 1) : 0;      // DevState::adam_corr
   a.corr_pre = corr_pre ? &h->st->adam_corr[slot][net] : nullptr; a.soft_pre = corr_pre ? &h->st->soft_now[slot] : nullptr;
@@ -376,8 +376,19 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   // 1536 blocks = 6 per CU, all resident at once (68 VGPRs: 7 waves per SIMD): with the loads hoisted above the prologue
   // same-box A/B gives 18.4 us per launch against 19.3 at 2048 (a second, short round of blocks), 19.4 at 1792, 18.7 at
   // 1280, 21.5 at 4096 (round 2, before the hoist: 512 .. 8192 within +-3 %, profiles/r02_adam_probe.txt)
-  const int blocks = (int)std::min<size_t>((a.n4 + 255) / 256, (size_t)1536);
-  if (tick && h->cap_u >= 0 && h->cap_u + 1 < kMultiU) {
+  if (fl != nullptr) {
+    if (begin != 0 || tick != nullptr || a.w_sh != nullptr || h->fp16 || !corr_pre) return fail("adam_launch: a first-layer rider needs the whole, unshared fp32 arena inside an update");
+    a.skip4 = layout_of(h, net).w_off[1] / 4;
+  }
+  const int blocks = (int)std::min<size_t>((a.n4 - a.skip4 + 255) / 256 + (fl ? fl->blocks : 0), (size_t)1536);   // riders + the strided pass: what is resident at once
+  if (fl != nullptr) {
+    if (blocks <= fl->blocks) return fail("adam_launch: no optimiser workgroups beside the first-layer riders");
+    const bool timed = lt.start != nullptr;
+    if (fl->Kp == 64) { if (timed) hipExtLaunchKernelGGL(k_adam_soft_fwd1<1>, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL(k_adam_soft_fwd1<1>, dim3(blocks), dim3(256), 0, st, a, *fl); }
+    else { if (timed) hipExtLaunchKernelGGL(k_adam_soft_fwd1<2>, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL(k_adam_soft_fwd1<2>, dim3(blocks), dim3(256), 0, st, a, *fl); }
+    if (timed) lt.start = lt.stop = nullptr;
+  }
+  else if (tick && h->cap_u >= 0 && h->cap_u + 1 < kMultiU) {
     // inside a multi-update graph: the next update's gather rides in this, the update's last launch (k_adam_soft_gather).
     // At small minibatches the grid stays at what is resident at once; a large minibatch's gather (1025 workgroups at 4096
     // rows) must not thin the optimiser's own grid — its blocks drain within a few us and the rest of the grid moves in
@@ -770,7 +781,16 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // ClipGradients + Adam + Net::Update of the critic, soft update of critic_target fused (one pass)
     FwdPass pC2{DQNHIP_CRITIC, &lc, h->act[4]};
     h->act[4][0] = h->Xc_pl;
+    // the first layer of critic(s, mu(s)) rides in the critic's optimiser launch (FirstLayerRider: the workgroups that own W1 run it
+    // on the weights they have just stepped); DQNHIP_TUNE_SEPARATE_FIRST_LAYER: a launch of its own (same bits)
+    const bool ride_l0 = !dp && !h->fp16 && h->shared_fl[DQNHIP_CRITIC] == 0 && !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_FIRST_LAYER) &&
+                         (lc.kp[0] == 64 || lc.kp[0] == 128) && lc.dims[1] % 16 == 0 && B % 16 == 0 && B <= 512 && L >= 2 && lc.w_off[0] == 0 &&
+                         lc.b_off[0] == (size_t)lc.dims[1] * lc.kp[0];
     if (dp) RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr));
+    else if (ride_l0) {
+      const FirstLayerRider fl{h->Xc_pl, lc.kp[0], h->act[4][1], lc.kp[1], B, lc.kp[0], lc.dims[1], lc.dims[1] / 16};
+      RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena, nullptr, true, &fl));
+    }
     else RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
     // The seed of BackwardFrom(q_values_layer) [:918-923] — q diff = -1 per row, taken through the head and the top
     // layer's ReLU, input gradient only (the reference's discarded critic dW, SURVEY a11, is never computed) — does not
@@ -779,7 +799,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // that used to sit between the forward and the backward chain (same arithmetic, one launch more).
     const bool fused_seed = !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_HEAD_SEED);
     if (fused_seed) { pC2.seed_w = wat(h, DQNHIP_CRITIC, lc.hw_off); pC2.seed_out = h->dZc[L]; }
-    RC(tower_forward(h, st, &pC2, 1, B));                // critic(s, mu(s)), UPDATED weights [:913-916]
+    RC(tower_forward(h, st, &pC2, 1, B, ride_l0 ? 1 : 0));   // critic(s, mu(s)), UPDATED weights [:913-916]
     const QHeadRider qr{h->act[4][L], wat(h, DQNHIP_CRITIC, lc.hw_off), wat(h, DQNHIP_CRITIC, lc.hb_off), h->q2, h->q_partial, Hc, B, (B + 3) / 4};
     if (!fused_seed) {
       HeadBwdArgs a{}; a.dyh = nullptr; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X4 = h->act[4][L];

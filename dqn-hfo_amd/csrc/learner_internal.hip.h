@@ -241,7 +241,7 @@ struct FwdPass { int net; const NetLayout* l; float** act; const float* seed_w =
                  const float* dot_w = nullptr; float* dot_out = nullptr; };   // dot_w / dot_out: GemmProblem::dot_w, same layer
 
 int layer_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, int i);
-int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows);
+int tower_forward(H* h, hipStream_t st, const FwdPass* passes, int n, int rows, int first_layer = 0);   // first_layer 1: layer 0 came out of a FirstLayerRider
 template <int NH, int MODE>
 int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nullptr) {
   HeadArgs2 a2{}; a2.p[0] = a; if (b) a2.p[1] = *b;
@@ -263,7 +263,7 @@ inline void shard_range(const H* h, int net, size_t& lo, size_t& hi, int rank = 
   lo = r * slice; hi = lo + slice;
 }
 int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick = nullptr,
-                bool corr_pre = true);
+                bool corr_pre = true, const FirstLayerRider* fl = nullptr);
 int sumsq_launch(H* h, int net, size_t begin = 0, size_t end = 0);
 int to_bf16_launch(H* h, int net);                       // k_to_bf16: the bf16 transfer image of a gradient arena
 int shard_scal_launch(H* h, float* tail);                // k_shard_scal: this rank's share of the clip norm -> tail[3]

@@ -1170,6 +1170,7 @@ struct AdamArgs {
   _Float16* w16; _Float16* wt16;             // fp16 mode: fp16 mirrors of w / wt, same offsets (null otherwise)
   float* w_sh; float* wt_sh; size_t n4_sh;   // float4 [0, n4_sh) of w / wt live in another learner's arena (ShareParameters)
   size_t n4;                      // arena length / 4
+  size_t skip4;                   // the strided pass starts here: float4 [0, skip4) belong to the launch's first-layer riders (0: none)
   const float* partial; int n_partial;
   const float* corr_pre;          // this step's bias correction, evaluated earlier in the update (DevState::adam_corr); null: here
   const int* soft_pre;            // with corr_pre: this update's soft-update switch (DevState::soft_now)
@@ -1187,6 +1188,8 @@ struct AdamArgs {
 // `nblk` 256-thread blocks strides over the arena slice
 // per-launch scalars of the optimiser pass into s[4..7]: clip scale, lr * Adam correction, soft-update
 // switch, skip flag.  Every block re-derives them from the same partials in the same order.
+// PRE: the caller guarantees corr_pre / soft_pre (inside an update) — the stand-alone path's two double pow() are not compiled in
+template <bool PRE = false>
 __device__ __forceinline__ void adam_scalars(const AdamArgs& a, int blk, float* s /*>= 8 floats*/) {
   // every block re-derives the same global L2 norm from the partials, in the
   // same order -> bit-identical scale everywhere, no extra launch
@@ -1201,7 +1204,7 @@ __device__ __forceinline__ void adam_scalars(const AdamArgs& a, int blk, float* 
     const float sumsq = (s[0] + s[1]) + (s[2] + s[3]);
     const float l2 = sqrtf(sumsq);
     s[4] = (a.clip >= 0.0f && l2 > a.clip) ? a.clip / l2 : 1.0f;
-    if (a.corr_pre != nullptr) {                         // inside an update: both were left in DevState by its first launch
+    if (PRE || a.corr_pre != nullptr) {                  // inside an update: both were left in DevState by its first launch
       s[5] = a.lr * *a.corr_pre;
       s[6] = *a.soft_pre ? 1.0f : 0.0f;
     } else {
@@ -1220,7 +1223,37 @@ __device__ __forceinline__ void adam_scalars(const AdamArgs& a, int blk, float* 
   }
   __syncthreads();
 }
-template <int U = 1, int NT = 0>
+// one float4 of the optimiser step, in place (the strided pass and the first-layer riders share it: same expression, same bits)
+__device__ __forceinline__ void adam_apply4(const AdamArgs& a, float scale, float step, bool soft, const f32x4& g, f32x4& m, f32x4& v, f32x4& w, f32x4& wt) {
+  const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
+  const float tau = a.tau, omt = 1 - a.tau;
+  const float* gp = reinterpret_cast<const float*>(&g); float* mp = reinterpret_cast<float*>(&m);
+  float* vp = reinterpret_cast<float*>(&v); float* wp = reinterpret_cast<float*>(&w);
+  float* tp = reinterpret_cast<float*>(&wt);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gi = gp[e] * scale;
+    const float mi = fmaf(omb1, gi, a.beta1 * mp[e]);
+    const float vi = fmaf(omb2, gi * gi, a.beta2 * vp[e]);
+    const float upd = step * (mi / (sqrtf(vi) + a.eps));
+    const float wi = wp[e] - upd;
+    mp[e] = mi; vp[e] = vi; wp[e] = wi;
+    if (soft) tp[e] = fmaf(tau, wi, omt * tp[e]);
+  }
+}
+// ... and one element (a first-layer rider's bias: one per thread)
+__device__ __forceinline__ void adam_apply1(const AdamArgs& a, float scale, float step, bool soft, float g, float& m, float& v, float& w, float& wt) {
+  const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
+  const float tau = a.tau, omt = 1 - a.tau;
+  const float gi = g * scale;
+  const float mi = fmaf(omb1, gi, a.beta1 * m);
+  const float vi = fmaf(omb2, gi * gi, a.beta2 * v);
+  const float upd = step * (mi / (sqrtf(vi) + a.eps));
+  const float wi = w - upd;
+  m = mi; v = vi; w = wi;
+  if (soft) wt = fmaf(tau, wi, omt * wt);
+}
+template <int U = 1, int NT = 0, bool PRE = false>
 __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int nblk, float* s /*>= 8 floats*/) {
   // U float4 per array in flight per thread (U * 5 x 16-B loads before the first use); NT: the gradient is
   // read exactly once per update and never again -> non-temporal
@@ -1245,34 +1278,21 @@ __device__ __forceinline__ void adam_soft_body(const AdamArgs& a, int blk, int n
   // derived: none of them depends on the clip scale, and the scalars' own chain (partials from the L2 of other XCDs ->
   // wave sums -> barrier -> sqrt / divide in one lane -> barrier) is ~1.5 us that every block would otherwise spend
   // with nothing in flight.
-  size_t i0 = (size_t)blk * (256 * U) + threadIdx.x;
+  size_t i0 = a.skip4 + (size_t)blk * (256 * U) + threadIdx.x;
   if (i0 < a.n4) load(i0);
-  adam_scalars(a, blk, s);
+  adam_scalars<PRE>(a, blk, s);
   if (s[7] != 0.0f) return;
   const float scale = s[4];
   const float step = s[5];
-  const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
   const bool soft = s[6] != 0.0f;
-  const float tau = a.tau, omt = 1 - a.tau;
   for (bool first = true; i0 < a.n4; i0 += (size_t)nblk * (256 * U), first = false) {
     if (!first) load(i0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t i = i0 + (size_t)u * 256;
       if (i >= a.n4) continue;
-      float* gp = reinterpret_cast<float*>(&g[u]); float* mp = reinterpret_cast<float*>(&m[u]);
-      float* vp = reinterpret_cast<float*>(&v[u]); float* wp = reinterpret_cast<float*>(&w[u]);
-      float* tp = reinterpret_cast<float*>(&wt[u]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float gi = gp[e] * scale;
-        const float mi = fmaf(omb1, gi, a.beta1 * mp[e]);
-        const float vi = fmaf(omb2, gi * gi, a.beta2 * vp[e]);
-        const float upd = step * (mi / (sqrtf(vi) + a.eps));
-        const float wi = wp[e] - upd;
-        mp[e] = mi; vp[e] = vi; wp[e] = wi;
-        if (soft) tp[e] = fmaf(tau, wi, omt * tp[e]);
-      }
+      adam_apply4(a, scale, step, soft, g[u], m[u], v[u], w[u], wt[u]);
+      const float* wp = reinterpret_cast<const float*>(&w[u]); const float* tp = reinterpret_cast<const float*>(&wt[u]);
       reinterpret_cast<f32x4*>(a.m)[i] = m[u];
       reinterpret_cast<f32x4*>(a.v)[i] = v[u];
       *wq[u] = w[u];
@@ -1324,6 +1344,135 @@ static __global__ __launch_bounds__(256) void k_adam_soft_gather(AdamArgs a, Gat
     __syncthreads();
     tick_body(a.tick, s, sq, skipped);
   }
+}
+
+// ---- the first tower layer of the pass that follows, inside the optimiser launch (round 5) -------------------------------------
+// The launch after the critic's optimiser pass is the first layer of critic(s, mu(s)): K = S + 10 padded to 64 / 128, a 5-us
+// launch-floor link whose only late operand is the layer's own, just-updated weights.  Here the launch's first r.blocks
+// workgroups each OWN 16 output rows of W1 (and their 16 biases): they take the step on that slice (adam_apply4: the strided pass's
+// arithmetic), keep the new weights in LDS and run the layer for those 16 outputs over every minibatch row — the split of the
+// reduction over the four waves, the step order and the (w0 + w1) + (w2 + w3) reduction of fwd_direct_body, so the activations
+// are bit-identical to that launch's.  The strided pass belongs to the other workgroups and starts behind the slice
+// (AdamArgs::skip4).  The riders are issued first and done after ~10 us of a 20-us pass.
+// (First form, measured: the riders also took their share of the strided pass and walked the rows one 16-row tile at a time,
+// every step behind its own load round trip: 26.8 us per launch against 19.7 + 5.0.)
+struct FirstLayerRider {
+  const float* X; int ldx;      // [rows][Kp]: the layer's input panel, complete before this launch
+  float* Y; int ldy;            // [rows][N] out
+  int rows, Kp, N;              // Kp = 64 G, rows % 16 == 0, N % 16 == 0; W1 = arena float4 [0, N Kp / 4), b1 behind it
+  int blocks;                   // N / 16
+};
+template <int G>
+struct FirstLayerWork {
+  const AdamArgs& a; const FirstLayerRider& r; const int blk; float* sW; float* sB; float* park;
+  __device__ __forceinline__ FirstLayerWork(const AdamArgs& a_, const FirstLayerRider& r_, int blk_, float* sW_, float* sB_, float* park_)
+      : a(a_), r(r_), blk(blk_), sW(sW_), sB(sB_), park(park_) {}
+  static constexpr int NH = G == 1 ? 4 : 0;    // (G = 2: the step's own operands are 45 of the 80 registers)
+  f32x4 g[G], m[G], v[G], w[G], wt[G], qf[4][G];
+  float bg, bm, bv, bw, bwt;
+  __device__ __forceinline__ size_t widx(int u) const { return ((size_t)blk * G + u) * 256 + threadIdx.x; }
+  __device__ __forceinline__ size_t bidx() const { return (size_t)r.N * r.Kp + (size_t)blk * 16 + threadIdx.x; }
+  // everything the step on this workgroup's slice reads, requested in ONE round trip before the launch's scalars are derived
+  // (the memory system is saturated by the strided pass beside it: every dependent round trip costs ~3 us here)
+  __device__ __forceinline__ void request() {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const size_t i = widx(u);
+      g[u] = reinterpret_cast<const f32x4*>(a.g)[i]; m[u] = reinterpret_cast<const f32x4*>(a.m)[i];
+      v[u] = reinterpret_cast<const f32x4*>(a.v)[i]; w[u] = reinterpret_cast<const f32x4*>(a.w)[i]; wt[u] = reinterpret_cast<const f32x4*>(a.wt)[i];
+    }
+    if (threadIdx.x < 16) { const size_t i = bidx(); bg = a.g[i]; bm = a.m[i]; bv = a.v[i]; bw = a.w[i]; bwt = a.wt[i]; }
+    // ... and the first row tiles' operands of the layer (as many as the 80-register budget holds beside the step's operands)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int T = r.rows >> 4;
+    const float* xq = r.X + (size_t)li * r.ldx + wave * (r.Kp >> 2) + lg * 4;
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+#pragma unroll
+      for (int kb = 0; kb < G; ++kb) qf[j][kb] = *reinterpret_cast<const f32x4*>(xq + (size_t)(j < T ? j : T - 1) * 16 * r.ldx + kb * 16);
+  }
+  __device__ __forceinline__ void run(float scale, float step, bool soft, bool apply) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int Kw = r.Kp >> 2, T = r.rows >> 4;
+    if (apply) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) adam_apply4(a, scale, step, soft, g[u], m[u], v[u], w[u], wt[u]);
+      if (threadIdx.x < 16) adam_apply1(a, scale, step, soft, bg, bm, bv, bw, bwt);
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const size_t i = widx(u);
+      if (apply) {
+        reinterpret_cast<f32x4*>(a.m)[i] = m[u]; reinterpret_cast<f32x4*>(a.v)[i] = v[u]; reinterpret_cast<f32x4*>(a.w)[i] = w[u];
+        if (soft) reinterpret_cast<f32x4*>(a.wt)[i] = wt[u];
+      }
+      reinterpret_cast<f32x4*>(sW)[u * 256 + threadIdx.x] = w[u];
+    }
+    if (threadIdx.x < 16) {
+      const size_t i = bidx();
+      if (apply) { a.m[i] = bm; a.v[i] = bv; a.w[i] = bw; if (soft) a.wt[i] = bwt; }
+      sB[threadIdx.x] = bw;
+    }
+    const float* xq = r.X + (size_t)li * r.ldx + wave * Kw + lg * 4;
+#pragma unroll
+    for (int j = NH; j < 4; ++j)          // (the rest of the first group: behind the step's stores, whose registers they take over)
+#pragma unroll
+      for (int kb = 0; kb < G; ++kb) qf[j][kb] = *reinterpret_cast<const f32x4*>(xq + (size_t)(j < T ? j : T - 1) * 16 * r.ldx + kb * 16);
+    __syncthreads();
+    // the layer: outputs [16 blk, +16) x every row (fwd_direct_body's arithmetic, element for element), four row tiles per step:
+    // wave w reduces tile 4 t4 + w
+    const float* pw = sW + li * r.Kp + wave * Kw + lg * 4;
+    for (int t4 = 0; t4 < T; t4 += 4) {
+      f32x4 acc[4], pf[G];
+#pragma unroll
+      for (int kb = 0; kb < G; ++kb) pf[kb] = *reinterpret_cast<const f32x4*>(pw + kb * 16);      // (re-read per step: 8 VGPRs the 80-register budget does not have)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < G; ++kb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[j] = DQN_MFMA(pf[kb][s], qf[j][kb][s], acc[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kb = 0; kb < G; ++kb)
+          qf[j][kb] = *reinterpret_cast<const f32x4*>(xq + (size_t)(t4 + 4 + j < T ? t4 + 4 + j : T - 1) * 16 * r.ldx + kb * 16);   // (beyond the last tile: a valid row, unused)
+      f32x4* pk = reinterpret_cast<f32x4*>(park);
+      if (t4 > 0) __syncthreads();          // (one 16-KB parking area: six workgroups per CU must keep fitting the LDS)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pk[(j * 4 + wave) * 64 + lane] = acc[j];
+      __syncthreads();
+      if (t4 + wave < T) {
+        const f32x4* pj = pk + wave * 256;
+        const f32x4 a0 = pj[lane], a1 = pj[64 + lane], a2 = pj[128 + lane], a3 = pj[192 + lane];
+        f32x4 o;
+        o.x = (a0.x + a1.x) + (a2.x + a3.x); o.y = (a0.y + a1.y) + (a2.y + a3.y);
+        o.z = (a0.z + a1.z) + (a2.z + a3.z); o.w = (a0.w + a1.w) + (a2.w + a3.w);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(sB + lg * 4);
+        o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w;
+        o.x = lrelu_fwd(o.x); o.y = lrelu_fwd(o.y); o.z = lrelu_fwd(o.z); o.w = lrelu_fwd(o.w);
+        *reinterpret_cast<f32x4*>(r.Y + (size_t)((t4 + wave) * 16 + li) * r.ldy + blk * 16 + (lg << 2)) = o;
+      }
+    }
+  }
+};
+template <int G>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_adam_soft_fwd1(AdamArgs a, FirstLayerRider r) {   // (six workgroups per CU, as k_adam_soft: 1536 resident at once)
+  __shared__ float s[8];
+  __shared__ __attribute__((aligned(16))) float sW[16 * 64 * G];
+  __shared__ __attribute__((aligned(16))) float sB[16];
+  __shared__ __attribute__((aligned(16))) float park[4096];
+  if ((int)blockIdx.x < r.blocks) {
+    FirstLayerWork<G> work(a, r, (int)blockIdx.x, sW, sB, park);
+    work.request();
+    adam_scalars<true>(a, -1, s);          // (-1: the strided pass's first workgroup reports a skipped step)
+    // (a skipped step — non-finite gradient norm — still runs the layer, on the weights as they are)
+    work.run(s[4], s[5], s[6] != 0.0f, s[7] == 0.0f);
+    return;
+  }
+  adam_soft_body<1, 0, true>(a, (int)blockIdx.x - r.blocks, (int)gridDim.x - r.blocks, s);
 }
 
 // Sum of up to 8 co-located gradient arenas in rank order, written back to all (dqnhip_reduce_gradients_local)

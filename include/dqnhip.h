@@ -127,6 +127,9 @@ typedef struct dqnhip_config {
  * arrive in 16-column pieces from the critics' top forward layers).  The two forms differ by fp32 round-off only (another fixed
  * summation order for q', q; the per-row scalar dq applied after the dgrad's reduction instead of before). */
 #define DQNHIP_TUNE_SEPARATE_Q_TRAIN 16
+/* fp32 learner: the first tower layer of critic(s, mu(s)) in a launch of its own instead of inside the critic's optimiser launch
+ * (FirstLayerRider, round 5: the optimiser workgroups that own W1 run the layer on the weights they have just stepped).  Same bits. */
+#define DQNHIP_TUNE_SEPARATE_FIRST_LAYER 32
 
 typedef struct dqnhip_learner* dqnhip_handle;
 

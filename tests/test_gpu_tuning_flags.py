@@ -217,3 +217,29 @@ def test_q_train_inside_the_top_dgrad_equals_its_own_launch(pkg, gpu, B, hidden,
     for net, (x, y) in enumerate(zip(wa, wb)):
         dd = np.abs(x - y)
         assert dd.max() <= 2 * 3 * lr[net] + 1e-7 and dd.mean() <= 0.01 * lr[net] + 1e-9, (net, dd.max(), dd.mean())
+
+
+@pytest.mark.parametrize("B,hidden,S", [
+    (256, (1024, 1024, 1024, 1024), 58),       # BASELINE configs[1]: K = 68 -> 128, two float4 of W1 per rider thread
+    (256, (1024, 1024), 40),                   # K = 50 -> 64: one float4 per thread
+    (512, (1024, 512, 256, 128), 59),          # the reference's tower at 512 rows
+    (32, (1024, 512, 256, 128), 59),           # the reference's defaults: two row tiles per rider
+    (64, (192, 64), 77),                       # 12 riders; K = 87 -> 128
+    (1024, (256, 256), 58),                    # more than 512 rows: the layer keeps its own launch on both sides
+])
+def test_first_layer_inside_the_optimiser_launch_equals_its_own_launch(pkg, gpu, B, hidden, S):
+    """fp32 learner: the first tower layer of critic(s, mu(s)) computed by the optimiser workgroups that own W1 / b1, on the
+    weights they have just stepped (FirstLayerRider, default), against a launch of its own (DQNHIP_TUNE_SEPARATE_FIRST_LAYER).
+    The same Adam arithmetic on every element and fwd_direct_body's reduction order: every result bit-identical, eager and
+    graph replay."""
+    a = _run32(pkg, 0, B, hidden, S)
+    b = _run32(pkg, pkg.capi.TUNE_SEPARATE_FIRST_LAYER, B, hidden, S)
+    assert a[0] == b[0], (a[0], b[0])
+    for (qa, da), (qb, db) in zip(a[1], b[1]):
+        np.testing.assert_array_equal(qa, qb); np.testing.assert_array_equal(da, db)
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
+    g = _run32(pkg, 0, B, hidden, S, use_graph=True)
+    assert a[0] == g[0]
+    for x, y in zip(a[2], g[2]):
+        np.testing.assert_array_equal(x, y)
