@@ -271,7 +271,7 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
         ms_b = d.BenchmarkBlocking(1000, 100, seed=1, pipelined=False)
         out["configs0_ref_defaults_b32"] = {"ms_per_update": round(dt * 1e3, 4), "updates_per_s": round(1 / dt, 1),
                                             "blocking_ms_per_update": round(ms_b, 4), "blocking_updates_per_s": round(1e3 / ms_b, 1),
-                                            "note": "launch-bound: 30 launches per update"}
+                                            "note": "launch-bound: ~29 launches per update, each at its ~5-us floor"}
         d.read_stats(); d.close()
         # configs[2]: 1v1 (S = 68), 64 parallel workers feeding one replay buffer
         d = pkg.DQN(68, minibatch=B, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, use_graph=True)
