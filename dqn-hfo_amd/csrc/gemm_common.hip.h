@@ -41,6 +41,10 @@ struct GemmProblem {
   // dot_out[q][p / 16] = sum over the 16 finished activations C[q][p .. p+15] of C * dot_w (fixed order: a lane's four columns
   // as an fma chain from 0, then (g0 + g1) + (g2 + g3) over the four lane groups) — k_dgrad_qtrain sums the Pdim / 16 pieces of a row
   const float* dot_w; float* dot_out;
+  // FWD (first_layers_launch, the state half of critic_target's first layer): the workgroups also leave (column j: row tile j mod tiles_q) columns
+  // [xcopy_col, +xcopy_n) of their 16 TP rows of P transposed, xcopy_dst[j][p] = P[p][xcopy_col + j] (the action-column weights the
+  // target actor's head kernel applies: there one coalesced float4 per action instead of 40 strided dwords per thread); null: none
+  float* xcopy_dst; int xcopy_col, xcopy_n;
   int mode;                  // mixed-mode launches (gemm_bwd_pair_direct): GEMM_DGRAD / GEMM_WGRAD
   int tiles_p, tiles_q, tile_base;
 };

@@ -187,6 +187,10 @@ __device__ __forceinline__ void fwd_direct_body(const GemmProblem& pr, int tile_
       if (e < NACC) dwp[j] = *reinterpret_cast<const f32x4*>(pr.dot_w + p0 + (e % TP) * 16 + (lg << 2));
     }
   }
+  if (pr.xcopy_dst != nullptr && (int)threadIdx.x < 16 * TP) {      // (column j by the workgroup of row tile j mod tiles_q: one or two dwords per thread)
+    const float* src = pr.P + (size_t)(p0 + threadIdx.x) * pr.ldp + pr.xcopy_col;
+    for (int j = tile_q; j < pr.xcopy_n; j += pr.tiles_q) pr.xcopy_dst[(size_t)j * pr.Pdim + p0 + threadIdx.x] = src[j];
+  }
   park_accumulators<NACC>(smem, acc, wave, lane);
   __syncthreads();
 #pragma unroll

@@ -682,6 +682,37 @@ int sync_dirty16(H* h) {
 }
 
 // ---- the update, in three phases (see dqnhip.h) ---------------------------------
+// Step(1)'s four first tower layers in ONE launch (round 5): actor_target(s'), actor(s), critic(s, a) — each exactly what
+// layer_forward(…, 0) computes — and the STATE half of critic_target(s', mu'(s'))'s first layer (K = the state columns; no bias, no
+// ReLU; into h->Zs).  Its action half is a rank-10 update per row that the target actor's head kernel applies itself
+// (HeadArgs::l1_*), so the launch of the critics' first layers between the heads and the critics' second layer is gone.
+// with_actor false (the data-parallel overlap form): the online actor's whole forward runs later (phase 11) — three problems.
+int first_layers_launch(H* h, hipStream_t st, int rows, bool with_actor) {
+  const NetLayout &la = h->la, &lc = h->lc;
+  GemmBatch b{}; b.n = with_actor ? 4 : 3;
+  auto fill = [&](GemmProblem& p, int net, const NetLayout& l, const float* X, float* Y, int kred, bool finish) {
+    p.P = wat(h, net, l.w_off[0]); p.ldp = l.kp[0];
+    p.Q = X; p.ldq = l.kp[0];
+    p.C = Y; p.ldc = l.kp[1];
+    p.Pdim = l.dims[1]; p.Qdim = rows; p.Kred = kred;
+    p.bias = finish ? wat(h, net, l.b_off[0]) : nullptr; p.relu = finish ? 1 : 0;
+  };
+  fill(b.prob[0], DQNHIP_ACTOR_TARGET, la, h->act[0][0], h->act[0][1], la.kp[0], true);
+  fill(b.prob[1], DQNHIP_CRITIC, lc, h->act[3][0], h->act[3][1], lc.kp[0], true);
+  fill(b.prob[2], DQNHIP_CRITIC_TARGET, lc, h->act[2][0], h->Zs, round_up(h->S, 64), false);
+  b.prob[2].xcopy_dst = h->Wact_t; b.prob[2].xcopy_col = h->S; b.prob[2].xcopy_n = kNO;
+  if (with_actor) fill(b.prob[3], DQNHIP_ACTOR, la, h->act[1][0], h->act[1][1], la.kp[0], true);
+  ScopedTiming t(h, 6, st);
+  HIPCHK((fwd_direct_launch<4, 2>(b, st)));
+  return 0;
+}
+inline bool first_layers_merged(const H* h) {
+  const NetLayout &la = h->la, &lc = h->lc;
+  return h->Zs != nullptr && !h->fp16 && !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS) && h->L >= 2 &&
+         h->B % 32 == 0 && h->B < 1024 && la.kp[0] < 512 && lc.kp[0] < 512 && la.dims[1] % 64 == 0 && lc.dims[1] % 64 == 0 && lc.dims[1] <= 1024 &&
+         round_up(h->S, 64) <= lc.kp[0];
+}
+
 int run_phase(H* h, int phase, const int* idx_dev) {
   if (h->fp16) return run_phase16(h, phase, idx_dev);
   const int B = h->B, L = h->L;
@@ -727,19 +758,27 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       pCT.dot_w = wat(h, DQNHIP_CRITIC_TARGET, lc.hw_off); pCT.dot_out = h->qdot[0];
     }
     FwdPass cp[2] = {pCT, pC1};
+    // all four first layers of Step(1) in the update's first GEMM launch, critic_target's action half in the head kernel (first_layers_launch);
+    // DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS: the critics' first layers in a launch of their own behind the heads
+    const bool merged_l0 = first_layers_merged(h);
+    if (merged_l0) {
+      RC(first_layers_launch(h, st, B, !split));
+      hAT.l1_zs = h->Zs; hAT.l1_wt = h->Wact_t;
+      hAT.l1_b = wat(h, DQNHIP_CRITIC_TARGET, lc.b_off[0]); hAT.l1_y = h->act[2][1]; hAT.l1_ld = lc.kp[1]; hAT.l1_n = lc.dims[1];
+    }
     if (split) {
       // data-parallel overlap form: the online actor's forward (phase 11) is left out so that it can
       // run while the critic gradients are being all-reduced
-      RC(tower_forward(h, st, &pAT, 1, B));
+      RC(tower_forward(h, st, &pAT, 1, B, merged_l0 ? 1 : 0));
       RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT)));
     } else {
       // actor_target(s') [src/dqn.cpp:889-891] and actor(s) [:910-911, pre-update weights] layer by layer in one
       // launch each, then critic_target(s', mu'(s')) and the critic(s, a) train forward [:904] likewise
       FwdPass ap[2] = {pAT, pA};
-      RC(tower_forward(h, st, ap, 2, B));
+      RC(tower_forward(h, st, ap, 2, B, merged_l0 ? 1 : 0));
       RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));     // both actors' heads in one launch
     }
-    RC(tower_forward(h, st, cp, 2, B));
+    RC(tower_forward(h, st, cp, 2, B, merged_l0 ? 1 : 0));
     HeadTrainArgs qt_args{};
     {
       HeadTrainArgs t{};
@@ -1014,8 +1053,10 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
   for (int p = 0; p < 5; ++p)
     for (int i = 1; i <= L; ++i) RC(dalloc(&h->act[p][i], (size_t)B * layout_of(h, p >= 2).kp[i]));
   for (int i = 0; i <= L; ++i) { RC(dalloc(&h->dZa[i], (size_t)B * h->la.kp[i])); RC(dalloc(&h->dZc[i], (size_t)B * h->lc.kp[i])); }
-  RC(dalloc(&h->U3, (size_t)B * h->lc.kp[L]));
-  for (int j = 0; j < 2; ++j) RC(dalloc(&h->qdot[j], (size_t)B * (h->lc.kp[L] / 16)));        // the training pass's head-seed panel (k_dgrad_qtrain)
+  RC(dalloc(&h->U3, (size_t)B * h->lc.kp[L]));        // the training pass's head-seed panel (k_dgrad_qtrain)
+  for (int j = 0; j < 2; ++j) RC(dalloc(&h->qdot[j], (size_t)B * (h->lc.kp[L] / 16)));
+  RC(dalloc(&h->Wact_t, (size_t)kNO * h->lc.dims[1]));  // critic_target's first-layer action-column weights, transposed (GemmProblem::xcopy_dst)
+  RC(dalloc(&h->Zs, (size_t)B * h->lc.kp[1]));   // the state half of critic_target's first layer (first_layers_launch)
   RC(dalloc(&h->mb_reward, B)); RC(dalloc(&h->mb_mc, B)); RC(dalloc(&h->mb_term, B));
   HIPCHK(hipMalloc(&h->mb_idx, B * sizeof(int)));
   HIPCHK(hipHostMalloc((void**)&h->idx_pinned, B * sizeof(int), hipHostMallocMapped));
@@ -1131,7 +1172,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   hipFree(h->Xa_s); hipFree(h->Xa_n); hipFree(h->Xc_tr); hipFree(h->Xc_pl); hipFree(h->Xc_nx);
   for (int p = 0; p < 5; ++p) for (int i = 1; i <= h->L; ++i) hipFree(h->act[p][i]);
   for (int i = 0; i <= h->L; ++i) { hipFree(h->dZa[i]); hipFree(h->dZc[i]); }
-  hipFree(h->mb_reward); hipFree(h->mb_mc); hipFree(h->mb_term); hipFree(h->mb_idx); hipFree(h->U3); hipFree(h->qdot[0]); hipFree(h->qdot[1]);
+  hipFree(h->mb_reward); hipFree(h->mb_mc); hipFree(h->mb_term); hipFree(h->mb_idx); hipFree(h->U3); hipFree(h->qdot[0]); hipFree(h->qdot[1]); hipFree(h->Zs); hipFree(h->Wact_t);
   hipHostFree(h->idx_pinned); hipHostFree(h->pinned_stats);
   hipFree(h->aout_t16); hipFree(h->aout16); hipFree(h->dA16);
   hipFree(h->q_t); hipFree(h->q1); hipFree(h->q2); hipFree(h->y); hipFree(h->dq);

@@ -143,6 +143,8 @@ struct dqnhip_learner {
   float* dZc[kMaxL + 1] = {nullptr};
   float *mb_reward = nullptr, *mb_mc = nullptr, *mb_term = nullptr;
   float* qdot[2] = {nullptr, nullptr};   // [B][kp[L] / 16]: the head dot products of critic_target(s', .) / critic(s, a) in 16-column pieces (GemmProblem::dot_w)
+  float* Wact_t = nullptr;              // [kNO][dims[1]] (first_layers_launch)
+  float* Zs = nullptr;                  // [B][kp[1]]: the state half of critic_target's first layer, before bias / ReLU (first_layers_launch)
   float* U3 = nullptr;                  // [B][kp[L]]: (-w_h) lrelu'(x_L) of the critic(s, a) training pass (left by its top forward layer for k_dgrad_qtrain)
   int* mb_idx = nullptr;
   int* idx_pinned = nullptr;

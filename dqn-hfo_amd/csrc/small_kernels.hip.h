@@ -302,6 +302,12 @@ struct HeadArgs {
   float* out16;                        // [rows][16]
   float* xc; int ldxc; int xc_col;     // also written into a critic input panel (may be null)
   _Float16* xc16; int ldxc16;          // fp16 learner: and into that panel's fp16 copy (may be null)
+  // HEAD_ACTOR, the target actor's head inside Step(1) (round 5; null: off): the block that has just formed mu'(s') of a row also
+  // FINISHES the first tower layer of critic_target(s', mu'(s')) for that row.  The layer's state half
+  // l1_zs[row][n] = sum_{k < S} W1[n][k] s'[k] came out of the update's first GEMM launch (no bias, no ReLU); here
+  // l1_y[row][n] = lrelu((l1_zs[row][n] + sum_a W1[n][S + a] mu'[a]) + b1[n]), a in action order (an fma chain on l1_zs).
+  // (With the action-column weights read in place — 40 dwords 512 B apart per thread — this kernel took 6.8 instead of 4.9 us.)
+  const float* l1_zs; const float* l1_wt; const float* l1_b; float* l1_y; int l1_ld; int l1_n;   // l1_wt[a][n] = W1[n][S + a] (GemmProblem::xcopy_dst); l1_n <= 1024, % 4 == 0
   // HEAD_Q*
   float* q;                            // [rows]
   // HEAD_Q_TRAIN: TD target + Euclidean loss
@@ -330,11 +336,29 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
     for (int j = 0; j < NH; ++j)
       wreg[j] = (threadIdx.x * 4 < a.H) ? *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + threadIdx.x * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // (l1: this thread's four outputs' action-column weights and biases do not depend on the row)
+  constexpr bool kL1 = (MODE == HEAD_ACTOR && NH == kNO);
+  __shared__ float s_mu[kAP];
+  float l1w[kL1 ? 4 : 1][kL1 ? kNO : 1];
+  f32x4 l1b = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool l1_on = kL1 && a.l1_y != nullptr && (int)threadIdx.x * 4 < a.l1_n;
+  if constexpr (kL1) {
+    if (l1_on) {
+#pragma unroll
+      for (int j = 0; j < kNO; ++j) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.l1_wt + (size_t)j * a.l1_n + threadIdx.x * 4);
+        l1w[0][j] = w4.x; l1w[1][j] = w4.y; l1w[2][j] = w4.z; l1w[3][j] = w4.w;
+      }
+      l1b = *reinterpret_cast<const f32x4*>(a.l1_b + threadIdx.x * 4);
+    }
+  }
   for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
     float acc[NH];
 #pragma unroll
     for (int j = 0; j < NH; ++j) acc[j] = 0.0f;
     const size_t x0 = (size_t)row * a.ldx;
+    f32x4 zs = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (kL1) { if (l1_on) zs = *reinterpret_cast<const f32x4*>(a.l1_zs + (size_t)row * a.l1_ld + threadIdx.x * 4); }
     auto dots = [&](auto tag) {
       for (int k = threadIdx.x * 4; k < a.H; k += 1024) {
         const f32x4 xv = head_ld4t<decltype(tag)::value>(a.X, a.X16, x0 + k);
@@ -361,6 +385,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
         a.out16[(size_t)row * kAP + j] = v;
         if (a.xc != nullptr && j < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + j] = v;
         if (a.xc16 != nullptr && j < NH) a.xc16[(size_t)row * a.ldxc16 + a.xc_col + j] = (_Float16)v;
+        if constexpr (kL1) s_mu[j] = v;
       } else {
         if (j == 0) {
           a.q[row] = v;
@@ -369,6 +394,22 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
       }
     }
     __syncthreads();                       // s_acc is rewritten by the next row
+    if constexpr (kL1) {
+      if (a.l1_y != nullptr) {             // (uniform)
+        if (l1_on) {
+          float o[4] = {zs.x, zs.y, zs.z, zs.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int j = 0; j < kNO; ++j) o[e] = fmaf(l1w[e][j], s_mu[j], o[e]);
+          }
+          f32x4 y;
+          y.x = lrelu_fwd(o[0] + l1b.x); y.y = lrelu_fwd(o[1] + l1b.y); y.z = lrelu_fwd(o[2] + l1b.z); y.w = lrelu_fwd(o[3] + l1b.w);
+          *reinterpret_cast<f32x4*>(a.l1_y + (size_t)row * a.l1_ld + threadIdx.x * 4) = y;
+        }
+        __syncthreads();                   // s_mu is rewritten by the next row
+      }
+    }
   }
 }
 

@@ -130,6 +130,11 @@ typedef struct dqnhip_config {
 /* fp32 learner: the first tower layer of critic(s, mu(s)) in a launch of its own instead of inside the critic's optimiser launch
  * (FirstLayerRider, round 5: the optimiser workgroups that own W1 run the layer on the weights they have just stepped).  Same bits. */
 #define DQNHIP_TUNE_SEPARATE_FIRST_LAYER 32
+/* fp32 learner, Step(1): the two critics' first tower layers in a launch of their own behind the actor heads, instead of
+ * critic(s, a)'s in the update's first GEMM launch and critic_target(s', mu'(s'))'s split into a state half (that launch) and an
+ * action half applied by the target actor's head kernel (round 5).  critic_target's first layer then differs by fp32 round-off
+ * (another summation order); everything else is the same arithmetic. */
+#define DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS 64
 
 typedef struct dqnhip_learner* dqnhip_handle;
 

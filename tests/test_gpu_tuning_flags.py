@@ -243,3 +243,52 @@ def test_first_layer_inside_the_optimiser_launch_equals_its_own_launch(pkg, gpu,
     assert a[0] == g[0]
     for x, y in zip(a[2], g[2]):
         np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("B,hidden,S", [
+    (256, (1024, 1024, 1024, 1024), 58),       # BASELINE configs[1]: state half K = 64 of a 128-wide critic panel
+    (256, (1024, 512, 256, 128), 59),          # the reference's tower
+    (64, (256, 128), 68),                      # S = 68: the state half spans both 64-column halves of the panel (action columns still zero)
+    (32, (1024, 512, 256, 128), 59),           # the reference's defaults
+    (512, (192, 64), 77),                      # 192 outputs: a partial last thread group in the head kernel
+    (1024, (256, 256), 58),                    # 1024 rows: the wave-per-row head kernel -> both sides keep the launch (identical)
+])
+def test_critic_first_layers_merged_equal_their_own_launch(pkg, gpu, B, hidden, S):
+    """fp32 learner, Step(1): critic(s, a)'s first layer in the update's first GEMM launch and critic_target(s', mu'(s'))'s split into
+    a state half (same launch) and a rank-10 action half applied by the target actor's head kernel (default) against the critics'
+    first-layer launch behind the heads (DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS).  Only critic_target's first layer changes its
+    summation order: q' and everything downstream agree to fp32 round-off."""
+    out = {}
+    for tuning in (0, pkg.capi.TUNE_SEPARATE_CRITIC_FIRST_LAYERS):
+        d = pkg.DQN(S, minibatch=B, hidden=hidden, memory=4096, seed=3, tuning=tuning)
+        d.add_transitions_arrays(*synth_replay(np.random.default_rng(5), 2000, S))
+        rng = np.random.default_rng(7)
+        rec = []
+        for u in range(3):
+            idx = rng.integers(0, 2000, B).astype(np.int32)
+            d.update_phase(0, idx)
+            first = {k: d.debug_read(k) for k in ("q_target", "q_train", "y")}
+            first["l1_ct"], first["l1_c"], first["l1_a"] = d.debug_read("act2_1"), d.debug_read("act3_1"), d.debug_read("act1_1")
+            first["gc"] = d.get_params(1, pkg.KIND_G)
+            d.update_phase(1); d.update_phase(2)
+            first["stats"] = d.read_stats()
+            rec.append(first)
+        out[tuning] = (rec, [d.get_params(n).astype(np.float64) for n in range(4)])
+        d.close()
+    (ra, wa), (rb, wb) = out[0], out[pkg.capi.TUNE_SEPARATE_CRITIC_FIRST_LAYERS]
+    # first update (same weights): the layers whose arithmetic did not change are bit-identical, critic_target's agrees to round-off
+    np.testing.assert_array_equal(ra[0]["l1_c"], rb[0]["l1_c"]); np.testing.assert_array_equal(ra[0]["l1_a"], rb[0]["l1_a"])
+    np.testing.assert_array_equal(ra[0]["q_train"], rb[0]["q_train"])
+    scale = max(1.0, float(np.abs(rb[0]["l1_ct"]).max()))
+    np.testing.assert_allclose(ra[0]["l1_ct"], rb[0]["l1_ct"], rtol=0, atol=4e-6 * scale)
+    for k in ("q_target", "y"):
+        sc = max(1.0, float(np.abs(rb[0][k]).max()))
+        np.testing.assert_allclose(ra[0][k], rb[0][k], rtol=0, atol=4e-6 * sc)
+    rel = np.linalg.norm(ra[0]["gc"].astype(np.float64) - rb[0]["gc"]) / np.linalg.norm(rb[0]["gc"])
+    assert rel <= 2e-5, rel
+    for a, b in zip(ra, rb):
+        assert np.allclose(a["stats"], b["stats"], rtol=1e-4, atol=1e-6), (a["stats"], b["stats"])
+    lr = {0: 1e-5, 1: 1e-3, 2: 1e-5 * 1e-3, 3: 1e-3 * 1e-3}
+    for net, (x, y) in enumerate(zip(wa, wb)):
+        dd = np.abs(x - y)
+        assert dd.max() <= 2 * 3 * lr[net] + 1e-7 and dd.mean() <= 0.01 * lr[net] + 1e-9, (net, dd.max(), dd.mean())
