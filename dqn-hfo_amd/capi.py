@@ -15,6 +15,7 @@ TUNE_SEPARATE_ACTOR_HEAD_BWD = 8
 TUNE_SEPARATE_Q_TRAIN = 16
 TUNE_SEPARATE_FIRST_LAYER = 32
 TUNE_SEPARATE_CRITIC_FIRST_LAYERS = 64
+TUNE_LATE_GATHER = 128
 ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET = 0, 1, 2, 3
 KIND_W, KIND_M, KIND_V, KIND_G = 0, 1, 2, 3
 

@@ -328,6 +328,21 @@ int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
 
 // The gather of one update (src/dqn.cpp:846-887).  pos: -1 outside multi-update graphs; else the update's position in the
 // graph being captured (0: a launch of its own that also stores DevState::gbase; k >= 1: rides in update k-1's last launch)
+// Inside a multi-update graph (cap_u >= 0): does the next update's gather ride in the critic's optimiser launch and do its four first
+// layers ride in the actor's (k_adam_soft_fwd1_gather / k_adam_soft_l0)?  Needs every piece those riders stand on.
+bool first_layers_merged(const H* h);
+inline bool critic_l0_rides(const H* h, bool dp) {
+  const NetLayout& lc = h->lc;
+  return !dp && !h->fp16 && h->shared_fl[DQNHIP_CRITIC] == 0 && !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_FIRST_LAYER) &&
+         (lc.kp[0] == 64 || lc.kp[0] == 128) && lc.dims[1] % 16 == 0 && h->B % 16 == 0 && h->B <= 512 && h->L >= 2 && lc.w_off[0] == 0 &&
+         lc.b_off[0] == (size_t)lc.dims[1] * lc.kp[0];
+}
+bool early_l0(const H* h) {
+  const NetLayout& la = h->la;
+  const bool dp = h->cfg.dp_world > 1 || h->dp_half || h->dp_shard;
+  return h->cap_u >= 0 && h->Xa_s2[1] != nullptr && !(h->cfg.tuning_flags & DQNHIP_TUNE_LATE_GATHER) && critic_l0_rides(h, dp) && first_layers_merged(h) &&
+         h->shared_fl[DQNHIP_ACTOR] == 0 && la.kp[0] == 64 && la.dims[1] % 16 == 0 && la.w_off[0] == 0 && la.b_off[0] == (size_t)la.dims[1] * la.kp[0];
+}
 GatherArgs gather_args(H* h, const int* idx_dev, int pos) {
   const NetLayout &la = h->la, &lc = h->lc;
   GatherArgs g{};
@@ -338,7 +353,8 @@ GatherArgs gather_args(H* h, const int* idx_dev, int pos) {
     g.o = GatherOut{nullptr, nullptr, la.kp[0], nullptr, nullptr, nullptr, lc.kp[0], h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx,
                     h->act16[1][0], h->act16[0][0], h->act16[3][0], h->act16[4][0], h->act16[2][0]};
   else
-    g.o = GatherOut{h->Xa_s, h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl, h->Xc_nx, lc.kp[0], h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
+    g.o = GatherOut{h->Xa_s2[pos > 0 && early_l0(h) ? (pos & 1) : 0], h->Xa_n, la.kp[0], h->Xc_tr, h->Xc_pl2[pos > 0 && early_l0(h) ? (pos & 1) : 0], h->Xc_nx, lc.kp[0],
+                    h->mb_reward, h->mb_mc, h->mb_term, h->mb_idx};
   const int slot = pos > 0 ? (pos & 1) : 0;
   g.corr = h->st->adam_corr[slot]; g.soft_now = &h->st->soft_now[slot];
   g.beta1 = h->cfg.momentum; g.beta2 = h->cfg.momentum2; g.soft_update_freq = h->cfg.soft_update_freq;
@@ -350,7 +366,7 @@ GatherArgs gather_args(H* h, const int* idx_dev, int pos) {
 // clip + Adam + Net::Update + soft target update over arena floats [begin, end)
 // corr_pre: the update's first launch (k_gather) has left this step's bias correction in DevState::adam_corr
 int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick,
-                bool corr_pre, const FirstLayerRider* fl) {
+                bool corr_pre, const FirstLayerRider* fl, const GatherArgs* early_gather, const NextL0* next_l0) {
   AdamArgs a{};
   const int slot = h->cap_u > 0 ? (h->cap_u & 1) : 0;      // DevState::adam_corr
   a.corr_pre = corr_pre ? &h->st->adam_corr[slot][net] : nullptr; a.soft_pre = corr_pre ? &h->st->soft_now[slot] : nullptr;
@@ -376,19 +392,32 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   // 1536 blocks = 6 per CU, all resident at once (68 VGPRs: 7 waves per SIMD): with the loads hoisted above the prologue
   // same-box A/B gives 18.4 us per launch against 19.3 at 2048 (a second, short round of blocks), 19.4 at 1792, 18.7 at
   // 1280, 21.5 at 4096 (round 2, before the hoist: 512 .. 8192 within +-3 %, profiles/r02_adam_probe.txt)
-  if (fl != nullptr) {
-    if (begin != 0 || tick != nullptr || a.w_sh != nullptr || h->fp16 || !corr_pre) return fail("adam_launch: a first-layer rider needs the whole, unshared fp32 arena inside an update");
+  if (fl != nullptr || next_l0 != nullptr) {
+    if (begin != 0 || (fl && tick != nullptr) || a.w_sh != nullptr || h->fp16 || !corr_pre) return fail("adam_launch: a first-layer rider needs the whole, unshared fp32 arena inside an update");
     a.skip4 = layout_of(h, net).w_off[1] / 4;
   }
   const int blocks = (int)std::min<size_t>((a.n4 - a.skip4 + 255) / 256 + (fl ? fl->blocks : 0), (size_t)1536);   // riders + the strided pass: what is resident at once
-  if (fl != nullptr) {
+  if (next_l0 != nullptr) {
+    // the actor's launch inside a multi-update graph that gathered early: the next update's four first layers ride here (k_adam_soft_l0)
+    if (tick == nullptr) return fail("adam_launch: the next update's first layers ride in the update's last launch");
+    const int riders = next_l0->a.blocks + next_l0->c.blocks + next_l0->ct.blocks;
+    const int ablocks = std::min(blocks, std::max(1536 - riders, 1280));
+    hipLaunchKernelGGL(k_adam_soft_l0, dim3(riders + ablocks), dim3(256), 0, st, a, next_l0->a, next_l0->c, next_l0->ct);
+  }
+  else if (fl != nullptr && early_gather != nullptr) {
+    if (blocks <= fl->blocks) return fail("adam_launch: no optimiser workgroups beside the first-layer riders");
+    const int ablocks = std::min(blocks, std::max(1536 - early_gather->blocks, 1280));
+    if (fl->Kp == 64) hipLaunchKernelGGL(k_adam_soft_fwd1_gather<1>, dim3(early_gather->blocks + ablocks), dim3(256), 0, st, a, *fl, *early_gather);
+    else hipLaunchKernelGGL(k_adam_soft_fwd1_gather<2>, dim3(early_gather->blocks + ablocks), dim3(256), 0, st, a, *fl, *early_gather);
+  }
+  else if (fl != nullptr) {
     if (blocks <= fl->blocks) return fail("adam_launch: no optimiser workgroups beside the first-layer riders");
     const bool timed = lt.start != nullptr;
     if (fl->Kp == 64) { if (timed) hipExtLaunchKernelGGL(k_adam_soft_fwd1<1>, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL(k_adam_soft_fwd1<1>, dim3(blocks), dim3(256), 0, st, a, *fl); }
     else { if (timed) hipExtLaunchKernelGGL(k_adam_soft_fwd1<2>, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL(k_adam_soft_fwd1<2>, dim3(blocks), dim3(256), 0, st, a, *fl); }
     if (timed) lt.start = lt.stop = nullptr;
   }
-  else if (tick && h->cap_u >= 0 && h->cap_u + 1 < kMultiU) {
+  else if (tick && h->cap_u >= 0 && h->cap_u + 1 < kMultiU && !early_l0(h)) {
     // inside a multi-update graph: the next update's gather rides in this, the update's last launch (k_adam_soft_gather).
     // At small minibatches the grid stays at what is resident at once; a large minibatch's gather (1025 workgroups at 4096
     // rows) must not thin the optimiser's own grid — its blocks drain within a few us and the rest of the grid moves in
@@ -706,7 +735,7 @@ int first_layers_launch(H* h, hipStream_t st, int rows, bool with_actor) {
   HIPCHK((fwd_direct_launch<4, 2>(b, st)));
   return 0;
 }
-inline bool first_layers_merged(const H* h) {
+bool first_layers_merged(const H* h) {
   const NetLayout &la = h->la, &lc = h->lc;
   return h->Zs != nullptr && !h->fp16 && !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS) && h->L >= 2 &&
          h->B % 32 == 0 && h->B < 1024 && la.kp[0] < 512 && lc.kp[0] < 512 && la.dims[1] % 64 == 0 && lc.dims[1] % 64 == 0 && lc.dims[1] <= 1024 &&
@@ -714,6 +743,10 @@ inline bool first_layers_merged(const H* h) {
 }
 
 int run_phase(H* h, int phase, const int* idx_dev) {
+  {   // the current update's copies of the two double-buffered panels (early_l0: by update parity inside a multi-update graph)
+    const int par = early_l0(h) ? (h->cap_u & 1) : 0;
+    h->Xa_s = h->Xa_s2[par]; h->Xc_pl = h->Xc_pl2[par]; h->act[1][0] = h->Xa_s; h->act[4][0] = h->Xc_pl;
+  }
   if (h->fp16) return run_phase16(h, phase, idx_dev);
   const int B = h->B, L = h->L;
   const NetLayout &la = h->la, &lc = h->lc;
@@ -762,7 +795,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS: the critics' first layers in a launch of their own behind the heads
     const bool merged_l0 = first_layers_merged(h);
     if (merged_l0) {
-      RC(first_layers_launch(h, st, B, !split));
+      if (!(early_l0(h) && h->cap_u > 0)) RC(first_layers_launch(h, st, B, !split));     // (else: they rode in the previous update's last launch, k_adam_soft_l0)
       hAT.l1_zs = h->Zs; hAT.l1_wt = h->Wact_t;
       hAT.l1_b = wat(h, DQNHIP_CRITIC_TARGET, lc.b_off[0]); hAT.l1_y = h->act[2][1]; hAT.l1_ld = lc.kp[1]; hAT.l1_n = lc.dims[1];
     }
@@ -822,13 +855,16 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     h->act[4][0] = h->Xc_pl;
     // the first layer of critic(s, mu(s)) rides in the critic's optimiser launch (FirstLayerRider: the workgroups that own W1 run it
     // on the weights they have just stepped); DQNHIP_TUNE_SEPARATE_FIRST_LAYER: a launch of its own (same bits)
-    const bool ride_l0 = !dp && !h->fp16 && h->shared_fl[DQNHIP_CRITIC] == 0 && !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_FIRST_LAYER) &&
-                         (lc.kp[0] == 64 || lc.kp[0] == 128) && lc.dims[1] % 16 == 0 && B % 16 == 0 && B <= 512 && L >= 2 && lc.w_off[0] == 0 &&
-                         lc.b_off[0] == (size_t)lc.dims[1] * lc.kp[0];
+    const bool ride_l0 = critic_l0_rides(h, dp);
     if (dp) RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr));
     else if (ride_l0) {
       const FirstLayerRider fl{h->Xc_pl, lc.kp[0], h->act[4][1], lc.kp[1], B, lc.kp[0], lc.dims[1], lc.dims[1] / 16};
-      RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena, nullptr, true, &fl));
+      if (early_l0(h) && h->cap_u + 1 < kMultiU) {
+        // the NEXT update's gather rides here (its panels: the other parity), so that its first layers can ride in the actor's launch
+        const GatherArgs g = gather_args(h, nullptr, h->cap_u + 1);
+        RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena, nullptr, true, &fl, &g));
+      }
+      else RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena, nullptr, true, &fl));
     }
     else RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
     // The seed of BackwardFrom(q_values_layer) [:918-923] — q diff = -1 per row, taken through the head and the top
@@ -881,6 +917,17 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
                         dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world), h->stats_dev};
     if (dp) RC(dp_optimiser_step(h, st, 0, actor_tail, &tick));
+    else if (early_l0(h) && h->cap_u + 1 < kMultiU) {
+      // the next update's first layers ride here: its panels (gathered in this update's critic launch) are those of the other parity
+      const int pn = (h->cap_u + 1) & 1;
+      NextL0 n{};
+      n.a = ActorL0{h->Xa_s2[pn], h->Xa_n, la.kp[0], h->act[1][1], h->act[0][1], la.kp[1], B, la.dims[1], la.dims[1] / 16};
+      n.c = PlainL0{h->w[DQNHIP_CRITIC] + lc.w_off[0], lc.kp[0], h->w[DQNHIP_CRITIC] + lc.b_off[0], h->Xc_tr, lc.kp[0], h->act[3][1], lc.kp[1],
+                    B, lc.kp[0], lc.dims[1], nullptr, 0, 0, lc.dims[1] / 16};
+      n.ct = PlainL0{h->w[DQNHIP_CRITIC_TARGET] + lc.w_off[0], lc.kp[0], nullptr, h->Xc_nx, lc.kp[0], h->Zs, lc.kp[1],
+                     B, round_up(h->S, 64), lc.dims[1], h->Wact_t, h->S, kNO, lc.dims[1] / 16};
+      RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick, true, nullptr, nullptr, &n));
+    }
     else RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick));
     h->h_actor_iter += 1; h->h_critic_iter += 1;
     return 0;
@@ -1048,6 +1095,9 @@ static int create_impl(H* h, const dqnhip_config* cfg) {
   // panels and activations
   RC(dalloc(&h->Xa_s, (size_t)B * h->la.kp[0])); RC(dalloc(&h->Xa_n, (size_t)B * h->la.kp[0]));
   RC(dalloc(&h->Xc_tr, (size_t)B * h->lc.kp[0])); RC(dalloc(&h->Xc_pl, (size_t)B * h->lc.kp[0]));
+  h->Xa_s2[0] = h->Xa_s; h->Xc_pl2[0] = h->Xc_pl;
+  if (!h->fp16) { RC(dalloc(&h->Xa_s2[1], (size_t)B * h->la.kp[0])); RC(dalloc(&h->Xc_pl2[1], (size_t)B * h->lc.kp[0])); }
+  else { h->Xa_s2[1] = nullptr; h->Xc_pl2[1] = nullptr; }
   RC(dalloc(&h->Xc_nx, (size_t)B * h->lc.kp[0]));
   h->act[0][0] = h->Xa_n; h->act[1][0] = h->Xa_s; h->act[2][0] = h->Xc_nx; h->act[3][0] = h->Xc_tr; h->act[4][0] = h->Xc_pl;
   for (int p = 0; p < 5; ++p)
@@ -1169,7 +1219,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   if (h->own_grad) hipFree(h->grad_base);
   hipFree(h->ring.state); hipFree(h->ring.next); hipFree(h->ring.act); hipFree(h->ring.reward);
   hipFree(h->ring.mc); hipFree(h->ring.term); hipFree(h->st); hipFree(h->done_counter);
-  hipFree(h->Xa_s); hipFree(h->Xa_n); hipFree(h->Xc_tr); hipFree(h->Xc_pl); hipFree(h->Xc_nx);
+  hipFree(h->Xa_s2[0]); hipFree(h->Xa_s2[1]); hipFree(h->Xa_n); hipFree(h->Xc_tr); hipFree(h->Xc_pl2[0]); hipFree(h->Xc_pl2[1]); hipFree(h->Xc_nx);
   for (int p = 0; p < 5; ++p) for (int i = 1; i <= h->L; ++i) hipFree(h->act[p][i]);
   for (int i = 0; i <= h->L; ++i) { hipFree(h->dZa[i]); hipFree(h->dZc[i]); }
   hipFree(h->mb_reward); hipFree(h->mb_mc); hipFree(h->mb_term); hipFree(h->mb_idx); hipFree(h->U3); hipFree(h->qdot[0]); hipFree(h->qdot[1]); hipFree(h->Zs); hipFree(h->Wact_t);

@@ -138,6 +138,9 @@ struct dqnhip_learner {
   int next_phase = 0;                   // dqnhip_update_phase order check (0: an update may start)
   // minibatch panels / activations: pass 0 AT, 1 A, 2 CT, 3 C1, 4 C2
   float* Xa_s = nullptr; float* Xa_n = nullptr; float* Xc_tr = nullptr; float* Xc_pl = nullptr; float* Xc_nx = nullptr;
+  // inside multi-update graphs that gather one launch group early (early_l0): the two panels an update still reads after the next
+  // update's gather has run exist twice, by update parity; Xa_s / Xc_pl (and act[1][0] / act[4][0]) point at the current update's
+  float* Xa_s2[2] = {nullptr, nullptr}; float* Xc_pl2[2] = {nullptr, nullptr};
   float* act[5][kMaxL + 1] = {{nullptr}};
   float* dZa[kMaxL + 1] = {nullptr};
   float* dZc[kMaxL + 1] = {nullptr};
@@ -264,8 +267,9 @@ inline void shard_range(const H* h, int net, size_t& lo, size_t& hi, int rank = 
   const size_t r = (size_t)(rank < 0 ? h->cfg.dp_rank : rank);
   lo = r * slice; hi = lo + slice;
 }
+struct NextL0 { ActorL0 a; PlainL0 c, ct; };           // the next update's first layers as riders of the actor's optimiser launch
 int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick = nullptr,
-                bool corr_pre = true, const FirstLayerRider* fl = nullptr);
+                bool corr_pre = true, const FirstLayerRider* fl = nullptr, const GatherArgs* early_gather = nullptr, const NextL0* next_l0 = nullptr);
 int sumsq_launch(H* h, int net, size_t begin = 0, size_t end = 0);
 int to_bf16_launch(H* h, int net);                       // k_to_bf16: the bf16 transfer image of a gradient arena
 int shard_scal_launch(H* h, float* tail);                // k_shard_scal: this rank's share of the clip norm -> tail[3]

@@ -1403,6 +1403,50 @@ struct FirstLayerRider {
   int rows, Kp, N;              // Kp = 64 G, rows % 16 == 0, N % 16 == 0; W1 = arena float4 [0, N Kp / 4), b1 behind it
   int blocks;                   // N / 16
 };
+// One step of a first-layer rider: the four 16-row tiles [t4, t4 + 4) of outputs [out0, out0 + 16) — fwd_direct_body's arithmetic,
+// element for element (the reduction split over the four waves, its step order, (w0 + w1) + (w2 + w3)).  pw: this lane's weight
+// fragments (row li of the 16, k = wave Kw + 16 kb + 4 lg; LDS or global); qf: the tiles' operands, requested earlier; the
+// operands of step t4 + 4 are requested into qf behind the MFMAs; wave w reduces tile t4 + w.  bias16: the 16 outputs' biases
+// (LDS or global; null: none).  One 16-KB parking area per workgroup (six workgroups per CU must keep fitting the LDS).
+template <int G>
+__device__ __forceinline__ void l0_step(const float* pw, const float* xq, int ldx, f32x4 (&qf)[4][G], int t4, int T, const float* bias16, bool relu,
+                                        float* Y, int ldy, int out0, float* park, bool first) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  f32x4 acc[4], pf[G];
+#pragma unroll
+  for (int kb = 0; kb < G; ++kb) pf[kb] = *reinterpret_cast<const f32x4*>(pw + kb * 16);      // (re-read per step: 8 VGPRs the 80-register budget does not have)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < G; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[j] = DQN_MFMA(pf[kb][s], qf[j][kb][s], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int kb = 0; kb < G; ++kb)
+      qf[j][kb] = *reinterpret_cast<const f32x4*>(xq + (size_t)(t4 + 4 + j < T ? t4 + 4 + j : T - 1) * 16 * ldx + kb * 16);   // (beyond the last tile: a valid row, unused)
+  f32x4* pk = reinterpret_cast<f32x4*>(park);
+  if (!first) __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pk[(j * 4 + wave) * 64 + lane] = acc[j];
+  __syncthreads();
+  if (t4 + wave < T) {
+    const f32x4* pj = pk + wave * 256;
+    const f32x4 a0 = pj[lane], a1 = pj[64 + lane], a2 = pj[128 + lane], a3 = pj[192 + lane];
+    f32x4 o;
+    o.x = (a0.x + a1.x) + (a2.x + a3.x); o.y = (a0.y + a1.y) + (a2.y + a3.y);
+    o.z = (a0.z + a1.z) + (a2.z + a3.z); o.w = (a0.w + a1.w) + (a2.w + a3.w);
+    if (bias16 != nullptr) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(bias16 + lg * 4);
+      o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w;
+    }
+    if (relu) { o.x = lrelu_fwd(o.x); o.y = lrelu_fwd(o.y); o.z = lrelu_fwd(o.z); o.w = lrelu_fwd(o.w); }
+    *reinterpret_cast<f32x4*>(Y + (size_t)((t4 + wave) * 16 + li) * ldy + out0 + (lg << 2)) = o;
+  }
+}
 template <int G>
 struct FirstLayerWork {
   const AdamArgs& a; const FirstLayerRider& r; const int blk; float* sW; float* sB; float* park;
@@ -1460,43 +1504,9 @@ struct FirstLayerWork {
 #pragma unroll
       for (int kb = 0; kb < G; ++kb) qf[j][kb] = *reinterpret_cast<const f32x4*>(xq + (size_t)(j < T ? j : T - 1) * 16 * r.ldx + kb * 16);
     __syncthreads();
-    // the layer: outputs [16 blk, +16) x every row (fwd_direct_body's arithmetic, element for element), four row tiles per step:
-    // wave w reduces tile 4 t4 + w
+    // the layer: outputs [16 blk, +16) x every row, four row tiles per step (l0_step)
     const float* pw = sW + li * r.Kp + wave * Kw + lg * 4;
-    for (int t4 = 0; t4 < T; t4 += 4) {
-      f32x4 acc[4], pf[G];
-#pragma unroll
-      for (int kb = 0; kb < G; ++kb) pf[kb] = *reinterpret_cast<const f32x4*>(pw + kb * 16);      // (re-read per step: 8 VGPRs the 80-register budget does not have)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < G; ++kb)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) acc[j] = DQN_MFMA(pf[kb][s], qf[j][kb][s], acc[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int kb = 0; kb < G; ++kb)
-          qf[j][kb] = *reinterpret_cast<const f32x4*>(xq + (size_t)(t4 + 4 + j < T ? t4 + 4 + j : T - 1) * 16 * r.ldx + kb * 16);   // (beyond the last tile: a valid row, unused)
-      f32x4* pk = reinterpret_cast<f32x4*>(park);
-      if (t4 > 0) __syncthreads();          // (one 16-KB parking area: six workgroups per CU must keep fitting the LDS)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pk[(j * 4 + wave) * 64 + lane] = acc[j];
-      __syncthreads();
-      if (t4 + wave < T) {
-        const f32x4* pj = pk + wave * 256;
-        const f32x4 a0 = pj[lane], a1 = pj[64 + lane], a2 = pj[128 + lane], a3 = pj[192 + lane];
-        f32x4 o;
-        o.x = (a0.x + a1.x) + (a2.x + a3.x); o.y = (a0.y + a1.y) + (a2.y + a3.y);
-        o.z = (a0.z + a1.z) + (a2.z + a3.z); o.w = (a0.w + a1.w) + (a2.w + a3.w);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(sB + lg * 4);
-        o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w;
-        o.x = lrelu_fwd(o.x); o.y = lrelu_fwd(o.y); o.z = lrelu_fwd(o.z); o.w = lrelu_fwd(o.w);
-        *reinterpret_cast<f32x4*>(r.Y + (size_t)((t4 + wave) * 16 + li) * r.ldy + blk * 16 + (lg << 2)) = o;
-      }
-    }
+    for (int t4 = 0; t4 < T; t4 += 4) l0_step<G>(pw, xq, r.ldx, qf, t4, T, sB, true, r.Y, r.ldy, blk * 16, park, t4 == 0);
   }
 };
 template <int G>
@@ -1514,6 +1524,138 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
     return;
   }
   adam_soft_body<1, 0, true>(a, (int)blockIdx.x - r.blocks, (int)gridDim.x - r.blocks, s);
+}
+
+// ... with the NEXT update's gather in the same launch (multi-update graphs, round 5: the gather moves from the update's last launch
+// to this one, so that the next update's first-layer inputs are complete BEFORE the actor's optimiser launch — k_adam_soft_l0)
+template <int G>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_adam_soft_fwd1_gather(AdamArgs a, FirstLayerRider r, GatherArgs g) {
+  __shared__ float s[8];
+  __shared__ __attribute__((aligned(16))) float sW[16 * 64 * G];
+  __shared__ __attribute__((aligned(16))) float sB[16];
+  __shared__ __attribute__((aligned(16))) float park[4096];
+  const int b = (int)blockIdx.x;
+  if (b < r.blocks) {
+    FirstLayerWork<G> work(a, r, b, sW, sB, park);
+    work.request();
+    adam_scalars<true>(a, -1, s);
+    work.run(s[4], s[5], s[6] != 0.0f, s[7] == 0.0f);
+    return;
+  }
+  if (b < r.blocks + g.blocks) { gather_block(g, b - r.blocks); return; }
+  adam_soft_body<1, 0, true>(a, b - r.blocks - g.blocks, (int)gridDim.x - r.blocks - g.blocks, s);
+}
+
+// ---- the NEXT update's four first tower layers inside the actor's optimiser launch (round 5) -------------------------------------
+// With the next update's minibatch panels gathered one launch group earlier (above; the two panels this update still reads exist
+// twice), nothing but the actor's own step stands between this launch and the next update's first GEMM launch
+// (first_layers_launch).  The workgroups that own 16 rows of the ACTOR's W1 take the step in registers — which also gives them
+// the target actor's soft-updated rows — and run actor(s) and actor_target(s') for those outputs (ActorL0); critic(s, a)'s first
+// layer and the state half of critic_target's read weights that have been final since the critic's step: plain riders (PlainL0).
+// Every element as fwd_direct_body computes it.  The next update then starts at its second layer.
+struct ActorL0 {
+  const float* Xs; const float* Xn; int ldx;   // the next update's state / next-state panels [rows][64]
+  float* Ys; float* Yn; int ldy;               // actor(s), actor_target(s') first-layer activations
+  int rows, N;                                 // Kp = 64 (one float4 of W1 per rider thread)
+  int blocks;                                  // N / 16
+};
+struct PlainL0 {
+  const float* W; int ldw; const float* bias;  // [N][ldw]; bias null: none (and no ReLU: a partial pre-activation)
+  const float* X; int ldx; float* Y; int ldy;
+  int rows, Kred, N;                           // Kred = 64 or 128 (<= ldw)
+  float* xcopy_dst; int xcopy_col, xcopy_n;    // GemmProblem::xcopy_dst (null: none)
+  int blocks;                                  // N / 16
+};
+struct ActorL0Work {
+  const AdamArgs& a; const ActorL0& r; const int blk; float* sW; float* sB; float* park;
+  __device__ __forceinline__ ActorL0Work(const AdamArgs& a_, const ActorL0& r_, int blk_, float* sW_, float* sB_, float* park_)
+      : a(a_), r(r_), blk(blk_), sW(sW_), sB(sB_), park(park_) {}
+  f32x4 g, m, v, w, wt, qs[4][1], qn[4][1];
+  float bg, bm, bv, bw, bwt;
+  __device__ __forceinline__ size_t widx() const { return (size_t)blk * 256 + threadIdx.x; }
+  __device__ __forceinline__ size_t bidx() const { return (size_t)r.N * 64 + (size_t)blk * 16 + threadIdx.x; }
+  __device__ __forceinline__ void request() {
+    const size_t i = widx();
+    g = reinterpret_cast<const f32x4*>(a.g)[i]; m = reinterpret_cast<const f32x4*>(a.m)[i];
+    v = reinterpret_cast<const f32x4*>(a.v)[i]; w = reinterpret_cast<const f32x4*>(a.w)[i]; wt = reinterpret_cast<const f32x4*>(a.wt)[i];
+    if (threadIdx.x < 16) { const size_t j = bidx(); bg = a.g[j]; bm = a.m[j]; bv = a.v[j]; bw = a.w[j]; bwt = a.wt[j]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int T = r.rows >> 4;
+    const size_t x0 = (size_t)li * r.ldx + wave * 16 + lg * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t x = x0 + (size_t)(j < T ? j : T - 1) * 16 * r.ldx;
+      qs[j][0] = *reinterpret_cast<const f32x4*>(r.Xs + x);
+    }
+  }
+  __device__ __forceinline__ void run(float scale, float step, bool soft, bool apply) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int T = r.rows >> 4;
+    if (apply) {
+      adam_apply4(a, scale, step, soft, g, m, v, w, wt);
+      if (threadIdx.x < 16) adam_apply1(a, scale, step, soft, bg, bm, bv, bw, bwt);
+      const size_t i = widx();
+      reinterpret_cast<f32x4*>(a.m)[i] = m; reinterpret_cast<f32x4*>(a.v)[i] = v; reinterpret_cast<f32x4*>(a.w)[i] = w;
+      if (soft) reinterpret_cast<f32x4*>(a.wt)[i] = wt;
+      if (threadIdx.x < 16) { const size_t j = bidx(); a.m[j] = bm; a.v[j] = bv; a.w[j] = bw; if (soft) a.wt[j] = bwt; }
+    }
+    reinterpret_cast<f32x4*>(sW)[threadIdx.x] = w; reinterpret_cast<f32x4*>(sW)[256 + threadIdx.x] = wt;
+    if (threadIdx.x < 16) { sB[threadIdx.x] = bw; sB[16 + threadIdx.x] = bwt; }
+    const float* xs = r.Xs + (size_t)li * r.ldx + wave * 16 + lg * 4;
+    const float* xn = r.Xn + (size_t)li * r.ldx + wave * 16 + lg * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qn[j][0] = *reinterpret_cast<const f32x4*>(xn + (size_t)(j < T ? j : T - 1) * 16 * r.ldx);   // (behind the step's stores, whose registers they take over)
+    __syncthreads();
+    const float* pw = sW + li * 64 + wave * 16 + lg * 4;
+    for (int t4 = 0; t4 < T; t4 += 4) {      // the two nets take turns: each one's next operands are in flight under the other's step
+      l0_step<1>(pw, xs, r.ldx, qs, t4, T, sB, true, r.Ys, r.ldy, blk * 16, park, t4 == 0);
+      l0_step<1>(pw + 16 * 64, xn, r.ldx, qn, t4, T, sB + 16, true, r.Yn, r.ldy, blk * 16, park, false);
+    }
+  }
+};
+template <int G>
+__device__ __forceinline__ void plain_l0_run(const PlainL0& p, int blk, float* park) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  const int Kw = 16 * G, T = p.rows >> 4;
+  const float* xq = p.X + (size_t)li * p.ldx + wave * Kw + lg * 4;
+  f32x4 qf[4][G];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int kb = 0; kb < G; ++kb) qf[j][kb] = *reinterpret_cast<const f32x4*>(xq + (size_t)(j < T ? j : T - 1) * 16 * p.ldx + kb * 16);
+  if (p.xcopy_dst != nullptr && threadIdx.x < 16) {
+    const float* src = p.W + (size_t)(blk * 16 + threadIdx.x) * p.ldw + p.xcopy_col;
+    for (int j = 0; j < p.xcopy_n; ++j) p.xcopy_dst[(size_t)j * p.N + blk * 16 + threadIdx.x] = src[j];
+  }
+  const float* pw = p.W + (size_t)(blk * 16 + li) * p.ldw + wave * Kw + lg * 4;
+  const float* b16 = p.bias != nullptr ? p.bias + blk * 16 : nullptr;
+  for (int t4 = 0; t4 < T; t4 += 4) l0_step<G>(pw, xq, p.ldx, qf, t4, T, b16, p.bias != nullptr, p.Y, p.ldy, blk * 16, park, t4 == 0);
+}
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_adam_soft_l0(AdamArgs a, ActorL0 ra, PlainL0 p0, PlainL0 p1) {
+  __shared__ float s[8];
+  __shared__ double sq[4];
+  __shared__ __attribute__((aligned(16))) float sW[2 * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float sB[32];
+  __shared__ __attribute__((aligned(16))) float park[4096];
+  int b = (int)blockIdx.x;
+  if (b < ra.blocks) {
+    ActorL0Work work(a, ra, b, sW, sB, park);
+    work.request();
+    adam_scalars<true>(a, -1, s);
+    work.run(s[4], s[5], s[6] != 0.0f, s[7] == 0.0f);
+    return;
+  }
+  b -= ra.blocks;
+  if (b < p0.blocks) { if (p0.Kred == 64) plain_l0_run<1>(p0, b, park); else plain_l0_run<2>(p0, b, park); return; }
+  b -= p0.blocks;
+  if (b < p1.blocks) { if (p1.Kred == 64) plain_l0_run<1>(p1, b, park); else plain_l0_run<2>(p1, b, park); return; }
+  b -= p1.blocks;
+  adam_soft_body<1, 0, true>(a, b, (int)gridDim.x - ra.blocks - p0.blocks - p1.blocks, s);
+  if (a.tick_on && b == 0) {
+    const bool skipped = s[7] != 0.0f;
+    __syncthreads();
+    tick_body(a.tick, s, sq, skipped);
+  }
 }
 
 // Sum of up to 8 co-located gradient arenas in rank order, written back to all (dqnhip_reduce_gradients_local)

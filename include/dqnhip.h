@@ -135,6 +135,10 @@ typedef struct dqnhip_config {
  * action half applied by the target actor's head kernel (round 5).  critic_target's first layer then differs by fp32 round-off
  * (another summation order); everything else is the same arithmetic. */
 #define DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS 64
+/* fp32 learner, multi-update graphs (dqnhip_update_async_n): the next update's gather in the update's LAST launch and its four first
+ * layers in a launch of their own (rounds 3-5), instead of the gather in the critic's optimiser launch and the first layers as riders
+ * of the actor's optimiser launch (round 5).  Same bits. */
+#define DQNHIP_TUNE_LATE_GATHER 128
 
 typedef struct dqnhip_learner* dqnhip_handle;
 

@@ -292,3 +292,28 @@ def test_critic_first_layers_merged_equal_their_own_launch(pkg, gpu, B, hidden, 
     for net, (x, y) in enumerate(zip(wa, wb)):
         dd = np.abs(x - y)
         assert dd.max() <= 2 * 3 * lr[net] + 1e-7 and dd.mean() <= 0.01 * lr[net] + 1e-9, (net, dd.max(), dd.mean())
+
+
+@pytest.mark.parametrize("B,hidden,S,n", [
+    (256, (1024, 1024, 1024, 1024), 58, 35),   # BASELINE configs[1]: two full graphs + three single updates
+    (64, (256, 128, 64, 64), 59, 16),          # the reference-like small tower, one graph
+    (32, (1024, 512, 256, 128), 59, 20),       # the reference's defaults
+    (256, (1024, 1024), 68, 17),               # S = 68: the actor's panel is 128 wide -> both sides gather late (identical)
+])
+def test_early_gather_and_next_update_first_layers_equal_the_late_form(pkg, gpu, B, hidden, S, n):
+    """fp32 learner, dqnhip_update_async_n: the next update's gather in the critic's optimiser launch and its four first layers as
+    riders of the actor's optimiser launch (k_adam_soft_fwd1_gather / k_adam_soft_l0, default) against the gather in the update's
+    last launch and the first layers in a launch of their own (DQNHIP_TUNE_LATE_GATHER).  The same arithmetic on the same
+    values, two minibatch panels by update parity: every parameter, Adam moment and statistic bit-identical."""
+    out = []
+    for tuning in (0, pkg.capi.TUNE_LATE_GATHER):
+        d = pkg.DQN(S, minibatch=B, hidden=hidden, memory=4096, seed=11, tuning=tuning, use_graph=True)
+        d.add_transitions_arrays(*synth_replay(np.random.default_rng(2), 3000, S))
+        d.update_async_n(n)
+        st = d.read_stats()
+        w = [d.get_params(k) for k in range(4)] + [d.get_params(k, kind) for k in (0, 1) for kind in (pkg.KIND_M, pkg.KIND_V)]
+        out.append((st, w, (d.actor_iter(), d.critic_iter())))
+        d.close()
+    assert out[0][0] == out[1][0] and out[0][2] == out[1][2] == (n, n)
+    for x, y in zip(out[0][1], out[1][1]):
+        np.testing.assert_array_equal(x, y)
