@@ -809,7 +809,7 @@ def main():
                                           "global-minibatch updates" if args.strong else "minibatch-%d updates" % B)) if use_dp else
                                       ("replicas x%d" % world if world > 1 else "single"),
                        "hip_graph": (not args.no_graph) and (not use_dp or (native and dqn.dp_graph_active())), "prewarm_updates": prewarm,
-                       "enqueue": ("%s(K): K updates in one call, replayed sixteen per hipGraph launch, each gather riding in the previous update's last launch"
+                       "enqueue": ("%s(K): K updates in one call, replayed sixteen per hipGraph launch, each update's gather and first tower layers riding in the previous update's optimiser launches"
                                    % ("dqnhip_dp_update_n" if use_dp else "dqnhip_update_async_n") if batched_enqueue
                                    else "one call (one hipGraph launch) per update"),
                        **({"ms_per_step_one_update_per_graph_launch": round(one_per_launch_ms, 5)} if one_per_launch_ms else {}),

@@ -1,6 +1,6 @@
 """dqnhip_update_async_n: n updates with on-device sampling in one call — the reference's inner loops
 `for (i < n_updates) dqn->Update()` (src/dqn_main.cpp:359-361) and DQN::Benchmark (src/dqn.cpp:487-498).  With use_graph
-the updates are replayed sixteen to a hipGraph launch (the gather of update u + 1 riding in update u's last launch); whatever the grouping, the state must be exactly what n single calls
+the updates are replayed sixteen to a hipGraph launch (the gather and the first layers of update u + 1 riding in update u's two optimiser launches); whatever the grouping, the state must be exactly what n single calls
 leave."""
 import numpy as np
 import pytest
