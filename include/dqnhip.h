@@ -190,7 +190,8 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host);
  * dqn->Update()` (src/dqn_main.cpp:359-361) and DQN::Benchmark (src/dqn.cpp:487-498) as ONE call.  Exactly the
  * state n calls of dqnhip_update_async(h, NULL) leave (bit for bit); with use_graph the updates are replayed
  * sixteen to a hipGraph launch: the GPU idles ~8 us between two graph launches, and inside such a graph the minibatch
- * gather of update u + 1 rides in update u's last launch instead of heading the next chain (~5 us). */
+ * gather and the four first tower layers of update u + 1 ride in update u's two optimiser launches instead of heading the
+ * next chain (~12 us; DQNHIP_TUNE_LATE_GATHER: the gather alone, in update u's last launch). */
 int dqnhip_update_async_n(dqnhip_handle h, int32_t n);
 
 /* Data-parallel form of the same update, cut at its two exchange points:
