@@ -1037,7 +1037,8 @@ __device__ __forceinline__ void bwd_seq_block(const GemmBatch& batch, const int 
   int tile_p, tile_q;
   // wgrad first (measured 14.9 us; dgrad first 15.3, also with the wgrad ring pre-issued under the
   // dgrad epilogue; round 5: wgrad first with the dgrad tile's first operand requests issued BEFORE the wgrad tile parks /
-  // reduces / stores — 15.0-15.1 against 14.7 us: the epilogue's stores queue behind the requests)
+  // reduces / stores — 15.0-15.1 against 14.7 us; the same requests issued before the WHOLE wgrad tile — 14.9: three cold loads
+  // in flight do not pay for the registers and wait counts they hold through the other tile)
   const GemmProblem& pw = batch.prob[1];
   if (b < pw.tiles_p * pw.tiles_q) {
     tile_of_problem(pw, b, tile_p, tile_q);
