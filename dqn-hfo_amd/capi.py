@@ -16,6 +16,9 @@ TUNE_SEPARATE_Q_TRAIN = 16
 TUNE_SEPARATE_FIRST_LAYER = 32
 TUNE_SEPARATE_CRITIC_FIRST_LAYERS = 64
 TUNE_LATE_GATHER = 128
+# dqnhip_update_plan.forms bits (DQNHIP_PLAN_*), in bit order
+PLAN_FORMS = ("fp16", "data_parallel", "bwd_shifted_critic", "bwd_shifted_actor", "head_wgrad_rides_critic", "head_wgrad_rides_actor",
+              "q_train_in_dgrad", "head_seed_fused", "dqda_head_bwd", "critic_l0_rides", "first_layers_merged", "early_gather_l0")
 ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET = 0, 1, 2, 3
 KIND_W, KIND_M, KIND_V, KIND_G = 0, 1, 2, 3
 
@@ -34,6 +37,12 @@ class Config(C.Structure):
         ("grad_arena_bytes", C.c_size_t), ("precision", C.c_int32), ("loss_scale", C.c_float),
         ("tuning_flags", C.c_int32),
     ]
+
+
+class UpdatePlan(C.Structure):
+    """struct dqnhip_update_plan (include/dqnhip.h)."""
+    _fields_ = [("struct_size", C.c_int32), ("forms", C.c_int32), ("launches_single", C.c_int32), ("launches_graph_first", C.c_int32),
+                ("launches_in_graph", C.c_int32), ("updates_per_graph", C.c_int32), ("collectives", C.c_int32), ("reserved", C.c_int32)]
 
 
 fp = C.POINTER(C.c_float)
@@ -57,6 +66,7 @@ SIGNATURES = {
     "dqnhip_update_abort": (C.c_int, [H]),
     "dqnhip_apply_update": (C.c_int, [H, C.c_int32]),
     "dqnhip_apply_update_sharded": (C.c_int, [H, C.c_int32, C.c_int32]),
+    "dqnhip_get_update_plan": (C.c_int, [H, C.POINTER(UpdatePlan)]),
     "dqnhip_grad_buffer": (C.c_int, [H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "dqnhip_read_stats": (C.c_int, [H, fp, fp]),
     "dqnhip_dp_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),

@@ -281,12 +281,24 @@ DQN::DQN(caffe::SolverParameter& actor_solver_param, caffe::SolverParameter& cri
 // rank 0's weights, Adam history and iterations, taken at the next Update() / UpdateActorCritic(): the first point every rank
 // passes in the same order.  The flag is also set by the constructor, so the FIRST update of every rank broadcasts whether or not
 // that rank restored anything (symmetric: one rank with a snapshot and one without still meet in the same collective).
+// That broadcast is symmetric only BEFORE the first update: afterwards a Restore* / Load* on one rank alone would arm it on that rank
+// alone (a collective with no peer), and ranks may pass Update() a different number of times per episode.  So after the group's
+// first update these four calls are refused on a data-parallel learner (RearmReplicaSync): restore before training starts, on every
+// rank alike — what the reference's driver does (src/dqn_main.cpp:268-282).
 void DQN::SyncReplicasIfPending() {
   if (!dp_ || !dp_sync_pending_) return;
   LOG(INFO) << "[Agent" << tid_ << "] data-parallel: re-synchronising the replicas from rank 0 (weights, Adam history, iterations)";
   DQNHIP_CK(dqnhip_dp_broadcast_params(h_, 0));
   dp_sync_pending_ = false;
+  dp_synced_once_ = true;
   last_snapshot_iter_ = max_iter();
+}
+void DQN::RearmReplicaSync(const char* what) {
+  if (!dp_) return;
+  if (dp_synced_once_)
+    LOG(FATAL) << "[Agent" << tid_ << "] " << what << " on a data-parallel learner after its first Update(): the re-synchronising broadcast is a "
+               << "collective that only this rank would enter.  Restore / load before the first update, with the same calls on every rank.";
+  dp_sync_pending_ = true;
 }
 
 DQN::~DQN() { DQNHIP_CK(dqnhip_destroy(h_)); }
@@ -308,10 +320,10 @@ void DQN::Benchmark(int iterations) {
   LOG(INFO) << "*** Benchmark ends ***";
 }
 
-void DQN::RestoreActorSolver(const std::string& f) { DQNHIP_CK(dqnhip_solver_restore(h_, DQNHIP_ACTOR, f.c_str())); last_snapshot_iter_ = max_iter(); dp_sync_pending_ = dp_; }
-void DQN::RestoreCriticSolver(const std::string& f) { DQNHIP_CK(dqnhip_solver_restore(h_, DQNHIP_CRITIC, f.c_str())); last_snapshot_iter_ = max_iter(); dp_sync_pending_ = dp_; }
-void DQN::LoadActorWeights(const std::string& f) { DQNHIP_CK(dqnhip_load_caffemodel(h_, DQNHIP_ACTOR, f.c_str())); dp_sync_pending_ = dp_; }
-void DQN::LoadCriticWeights(const std::string& f) { DQNHIP_CK(dqnhip_load_caffemodel(h_, DQNHIP_CRITIC, f.c_str())); dp_sync_pending_ = dp_; }
+void DQN::RestoreActorSolver(const std::string& f) { RearmReplicaSync("RestoreActorSolver"); DQNHIP_CK(dqnhip_solver_restore(h_, DQNHIP_ACTOR, f.c_str())); last_snapshot_iter_ = max_iter(); }
+void DQN::RestoreCriticSolver(const std::string& f) { RearmReplicaSync("RestoreCriticSolver"); DQNHIP_CK(dqnhip_solver_restore(h_, DQNHIP_CRITIC, f.c_str())); last_snapshot_iter_ = max_iter(); }
+void DQN::LoadActorWeights(const std::string& f) { RearmReplicaSync("LoadActorWeights"); DQNHIP_CK(dqnhip_load_caffemodel(h_, DQNHIP_ACTOR, f.c_str())); }
+void DQN::LoadCriticWeights(const std::string& f) { RearmReplicaSync("LoadCriticWeights"); DQNHIP_CK(dqnhip_load_caffemodel(h_, DQNHIP_CRITIC, f.c_str())); }
 void DQN::LoadReplayMemory(const std::string& f) {
   LOG(INFO) << "Loading replay memory from " << f;
   DQNHIP_CK(dqnhip_load_replay_memory(h_, f.c_str()));

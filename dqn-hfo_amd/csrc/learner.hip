@@ -326,23 +326,50 @@ int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
   return 0;
 }
 
+// ---- the plan: which merged forms this learner's update takes ------------------------------------------------------------------
+// ONE place decides (every predicate the launch sequence below branches on), run_phase / run_phase16 read it, and
+// dqnhip_get_update_plan reports it together with the launch counts of a captured update: a predicate that silently stops matching at a
+// BASELINE shape is a red test (tests/test_gpu_update_plan.py), not a slower bench.  A pure function of the learner's state (shapes,
+// tuning flags, sharing, data-parallel mode): evaluated per call, never cached, so there is no stale copy to invalidate.
+UpdatePlan plan_of(const H* h) {
+  const NetLayout &la = h->la, &lc = h->lc;
+  const int B = h->B, L = h->L, Hh = la.dims[L], Hc = lc.dims[L];
+  const int tf = h->cfg.tuning_flags;
+  UpdatePlan p{};
+  p.fp16 = h->fp16;
+  p.dp = h->cfg.dp_world > 1 || h->dp_half || h->dp_shard;     // (a one-rank group with bf16 exchange / a sharded optimiser runs the N-rank code path)
+  p.fused_seed = !(tf & DQNHIP_TUNE_SEPARATE_HEAD_SEED);
+  if (h->fp16) return p;                                         // (the fp16 learner's merged forms: run_phase16)
+  p.shifted_c = bwd_is_shifted(h, lc, B); p.shifted_a = bwd_is_shifted(h, la, B);
+  // the head's own dW / db ride in the net's last backward launch (the first layer's narrow wgrad)
+  p.head_rides_c = !head_big_ok(h, B, Hc) && head_wgrad_can_ride(lc, B);
+  p.head_rides_a = !head_big_ok(h, B, Hh) && head_wgrad_can_ride(la, B);
+  // Step(1)'s head arithmetic inside the critic's top-layer dgrad launch (k_dgrad_qtrain; one 16-column piece per lane: H / 16 <= 64)
+  p.fuse_q = h->U3 != nullptr && !(tf & DQNHIP_TUNE_SEPARATE_Q_TRAIN) && p.head_rides_c && p.shifted_c && Hc >= 512 && Hc <= 1024 && Hc % 256 == 0;
+  // dQ/da's last step, the inverting gradients and the actor heads' backward in ONE launch (k_dqda_head_bwd): 16 columns from the first
+  // action column inside the panel row, H a multiple of 256, fewer than 1024 rows
+  p.fuse_head = p.head_rides_a && !(tf & DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) && B % 16 == 0 && B < 1024 && Hh % 256 == 0 &&
+                h->S + 16 <= lc.kp[0] && L >= 1 && lc.dims[1] % 64 == 0;
+  // the first layer of critic(s, mu(s)) rides in the critic's optimiser launch (FirstLayerRider).  Data-parallel learners too (round 6):
+  // the launch sits behind the critic's exchange point, its norm then comes from k_sumsq's partials; only a SHARDED optimiser — whose
+  // pass covers 1/N of the arena — keeps the launch of its own
+  p.critic_l0 = !h->dp_shard && h->shared_fl[DQNHIP_CRITIC] == 0 && !(tf & DQNHIP_TUNE_SEPARATE_FIRST_LAYER) &&
+                (lc.kp[0] == 64 || lc.kp[0] == 128) && lc.dims[1] % 16 == 0 && B % 16 == 0 && B <= 512 && L >= 2 && lc.w_off[0] == 0 &&
+                lc.b_off[0] == (size_t)lc.dims[1] * lc.kp[0];
+  // Step(1)'s four first layers in one launch, critic_target's action half in the target actor's head kernel (first_layers_launch)
+  p.first_layers_merged = h->Zs != nullptr && !(tf & DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS) && L >= 2 && B % 32 == 0 && B < 1024 && la.kp[0] < 512 &&
+                          lc.kp[0] < 512 && la.dims[1] % 64 == 0 && lc.dims[1] % 64 == 0 && lc.dims[1] <= 1024 && round_up(h->S, 64) <= lc.kp[0];
+  // inside a multi-update graph: the next update's gather rides in the critic's optimiser launch and its four first layers in the
+  // actor's (k_adam_soft_fwd1_gather / k_adam_soft_l0).  Needs every piece those riders stand on.
+  p.early_l0 = h->Xa_s2[1] != nullptr && !(tf & DQNHIP_TUNE_LATE_GATHER) && p.critic_l0 && p.first_layers_merged && h->shared_fl[DQNHIP_ACTOR] == 0 &&
+               la.kp[0] == 64 && la.dims[1] % 16 == 0 && la.w_off[0] == 0 && la.b_off[0] == (size_t)la.dims[1] * la.kp[0];
+  return p;
+}
+// ... while a multi-update graph is being captured (cap_u: the position of the update in it)
+inline bool early_l0(const H* h) { return h->cap_u >= 0 && plan_of(h).early_l0; }
+
 // The gather of one update (src/dqn.cpp:846-887).  pos: -1 outside multi-update graphs; else the update's position in the
 // graph being captured (0: a launch of its own that also stores DevState::gbase; k >= 1: rides in update k-1's last launch)
-// Inside a multi-update graph (cap_u >= 0): does the next update's gather ride in the critic's optimiser launch and do its four first
-// layers ride in the actor's (k_adam_soft_fwd1_gather / k_adam_soft_l0)?  Needs every piece those riders stand on.
-bool first_layers_merged(const H* h);
-inline bool critic_l0_rides(const H* h, bool dp) {
-  const NetLayout& lc = h->lc;
-  return !dp && !h->fp16 && h->shared_fl[DQNHIP_CRITIC] == 0 && !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_FIRST_LAYER) &&
-         (lc.kp[0] == 64 || lc.kp[0] == 128) && lc.dims[1] % 16 == 0 && h->B % 16 == 0 && h->B <= 512 && h->L >= 2 && lc.w_off[0] == 0 &&
-         lc.b_off[0] == (size_t)lc.dims[1] * lc.kp[0];
-}
-bool early_l0(const H* h) {
-  const NetLayout& la = h->la;
-  const bool dp = h->cfg.dp_world > 1 || h->dp_half || h->dp_shard;
-  return h->cap_u >= 0 && h->Xa_s2[1] != nullptr && !(h->cfg.tuning_flags & DQNHIP_TUNE_LATE_GATHER) && critic_l0_rides(h, dp) && first_layers_merged(h) &&
-         h->shared_fl[DQNHIP_ACTOR] == 0 && la.kp[0] == 64 && la.dims[1] % 16 == 0 && la.w_off[0] == 0 && la.b_off[0] == (size_t)la.dims[1] * la.kp[0];
-}
 GatherArgs gather_args(H* h, const int* idx_dev, int pos) {
   const NetLayout &la = h->la, &lc = h->lc;
   GatherArgs g{};
@@ -442,17 +469,20 @@ int sumsq_launch(H* h, int net, size_t begin, size_t end) {
   HIPCHK(hipGetLastError());
   return 0;
 }
-// the optimiser step of one net inside a data-parallel update (phase 1: critic, phase 2: actor + bookkeeping)
-int dp_optimiser_step(H* h, hipStream_t st, int net, float* tail, const TickArgs* tick) {
+// the optimiser step of one net inside a data-parallel update (phase 1: critic, phase 2: actor + bookkeeping); fl / early_gather /
+// next_l0: the riders of adam_launch (replicated optimiser only: a sharded pass covers 1/N of the arena)
+int dp_optimiser_step(H* h, hipStream_t st, int net, float* tail, const TickArgs* tick, const FirstLayerRider* fl = nullptr,
+                      const GatherArgs* early_gather = nullptr, const NextL0* next_l0 = nullptr) {
   const NetLayout& l = layout_of(h, net);
   if (h->dp_shard) {
+    if (fl || early_gather || next_l0) return fail("internal: riders in a sharded optimiser launch");
     // the exchange left this rank's slice of the reduced gradient in place and the group's sum of squares in tail[3]
     size_t lo, hi; shard_range(h, net, lo, hi);
     RC(adam_launch(h, st, net, tail + 3, 1, lo, hi, tick));
     return dp_allgather_weights(h, net);
   }
   RC(sumsq_launch(h, net));
-  return adam_launch(h, st, net, h->part_dp, h->n_part_dp, 0, l.arena, tick);
+  return adam_launch(h, st, net, h->part_dp, h->n_part_dp, 0, l.arena, tick, true, fl, early_gather, next_l0);
 }
 
 // ---- mixed-precision building blocks (hgemm.hip.h) --------------------------------------------
@@ -590,7 +620,8 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
 int run_phase16(H* h, int phase, const int* idx_dev) {
   const int B = h->B, L = h->L;
   const NetLayout &la = h->la, &lc = h->lc;
-  const bool dp = h->cfg.dp_world > 1 || h->dp_half || h->dp_shard;     // (a one-rank group with bf16 exchange / a sharded optimiser runs the N-rank code path)
+  const UpdatePlan P = plan_of(h);
+  const bool dp = P.dp;
   const float inv_batch = 1.0f / (float)(B * h->cfg.dp_world);
   float* actor_tail = (h->dp_half || h->dp_shard) ? h->dp_tails + 4 : h->g[0] + la.arena;
   float* critic_tail = (h->dp_half || h->dp_shard) ? h->dp_tails : h->g[1] + lc.arena;
@@ -659,7 +690,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     // As on the fp32 path: the seed of the dq = -1 pass comes out of the top layer's forward epilogue (HGemm::seed_w, the
     // scaled fp16 panel the dgrad chain reads) and q(s, mu(s)) rides in a later launch-floor launch — here the actor heads'
     // backward (HeadBwdArgs::qr_*).  DQNHIP_TUNE_SEPARATE_HEAD_SEED: the head-backward launch of their own.
-    const bool fused_seed = !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_HEAD_SEED);
+    const bool fused_seed = P.fused_seed;
     for (int i = 0; i < L; ++i) {
       HGemm g = fwd16_problem(h, 4, DQNHIP_CRITIC, B, i);
       if (fused_seed && i == L - 1) { g.seed_w = wat(h, DQNHIP_CRITIC, lc.hw_off); g.CS16 = h->dZ16[1][L]; g.ldcs16 = Hc; g.seed_scale = h->ls_q; }
@@ -735,22 +766,13 @@ int first_layers_launch(H* h, hipStream_t st, int rows, bool with_actor) {
   HIPCHK((fwd_direct_launch<4, 2>(b, st)));
   return 0;
 }
-bool first_layers_merged(const H* h) {
-  const NetLayout &la = h->la, &lc = h->lc;
-  return h->Zs != nullptr && !h->fp16 && !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS) && h->L >= 2 &&
-         h->B % 32 == 0 && h->B < 1024 && la.kp[0] < 512 && lc.kp[0] < 512 && la.dims[1] % 64 == 0 && lc.dims[1] % 64 == 0 && lc.dims[1] <= 1024 &&
-         round_up(h->S, 64) <= lc.kp[0];
-}
-
 int run_phase(H* h, int phase, const int* idx_dev) {
-  {   // the current update's copies of the two double-buffered panels (early_l0: by update parity inside a multi-update graph)
-    const int par = early_l0(h) ? (h->cap_u & 1) : 0;
-    h->Xa_s = h->Xa_s2[par]; h->Xc_pl = h->Xc_pl2[par]; h->act[1][0] = h->Xa_s; h->act[4][0] = h->Xc_pl;
-  }
+  const UpdatePlan P = plan_of(h);
+  select_panels(h, early_l0(h) ? (h->cap_u & 1) : 0);
   if (h->fp16) return run_phase16(h, phase, idx_dev);
   const int B = h->B, L = h->L;
   const NetLayout &la = h->la, &lc = h->lc;
-  const bool dp = h->cfg.dp_world > 1 || h->dp_half || h->dp_shard;     // (a one-rank group with bf16 exchange / a sharded optimiser runs the N-rank code path)
+  const bool dp = P.dp;
   const float inv_batch = 1.0f / (float)(B * h->cfg.dp_world);
   float* actor_tail = (h->dp_half || h->dp_shard) ? h->dp_tails + 4 : h->g[0] + la.arena;
   float* critic_tail = (h->dp_half || h->dp_shard) ? h->dp_tails : h->g[1] + lc.arena;
@@ -783,8 +805,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     hA.out16 = h->aout16; hA.xc = h->Xc_pl; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
     // Step(1)'s head arithmetic (q', q, TD target, loss, dq, dZ_L) inside the critic's top-layer dgrad launch (k_dgrad_qtrain)
     // instead of a launch of its own: the online critic's top forward layer then also leaves U = (-w_h) lrelu'(x_L)
-    const bool fuse_q = h->U3 != nullptr && !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_Q_TRAIN) && !head_big_ok(h, B, Hc) && head_wgrad_can_ride(lc, B) &&
-                        bwd_is_shifted(h, lc, B) && lc.dims[L] >= 512 && lc.dims[L] <= 1024 && lc.dims[L] % 256 == 0;   // (one 16-column piece per lane: H / 16 <= 64)
+    const bool fuse_q = P.fuse_q;
     if (fuse_q) {
       pC1.seed_w = wat(h, DQNHIP_CRITIC, lc.hw_off); pC1.seed_out = h->U3;
       pC1.dot_w = pC1.seed_w; pC1.dot_out = h->qdot[1];
@@ -793,7 +814,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     FwdPass cp[2] = {pCT, pC1};
     // all four first layers of Step(1) in the update's first GEMM launch, critic_target's action half in the head kernel (first_layers_launch);
     // DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS: the critics' first layers in a launch of their own behind the heads
-    const bool merged_l0 = first_layers_merged(h);
+    const bool merged_l0 = P.first_layers_merged;
     if (merged_l0) {
       if (!(early_l0(h) && h->cap_u > 0)) RC(first_layers_launch(h, st, B, !split));     // (else: they rode in the previous update's last launch, k_adam_soft_l0)
       hAT.l1_zs = h->Zs; hAT.l1_wt = h->Wact_t;
@@ -821,7 +842,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       t.q_target = h->q_t; t.q = h->q1; t.y = h->y; t.dq = h->dq; t.loss_partial = h->loss_partial;
       t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch; t.st = h->st;
       // with the head's dW / db riding in the net's last backward launch, the head's dZ comes out of this launch too
-      if (!head_big_ok(h, B, Hc) && head_wgrad_can_ride(lc, B)) t.dZ = h->dZc[L];
+      if (P.head_rides_c) t.dZ = h->dZc[L];
       t.pdt = h->qdot[0]; t.pd = h->qdot[1];
       qt_args = t;
       if (!fuse_q) {
@@ -836,7 +857,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       a.H = Hc; a.rows = B; a.dZ = h->dZc[L]; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
       // the head's own gradients ride in the net's last backward launch (the first layer's narrow wgrad)
-      const bool ride = !head_big_ok(h, B, Hc) && head_wgrad_can_ride(lc, B);
+      const bool ride = P.head_rides_c;
       HeadWgradRider r{h->dq, 1, h->act[3][L], Hc, B, a.dW, a.db, a.partial, Hc / kRiderCW};
       if (!ride) RC(head_backward<1>(h, st, a));          // (riding: dZ came out of k_head_q_train, dW / db come from the rider)
       RC(tower_backward(h, st, lc, DQNHIP_CRITIC, h->g[1], h->part[1], h->act[3], h->dZc, B, true, false, 0, -1, ride ? &r : nullptr, nullptr, nullptr,
@@ -855,24 +876,24 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     h->act[4][0] = h->Xc_pl;
     // the first layer of critic(s, mu(s)) rides in the critic's optimiser launch (FirstLayerRider: the workgroups that own W1 run it
     // on the weights they have just stepped); DQNHIP_TUNE_SEPARATE_FIRST_LAYER: a launch of its own (same bits)
-    const bool ride_l0 = critic_l0_rides(h, dp);
-    if (dp) RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr));
-    else if (ride_l0) {
+    const bool ride_l0 = P.critic_l0;
+    if (ride_l0) {
       const FirstLayerRider fl{h->Xc_pl, lc.kp[0], h->act[4][1], lc.kp[1], B, lc.kp[0], lc.dims[1], lc.dims[1] / 16};
-      if (early_l0(h) && h->cap_u + 1 < kMultiU) {
-        // the NEXT update's gather rides here (its panels: the other parity), so that its first layers can ride in the actor's launch
-        const GatherArgs g = gather_args(h, nullptr, h->cap_u + 1);
-        RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena, nullptr, true, &fl, &g));
-      }
-      else RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena, nullptr, true, &fl));
+      // inside a multi-update graph the NEXT update's gather rides here too (its panels: the other parity), so that its first layers
+      // can ride in the actor's launch
+      const bool eg = early_l0(h) && h->cap_u + 1 < kMultiU;
+      const GatherArgs g = eg ? gather_args(h, nullptr, h->cap_u + 1) : GatherArgs{};
+      if (dp) RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr, &fl, eg ? &g : nullptr));
+      else RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena, nullptr, true, &fl, eg ? &g : nullptr));
     }
+    else if (dp) RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr));
     else RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
     // The seed of BackwardFrom(q_values_layer) [:918-923] — q diff = -1 per row, taken through the head and the top
     // layer's ReLU, input gradient only (the reference's discarded critic dW, SURVEY a11, is never computed) — does not
     // depend on q: it comes out of the top tower layer's forward epilogue, and q(s, mu(s)) itself [:913-916], which only
     // the statistics read, rides in the chain's last launch.  DQNHIP_TUNE_SEPARATE_HEAD_SEED: the head-backward launch
     // that used to sit between the forward and the backward chain (same arithmetic, one launch more).
-    const bool fused_seed = !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_HEAD_SEED);
+    const bool fused_seed = P.fused_seed;
     if (fused_seed) { pC2.seed_w = wat(h, DQNHIP_CRITIC, lc.hw_off); pC2.seed_out = h->dZc[L]; }
     RC(tower_forward(h, st, &pC2, 1, B, ride_l0 ? 1 : 0));   // critic(s, mu(s)), UPDATED weights [:913-916]
     const QHeadRider qr{h->act[4][L], wat(h, DQNHIP_CRITIC, lc.hw_off), wat(h, DQNHIP_CRITIC, lc.hb_off), h->q2, h->q_partial, Hc, B, (B + 3) / 4};
@@ -886,9 +907,8 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // ONE launch (k_dqda_head_bwd) when the actor head's own gradients ride in the actor's last backward launch and the shapes
     // allow it (16 columns from the first action column inside the panel row, H a multiple of 256, fewer than 1024 rows);
     // DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD: the narrow dgrad launch + k_head_bwd<10> (same arithmetic, one launch more)
-    const bool ride_a = !head_big_ok(h, B, Hh) && head_wgrad_can_ride(la, B);
-    const bool fuse_head = ride_a && !(h->cfg.tuning_flags & DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) && B % 16 == 0 && Hh % 256 == 0 &&
-                           h->S + 16 <= lc.kp[0] && L >= 1 && lc.dims[1] % 64 == 0;
+    const bool ride_a = P.head_rides_a;
+    const bool fuse_head = P.fuse_head;
     DqdaHeadArgs fz{};
     fz.aout16 = h->aout16; fz.dA16 = h->dA16; fz.W = wat(h, DQNHIP_ACTOR, la.hw_off); fz.X4 = h->act[1][L]; fz.dZ = h->dZa[L]; fz.H = Hh; fz.rows = B;
     RC(tower_backward(h, st, lc, DQNHIP_CRITIC, nullptr, nullptr, h->act[4], h->dZc, B, false, true, h->S, h->S + kNO, nullptr, fused_seed ? &qr : nullptr,
@@ -916,8 +936,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // (critic_loss, avg_q) and advances the iteration / sampling counters
     const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
                         dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world), h->stats_dev};
-    if (dp) RC(dp_optimiser_step(h, st, 0, actor_tail, &tick));
-    else if (early_l0(h) && h->cap_u + 1 < kMultiU) {
+    if (early_l0(h) && h->cap_u + 1 < kMultiU) {
       // the next update's first layers ride here: its panels (gathered in this update's critic launch) are those of the other parity
       const int pn = (h->cap_u + 1) & 1;
       NextL0 n{};
@@ -926,8 +945,10 @@ int run_phase(H* h, int phase, const int* idx_dev) {
                     B, lc.kp[0], lc.dims[1], nullptr, 0, 0, lc.dims[1] / 16};
       n.ct = PlainL0{h->w[DQNHIP_CRITIC_TARGET] + lc.w_off[0], lc.kp[0], nullptr, h->Xc_nx, lc.kp[0], h->Zs, lc.kp[1],
                      B, round_up(h->S, 64), lc.dims[1], h->Wact_t, h->S, kNO, lc.dims[1] / 16};
-      RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick, true, nullptr, nullptr, &n));
+      if (dp) RC(dp_optimiser_step(h, st, 0, actor_tail, &tick, nullptr, nullptr, &n));
+      else RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick, true, nullptr, nullptr, &n));
     }
+    else if (dp) RC(dp_optimiser_step(h, st, 0, actor_tail, &tick));
     else RC(adam_launch(h, st, 0, h->part[0], la.n_part, 0, la.arena, &tick));
     h->h_actor_iter += 1; h->h_critic_iter += 1;
     return 0;
@@ -1257,6 +1278,7 @@ static int capture_graph(H* h, int which, const int* idx_fixed = nullptr) {
     for (int p = 0; p < 3 && !rc; ++p) rc = run_phase(h, p, idx_dev);
   }
   h->cap_u = -1;
+  select_panels(h, 0);
   h->h_actor_iter = it_a; h->h_critic_iter = it_c;   // capture does not execute
   hipError_t e = hipStreamEndCapture(h->stream, &graph);
   if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
@@ -1264,6 +1286,72 @@ static int capture_graph(H* h, int which, const int* idx_fixed = nullptr) {
   e = hipGraphInstantiate(&h->graph_exec[which], graph, nullptr, nullptr, 0);
   hipGraphDestroy(graph);
   if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// kernel nodes of a captured sequence
+static int count_kernel_nodes(hipGraph_t g, int* out) {
+  size_t cnt = 0;
+  HIPCHK(hipGraphGetNodes(g, nullptr, &cnt));
+  std::vector<hipGraphNode_t> nodes(cnt);
+  if (cnt) HIPCHK(hipGraphGetNodes(g, nodes.data(), &cnt));
+  int k = 0;
+  for (hipGraphNode_t nd : nodes) {
+    hipGraphNodeType t;
+    HIPCHK(hipGraphNodeGetType(nd, &t));
+    if (t == hipGraphNodeTypeKernel) ++k;
+  }
+  *out = k;
+  return 0;
+}
+// the kernels `updates` consecutive updates launch — as a multi-update graph captures them (multi) or stand-alone.  A capture that
+// is thrown away: nothing executes, nothing is instantiated.
+static int count_launches(H* h, bool multi, int updates, int* out) {
+  hipGraph_t graph = nullptr;
+  HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  const int it_a = h->h_actor_iter, it_c = h->h_critic_iter;
+  int rc = 0;
+  for (int u = 0; u < updates && !rc; ++u) {
+    h->cap_u = multi ? u : -1;
+    for (int p = 0; p < 3 && !rc; ++p) rc = run_phase(h, p, nullptr);
+  }
+  h->cap_u = -1;
+  select_panels(h, 0);
+  h->h_actor_iter = it_a; h->h_critic_iter = it_c;
+  const std::string msg = g_err;
+  const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+  if (rc) { if (graph) hipGraphDestroy(graph); g_err = msg; return rc; }
+  if (e != hipSuccess) return fail("hipStreamEndCapture (plan): %s", hipGetErrorString(e));
+  rc = count_kernel_nodes(graph, out);
+  hipGraphDestroy(graph);
+  return rc;
+}
+
+int dqnhip_get_update_plan(dqnhip_handle h, dqnhip_update_plan* out) {
+  if (!h || !out) return fail("null argument");
+  if (out->struct_size != (int32_t)sizeof(dqnhip_update_plan)) return fail("dqnhip_update_plan.struct_size %d != %zu (ABI mismatch)", out->struct_size, sizeof(dqnhip_update_plan));
+  if (h->next_phase != 0) return fail("dqnhip_get_update_plan: a phased update is in progress (next phase %d)", h->next_phase);
+  if (h->timing) return fail("dqnhip_get_update_plan: kernel timing is on (timed launches are not captured)");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const UpdatePlan p = plan_of(h);
+  memset(out, 0, sizeof *out);
+  out->struct_size = (int32_t)sizeof *out;
+  out->forms = (p.fp16 ? DQNHIP_PLAN_FP16 : 0) | (p.dp ? DQNHIP_PLAN_DATA_PARALLEL : 0) | (p.shifted_c ? DQNHIP_PLAN_BWD_SHIFTED_CRITIC : 0) |
+               (p.shifted_a ? DQNHIP_PLAN_BWD_SHIFTED_ACTOR : 0) | (p.head_rides_c ? DQNHIP_PLAN_HEAD_WGRAD_RIDES_CRITIC : 0) |
+               (p.head_rides_a ? DQNHIP_PLAN_HEAD_WGRAD_RIDES_ACTOR : 0) | (p.fuse_q ? DQNHIP_PLAN_Q_TRAIN_IN_DGRAD : 0) |
+               (p.fused_seed ? DQNHIP_PLAN_HEAD_SEED_FUSED : 0) | (p.fuse_head ? DQNHIP_PLAN_DQDA_HEAD_BWD : 0) |
+               (p.critic_l0 ? DQNHIP_PLAN_CRITIC_L0_RIDES : 0) | (p.first_layers_merged ? DQNHIP_PLAN_FIRST_LAYERS_MERGED : 0) |
+               (p.early_l0 ? DQNHIP_PLAN_EARLY_GATHER_L0 : 0);
+  out->updates_per_graph = kMultiU;
+  // per net and update: one all-reduce (per-layer buckets: one per tower layer + the head slice; bf16 exchange: the tails travel in a
+  // second call beside the actor's; sharded optimiser: reduce-scatter + the 4-float all-reduce + 2 (fp16 learner: 4) all-gathers)
+  if (h->comm) out->collectives = h->dp_shard ? 2 * (2 + (h->fp16 ? 4 : 2)) : h->dp_per_layer ? 2 * (h->L + 1) : h->dp_half ? 3 : 2;
+  if (h->dp_shard) return 0;
+  int n1 = 0, nf = 0, n2 = 0;
+  RC(count_launches(h, false, 1, &n1));
+  RC(count_launches(h, true, 1, &nf));
+  RC(count_launches(h, true, 2, &n2));
+  out->launches_single = n1; out->launches_graph_first = nf; out->launches_in_graph = n2 - nf;
   return 0;
 }
 

@@ -138,6 +138,7 @@ int dp_capture(H* h, bool multi = false) {
     rc = dp_sequence(h, nullptr);
   }
   h->cap_u = -1;
+  select_panels(h, 0);
   h->h_actor_iter = it_a; h->h_critic_iter = it_c;   // capture does not execute
   hipError_t e = hipStreamEndCapture(h->stream, &graph);
   if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
@@ -273,15 +274,19 @@ int dqnhip_dp_init(dqnhip_handle h, const void* id, size_t bytes, int32_t flags)
     NCCLCHK(ncclGetVersion(&ver));
     h->rccl_version = ver;
     int* dv = nullptr;
-    HIPCHK(hipMalloc(&dv, 2 * sizeof(int)));
     const int hv[2] = {ver, -ver};
-    HIPCHK(hipMemcpyAsync(dv, hv, sizeof hv, hipMemcpyHostToDevice, h->stream));
-    ncclResult_t r = ncclAllReduce(dv, dv, 2, ncclInt32, ncclMax, h->comm, h->stream);
     int got[2] = {0, 0};
-    if (r == ncclSuccess) { hipMemcpyAsync(got, dv, sizeof got, hipMemcpyDeviceToHost, h->stream); hipStreamSynchronize(h->stream); }
-    hipFree(dv);
-    if (r != ncclSuccess || got[0] != -got[1]) {
+    // every step checked, dv freed on every path: a failed copy must not read as "all ranks agree" ({0, 0} satisfies got[0] == -got[1])
+    hipError_t e = hipMalloc(&dv, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(dv, hv, sizeof hv, hipMemcpyHostToDevice, h->stream);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = ncclAllReduce(dv, dv, 2, ncclInt32, ncclMax, h->comm, h->stream);
+    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(got, dv, sizeof got, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(h->stream);
+    if (dv) hipFree(dv);
+    if (e != hipSuccess || r != ncclSuccess || got[0] != -got[1] || got[0] != ver) {
       ncclCommDestroy(h->comm); h->comm = nullptr;
+      if (e != hipSuccess) return fail("dp_init: the version cross-check failed: %s", hipGetErrorString(e));
       if (r != ncclSuccess) return fail("dp_init: the version all-reduce failed: %s", ncclGetErrorString(r));
       return fail("dp_init: the ranks of this group loaded different RCCL builds (versions %d .. %d; this rank: %d from %s) — start every rank from "
                   "the same kind of host process (all with PyTorch's bundled librccl, or all with /opt/rocm's)", -got[1], got[0], ver, rccl_path());

@@ -252,8 +252,10 @@ int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nu
   HeadArgs2 a2{}; a2.p[0] = a; if (b) a2.p[1] = *b;
   if (NH > 1 && a.rows >= 1024 && a.H <= 1024 && a.H % 4 == 0)   // (single-head: the block-per-row form measured faster, 6.6 vs 8.8 us)
     hipLaunchKernelGGL((k_head_fwd_rows<NH, MODE>), dim3(256, b ? 2 : 1), dim3(256), 0, st, a2);
+  else if (a.l1_y != nullptr || (b && b->l1_y != nullptr))      // Step(1): the target actor's head also finishes critic_target's first layer
+    hipLaunchKernelGGL((k_head_fwd<NH, MODE, true>), dim3(std::min(a.rows, 1024), b ? 2 : 1), dim3(256), 0, st, a2);
   else
-    hipLaunchKernelGGL((k_head_fwd<NH, MODE>), dim3(std::min(a.rows, 1024), b ? 2 : 1), dim3(256), 0, st, a2);
+    hipLaunchKernelGGL((k_head_fwd<NH, MODE, false>), dim3(std::min(a.rows, 1024), b ? 2 : 1), dim3(256), 0, st, a2);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -267,6 +269,22 @@ inline void shard_range(const H* h, int net, size_t& lo, size_t& hi, int rank = 
   const size_t r = (size_t)(rank < 0 ? h->cfg.dp_rank : rank);
   lo = r * slice; hi = lo + slice;
 }
+// Which merged forms the update of a learner takes (plan_of, learner.hip: the one place that decides; dqnhip_get_update_plan reports it)
+struct UpdatePlan {
+  bool fp16, dp;
+  bool shifted_c, shifted_a;        // the shifted backward schedule (tower_backward) for the critic's Step(1) / the actor's backward
+  bool head_rides_c, head_rides_a;  // the head's dW / db as rider blocks of the net's last backward launch
+  bool fuse_q;                      // k_dgrad_qtrain: Step(1)'s head arithmetic inside the critic's top-layer dgrad launch
+  bool fused_seed;                  // the dq = -1 seed from the top layer's forward epilogue, q(s, mu(s)) as rider blocks
+  bool fuse_head;                   // k_dqda_head_bwd: dQ/da's last step + inverting gradients + actor heads' backward in one launch
+  bool critic_l0;                   // the first layer of critic(s, mu(s)) inside the critic's optimiser launch
+  bool first_layers_merged;         // Step(1)'s four first layers in one launch (critic_target's action half in the head kernel)
+  bool early_l0;                    // multi-update graphs: next gather in the critic's optimiser launch, next first layers in the actor's
+};
+UpdatePlan plan_of(const H* h);
+// the current update's copies of the two double-buffered panels (by update parity inside a multi-update graph that gathers early;
+// parity 0 everywhere else — every capture ends by selecting parity 0 again)
+inline void select_panels(H* h, int par) { h->Xa_s = h->Xa_s2[par]; h->Xc_pl = h->Xc_pl2[par]; h->act[1][0] = h->Xa_s; h->act[4][0] = h->Xc_pl; }
 struct NextL0 { ActorL0 a; PlainL0 c, ct; };           // the next update's first layers as riders of the actor's optimiser launch
 int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_partial, size_t begin, size_t end, const TickArgs* tick = nullptr,
                 bool corr_pre = true, const FirstLayerRider* fl = nullptr, const GatherArgs* early_gather = nullptr, const NextL0* next_l0 = nullptr);

@@ -320,7 +320,9 @@ struct HeadArgs {
 
 struct HeadArgs2 { HeadArgs p[2]; };
 
-template <int NH, int MODE>
+// L1: compiled with the target actor's first-layer epilogue (HeadArgs::l1_*; Step(1) only — the acting path and the critic heads
+// instantiate L1 = false and carry neither its 44 registers nor its LDS row)
+template <int NH, int MODE, bool L1 = false>
 __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
   // one block per row (grid-strided when there are more rows than blocks): the 4 waves split K
   // (each lane one float4 strip per 1024 columns), butterfly within the wave, then the 4 wave
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
       wreg[j] = (threadIdx.x * 4 < a.H) ? *reinterpret_cast<const f32x4*>(a.W + (size_t)j * a.H + threadIdx.x * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // (l1: this thread's four outputs' action-column weights and biases do not depend on the row)
-  constexpr bool kL1 = (MODE == HEAD_ACTOR && NH == kNO);
+  constexpr bool kL1 = (L1 && MODE == HEAD_ACTOR && NH == kNO);
   __shared__ float s_mu[kAP];
   float l1w[kL1 ? 4 : 1][kL1 ? kNO : 1];
   f32x4 l1b = f32x4{0.f, 0.f, 0.f, 0.f};

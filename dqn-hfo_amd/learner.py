@@ -555,6 +555,16 @@ class DQN:
         self._ck(self.lib.dqnhip_get_stream(self.h, C.byref(s)))
         return s.value
 
+    def update_plan(self):
+        """The launch plan of this learner's update (dqnhip_get_update_plan): the merged forms it takes, by name, and the kernels per
+        update counted from a capture of the sequence dqnhip_update* enqueues."""
+        p = capi.UpdatePlan()
+        p.struct_size = C.sizeof(capi.UpdatePlan)
+        self._ck(self.lib.dqnhip_get_update_plan(self.h, C.byref(p)))
+        return {"forms": [n for i, n in enumerate(capi.PLAN_FORMS) if p.forms >> i & 1], "launches_single": p.launches_single,
+                "launches_graph_first": p.launches_graph_first, "launches_in_graph": p.launches_in_graph,
+                "updates_per_graph": p.updates_per_graph, "collectives": p.collectives}
+
     def set_kernel_timing(self, enable):
         self._ck(self.lib.dqnhip_set_kernel_timing(self.h, int(enable)))
 

@@ -145,7 +145,9 @@ class DQN {
   int minibatch_;
   bool dp_ = false;                                    // -dp_rendezvous given: UpdateActorCritic() is one rank's share of a data-parallel update
   bool dp_sync_pending_ = false;                       // a Restore* / Load* ran since the group's last broadcast: re-sync at the next update
+  bool dp_synced_once_ = false;                        // the group's first update has passed: Restore* / Load* are refused from here on (one-sided collective)
   void SyncReplicasIfPending();
+  void RearmReplicaSync(const char* what);
   dqnhip_handle h_;
 };
 

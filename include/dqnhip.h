@@ -229,6 +229,38 @@ int dqnhip_apply_update(dqnhip_handle h, int32_t net);
  * summation order of the norm (identical bits whenever the clip is inactive). */
 int dqnhip_apply_update_sharded(dqnhip_handle h, int32_t net, int32_t world);
 
+/* ---- the launch plan of this learner's update ---------------------------------------------
+ * No reference counterpart (Caffe runs one layer at a time).  Which merged forms of the launch sequence behind
+ * dqnhip_update* this learner takes — they depend on its shapes, its tuning flags, sharing and the data-parallel mode —
+ * and how many kernels one update launches, COUNTED from a stream capture of the very sequence dqnhip_update* enqueues
+ * (nothing executes).  Exists so that a shape predicate that stops matching shows up as a failed assertion
+ * (tests/test_gpu_update_plan.py; bench.py prints it in `config.plan`) instead of as a silently slower schedule. */
+#define DQNHIP_PLAN_FP16 1                      /* cfg.precision == DQNHIP_FP16 */
+#define DQNHIP_PLAN_DATA_PARALLEL 2             /* phases cut for an exchange: dp_world > 1, or a one-rank group with bf16 exchange / sharded optimiser */
+#define DQNHIP_PLAN_BWD_SHIFTED_CRITIC 4        /* the shifted backward schedule (see DQNHIP_TUNE_BWD_UNSHIFTED) in Step(1) */
+#define DQNHIP_PLAN_BWD_SHIFTED_ACTOR 8         /* ... in the actor's backward */
+#define DQNHIP_PLAN_HEAD_WGRAD_RIDES_CRITIC 16  /* the critic head's dW / db as rider blocks of the net's last backward launch */
+#define DQNHIP_PLAN_HEAD_WGRAD_RIDES_ACTOR 32   /* ... the actor heads' */
+#define DQNHIP_PLAN_Q_TRAIN_IN_DGRAD 64         /* k_dgrad_qtrain (see DQNHIP_TUNE_SEPARATE_Q_TRAIN) */
+#define DQNHIP_PLAN_HEAD_SEED_FUSED 128         /* the dq = -1 seed from the top layer's forward epilogue (DQNHIP_TUNE_SEPARATE_HEAD_SEED) */
+#define DQNHIP_PLAN_DQDA_HEAD_BWD 256           /* k_dqda_head_bwd (DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) */
+#define DQNHIP_PLAN_CRITIC_L0_RIDES 512         /* critic(s, mu(s))'s first layer inside the critic's optimiser launch (DQNHIP_TUNE_SEPARATE_FIRST_LAYER) */
+#define DQNHIP_PLAN_FIRST_LAYERS_MERGED 1024    /* Step(1)'s four first layers in one launch (DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS) */
+#define DQNHIP_PLAN_EARLY_GATHER_L0 2048        /* multi-update graphs: next gather / next first layers ride in the two optimiser launches (DQNHIP_TUNE_LATE_GATHER) */
+typedef struct dqnhip_update_plan {
+  int32_t struct_size;          /* in: sizeof(dqnhip_update_plan) */
+  int32_t forms;                /* DQNHIP_PLAN_* bits */
+  int32_t launches_single;      /* kernels of one stand-alone update: eager, dqnhip_update, the one-update graph */
+  int32_t launches_graph_first; /* ... of the first update of a multi-update graph (dqnhip_update_async_n / dqnhip_dp_update_n) */
+  int32_t launches_in_graph;    /* ... of every later update of such a graph */
+  int32_t updates_per_graph;    /* 16 */
+  int32_t collectives;          /* RCCL calls per update once a communicator is up (not counted in launches_*), else 0 */
+  int32_t reserved;
+} dqnhip_update_plan;
+/* Fails while a phased update is in progress or kernel timing is on; launches_* are 0 for a sharded optimiser (its
+ * sequence contains collectives and is not captured here). */
+int dqnhip_get_update_plan(dqnhip_handle h, dqnhip_update_plan* out);
+
 /* Device pointer + length (floats) of one net's gradient arena, including a
  * 4-float tail [loss_sum, q_sum, 0, 0] so the two reported scalars ride in the
  * same all-reduce.  net = DQNHIP_ACTOR or DQNHIP_CRITIC. */

@@ -1,0 +1,104 @@
+"""north_star's parity criteria at BASELINE's shapes on EVERY seed of a fixed list — no seed chosen by a scan.
+
+tests/test_gpu_update_parity.py pins the BASE shape on one seed for which learner and oracle happen to take the same ReLU
+branch in every unit (13 of 40 seeds did, profiles/r05_flip_scan_b256.txt): an existence proof that breaks whenever a summation
+order changes.  This file states what must hold whatever the order is (reference work: src/dqn.cpp:889-916, the forward
+quantities of UpdateActorCritic, and :918-965, its gradients):
+
+  * update 1 from identical states, every seed: the four Q vectors within 1e-4 (+1e-5 relative), mu(s) within 1e-4, the reported
+    (critic_loss, avg_q), and the action indices GetAction derives from the UPDATED actor on 512 probe states — exact, with the
+    decision margin asserted;
+  * gradients: 1e-5 (Frobenius, against the C oracle) on every pass in which both sides stored the same activation signs; where
+    k units landed on the other side of zero (a pre-activation within fp32 round-off of 0: legitimate on either side) the bound
+    is 1e-5 + k x PER_FLIP, PER_FLIP = five times the largest per-unit effect measured (no cap on k);
+  * at least a quarter of the seeds are flip-free throughout (printed), so the tight bound is exercised.
+"""
+import numpy as np
+import pytest
+
+from helpers import make_pair
+from oracle import c_oracle
+from test_gpu_update_parity import QRTOL, QTOL, _fro, _sign_flips
+
+pytestmark = pytest.mark.gpu
+
+TOWER = (1024, 1024, 1024, 1024)
+SEEDS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12)          # consecutive: not selected
+PER_FLIP = 2.5e-3   # gradient error one flipped unit may add (relative Frobenius); measured per-unit effects: 1e-4 .. 5e-4 at 256 rows
+
+
+def _first_update(pkg, B, seed, n_replay=2048):
+    dqn, orc, data, rng = make_pair(pkg, B=B, S=58, hidden=TOWER, wscale=2.0, seed=seed, n_replay=n_replay)
+    idx = rng.integers(0, n_replay, size=B)
+    rec = {"seed": seed}
+    dqn.update_phase(0, idx); orc.update_phase(0, idx)
+    f_c1, _ = _sign_flips(dqn, orc, 3, "C")
+    rec["flips_c1"] = f_c1
+    rec["g_critic"] = _fro(dqn.get_params(1, 3), orc.grad_view(1).copy())
+    dqn.update_phase(1); orc.update_phase(1, idx)
+    f_a, _ = _sign_flips(dqn, orc, 1, "A")
+    f_c2, _ = _sign_flips(dqn, orc, 4, "C")
+    rec["flips_a"], rec["flips_c2"] = f_a, f_c2
+    rec["g_actor"] = _fro(dqn.get_params(0, 3), orc.grad_view(0).copy())
+    dqn.update_phase(2); orc.update_phase(2, idx)
+    # forward quantities: every seed, whatever flipped
+    for name in ("q_target", "y", "q_train", "q_policy"):
+        a, b = dqn.debug_read(name), orc.debug_read(name)
+        rec[name] = float(np.abs(a - b).max())
+        np.testing.assert_allclose(a, b, rtol=QRTOL, atol=QTOL, err_msg="%s seed %d" % (name, seed))
+    a1, a2 = dqn.debug_read("actor_out"), orc.debug_read("actor_out")
+    rec["actor_out"] = float(np.abs(a1 - a2).max())
+    assert rec["actor_out"] <= 1e-4 * max(1.0, float(np.abs(a2).max())), rec
+    (l1, q1), (l2, q2) = dqn.read_stats(), orc.last_stats()
+    assert abs(l1 - l2) <= 1e-4 * max(1.0, abs(l2)), (seed, l1, l2)
+    assert abs(q1 - q2) <= QTOL + QRTOL * abs(q2), (seed, q1, q2)
+    # action indices of the UPDATED actor, exact, and not by luck
+    probe = data[0][:512]
+    out_h, out_o = dqn.SelectActionGreedily(probe), orc.actor_forward(probe)
+    err = float(np.abs(out_h - out_o).max())
+    assert err <= QTOL, (seed, err)
+    act_o = c_oracle.get_action(out_o)[0]
+    assert [pkg.GetAction(o).action for o in out_h] == list(act_o), seed
+    lg = np.sort(out_o[:, [0, 1, 3]], axis=1)
+    margin = float((lg[:, -1] - lg[:, -2]).min())
+    rec["margin_over_err"] = margin / max(err, 1e-30)
+    # (a probe state whose two best logits tie to within round-off would make "exact" luck: assert there is none)
+    assert margin > 4 * err, (seed, margin, err)
+    dqn.close(); orc.close()
+    return rec
+
+
+def _check_gradients(recs):
+    free = 0
+    for r in recs:
+        k_c = r["flips_c1"]
+        k_a = r["flips_c1"] + r["flips_a"] + r["flips_c2"]     # a flip in the critic's step moves its weights, hence everything after
+        assert r["g_critic"] <= 1e-5 + k_c * PER_FLIP, r
+        assert r["g_actor"] <= 1e-5 + k_a * PER_FLIP, r
+        free += k_a == 0
+    return free
+
+
+def test_base_shape_every_seed(pkg, gpu):
+    """BASELINE configs[1]: minibatch 256, 4 x 1024, S = 58."""
+    recs = [_first_update(pkg, 256, s) for s in SEEDS]
+    for r in recs:
+        print({k: (v if isinstance(v, int) else float("%.3g" % v)) for k, v in r.items()})
+    free = _check_gradients(recs)
+    print("flip-free seeds: %d of %d" % (free, len(recs)))
+    assert 4 * free >= len(recs), (free, len(recs))
+
+
+def test_4096_rows_every_seed(pkg, gpu):
+    """configs[4]'s minibatch on the fp32 learner: 16 x the units, so some unit almost surely flips somewhere — the forward criteria
+    hold regardless, the gradient bound is flip-proportional, and at least one PASS (critic training pass, actor pass or critic
+    policy pass of some seed) must come out flip-free, where the tight bound then applies to that net's gradient."""
+    recs = [_first_update(pkg, 4096, s, n_replay=8192) for s in SEEDS[:3]]
+    for r in recs:
+        print({k: (v if isinstance(v, int) else float("%.3g" % v)) for k, v in r.items()})
+    _check_gradients(recs)
+    clean = [r for r in recs if r["flips_c1"] == 0]
+    print("flip-free critic training passes: %d of %d" % (len(clean), len(recs)))
+    assert clean, [(r["seed"], r["flips_c1"]) for r in recs]
+    for r in clean:
+        assert r["g_critic"] <= 1e-5, r
