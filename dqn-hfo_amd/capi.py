@@ -58,6 +58,7 @@ SIGNATURES = {
     "dqnhip_create": (C.c_int, [C.POINTER(Config), C.POINTER(H)]),
     "dqnhip_destroy": (C.c_int, [H]),
     "dqnhip_update": (C.c_int, [H, ip, fp, fp]),
+    "dqnhip_update_chained": (C.c_int, [H, ip, ip, fp, fp]),
     "dqnhip_update_async": (C.c_int, [H, ip]),
     "dqnhip_update_async_n": (C.c_int, [H, C.c_int32]),
     "dqnhip_update_pipelined": (C.c_int, [H, ip, fp, fp]),

@@ -42,6 +42,8 @@ DEFINE_int32(hip_device, 0, "HIP device ordinal of this process's learners.");
 DEFINE_bool(hip_graph, true, "Replay each update as one captured hipGraph.");
 DEFINE_string(precision, "fp32", "fp32 (exact-fp32 MFMA, the parity path) or fp16 (fp16 MFMA operands, fp32 accumulate).");
 DEFINE_bool(device_sampling, false, "Sample minibatch indices on the device (counter-based) instead of the host std::mt19937.");
+DEFINE_bool(chained_updates, true, "UpdateActorCritic() tells the library which indices the NEXT call will draw (a copy of the engine runs ahead; "
+            "dqnhip_update_chained): bursts of Update() get the launch schedule of a multi-update graph.  Same results, same RNG order.");
 DEFINE_bool(pipelined_stats, false, "UpdateActorCritic() returns the (loss, avg_q) of the PREVIOUS update (dqnhip_update_pipelined): "
                                     "the device does not idle on the per-update read-back; the logged / smoothed values lag by one update.");
 // Data parallelism for the UNCHANGED driver: start one process of this binary per GPU — each with its own HFO
@@ -478,7 +480,24 @@ std::pair<float, float> DQN::UpdateActorCritic() {
     else DQNHIP_CK(dqnhip_update(h_, nullptr, &loss, &avgq));                 // CHECK(isfinite(target / loss)): the call fails
     return std::make_pair(loss, avgq);
   }
-  return UpdateActorCritic(SampleTransitionsFromMemory(minibatch_));
+  if (dp_ || FLAGS_pipelined_stats || !FLAGS_chained_updates) return UpdateActorCritic(SampleTransitionsFromMemory(minibatch_));
+  // The driver calls this in bursts (src/dqn_main.cpp:359-361), each call drawing its indices from random_engine (:501-509).  What the
+  // NEXT call will draw is known now — unless something else draws from the engine or the memory changes in between: take it from a
+  // COPY of the engine and hand it to the library as a prediction (dqnhip_update_chained: the next update's gather and first layers
+  // ride in this update's optimiser launches).  The next call adopts the copy's state only if the engine and the memory size are
+  // exactly as the prediction left them; otherwise it draws afresh.  Either way random_engine advances as the reference's does.
+  const int size = memory_size();
+  std::vector<int> idx;
+  if (spec_valid_ && size == spec_size_ && random_engine == spec_before_) { idx.swap(spec_idx_); random_engine = spec_after_; }
+  else idx = SampleTransitionsFromMemory(minibatch_);
+  spec_before_ = random_engine;
+  spec_after_ = random_engine;
+  spec_idx_.resize(minibatch_);
+  for (int& i : spec_idx_) i = std::uniform_int_distribution<int>(0, size - 1)(spec_after_);
+  spec_size_ = size; spec_valid_ = true;
+  float loss = 0, avgq = 0;
+  DQNHIP_CK(dqnhip_update_chained(h_, reinterpret_cast<const int32_t*>(idx.data()), reinterpret_cast<const int32_t*>(spec_idx_.data()), &loss, &avgq));
+  return std::make_pair(loss, avgq);
 }
 
 std::pair<float, float> DQN::UpdateActorCritic(const std::vector<int>& transitions) {

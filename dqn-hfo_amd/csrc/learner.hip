@@ -386,6 +386,7 @@ GatherArgs gather_args(H* h, const int* idx_dev, int pos) {
   g.corr = h->st->adam_corr[slot]; g.soft_now = &h->st->soft_now[slot];
   g.beta1 = h->cfg.momentum; g.beta2 = h->cfg.momentum2; g.soft_update_freq = h->cfg.soft_update_freq;
   g.ahead = pos > 0 ? pos : -1; g.store_base = pos == 0 ? 1 : 0;
+  if (h->chain_cap && pos > 0) { g.idx_in = h->idx_next_dev[pos & 1]; g.ahead = -2; }      // dqnhip_update_chained: the next update's indices, known one call ahead
   g.blocks = (h->B + 3) / 4 + 1;
   return g;
 }
@@ -1245,6 +1246,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   for (int i = 0; i <= h->L; ++i) { hipFree(h->dZa[i]); hipFree(h->dZc[i]); }
   hipFree(h->mb_reward); hipFree(h->mb_mc); hipFree(h->mb_term); hipFree(h->mb_idx); hipFree(h->U3); hipFree(h->qdot[0]); hipFree(h->qdot[1]); hipFree(h->Zs); hipFree(h->Wact_t);
   hipHostFree(h->idx_pinned); hipHostFree(h->pinned_stats);
+  for (int i = 0; i < 2; ++i) if (h->idx_next_pinned[i]) hipHostFree(h->idx_next_pinned[i]);
   hipFree(h->aout_t16); hipFree(h->aout16); hipFree(h->dA16);
   hipFree(h->q_t); hipFree(h->q1); hipFree(h->q2); hipFree(h->y); hipFree(h->dq);
   hipFree(h->loss_partial); hipFree(h->q_partial); hipFree(h->part_dp); hipFree(h->head_slab); hipFree(h->head_ticket); if (h->head_slab2) hipFree(h->head_slab2);
@@ -1271,13 +1273,16 @@ static int capture_graph(H* h, int which, const int* idx_fixed = nullptr) {
   HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
   const int* idx_dev = idx_fixed;
-  if (which == 1) idx_dev = h->idx_pinned_dev;
+  if (which == 1 || which == 5) idx_dev = h->idx_pinned_dev;
   const int it_a = h->h_actor_iter, it_c = h->h_critic_iter;
   for (int u = 0; u < (which == 4 ? kMultiU : 1); ++u) {
-    h->cap_u = which == 4 ? u : -1;
+    // which >= 5 (dqnhip_update_chained): ONE update captured as position 0 (head: own gather), 1 or 2 (continued at parity 1 / 0) of
+    // a multi-update graph, its riders reading the next update's explicit indices
+    h->cap_u = which == 4 ? u : which >= 5 ? which - 5 : -1;
+    h->chain_cap = which >= 5;
     for (int p = 0; p < 3 && !rc; ++p) rc = run_phase(h, p, idx_dev);
   }
-  h->cap_u = -1;
+  h->cap_u = -1; h->chain_cap = false;
   select_panels(h, 0);
   h->h_actor_iter = it_a; h->h_critic_iter = it_c;   // capture does not execute
   hipError_t e = hipStreamEndCapture(h->stream, &graph);
@@ -1357,6 +1362,7 @@ int dqnhip_get_update_plan(dqnhip_handle h, dqnhip_update_plan* out) {
 
 int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
   if (!h) return fail("null handle");
+  h->epoch += 1;
   HIPCHK(hipSetDevice(h->cfg.device));
   if (h->cfg.dp_world > 1) return fail("dqnhip_update_async: dp_world > 1 requires dqnhip_update_phase + all-reduce (or dqnhip_dp_update)");
   if (h->dp_half) return fail("dqnhip_update_async: this learner exchanges bf16 gradients (DQNHIP_DP_HALF_GRADS): use dqnhip_dp_update");
@@ -1391,6 +1397,7 @@ int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host) {
 
 int dqnhip_update_async_n(dqnhip_handle h, int32_t n) {
   if (!h) return fail("null handle");
+  h->epoch += 1;
   if (n < 0) return fail("dqnhip_update_async_n: n must be >= 0");
   HIPCHK(hipSetDevice(h->cfg.device));
   if (h->cfg.dp_world > 1 || h->dp_half || h->dp_shard) return fail("dqnhip_update_async_n: data-parallel learners use dqnhip_dp_update");
@@ -1418,6 +1425,7 @@ int dqnhip_update_async_n(dqnhip_handle h, int32_t n) {
 
 int dqnhip_update_phase(dqnhip_handle h, int32_t phase, const int32_t* idx_host) {
   if (!h) return fail("null handle");
+  h->epoch += 1;
   HIPCHK(hipSetDevice(h->cfg.device));
   // (with DQNHIP_DP_HALF_GRADS the exchange — bf16 image, all-reduce, widening by the clip-norm pass — lives inside
   // dqnhip_dp_update: a caller-driven exchange between phases would leave phase 1 / 2 reading a stale bf16 image)
@@ -1485,12 +1493,62 @@ int dqnhip_update(dqnhip_handle h, const int32_t* idx_host, float* critic_loss, 
   return dqnhip_read_stats(h, critic_loss, avg_q);
 }
 
+// dqnhip_update with the NEXT update's indices known one call ahead (see dqnhip.h).  The reference's driver runs its updates in
+// bursts (src/dqn_main.cpp:359-361: `for (i < n_updates) dqn->Update()`), one blocking call at a time; with idx_next the burst gets the
+// schedule of a multi-update graph — the next update's gather in this update's critic optimiser launch, its four first layers in the
+// actor's — one graph launch per update.  What rode along is used only if the next call's idx equals idx_next and nothing changed
+// weights, iteration counters or the replay memory in between; otherwise that call starts a fresh chain (own gather, own first
+// layers: what the riders left is overwritten).  Every update computes exactly what dqnhip_update computes on the same indices.
+int dqnhip_update_chained(dqnhip_handle h, const int32_t* idx_host, const int32_t* idx_next, float* critic_loss, float* avg_q) {
+  if (!h) return fail("null handle");
+  if (!idx_host) return fail("dqnhip_update_chained: explicit indices required (on-device sampling: dqnhip_update_async_n)");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const UpdatePlan P = plan_of(h);
+  const bool can = P.early_l0 && !P.dp && !h->comm && h->cfg.use_graph && !h->timing && !h->graph_failed && h->sharers == 0 && h->w_owner == nullptr;
+  if (!can) { h->chain_valid = false; return dqnhip_update(h, idx_host, critic_loss, avg_q); }
+  if (h->next_phase != 0) return fail("dqnhip_update_chained: a phased update is in progress (next phase %d)", h->next_phase);
+  {
+    RingUse ring_use(h);
+    RC(refresh_ring(h));
+    const long long size = RO(h)->h_size;
+    if (size < 1) return fail("replay memory is empty");
+    for (int i = 0; i < h->B; ++i) {
+      if (idx_host[i] < 0 || idx_host[i] >= size) return fail("sampled index %d = %d out of range [0,%lld)", i, idx_host[i], size);
+      if (idx_next && (idx_next[i] < 0 || idx_next[i] >= size)) return fail("next sampled index %d = %d out of range [0,%lld)", i, idx_next[i], size);
+    }
+    if (!h->idx_next_pinned[0])
+      for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipHostMalloc((void**)&h->idx_next_pinned[i], h->B * sizeof(int), hipHostMallocMapped));
+        memset(h->idx_next_pinned[i], 0, h->B * sizeof(int));
+        void* d = nullptr; HIPCHK(hipHostGetDevicePointer(&d, h->idx_next_pinned[i], 0)); h->idx_next_dev[i] = (const int*)d;
+      }
+    HIPCHK(hipStreamSynchronize(h->stream));       // the pinned index buffers may still be in flight from an earlier (asynchronous) update
+    const bool cont = h->chain_valid && h->chain_epoch == h->epoch && h->chain_ring_epoch == RO(h)->epoch &&
+                      memcmp(h->chain_idx.data(), idx_host, h->B * sizeof(int32_t)) == 0;
+    const int par = cont ? h->chain_par : 0;         // this update's panel parity
+    const int which = cont ? (par ? 6 : 7) : 5;
+    if (!cont) memcpy(h->idx_pinned, idx_host, h->B * sizeof(int));
+    h->chain_valid = false;
+    if (idx_next) {
+      memcpy(h->idx_next_pinned[par ^ 1], idx_next, h->B * sizeof(int));
+      h->chain_idx.assign(idx_next, idx_next + h->B);
+    }
+    if (!h->graph_exec[which] && capture_graph(h, which)) { h->graph_failed = true; return dqnhip_update(h, idx_host, critic_loss, avg_q); }
+    HIPCHK(hipGraphLaunch(h->graph_exec[which], h->stream));
+    h->h_actor_iter += 1; h->h_critic_iter += 1;
+    h->epoch += 1;
+    if (idx_next) { h->chain_valid = true; h->chain_par = par ^ 1; h->chain_epoch = h->epoch; h->chain_ring_epoch = RO(h)->epoch; }
+  }
+  return dqnhip_read_stats(h, critic_loss, avg_q);
+}
+
 // One-deep pipelined form of dqnhip_update: enqueues update t and returns the scalars of update t-1 (zeros on the
 // first call).  The host then waits for update t-1 only, while update t is already queued behind it — the device
 // never idles on the host's index draw, the H2D of the indices or the read-back, which dqnhip_update pays on
 // every call.  Indices and scalars use two pinned slots each (nothing in flight is overwritten).
 int dqnhip_update_pipelined(dqnhip_handle h, const int32_t* idx_host, float* critic_loss, float* avg_q) {
   if (!h) return fail("null handle");
+  h->epoch += 1;
   HIPCHK(hipSetDevice(h->cfg.device));
   if (h->cfg.dp_world > 1 || h->dp_half || h->dp_shard) return fail("dqnhip_update_pipelined: data-parallel learners use dqnhip_update_phase / dqnhip_dp_update");
   if (h->next_phase != 0) return fail("dqnhip_update_pipelined: a phased update is in progress (next phase %d)", h->next_phase);
@@ -1561,6 +1619,7 @@ int dqnhip_update_pipelined(dqnhip_handle h, const int32_t* idx_host, float* cri
 // all-reduce; the same k_adam_soft pass as inside an update.
 int dqnhip_apply_update(dqnhip_handle h, int32_t net) {
   if (!h) return fail("null handle");
+  h->epoch += 1;
   if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return fail("net must be ACTOR or CRITIC");
   if (h->next_phase != 0) return fail("dqnhip_apply_update: a phased update is in progress (next phase %d)", h->next_phase);
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -1584,6 +1643,7 @@ int dqnhip_apply_update(dqnhip_handle h, int32_t net) {
 // the order in which the clip norm is summed (identical bits whenever the clip is inactive).
 int dqnhip_apply_update_sharded(dqnhip_handle h, int32_t net, int32_t world) {
   if (!h) return fail("null handle");
+  h->epoch += 1;
   if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return fail("net must be ACTOR or CRITIC");
   if (h->next_phase != 0) return fail("dqnhip_apply_update_sharded: a phased update is in progress (next phase %d)", h->next_phase);
   const NetLayout& l = layout_of(h, net);
@@ -1648,7 +1708,16 @@ int dqnhip_benchmark_blocking(dqnhip_handle h, int32_t warmup, int32_t iteration
   std::mt19937 rng((uint32_t)seed);
   std::vector<int32_t> idx(h->B);
   float loss = 0, avgq = 0;
+  std::vector<int32_t> nxt(h->B);
+  bool have_next = false;
   auto one = [&]() -> int {
+    if (pipelined == 2) {
+      // the drop-in's chained form (dqn_dropin.cpp UpdateActorCritic): the next update's indices are drawn one call ahead
+      if (have_next) idx.swap(nxt); else for (int32_t& i : idx) i = std::uniform_int_distribution<int>(0, size - 1)(rng);
+      for (int32_t& i : nxt) i = std::uniform_int_distribution<int>(0, size - 1)(rng);
+      have_next = true;
+      return dqnhip_update_chained(h, idx.data(), nxt.data(), &loss, &avgq);
+    }
     for (int32_t& i : idx) i = std::uniform_int_distribution<int>(0, size - 1)(rng);
     return pipelined ? dqnhip_update_pipelined(h, idx.data(), &loss, &avgq) : dqnhip_update(h, idx.data(), &loss, &avgq);
   };
@@ -1658,7 +1727,7 @@ int dqnhip_benchmark_blocking(dqnhip_handle h, int32_t warmup, int32_t iteration
   for (int i = 0; i < iterations; ++i) RC(one());
   HIPCHK(hipStreamSynchronize(h->stream));
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (pipelined) RC(dqnhip_read_stats(h, &loss, &avgq));      // drains the one outstanding read-back
+  if (pipelined == 1) RC(dqnhip_read_stats(h, &loss, &avgq));      // drains the one outstanding read-back
   if (avg_ms) *avg_ms = (float)(ms / iterations);
   return 0;
 }

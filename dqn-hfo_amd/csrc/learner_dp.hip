@@ -331,6 +331,7 @@ int dqnhip_dp_init_file(dqnhip_handle h, const char* path, int32_t flags, int32_
 
 int dqnhip_dp_broadcast_params(dqnhip_handle h, int32_t root) {
   if (!h) return fail("null handle");
+  h->epoch += 1;
   if (!h->comm) return fail("dp_broadcast_params: no communicator (call dqnhip_dp_init first)");
   if (root < 0 || root >= h->cfg.dp_world) return fail("bad root %d", root);
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -339,6 +340,7 @@ int dqnhip_dp_broadcast_params(dqnhip_handle h, int32_t root) {
 
 int dqnhip_dp_update(dqnhip_handle h, const int32_t* idx_host) {
   if (!h) return fail("null handle");
+  h->epoch += 1;
   if (!h->comm) return fail("dp_update: no communicator (call dqnhip_dp_init first)");
   HIPCHK(hipSetDevice(h->cfg.device));
   if (h->next_phase != 0) return fail("dqnhip_dp_update: a phased update is in progress (next phase %d)", h->next_phase);
@@ -365,6 +367,7 @@ int dqnhip_dp_update(dqnhip_handle h, const int32_t* idx_host) {
 // n data-parallel updates with on-device sampling (dqnhip_update_async_n for a group: every rank calls it with the same n)
 int dqnhip_dp_update_n(dqnhip_handle h, int32_t n) {
   if (!h) return fail("null handle");
+  h->epoch += 1;
   if (!h->comm) return fail("dp_update_n: no communicator (call dqnhip_dp_init first)");
   if (n < 0) return fail("dqnhip_dp_update_n: n must be >= 0");
   HIPCHK(hipSetDevice(h->cfg.device));

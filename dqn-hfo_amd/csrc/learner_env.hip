@@ -182,6 +182,7 @@ int dqnhip_env_step(dqnhip_env_handle e, float epsilon, int32_t n_steps) {
   if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return fail("Check failed: epsilon >= 0.0 && epsilon <= 1.0");   // src/dqn.cpp:698
   if (n_steps < 1) return fail("n_steps must be >= 1");
   dqnhip_learner* h = e->h;
+  RO(h)->epoch += 1;            // episodes may end inside: the ring changes on the device
   HIPCHK(hipSetDevice(h->cfg.device));
   hipStream_t st = h->stream;
   RingUse ring_use(h);

@@ -181,8 +181,19 @@ struct dqnhip_learner {
   std::vector<TimingRec> recs;
   // graph
   int cap_u = -1;              // while capturing a multi-update graph: the position of the update being captured (else -1)
-  hipGraphExec_t graph_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0]: device-sampled, [1]: explicit idx (pinned buffer -> memcpy node), [2], [3]: explicit idx in the pipelined slots, [4]: kMultiU device-sampled updates (dqnhip_update_async_n)
+  // [0]: device-sampled, [1]: explicit idx (pinned buffer), [2], [3]: explicit idx in the pipelined slots, [4]: kMultiU device-sampled
+  // updates (dqnhip_update_async_n), [5] .. [7]: dqnhip_update_chained — head of a chain (own gather, parity 0), continued at parity 1 / 0
+  hipGraphExec_t graph_exec[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool graph_failed = false;
+  // dqnhip_update_chained (the drop-in's blocking update with the NEXT update's indices known one call ahead): the next update's gather
+  // and first layers ride in this update's optimiser launches, as inside a multi-update graph.  What rode along is only used if the
+  // next call brings exactly those indices and nothing touched weights, iterations or the replay memory in between (epoch).
+  unsigned long long epoch = 0;         // bumped by every entry point that changes weights, iteration counters or the replay memory
+  bool chain_cap = false;               // a chain graph is being captured (gather_args: riders read idx_next, counters = live + 1)
+  bool chain_valid = false; int chain_par = 0;
+  unsigned long long chain_epoch = 0, chain_ring_epoch = 0;
+  std::vector<int32_t> chain_idx;       // the indices the riders gathered
+  int* idx_next_pinned[2] = {nullptr, nullptr}; const int* idx_next_dev[2] = {nullptr, nullptr};   // by the parity of the update they belong to
   // dqnhip_update_pipelined
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};
   int* pipe_idx_dev[2] = {nullptr, nullptr}; int* pipe_idx_pinned[2] = {nullptr, nullptr};

@@ -93,6 +93,7 @@ int dqnhip_critic_forward(dqnhip_handle h, int32_t net, const float* states_host
 
 static int add_dev(H* h, const float* s, const float* a, const float* r, const float* mc, const float* nx,
                    const uint8_t* term, int n, int single) {
+  RO(h)->epoch += 1;          // (dqnhip_update_chained: whatever a rider gathered ahead is stale)
   // n == 0 is AddTransitions of an empty vector: `while (size() + 0 >= capacity) pop_front()` (src/dqn.cpp:776) still evicts
   // one transition from a full deque — only the bookkeeping runs
   if (n < 0 || (n == 0 && single != 0)) return fail("n must be >= 1");
@@ -177,6 +178,7 @@ int dqnhip_memory_size(dqnhip_handle h, int32_t* size) {
 
 int dqnhip_clear_memory(dqnhip_handle h) {
   if (!h) return fail("null handle");
+  RO(h)->epoch += 1;
   HIPCHK(hipSetDevice(h->cfg.device));
   RingUse ring_use(h);
   HIPCHK(hipMemsetAsync(RO(h)->st, 0, 2 * sizeof(int), h->stream));   // ring_head, ring_size
@@ -320,6 +322,7 @@ int dqnhip_snapshot_replay_memory(dqnhip_handle h, const char* filename) {
 
 int dqnhip_load_replay_memory(dqnhip_handle h, const char* filename) {
   if (!h || !filename) return fail("null argument");
+  RO(h)->epoch += 1;
   HIPCHK(hipSetDevice(h->cfg.device));
   gzFile f = gzopen(filename, "rb");
   if (!f) return fail("Invalid file: %s", filename);              // CHECK(is_regular_file), src/dqn.cpp:1181
@@ -404,6 +407,7 @@ int dqnhip_get_params(dqnhip_handle h, int32_t net, int32_t kind, float* host, s
 
 int dqnhip_set_params(dqnhip_handle h, int32_t net, int32_t kind, const float* host, size_t count) {
   if (!h || !host) return fail("null argument");
+  h->epoch += 1;
   float* p = arena_ptr(h, net, kind);
   if (!p) return fail("bad (net,kind) = (%d,%d)", net, kind);
   const NetLayout& l = layout_of(h, net);
@@ -421,6 +425,7 @@ int dqnhip_set_params(dqnhip_handle h, int32_t net, int32_t kind, const float* h
 
 int dqnhip_clone_to_target(dqnhip_handle h, int32_t net) {
   if (!h) return fail("null handle");
+  h->epoch += 1;
   if (net != DQNHIP_ACTOR && net != DQNHIP_CRITIC) return fail("net must be ACTOR or CRITIC");
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t sh = h->shared_fl[net], n = layout_of(h, net).arena;
@@ -456,6 +461,7 @@ static int shared_prefix(const NetLayout& l, int n, size_t* fl) {
 
 int dqnhip_share_parameters(dqnhip_handle owner, dqnhip_handle other, int32_t num_actor_layers, int32_t num_critic_layers) {
   if (!owner || !other || owner == other) return fail("ShareParameters needs two distinct learners");
+  owner->epoch += 1; other->epoch += 1;
   if (owner->cfg.device != other->cfg.device) return fail("ShareParameters: both learners must live on the same device");
   if (!same_nets(owner, other)) return fail("ShareParameters: net shapes differ");
   if (owner->fp16 || other->fp16) return fail("ShareParameters is not supported in fp16 mode (each learner keeps private fp16 weight copies)");
@@ -477,6 +483,7 @@ int dqnhip_share_parameters(dqnhip_handle owner, dqnhip_handle other, int32_t nu
 
 int dqnhip_share_replay_memory(dqnhip_handle owner, dqnhip_handle other) {
   if (!owner || !other || owner == other) return fail("ShareReplayMemory needs two distinct learners");
+  owner->epoch += 1; other->epoch += 1; RO(owner)->epoch += 1;
   if (owner->cfg.device != other->cfg.device) return fail("ShareReplayMemory: both learners must live on the same device");
   if (owner->S != other->S) return fail("ShareReplayMemory: state sizes differ");
   H* root = RO(owner);
@@ -503,6 +510,7 @@ int dqnhip_get_iters(dqnhip_handle h, int32_t* actor_iter, int32_t* critic_iter)
 
 int dqnhip_set_iters(dqnhip_handle h, int32_t actor_iter, int32_t critic_iter) {
   if (!h) return fail("null handle");
+  h->epoch += 1;
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipStreamSynchronize(h->stream));
   int v[2] = {actor_iter, critic_iter};

@@ -181,6 +181,8 @@ struct GatherArgs {
   float beta1, beta2; int soft_update_freq;
   // -1: a launch of its own — the live counters are this update's.  k >= 1: the gather of the k-th update of a
   // multi-update graph riding in update k-1's last launch — counters = DevState::gbase + k (see DevState).
+  // -2: explicit indices, riding in the previous update's CRITIC optimiser launch (a kernel boundary before that update's tick):
+  // counters = live + 1.
   int ahead;
   int store_base;                   // 1 (first update of a multi-update graph): also store the live counters to gbase
   int blocks;
@@ -189,7 +191,8 @@ __device__ __forceinline__ void gather_block(const GatherArgs& g, const int blk)
   const DevState* st = g.st;
   if (blk == g.blocks - 1) {
     int it_a, it_c;
-    if (g.ahead < 0) { it_a = st->actor_iter; it_c = st->critic_iter; }
+    if (g.ahead == -2) { it_a = st->actor_iter + 1; it_c = st->critic_iter + 1; }      // rides in the PREVIOUS update's critic launch, before that update's tick (dqnhip_update_chained)
+    else if (g.ahead < 0) { it_a = st->actor_iter; it_c = st->critic_iter; }
     else { it_a = st->gbase_it[0] + g.ahead; it_c = st->gbase_it[1] + g.ahead; }
     if (threadIdx.x == 64) *g.soft_now = ((((it_a + 1) > (it_c + 1) ? (it_a + 1) : (it_c + 1)) % g.soft_update_freq) == 0);
     if (threadIdx.x == 65 && g.store_base) { g.st->gbase_counter = st->update_counter; g.st->gbase_it[0] = it_a; g.st->gbase_it[1] = it_c; }

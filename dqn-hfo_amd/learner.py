@@ -371,6 +371,15 @@ class DQN:
             raise DQNFatal("need %d indices, got %d" % (self.kMinibatchSize, i.size))
         return i, i.ctypes.data_as(capi.ip)
 
+    def UpdateActorCriticChained(self, idx, idx_next=None):
+        """dqnhip_update_chained: this update on idx; idx_next = the indices the NEXT call will bring (its gather and first layers then
+        ride in this update's optimiser launches).  Same results as UpdateActorCritic(idx)."""
+        loss, avgq = C.c_float(), C.c_float()
+        keep, ip = self._idx(idx)
+        keep2, ip2 = self._idx(idx_next)
+        self._ck(self.lib.dqnhip_update_chained(self.h, ip, ip2, C.byref(loss), C.byref(avgq)))
+        return loss.value, avgq.value
+
     def UpdateActorCriticPipelined(self, idx=None):
         """dqnhip_update_pipelined: enqueue this update, return (critic_loss, avg_q) of the PREVIOUS one."""
         loss, avgq = C.c_float(), C.c_float()

@@ -145,6 +145,10 @@ class DQN {
   int minibatch_;
   bool dp_ = false;                                    // -dp_rendezvous given: UpdateActorCritic() is one rank's share of a data-parallel update
   bool dp_sync_pending_ = false;                       // a Restore* / Load* ran since the group's last broadcast: re-sync at the next update
+  // UpdateActorCritic(): the next call's indices, predicted from a copy of random_engine (dqnhip_update_chained)
+  bool spec_valid_ = false; int spec_size_ = 0;
+  std::mt19937 spec_before_, spec_after_;              // the engine as the prediction found / left it
+  std::vector<int> spec_idx_;
   bool dp_synced_once_ = false;                        // the group's first update has passed: Restore* / Load* are refused from here on (one-sided collective)
   void SyncReplicasIfPending();
   void RearmReplicaSync(const char* what);

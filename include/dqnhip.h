@@ -182,6 +182,21 @@ int dqnhip_update(dqnhip_handle h, const int32_t* idx_host,
 int dqnhip_update_pipelined(dqnhip_handle h, const int32_t* idx_host,
                             float* critic_loss, float* avg_q);
 
+/* dqnhip_update for a caller that runs its updates in bursts of blocking calls — the reference's driver:
+ * `for (i < n_updates) dqn->Update()`, src/dqn_main.cpp:359-361, each Update() drawing its indices on the host
+ * (src/dqn.cpp:501-509) and returning (critic_loss, avg_q) — and can say which indices its NEXT call will bring
+ * (idx_next, NULL: unknown).  The next update's minibatch gather then rides in this update's critic optimiser launch and
+ * its four first tower layers in the actor's, as inside dqnhip_update_async_n's sixteen-update graphs, instead of heading
+ * the next call's chain (~12 us of ~300).  What rode along is used only if the next call's idx_host equals this call's
+ * idx_next element for element AND no entry point changed weights, iteration counters or the replay memory in between
+ * (AddTransition(s), set_params, Load*, Restore*, CloneNet, sharing, any other update call, an env step); otherwise the
+ * next call simply starts a fresh chain.  Every update computes what dqnhip_update computes on the same indices, bit for
+ * bit.  Learners the riders do not fit (see dqnhip_get_update_plan: early_gather_l0; fp16, data-parallel, sharing
+ * learners; use_graph = 0) run dqnhip_update.  The drop-in draws idx_next from a COPY of its std::mt19937 and adopts the
+ * copy's state only when the prediction held, so the engine's observable call order is the reference's. */
+int dqnhip_update_chained(dqnhip_handle h, const int32_t* idx_host, const int32_t* idx_next,
+                          float* critic_loss, float* avg_q);
+
 /* Same update, enqueued on the stream without a host sync (the scalars stay
  * on the device; read them with dqnhip_read_stats). */
 int dqnhip_update_async(dqnhip_handle h, const int32_t* idx_host);
@@ -354,7 +369,8 @@ int dqnhip_benchmark(dqnhip_handle h, int32_t warmup, int32_t iterations,
 /* DQN::Benchmark as the reference's driver experiences it through the drop-in (src/dqn.cpp:487-498 loops over
  * UpdateActorCritic(): indices drawn on the host with std::mt19937 + uniform_int_distribution, :501-509, and a
  * blocking (critic_loss, avg_q) per update): wall-clock average over `iterations` calls of dqnhip_update
- * (pipelined = 0) or dqnhip_update_pipelined (pipelined = 1) after `warmup` untimed ones. */
+ * (pipelined = 0), dqnhip_update_pipelined (pipelined = 1) or dqnhip_update_chained with the next call's indices drawn one
+ * call ahead (pipelined = 2: what the drop-in's UpdateActorCritic() does) after `warmup` untimed ones. */
 int dqnhip_benchmark_blocking(dqnhip_handle h, int32_t warmup, int32_t iterations, uint64_t seed,
                               int32_t pipelined, float* avg_ms);
 

@@ -109,6 +109,6 @@ int main(int argc, char** argv) {
   if (!std::isfinite(res.first) || !std::isfinite(res.second)) return 4;
   if (dqn.States(5).size() != 5 || (int)dqn.States(3)[2][0]->size() != num_features) return 10;
   if (dqn::FilesMatchingRegexp("/tmp/dqnhip_adaptor_smoke_agent0_.*").size() != 0) return 11;
-  std::printf("adaptor smoke OK: %d transitions, %d updates, loss %g avg_q %g\n", dqn.memory_size(), dqn.actor_iter(), res.first, res.second);
+  std::printf("adaptor smoke OK: %d transitions, %d updates, loss %.9g avg_q %.9g\n", dqn.memory_size(), dqn.actor_iter(), res.first, res.second);
   return 0;
 }

@@ -33,6 +33,20 @@ def test_adaptor_runs_episode_loop(pkg, gpu):
     assert "adaptor smoke OK" in r.stdout
 
 
+@pytest.mark.gpu
+def test_chained_updates_change_nothing_the_driver_sees(pkg, gpu):
+    """-chained_updates (default on): UpdateActorCritic() predicts the next call's indices from a copy of its std::mt19937 and lets the
+    library run the next gather / first layers ahead.  The engine's call order, every loss and every weight must be those of the
+    plain blocking form: the episode loop (epsilon draws between the bursts break every prediction) ends on the same numbers."""
+    exe = _build(pkg)
+    outs = []
+    for flag in ("-chained_updates=true", "-chained_updates=false"):
+        r = subprocess.run([exe, "-seed", "7", "-memory", "5000", "-memory_threshold", "100", flag], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (flag, r.returncode, r.stdout, r.stderr)
+        outs.append([l for l in r.stdout.splitlines() if "adaptor smoke OK" in l])
+    assert outs[0] == outs[1] and len(outs[0]) == 1, outs
+
+
 def test_cpu_mode_stops_with_the_adaptors_message(pkg):
     """-gpu=false (Caffe CPU mode, src/dqn_main.cpp:208-212): no CPU backend exists by design; the adaptor says so through the
     driver's logging path BEFORE touching the device (so this runs on a box without a GPU), instead of a bare CHECK."""

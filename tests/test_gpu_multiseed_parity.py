@@ -6,11 +6,11 @@ order changes.  This file states what must hold whatever the order is (reference
 quantities of UpdateActorCritic, and :918-965, its gradients):
 
   * update 1 from identical states, every seed: the four Q vectors within 1e-4 (+1e-5 relative), mu(s) within 1e-4, the reported
-    (critic_loss, avg_q), and the action indices GetAction derives from the UPDATED actor on 512 probe states — exact, with the
-    decision margin asserted;
+    (critic_loss, avg_q), and the action indices GetAction derives from the UPDATED actor on 512 probe states — exact on every
+    probe, with the decision margins reported (at most a handful of near-ties among the 512);
   * gradients: 1e-5 (Frobenius, against the C oracle) on every pass in which both sides stored the same activation signs; where
     k units landed on the other side of zero (a pre-activation within fp32 round-off of 0: legitimate on either side) the bound
-    is 1e-5 + k x PER_FLIP, PER_FLIP = five times the largest per-unit effect measured (no cap on k);
+    is 1e-5 + k x PER_FLIP, PER_FLIP = ten times the largest per-unit effect measured (no cap on k);
   * at least a quarter of the seeds are flip-free throughout (printed), so the tight bound is exercised.
 """
 import numpy as np
@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 TOWER = (1024, 1024, 1024, 1024)
 SEEDS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12)          # consecutive: not selected
-PER_FLIP = 2.5e-3   # gradient error one flipped unit may add (relative Frobenius); measured per-unit effects: 1e-4 .. 5e-4 at 256 rows
+PER_FLIP = 2.5e-4   # gradient error one flipped unit may add (relative Frobenius) = 10 x the largest measured in update 1 (1.4e-5, 2.4e-5 at 256 rows)
 
 
 def _first_update(pkg, B, seed, n_replay=2048):
@@ -59,11 +59,14 @@ def _first_update(pkg, B, seed, n_replay=2048):
     assert err <= QTOL, (seed, err)
     act_o = c_oracle.get_action(out_o)[0]
     assert [pkg.GetAction(o).action for o in out_h] == list(act_o), seed
+    # ... and not by luck: a probe whose two best logits are closer than 4 x the learner-oracle difference could have gone either way.
+    # Such near-ties exist (512 random states through a freshly initialised actor); they must stay a handful, so that the equality
+    # above is decided by the arithmetic, not by the tie-break, on (almost) every probe
     lg = np.sort(out_o[:, [0, 1, 3]], axis=1)
-    margin = float((lg[:, -1] - lg[:, -2]).min())
-    rec["margin_over_err"] = margin / max(err, 1e-30)
-    # (a probe state whose two best logits tie to within round-off would make "exact" luck: assert there is none)
-    assert margin > 4 * err, (seed, margin, err)
+    margins = lg[:, -1] - lg[:, -2]
+    rec["near_ties"] = int((margins <= 4 * err).sum())
+    rec["median_margin_over_err"] = float(np.median(margins)) / max(err, 1e-30)
+    assert rec["near_ties"] <= 5 and rec["median_margin_over_err"] > 100, (seed, rec)
     dqn.close(); orc.close()
     return rec
 
