@@ -281,6 +281,41 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
         out["configs2_64workers_s68"] = {"env_steps_per_s": round(64 / dt, 1), "us_per_batched_step": round(dt * 1e6, 2),
                                          "roofline": env_roofline(68, 64, dt * 1e6)}
         env.close(); d.close()
+        # BOTH halves of BASELINE's metric at once: the reference's loop interleaves acting and learning — an
+        # episode's steps, then `steps x update_ratio` updates (src/dqn_main.cpp:346-363, FLAGS_update_ratio 0.1) — on one thread per
+        # agent.  Here: `workers` batched env steps then the updates they owe, enqueued back to back on the learner's stream (the env
+        # front-end acts with the learner's actor and appends to its replay ring: the two are ordered, as in the reference), steady state.
+        tl = {}
+        for name, S_, workers, steps_per_burst in (("configs1_1_worker", S, 1, 160), ("configs2_64_workers_s68", 68, 64, 5), ("configs4_2048_workers", S, 2048, 1)):
+            d = pkg.DQN(S_, minibatch=B, hidden=HIDDEN, memory=400000, seed=1, device=local_rank, use_graph=True)
+            prefill(d, 100000, seed=7) if S_ == S else d.add_transitions_arrays(*__import__("synth").synth_replay(np.random.default_rng(3), 60000, S_))
+            env = pkg.EnvFrontEnd(d, workers, max_steps=100 if workers >= 1024 else 500, p_end=0.01, seed=5)
+            owed, bursts = 0.0, (40 if workers < 2048 else 12)
+            def burst():
+                nonlocal owed
+                env.step(0.1, steps_per_burst)
+                owed += workers * steps_per_burst * 0.1
+                k = int(owed); owed -= k
+                if k:
+                    d.update_async_n(k)
+                return k
+            for _ in range(3):
+                burst()
+            env.stats(); d.read_stats()
+            t1 = time.perf_counter(); n_up = sum(burst() for _ in range(bursts)); env.stats(); d.read_stats()
+            dt = time.perf_counter() - t1
+            # the same two loads alone, same learner, same process
+            t1 = time.perf_counter(); env.step(0.1, steps_per_burst * bursts); env.stats(); dt_env = time.perf_counter() - t1
+            d.update_async_n(64); d.read_stats()
+            t1 = time.perf_counter(); d.update_async_n(max(n_up, 64)); d.read_stats(); dt_up = time.perf_counter() - t1
+            tl[name] = {"workers": workers, "state_size": S_, "update_ratio": 0.1, "env_steps_per_burst": workers * steps_per_burst,
+                        "updates_per_s": round(n_up / dt, 1), "env_steps_per_s": round(workers * steps_per_burst * bursts / dt, 1),
+                        "isolated": {"env_steps_per_s": round(workers * steps_per_burst * bursts / dt_env, 1), "updates_per_s": round(max(n_up, 64) / dt_up, 1)},
+                        "time_share_model": round((workers * steps_per_burst * bursts / dt) / (workers * steps_per_burst * bursts / dt_env) + (n_up / dt) / (max(n_up, 64) / dt_up), 3)}
+            env.close(); d.close()
+        tl["what"] = ("env steps and the updates they owe (update_ratio 0.1, src/dqn_main.cpp:346-363) enqueued alternately on the learner's stream; "
+                      "time_share_model = concurrent / isolated rate, summed over the two loads (1.0 = the two simply share the stream's time)")
+        out["train_loop"] = tl
         # what ONE rank of configs[4] on 8 GPUs runs (4096 / 8 = 512 rows), with the communicator in place (one rank:
         # the all-reduce moves nothing): the captured data-parallel update against the eager one and against the plain
         # captured update -> what the collectives' launches and the bf16 conversion cost beside the kernels
@@ -744,13 +779,18 @@ def main():
     if rank == 0 and not dist_on and not args.no_subrecords:
         ms_b = dqn.BenchmarkBlocking(1000, 100, seed=1, pipelined=False)
         ms_p = dqn.BenchmarkBlocking(1000, 100, seed=1, pipelined=True)
+        ms_c = dqn.BenchmarkBlocking(1000, 100, seed=1, pipelined=2)
         ms_a = elapsed / args.steps * 1e3
-        dropin = {"blocking_ms_per_update": round(ms_b, 5), "blocking_updates_per_s": round(1e3 / ms_b, 1),
+        dropin = {"blocking_ms_per_update": round(ms_c, 5), "blocking_updates_per_s": round(1e3 / ms_c, 1),
+                  "blocking_form": "dqnhip_update_chained: what the drop-in's UpdateActorCritic() calls since round 6 (the next call's indices predicted "
+                                   "from a copy of the driver's std::mt19937; the next gather / first layers ride in this update's optimiser launches)",
+                  "unchained_blocking_ms_per_update": round(ms_b, 5), "unchained_blocking_updates_per_s": round(1e3 / ms_b, 1),
                   "pipelined_ms_per_update": round(ms_p, 5), "pipelined_updates_per_s": round(1e3 / ms_p, 1),
                   "async_headline_ms_per_update": round(ms_a, 5),
-                  "blocking_vs_async": round(ms_b / ms_a, 4), "pipelined_vs_async": round(ms_p / ms_a, 4),
-                  "what": "dqnhip_update(h, idx_host, &loss, &avg_q) x 1000 with host-drawn indices = DQN::UpdateActorCritic() of the "
-                          "drop-in (dqn_dropin.cpp), i.e. DQN::Benchmark / dqn_main.cpp:361; pipelined = dqnhip_update_pipelined "
+                  "blocking_vs_async": round(ms_c / ms_a, 4), "unchained_blocking_vs_async": round(ms_b / ms_a, 4), "pipelined_vs_async": round(ms_p / ms_a, 4),
+                  "what": "1000 blocking updates with host-drawn indices and a (loss, avg_q) read-back each = DQN::UpdateActorCritic() of the "
+                          "drop-in (dqn_dropin.cpp), i.e. DQN::Benchmark / dqn_main.cpp:361; unchained = plain dqnhip_update (-chained_updates=false, "
+                          "rounds 3-5); pipelined = dqnhip_update_pipelined "
                           "(-pipelined_stats: returns the previous update's scalars)"}
 
     # env-steps/sec (the other half of BASELINE.json's metric): N synthetic workers -> batched
@@ -790,6 +830,10 @@ def main():
 
     out = None
     if rank == 0:
+        try:
+            plan = dqn.update_plan()
+        except Exception as ex:        # (a sharded optimiser's sequence is not counted; never fatal for the line)
+            plan = {"error": str(ex)}
         ups = args.steps / elapsed
         value = ups if args.strong else ups * (world if world > 1 else 1)
         fl = sum(family_flops(B, S, HIDDEN).values())
@@ -814,6 +858,7 @@ def main():
                                    else "one call (one hipGraph launch) per update"),
                        **({"ms_per_step_one_update_per_graph_launch": round(one_per_launch_ms, 5)} if one_per_launch_ms else {}),
                        "tuning_flags": args.tuning,
+                       "plan": plan,        # dqnhip_get_update_plan: the merged launch forms this learner runs + kernels per update, counted from a capture
                        **({"n1_same_job": n1_same_job} if n1_same_job else {}),
                        **({"native_dp_error": native_error} if native_error else {}),
                        **({"captured_dp_probe": dp_probe} if use_dp and dp_probe is not None else {}),

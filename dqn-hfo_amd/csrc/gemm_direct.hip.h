@@ -501,6 +501,89 @@ __device__ __forceinline__ void wgrad_direct_body(const GemmProblem& pr, int til
   }
 }
 
+// ---- WGRAD, quadrants: no split-K (round 6 experiment) ---------------------------------------------------
+// At minibatches <= 512 the reduction (the rows) is only 256-512 deep; wgrad_direct_body still splits it four ways over the waves
+// and pays one LDS pass (64 KB parked, 256 KB read back per workgroup) to add the partial tiles.  Here each wave OWNS a 32 x 32
+// quadrant of the 64 x 64 tile over the WHOLE reduction: four accumulators, 8-byte operand loads (two columns per lane), no
+// parking, no barrier before the stores.  Same tile map, same db / sum-of-squares outputs (the partial is summed in another
+// fixed order); every dW element is ONE chain over the rows instead of four quarter chains.
+// Measured against wgrad_direct_body in the test harness (dqnhip_test_gemm mode 2, variant 3): profiles/r06_wgrad_quadrants.txt.
+template <int NS = 8>
+__device__ __forceinline__ void wgrad_quad_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wp = wave & 1, wq = wave >> 1;
+  const int p0 = tile_p * 64 + wp * 32, q0 = tile_q * 64 + wq * 32;
+  const int nst = pr.Kred >> 2;              // steps of 4 rows (lane group lg owns row 4 st + lg)
+  const float* pp = pr.P + (size_t)lg * pr.ldp + p0 + li * 2;
+  const float* qp = pr.Q + (size_t)lg * pr.ldq + q0 + li * 2;
+  const size_t ldp4 = (size_t)4 * pr.ldp, ldq4 = (size_t)4 * pr.ldq;
+  const bool want_db = (pr.db != nullptr) && (tile_p == 0) && (wp == 0);
+  f32x4 acc[4];     // index qc * 2 + pc
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x2 dbacc = f32x2{0.f, 0.f};
+  f32x2 rp[NS], rq[NS];
+#define WQ_LOAD(slot, st) { rp[slot] = *reinterpret_cast<const f32x2*>(pp + (size_t)(st) * ldp4); rq[slot] = *reinterpret_cast<const f32x2*>(qp + (size_t)(st) * ldq4); }
+#define WQ_COMPUTE(slot)                                                                \
+  {                                                                                     \
+    dbacc.x += rq[slot].x; dbacc.y += rq[slot].y;                                       \
+    _Pragma("unroll") for (int qc = 0; qc < 2; ++qc)                                    \
+    _Pragma("unroll") for (int pc = 0; pc < 2; ++pc)                                    \
+        acc[qc * 2 + pc] = DQN_MFMA(rp[slot][pc], rq[slot][qc], acc[qc * 2 + pc]);      \
+  }
+  const int nstN = nst - nst % NS;
+  if (nstN > 0) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { WQ_LOAD(i, i) DQN_PIN(); }
+    int st = 0;
+    for (; st + NS < nstN; st += NS) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) { WQ_COMPUTE(i) DQN_PIN(); WQ_LOAD(i, st + NS + i) DQN_PIN(); }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { WQ_COMPUTE(i) }
+  }
+  for (int st = nstN; st < nst; ++st) { WQ_LOAD(0, st) WQ_COMPUTE(0) }
+#undef WQ_LOAD
+#undef WQ_COMPUTE
+  // C/D map of acc[qc * 2 + pc]: lane (li, lg), register r = D[i = 4 lg + r][j = li] = dW[n = q0 + 2 li + qc][p = p0 + 2 (4 lg + r) + pc]
+  float ssq = 0.0f;
+#pragma unroll
+  for (int qc = 0; qc < 2; ++qc) {
+    const int n = q0 + li * 2 + qc;
+    const f32x4 a0 = acc[qc * 2 + 0], a1 = acc[qc * 2 + 1];
+    const f32x4 v0 = f32x4{a0.x, a1.x, a0.y, a1.y}, v1 = f32x4{a0.z, a1.z, a0.w, a1.w};     // p = p0 + 8 lg + 0..3, + 4..7
+    ssq = fmaf(v0.x, v0.x, ssq); ssq = fmaf(v0.y, v0.y, ssq); ssq = fmaf(v0.z, v0.z, ssq); ssq = fmaf(v0.w, v0.w, ssq);
+    ssq = fmaf(v1.x, v1.x, ssq); ssq = fmaf(v1.y, v1.y, ssq); ssq = fmaf(v1.z, v1.z, ssq); ssq = fmaf(v1.w, v1.w, ssq);
+    float* c = pr.C + (size_t)n * pr.ldc + p0 + (lg << 3);
+    *reinterpret_cast<f32x4*>(c) = v0; *reinterpret_cast<f32x4*>(c + 4) = v1;
+  }
+  if (want_db) {
+    f32x2 v = dbacc;      // add the 4 lane groups (rows m + 0..3)
+    v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64);
+    v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64);
+    if (lg == 0) {
+      *reinterpret_cast<f32x2*>(pr.db + q0 + li * 2) = v;
+      ssq = fmaf(v.x, v.x, ssq); ssq = fmaf(v.y, v.y, ssq);
+    }
+  }
+  if (pr.partial != nullptr) {
+    ssq = wave_sum64(ssq);
+    if (lane == 0) smem[wave] = ssq;
+    __syncthreads();
+    if (threadIdx.x == 0) pr.partial[tile_q * pr.tiles_p + tile_p] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+  }
+}
+template <int NS>
+__global__ __launch_bounds__(256) void gemm_wgrad_quad(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  wgrad_quad_body<NS>(batch.prob[pi], tile_p, tile_q, smem);
+}
+
 // ---- WGRAD, narrow: 16 columns of dY per workgroup ------------------------------------------
 // The first tower layer's dW_0[n][j] has only K_in = 64 / 128 columns j: with 64 x 64 tiles it is 16 / 32
 // workgroups whose waves each hold 4.2 us of MFMA (a latency-bound 8 us launch on a sliver of the chip).
@@ -1210,6 +1293,8 @@ inline hipError_t wgrad_direct_launch(GemmBatch& b, hipStream_t s) {
   return direct_launch(gemm_wgrad_direct<TPB, TQB>, b, 64 * TPB, 64 * TQB,
                        4 * TPB * 4 * TQB * 4 * 64 * 16 + 4 * TQB * 16 * 16, s);
 }
+template <int NS>
+inline hipError_t wgrad_quad_launch(GemmBatch& b, hipStream_t s) { return direct_launch(gemm_wgrad_quad<NS>, b, 64, 64, 64, s); }
 // mixed dgrad(64x16)/wgrad(64x64) launch; every problem carries its own mode
 template <int TQD, bool DLDS = false>
 inline hipError_t bwd_pair_direct_launch(GemmBatch& batch, hipStream_t stream) {

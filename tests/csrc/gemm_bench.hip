@@ -145,6 +145,9 @@ hipError_t launch_variant(int mode, int variant, GemmBatch& b, hipStream_t s) {
       case 0: return gemm_launch<GEMM_WGRAD, 64, 64, 2, 2>(b, s);
       case 1: return wgrad_direct_launch<1, 1>(b, s);  // 64x64
       case 2: return wgrad_narrow_launch<1>(b, s);     // 64 x 16 outputs (first layer)
+      case 3: return wgrad_quad_launch<8>(b, s);       // 64x64, one 32x32 quadrant per wave over the whole reduction (no split-K, no LDS pass)
+      case 4: return wgrad_quad_launch<4>(b, s);
+      case 5: return wgrad_quad_launch<16>(b, s);
     }
   }
   return hipErrorInvalidValue;

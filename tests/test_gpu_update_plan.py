@@ -16,21 +16,21 @@ FP32_ALL = {"bwd_shifted_critic", "bwd_shifted_actor", "head_wgrad_rides_critic"
 
 # (name, constructor arguments, data-parallel flags or None, forms, (single, graph_first, in_graph) launches)
 CASES = [
-    # BASELINE configs[1]: every merged form, 26 launches stand-alone, 25 inside a sixteen-update graph
-    ("configs1_b256_4x1024", dict(state_size=58, minibatch=256, hidden=TOWER), None, FP32_ALL, None),
+    # BASELINE configs[1]: every merged form, 26 launches stand-alone, 24 inside a sixteen-update graph (gather and first layers ride)
+    ("configs1_b256_4x1024", dict(state_size=58, minibatch=256, hidden=TOWER), None, FP32_ALL, (26, 26, 24)),
     # the reference's compile-time defaults (configs[0] on the GPU): 128-wide tower top -> no k_dgrad_qtrain / k_dqda_head_bwd
     # (both need a tower top that is a multiple of 256); layers narrower than 512 take the pair launches, not the shifted schedule
     ("configs0_b32_ref_tower", dict(state_size=59, minibatch=32, hidden=REF_TOWER), None,
-     {"head_wgrad_rides_critic", "head_wgrad_rides_actor", "head_seed_fused", "critic_l0_rides", "first_layers_merged", "early_gather_l0"}, None),
+     {"head_wgrad_rides_critic", "head_wgrad_rides_actor", "head_seed_fused", "critic_l0_rides", "first_layers_merged", "early_gather_l0"}, (28, 28, 26)),
     # configs[2]'s learner (S = 68: both first panels are 128 wide — the actor's first-layer riders of k_adam_soft_l0 are built for 64)
-    ("configs2_b256_s68", dict(state_size=68, minibatch=256, hidden=TOWER), None, FP32_ALL - {"early_gather_l0"}, None),
+    ("configs2_b256_s68", dict(state_size=68, minibatch=256, hidden=TOWER), None, FP32_ALL - {"early_gather_l0"}, (26, 26, 25)),
     # configs[3] / weak scaling: a rank of a replicated data-parallel group at 256 rows runs the same merged forms (round 6)
-    ("dp_rank_b256_half_grads", dict(state_size=58, minibatch=256, hidden=TOWER), dict(half_grads=True), FP32_ALL | {"data_parallel"}, None),
+    ("dp_rank_b256_half_grads", dict(state_size=58, minibatch=256, hidden=TOWER), dict(half_grads=True), FP32_ALL | {"data_parallel"}, (30, 30, 28)),
     # ... the per-rank shape of a 4096-row minibatch on 8 GPUs, fp32
-    ("dp_rank_b512_half_grads", dict(state_size=58, minibatch=512, hidden=TOWER), dict(half_grads=True), FP32_ALL | {"data_parallel"}, None),
+    ("dp_rank_b512_half_grads", dict(state_size=58, minibatch=512, hidden=TOWER), dict(half_grads=True), FP32_ALL | {"data_parallel"}, (30, 30, 28)),
     # configs[4] on one GPU, fp32: 4096 rows take the big head kernels; no rider fits
     ("configs4_b4096_fp32", dict(state_size=58, minibatch=4096, hidden=TOWER), None,
-     {"bwd_shifted_critic", "bwd_shifted_actor", "head_seed_fused"}, None),
+     {"bwd_shifted_critic", "bwd_shifted_actor", "head_seed_fused"}, (33, 33, 32)),
 ]
 
 
