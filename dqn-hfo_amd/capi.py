@@ -18,7 +18,7 @@ TUNE_SEPARATE_CRITIC_FIRST_LAYERS = 64
 TUNE_LATE_GATHER = 128
 # dqnhip_update_plan.forms bits (DQNHIP_PLAN_*), in bit order
 PLAN_FORMS = ("fp16", "data_parallel", "bwd_shifted_critic", "bwd_shifted_actor", "head_wgrad_rides_critic", "head_wgrad_rides_actor",
-              "q_train_in_dgrad", "head_seed_fused", "dqda_head_bwd", "critic_l0_rides", "first_layers_merged", "early_gather_l0")
+              "q_train_in_dgrad", "head_seed_fused", "dqda_head_bwd", "critic_l0_rides", "first_layers_merged", "early_gather_l0", "dp_tails_ride")
 ACTOR, CRITIC, ACTOR_TARGET, CRITIC_TARGET = 0, 1, 2, 3
 KIND_W, KIND_M, KIND_V, KIND_G = 0, 1, 2, 3
 

@@ -79,4 +79,39 @@ __device__ __forceinline__ float wave_sum64(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// sticky device flags (DevState::flags, small_kernels.hip.h)
+constexpr int kFlagTarget = 1;     // a TD target of the last update(s) was not finite
+constexpr int kFlagGradNorm = 2;   // a gradient L2 norm was not finite: that clip+Adam step was skipped
+
+// Data-parallel learners: the per-block loss / q partials reduced into the 4-float tails that ride in the gradient exchange
+// ([loss_sum, q_sum, target flag, 0]; tail[2] carries this rank's non-finite-target flag: it is raised from the rank's OWN replay
+// shard, so without it one rank would stop with "Target not finite!" while the others walk into the next collective).
+// One block of 256 threads, the reduction tree of tick_body (strided partials, butterfly, fixed cross-wave order).  A launch of its
+// own (k_tails) or — round 6 — ONE extra block of the net's last backward launch (everything it reads is complete launches earlier).
+struct TailsArgs {
+  const float* loss_partial; int n_loss; const double* q_partial; int n_q;
+  float inv_batch; float* critic_tail; float* actor_tail; const int* flags;
+  int on;                          // rider form: 1 = the launch's last block runs tails_block
+};
+__device__ __forceinline__ void tails_block(const TailsArgs& a, float* sdot /*[4]*/, double* sq /*[4]*/) {
+  const int t = threadIdx.x;
+  float dot = 0.0f; double qs = 0.0;
+  if (a.critic_tail != nullptr) for (int i = t; i < a.n_loss; i += 256) dot += a.loss_partial[i];
+  if (a.actor_tail != nullptr) for (int i = t; i < a.n_q; i += 256) qs += a.q_partial[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { dot += __shfl_xor(dot, off, 64); qs += __shfl_xor(qs, off, 64); }
+  if ((t & 63) == 0) { sdot[t >> 6] = dot; sq[t >> 6] = qs; }
+  __syncthreads();
+  if (t != 0) return;
+  if (a.critic_tail != nullptr) {
+    dot = (sdot[0] + sdot[1]) + (sdot[2] + sdot[3]);
+    a.critic_tail[0] = dot * a.inv_batch / 2.0f;   // EuclideanLoss: dot / num / 2
+    a.critic_tail[1] = 0.f; a.critic_tail[2] = (*a.flags & kFlagTarget) ? 1.0f : 0.f; a.critic_tail[3] = 0.f;
+  }
+  if (a.actor_tail != nullptr) {
+    qs = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+    a.actor_tail[0] = 0.f; a.actor_tail[1] = (float)qs; a.actor_tail[2] = 0.f; a.actor_tail[3] = 0.f;
+  }
+}
+
 }  // namespace dqnhip

@@ -1151,6 +1151,7 @@ struct HeadWgradRider {
   const float* X4; int H, rows;
   float* dW; float* db; float* partial;     // [NH][H], [NH], one sum-of-squares slot per rider block (H / 16)
   int blocks;                               // H / kRiderCW rider blocks, FIRST in the grid (0: none)
+  const _Float16* X416;                     // fp16 learner: the tower top in fp16 (then X4 is null).  Last member: aggregate initialisers of the fp32 call sites leave it null
 };
 constexpr int kRiderCW = 8;                    // columns per rider block (x 32 row groups)
 template <int NH>
@@ -1164,8 +1165,9 @@ __device__ __forceinline__ void head_wgrad_rider(const HeadWgradRider& r, const 
   constexpr int RB = 8;                        // every row of a 256-row minibatch in flight at once: the tower top was written
                                                // many launches ago (Infinity Cache / HBM latency, not L2)
   float xpre[RB];
+  auto ldx = [&](int m) -> float { return r.X416 != nullptr ? (float)r.X416[(size_t)m * r.H + k] : r.X4[(size_t)m * r.H + k]; };
 #pragma unroll
-  for (int u = 0; u < RB; ++u) xpre[u] = (m0 + u < m1) ? r.X4[(size_t)(m0 + u) * r.H + k] : 0.0f;
+  for (int u = 0; u < RB; ++u) xpre[u] = (m0 + u < m1) ? ldx(m0 + u) : 0.0f;
   for (int i = tid; i < r.rows * NH; i += 256) s_dy[i] = r.dy[(size_t)(i / NH) * r.lddy + (i % NH)];
   __syncthreads();
   float acc[NH];
@@ -1174,7 +1176,7 @@ __device__ __forceinline__ void head_wgrad_rider(const HeadWgradRider& r, const 
   for (int mb = m0; mb < m1; mb += RB) {
     float xb[RB];
 #pragma unroll
-    for (int u = 0; u < RB; ++u) xb[u] = (mb == m0) ? xpre[u] : ((mb + u < m1) ? r.X4[(size_t)(mb + u) * r.H + k] : 0.0f);
+    for (int u = 0; u < RB; ++u) xb[u] = (mb == m0) ? xpre[u] : ((mb + u < m1) ? ldx(mb + u) : 0.0f);
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
       const int m = mb + u;
@@ -1227,10 +1229,11 @@ __global__ __launch_bounds__(256) void gemm_wgrad_narrow_rider(const GemmBatch b
 // first layer's wgrad alone is 64-128 short workgroups — a 6-us launch of launch floor; beside a full wgrad it costs ~1.
 // Long workgroups first in the grid.
 template <int NH>
-__global__ __launch_bounds__(256) void gemm_wgrad_tail(const GemmBatch batch, const HeadWgradRider rider) {
+__global__ __launch_bounds__(256) void gemm_wgrad_tail(const GemmBatch batch, const HeadWgradRider rider, const TailsArgs tails) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int blk = (int)blockIdx.x;
   int tile_p, tile_q;
+  if (tails.on && blk == (int)gridDim.x - 1) { tails_block(tails, smem, reinterpret_cast<double*>(smem + 8)); return; }   // data-parallel learners: one more block, last in the grid
   if (blk < rider.blocks) { head_wgrad_rider<NH>(rider, blk, smem); return; }
   blk -= rider.blocks;
   const GemmProblem& p0 = batch.prob[1];
@@ -1351,18 +1354,19 @@ inline hipError_t wgrad_narrow_rider_launch(GemmBatch& batch, const HeadWgradRid
 }
 // prob[0]: wgrad on 64 x 64 tiles, prob[1]: narrow wgrad on 64 x 16 tiles; rider.blocks may be 0
 template <int NH>
-inline hipError_t wgrad_tail_launch(GemmBatch& batch, const HeadWgradRider& rider, hipStream_t stream) {
+inline hipError_t wgrad_tail_launch(GemmBatch& batch, const HeadWgradRider& rider, hipStream_t stream, const TailsArgs* tails_in = nullptr) {
+  TailsArgs tails{}; if (tails_in != nullptr) { tails = *tails_in; tails.on = 1; }
   GemmProblem& w1 = batch.prob[0]; GemmProblem& w0 = batch.prob[1];
   w1.tiles_p = w1.Pdim / 64; w1.tiles_q = w1.Qdim / 64; w1.tile_base = 0;
   w0.tiles_p = w0.Pdim / 64; w0.tiles_q = w0.Qdim / 16; w0.tile_base = w1.tiles_p * w1.tiles_q;
-  const int grid = w0.tile_base + w0.tiles_p * w0.tiles_q + rider.blocks;
+  const int grid = w0.tile_base + w0.tiles_p * w0.tiles_q + rider.blocks + (tails.on ? 1 : 0);
   batch.total_tiles = grid;
   const size_t need = rider.blocks ? (size_t)(rider.rows * NH + 16 * NH * 16) * sizeof(float) : 0;
   const size_t lds = std::max(need, (size_t)(4 * 16 * 64 * 16 + 4 * 16 * 16));
   if (lds > 80 * 1024) return hipErrorInvalidValue;          // two workgroups per CU
   LaunchTimer& lt = launch_timer();
-  if (lt.start) { hipExtLaunchKernelGGL((gemm_wgrad_tail<NH>), dim3(grid), dim3(256), lds, stream, lt.start, lt.stop, 0, batch, rider); lt.start = lt.stop = nullptr; }
-  else hipLaunchKernelGGL((gemm_wgrad_tail<NH>), dim3(grid), dim3(256), lds, stream, batch, rider);
+  if (lt.start) { hipExtLaunchKernelGGL((gemm_wgrad_tail<NH>), dim3(grid), dim3(256), lds, stream, lt.start, lt.stop, 0, batch, rider, tails); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL((gemm_wgrad_tail<NH>), dim3(grid), dim3(256), lds, stream, batch, rider, tails);
   return hipGetLastError();
 }
 template <bool DLDS>

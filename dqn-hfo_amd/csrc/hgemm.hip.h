@@ -38,6 +38,8 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#include "gemm_direct.hip.h"      // HeadWgradRider / head_wgrad_rider, TailsArgs: rider blocks of hgemm_group_db
+
 namespace dqnhip {
 
 typedef _Float16 h16;
@@ -748,15 +750,28 @@ __global__ __launch_bounds__(256) void k_db16_cols(Db16Batch b) {
 // of the chip — or 256 of 64 x 64 at four times the operand bytes per FLOP (455 TF at 4096 rows, r02 profile);
 // once the dgrad chain has produced every dZ panel the L wgrads are independent, and together they are
 // 3 x 64 + 8 = 200 tiles of 128 x 128 (+ 48 column-sum workgroups) at 4 x 1024: one round on 256 CUs.
+// Round 6: the launch also carries the net's head dW / db as rider blocks (HeadWgradRider, rider_nh = 1 critic / 10 actor heads /
+// 0 none — the fp32 learner's arrangement: the head-backward kernel then only produces dZ, and Step(1)'s needs no launch at all) and,
+// for data-parallel learners, the tails block (TailsArgs).  Grid: tiles, column-sum blocks, riders, tails.
 template <int WM, int WN>
-__global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_group_db(HGemmBatch batch, Db16Batch db) {
+__global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_group_db(HGemmBatch batch, Db16Batch db, int db_blocks, HeadWgradRider rider, int rider_nh, TailsArgs tails) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char hg_smem[];
   const int nt = batch.tile_end[batch.n - 1];
-  if ((int)blockIdx.x < nt) {
+  int b = (int)blockIdx.x;
+  if (b < nt) {
     int bid;
-    const int sel = hg_select(batch, (int)blockIdx.x, bid);
+    const int sel = hg_select(batch, b, bid);
     hgemm_body<WM, WN, 3>(batch.g[sel], bid);
-  } else db16_cols_block(db, (int)blockIdx.x - nt, reinterpret_cast<float*>(hg_smem));
+    return;
+  }
+  b -= nt;
+  if (b < db_blocks) { db16_cols_block(db, b, reinterpret_cast<float*>(hg_smem)); return; }
+  b -= db_blocks;
+  if (rider_nh != 0 && b < rider.blocks) {
+    if (rider_nh == 1) head_wgrad_rider<1>(rider, b, reinterpret_cast<float*>(hg_smem)); else head_wgrad_rider<10>(rider, b, reinterpret_cast<float*>(hg_smem));
+    return;
+  }
+  if (tails.on) tails_block(tails, reinterpret_cast<float*>(hg_smem), reinterpret_cast<double*>(hg_smem + 64));
 }
 inline hipError_t hgemm_group_db_prepare() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_group_db<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, HGCfg<1, 1>::LDS_BYTES);
@@ -766,18 +781,23 @@ inline hipError_t hgemm_group_db_prepare() {
 // gs: n reduction-major wgrads (mode 3); db_blocks = 64-column blocks of db (0: none).  big: 128 x 128 tiles
 // (every M, N a multiple of 128), else 64 x 64 split-K tiles.
 inline hipError_t hgemm_group_db_launch(const HGemm* gs, int n, bool big, const Db16Batch& db, int db_blocks, hipStream_t st,
-                                        hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+                                        hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, const HeadWgradRider* rider_in = nullptr, int rider_nh = 0,
+                                        const TailsArgs* tails_in = nullptr) {
   for (int i = 0; i < n; ++i) if (hgemm_mode(gs[i]) != 3) return hipErrorInvalidValue;
   HGemmBatch b; int wm, wn; long blocks;
   hipError_t e = hgemm_plan(gs, n, big ? 1 : 2, b, wm, wn, blocks);
   if (e != hipSuccess) return e;
-  const unsigned grid = (unsigned)(blocks + db_blocks);
+  HeadWgradRider rider{}; TailsArgs tails{};
+  if (rider_in != nullptr && rider_nh != 0) rider = *rider_in; else rider_nh = 0;
+  if (tails_in != nullptr) { tails = *tails_in; tails.on = 1; }
+  if (rider_nh != 0 && (size_t)(rider.rows * rider_nh + 256 * rider_nh) * sizeof(float) > (size_t)(big ? HGCfg<2, 2>::LDS_BYTES : HGCfg<1, 1>::LDS_BYTES)) return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)(blocks + db_blocks + (rider_nh ? rider.blocks : 0) + (tails.on ? 1 : 0));
   if (big) {
-    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, b, db);
-    else hipLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, b, db);
+    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, b, db, db_blocks, rider, rider_nh, tails);
+    else hipLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, b, db, db_blocks, rider, rider_nh, tails);
   } else {
-    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, b, db);
-    else hipLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, b, db);
+    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, b, db, db_blocks, rider, rider_nh, tails);
+    else hipLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, b, db, db_blocks, rider, rider_nh, tails);
   }
   return hipGetLastError();
 }

@@ -186,7 +186,7 @@ inline bool bwd_is_shifted(const H* h, const NetLayout& l, int rows) {
 int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* garena, float* partial,
                    float** act, float** dZ, int rows, bool want_w, bool input_grad, int in_lo = 0, int in_hi = -1,
                    const HeadWgradRider* rider = nullptr, const QHeadRider* qrider = nullptr, DqdaHeadArgs* fuse = nullptr,
-                   const HeadTrainArgs* qtrain = nullptr, const float* qtrain_seed = nullptr) {
+                   const HeadTrainArgs* qtrain = nullptr, const float* qtrain_seed = nullptr, const TailsArgs* tails = nullptr) {
   auto dgrad_of = [&](int i) {             // dZ[i] = (dZ[i+1] . W_i) * lrelu'(act[i])
     GemmProblem p{};
     p.mode = GEMM_DGRAD;
@@ -235,12 +235,13 @@ int tower_backward(H* h, hipStream_t st, const NetLayout& l, int net, float* gar
       GemmBatch b{}; b.n = 2; b.prob[0] = wgrad_of(1); b.prob[1] = wgrad_of(0);
       const HeadWgradRider none{};
       ScopedTiming t(h, 2, st);
-      if (l.NH == 1) HIPCHK((wgrad_tail_launch<1>(b, rider ? *rider : none, st))); else HIPCHK((wgrad_tail_launch<kNO>(b, rider ? *rider : none, st)));
+      if (l.NH == 1) HIPCHK((wgrad_tail_launch<1>(b, rider ? *rider : none, st, tails))); else HIPCHK((wgrad_tail_launch<kNO>(b, rider ? *rider : none, st, tails)));
       if (h->comm && h->dp_per_layer) RC(dp_reduce_slice(h, st, net, l.w_off[0], layer_slice(0) + layer_slice(1)));
     }
     if (qrider) return fail("internal: the q-head rider found no carrier launch");
     return 0;
   }
+  if (tails != nullptr) return fail("internal: the tails block rides in the shifted schedule's last launch only");
   for (int i = l.L - 1; i >= 0; --i) {
     GemmBatch bd{}, bw{};
     const bool need_dx = (i > 0 || input_grad);
@@ -331,6 +332,7 @@ int head_backward(H* h, hipStream_t st, HeadBwdArgs a) {
 // dqnhip_get_update_plan reports it together with the launch counts of a captured update: a predicate that silently stops matching at a
 // BASELINE shape is a red test (tests/test_gpu_update_plan.py), not a slower bench.  A pure function of the learner's state (shapes,
 // tuning flags, sharing, data-parallel mode): evaluated per call, never cached, so there is no stale copy to invalidate.
+inline bool bwd16_has_carrier(const H* h, int net, int rows);      // (with tower_backward16, below)
 UpdatePlan plan_of(const H* h) {
   const NetLayout &la = h->la, &lc = h->lc;
   const int B = h->B, L = h->L, Hh = la.dims[L], Hc = lc.dims[L];
@@ -339,8 +341,17 @@ UpdatePlan plan_of(const H* h) {
   p.fp16 = h->fp16;
   p.dp = h->cfg.dp_world > 1 || h->dp_half || h->dp_shard;     // (a one-rank group with bf16 exchange / a sharded optimiser runs the N-rank code path)
   p.fused_seed = !(tf & DQNHIP_TUNE_SEPARATE_HEAD_SEED);
-  if (h->fp16) return p;                                         // (the fp16 learner's merged forms: run_phase16)
+  if (h->fp16) {
+    // fp16 learner (round 6): the head's dW / db ride in the net's last backward launch (hgemm_group_db) when it exists and their
+    // staging fits its LDS; Step(1)'s k_head_q_train then also writes the scaled fp16 tower-top gradient — no head-backward launch
+    p.head_rides_c = bwd16_has_carrier(h, DQNHIP_CRITIC, B) && head_wgrad_can_ride(lc, B);
+    p.head_rides_a = bwd16_has_carrier(h, DQNHIP_ACTOR, B) && head_wgrad_can_ride(la, B) && !head_big_ok(h, B, Hh);
+    p.fuse_q = p.head_rides_c;
+    p.tails_ride = p.dp && bwd16_has_carrier(h, DQNHIP_CRITIC, B) && bwd16_has_carrier(h, DQNHIP_ACTOR, B);
+    return p;
+  }
   p.shifted_c = bwd_is_shifted(h, lc, B); p.shifted_a = bwd_is_shifted(h, la, B);
+  p.tails_ride = p.dp && p.shifted_c && p.shifted_a;        // data parallel: the tails block rides in each net's last backward launch
   // the head's own dW / db ride in the net's last backward launch (the first layer's narrow wgrad)
   p.head_rides_c = !head_big_ok(h, B, Hc) && head_wgrad_can_ride(lc, B);
   p.head_rides_a = !head_big_ok(h, B, Hh) && head_wgrad_can_ride(la, B);
@@ -549,8 +560,17 @@ int tower_forward16_pair(H* h, hipStream_t st, int p0, int net0, int p1, int net
 // sums in ONE launch (hgemm_group_db) — at that point every dZ panel is complete and the wgrads are independent.
 // cfg.tuning_flags & DQNHIP_TUNE_FP16_WGRAD_PER_LAYER restores the per-layer form (a layer's dgrad + wgrad sharing a
 // launch when both take the 64x64 tile; the bias sums riding in the first layer's wgrad launch).
+// does a weights-wanted backward of this net end in a hgemm_group_db launch (the carrier of the head's dW / db riders and of a
+// data-parallel learner's tails block)?  Grouped form: always; per-layer form: when the first layer's wgrad takes the 64 x 64 tile.
+inline bool bwd16_has_carrier(const H* h, int net, int rows) {
+  const NetLayout& l = layout_of(h, net);
+  if (l.L <= kHGemmMax && rows >= kGroupMinRows && !(h->cfg.tuning_flags & DQNHIP_TUNE_FP16_WGRAD_PER_LAYER)) return true;
+  HGemm g{}; g.ta = 1; g.tb = 1; g.M = l.dims[1]; g.N = h->k16[net & 1][0]; g.K = rows;
+  return hgemm_uses_small_tile(g) && g.K % 128 == 0 && g.M % 64 == 0 && g.N % 64 == 0;
+}
 int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float* dZ32_0, int rows,
-                     bool want_w, bool input_grad, float ls, float* partial = nullptr) {
+                     bool want_w, bool input_grad, float ls, float* partial = nullptr, const HeadWgradRider* rider = nullptr,
+                     const TailsArgs* tails = nullptr) {
   const NetLayout& l = layout_of(h, net);
   const int kind = net & 1;
   h16** dZ = h->dZ16[kind];
@@ -606,11 +626,12 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
   if (grouped) {
     // 128x128 tiles: a quarter of the operand bytes per FLOP of the 64x64 split-K tile (fp16 mode guarantees
     // hidden % 128 == 0, minibatch % 128 == 0 and a 128-wide first panel, so every wgrad tiles)
-    HIPCHK(hgemm_group_db_launch(gws, l.L, true, db, db_blocks, st, e0, e1));
+    HIPCHK(hgemm_group_db_launch(gws, l.L, true, db, db_blocks, st, e0, e1, rider, l.NH, tails));
   } else if (!input_grad && hgemm_uses_small_tile(gws[0]) && gws[0].K % 128 == 0) {
     // per-layer form: the first layer's wgrad (few tiles, long reduction) carries the column sums
-    HIPCHK(hgemm_group_db_launch(gws, 1, false, db, db_blocks, st, e0, e1));
+    HIPCHK(hgemm_group_db_launch(gws, 1, false, db, db_blocks, st, e0, e1, rider, l.NH, tails));
   } else {
+    if (rider != nullptr || tails != nullptr) return fail("internal: the fp16 backward found no carrier launch for its riders");
     if (!input_grad) HIPCHK(hgemm_launch(gws[0], st, 0, e0, e1));
     hipLaunchKernelGGL(k_db16_cols<0>, dim3(db_blocks), dim3(256), 0, st, db);
     HIPCHK(hipGetLastError());
@@ -666,20 +687,26 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       t.H = Hc; t.rows = B; t.reward = h->mb_reward; t.mc = h->mb_mc; t.term = h->mb_term;
       t.q_target = h->q_t; t.q = h->q1; t.y = h->y; t.dq = h->dq; t.loss_partial = h->loss_partial;
       t.gamma = h->cfg.gamma; t.beta = h->cfg.beta; t.inv_batch = inv_batch; t.st = h->st;
+      // round 6: with the head's dW / db riding in the net's last backward launch, the scaled fp16 tower-top gradient comes out of
+      // this launch too (HeadTrainArgs::dZ16) — Step(1) has no head-backward launch (as on the fp32 path since round 3)
+      if (P.fuse_q) { t.dZ16 = h->dZ16[1][L]; t.scale16 = h->ls_c; }
       hipLaunchKernelGGL(k_head_q_train, dim3((B + 3) / 4), dim3(256), 0, st, t);
       HIPCHK(hipGetLastError());
     }
+    const TailsArgs tails_c{(const float*)h->loss_partial, h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr, &h->st->flags, 0};
     {
       HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X416 = h->act16[3][L];
       a.H = Hc; a.rows = B; a.dZ = nullptr; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
-      if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->ls_c)); }
+      HeadWgradRider r{h->dq, 1, nullptr, Hc, B, a.dW, a.db, a.partial, Hc / kRiderCW, h->act16[3][L]};
+      if (P.head_rides_c) {}                                       // (dZ16 came out of k_head_q_train, dW / db come from the riders)
+      else if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->ls_c)); }
       else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_c; RC(head_backward<1>(h, st, a)); }
+      RC(tower_backward16(h, st, DQNHIP_CRITIC, 3, h->g[1], nullptr, B, true, false, h->ls_c, part16 ? h->part[1] : nullptr, P.head_rides_c ? &r : nullptr,
+                          P.tails_ride ? &tails_c : nullptr));
     }
-    RC(tower_backward16(h, st, DQNHIP_CRITIC, 3, h->g[1], nullptr, B, true, false, h->ls_c, part16 ? h->part[1] : nullptr));
-    if (dp) {
-      hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)h->loss_partial,
-                         h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr, (const DevState*)h->st);
+    if (dp && !P.tails_ride) {
+      hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, tails_c);
       HIPCHK(hipGetLastError());
     }
     return 0;
@@ -714,14 +741,17 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
         a.qr_W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.qr_X416 = h->act16[4][L]; a.qr_H = Hc;
       }
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
+      const HeadWgradRider r{h->dA16, kAP, nullptr, Hh, B, a.dW, a.db, a.partial, Hh / kRiderCW, h->act16[1][L]};   // dA16: the post-invert diffs this launch leaves
+      if (P.head_rides_a) { a.dW = nullptr; a.db = nullptr; a.partial = nullptr; }
       if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->ls_a)); }
       else { a.dZ16 = h->dZ16[0][L]; a.scale16 = h->ls_a; RC(head_backward<kNO>(h, st, a)); }
-    }
-    RC(tower_backward16(h, st, DQNHIP_ACTOR, 1, h->g[0], nullptr, B, true, false, h->ls_a, part16 ? h->part[0] : nullptr));
-    if (dp) {
-      hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)nullptr, 0,
-                         (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail, (const DevState*)h->st);
-      HIPCHK(hipGetLastError());
+      const TailsArgs tails_a{(const float*)nullptr, 0, (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail, &h->st->flags, 0};
+      RC(tower_backward16(h, st, DQNHIP_ACTOR, 1, h->g[0], nullptr, B, true, false, h->ls_a, part16 ? h->part[0] : nullptr, P.head_rides_a ? &r : nullptr,
+                          P.tails_ride ? &tails_a : nullptr));
+      if (dp && !P.tails_ride) {
+        hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, tails_a);
+        HIPCHK(hipGetLastError());
+      }
     }
     return 0;
   }
@@ -861,13 +891,14 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       const bool ride = P.head_rides_c;
       HeadWgradRider r{h->dq, 1, h->act[3][L], Hc, B, a.dW, a.db, a.partial, Hc / kRiderCW};
       if (!ride) RC(head_backward<1>(h, st, a));          // (riding: dZ came out of k_head_q_train, dW / db come from the rider)
+      // data parallel: [loss, q, flag] tails for the exchange — one more block of the backward's last launch, or a launch of its own
+      const TailsArgs tails_c{(const float*)h->loss_partial, h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr, &h->st->flags, 0};
       RC(tower_backward(h, st, lc, DQNHIP_CRITIC, h->g[1], h->part[1], h->act[3], h->dZc, B, true, false, 0, -1, ride ? &r : nullptr, nullptr, nullptr,
-                        fuse_q ? &qt_args : nullptr, fuse_q ? h->U3 : nullptr));
-    }
-    if (dp) {
-      hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)h->loss_partial,
-                         h->n_head_blocks, (const double*)nullptr, 0, inv_batch, critic_tail, (float*)nullptr, (const DevState*)h->st);
-      HIPCHK(hipGetLastError());
+                        fuse_q ? &qt_args : nullptr, fuse_q ? h->U3 : nullptr, P.tails_ride ? &tails_c : nullptr));
+      if (dp && !P.tails_ride) {
+        hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, tails_c);
+        HIPCHK(hipGetLastError());
+      }
     }
     return 0;
   }
@@ -923,12 +954,13 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       HeadWgradRider r{h->dA16, kAP, h->act[1][L], Hh, B, a.dW, a.db, a.partial, Hh / kRiderCW};   // dA16: the post-invert diffs this launch leaves
       if (ride) { a.dW = nullptr; a.db = nullptr; a.partial = nullptr; }
       if (!fuse_head) RC(head_backward<kNO>(h, st, a));
-      RC(tower_backward(h, st, la, DQNHIP_ACTOR, h->g[0], h->part[0], h->act[1], h->dZa, B, true, false, 0, -1, ride ? &r : nullptr));
-    }
-    if (dp) {
-      hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, (const float*)nullptr, 0,
-                         (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail, (const DevState*)h->st);
-      HIPCHK(hipGetLastError());
+      const TailsArgs tails_a{(const float*)nullptr, 0, (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail, &h->st->flags, 0};
+      RC(tower_backward(h, st, la, DQNHIP_ACTOR, h->g[0], h->part[0], h->act[1], h->dZa, B, true, false, 0, -1, ride ? &r : nullptr, nullptr, nullptr, nullptr, nullptr,
+                        P.tails_ride ? &tails_a : nullptr));
+      if (dp && !P.tails_ride) {
+        hipLaunchKernelGGL(k_tails, dim3(1), dim3(256), 0, st, tails_a);
+        HIPCHK(hipGetLastError());
+      }
     }
     return 0;
   }
@@ -1346,7 +1378,7 @@ int dqnhip_get_update_plan(dqnhip_handle h, dqnhip_update_plan* out) {
                (p.head_rides_a ? DQNHIP_PLAN_HEAD_WGRAD_RIDES_ACTOR : 0) | (p.fuse_q ? DQNHIP_PLAN_Q_TRAIN_IN_DGRAD : 0) |
                (p.fused_seed ? DQNHIP_PLAN_HEAD_SEED_FUSED : 0) | (p.fuse_head ? DQNHIP_PLAN_DQDA_HEAD_BWD : 0) |
                (p.critic_l0 ? DQNHIP_PLAN_CRITIC_L0_RIDES : 0) | (p.first_layers_merged ? DQNHIP_PLAN_FIRST_LAYERS_MERGED : 0) |
-               (p.early_l0 ? DQNHIP_PLAN_EARLY_GATHER_L0 : 0);
+               (p.early_l0 ? DQNHIP_PLAN_EARLY_GATHER_L0 : 0) | (p.tails_ride ? DQNHIP_PLAN_DP_TAILS_RIDE : 0);
   out->updates_per_graph = kMultiU;
   // per net and update: one all-reduce (per-layer buckets: one per tower layer + the head slice; bf16 exchange: the tails travel in a
   // second call beside the actor's; sharded optimiser: reduce-scatter + the 4-float all-reduce + 2 (fp16 learner: 4) all-gathers)

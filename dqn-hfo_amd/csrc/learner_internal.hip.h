@@ -291,6 +291,7 @@ struct UpdatePlan {
   bool critic_l0;                   // the first layer of critic(s, mu(s)) inside the critic's optimiser launch
   bool first_layers_merged;         // Step(1)'s four first layers in one launch (critic_target's action half in the head kernel)
   bool early_l0;                    // multi-update graphs: next gather in the critic's optimiser launch, next first layers in the actor's
+  bool tails_ride;                  // data parallel: the [loss, q, flag] tails block rides in each net's last backward launch (no k_tails launches)
 };
 UpdatePlan plan_of(const H* h);
 // the current update's copies of the two double-buffered panels (by update parity inside a multi-update graph that gathers early;

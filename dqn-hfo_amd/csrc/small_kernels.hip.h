@@ -48,8 +48,7 @@ struct DevState {
   unsigned long long gbase_counter;
   int gbase_it[2];
 };
-constexpr int kFlagTarget = 1;     // a TD target of the last update(s) was not finite
-constexpr int kFlagGradNorm = 2;   // a gradient L2 norm was not finite: that clip+Adam step was skipped
+// (kFlagTarget / kFlagGradNorm: gemm_common.hip.h)
 
 // ---- counter-based RNG (Philox-4x32-10) for SampleTransitionsFromMemory ------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -520,6 +519,9 @@ struct HeadTrainArgs {
   // row of X and W through its registers; the head's own dW / db ride elsewhere (head_wgrad_rider), so with this the
   // critic's head-backward launch of Step(1) is gone.
   float* dZ;
+  // fp16 learner (round 6): the same gradient as the scaled fp16 panel its GEMMs read, dZ16[row][k] = (h16)(dZ * scale16) — with it
+  // the fp16 learner's k_head_bwd<1> / k_head_bwd_big<1> + k_head_wred<1> launches of Step(1) are gone as well
+  _Float16* dZ16; float scale16;
   // k_dgrad_qtrain: the two head dot products in 16-column pieces, [rows][H / 16], left by the top forward layers (GemmProblem::dot_w)
   const float* pdt; const float* pd;
 };
@@ -557,17 +559,23 @@ static __global__ __launch_bounds__(256) void k_head_q_train(HeadTrainArgs a) {
     a.dq[row] = dq_row;
     d2 = d * d;
   }
-  if (a.dZ != nullptr && row < a.rows) {                 // (fp32 tower top only; wave-uniform condition)
+  if ((a.dZ != nullptr || a.dZ16 != nullptr) && row < a.rows) {     // (wave-uniform condition)
     const float dqv = __shfl(dq_row, 0, 64);
     const size_t x0 = (size_t)row * a.H;
-    for (int k = lane * 4; k < a.H; k += 256) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(a.X + x0 + k), wv = *reinterpret_cast<const f32x4*>(a.W + k);
-      // k_head_bwd<1>'s arithmetic: s0 = fma(d, w, 0) = d * w, then * lrelu'(x)
-      f32x4 dz;
-      dz.x = (dqv * wv.x) * lrelu_mask(xv.x); dz.y = (dqv * wv.y) * lrelu_mask(xv.y);
-      dz.z = (dqv * wv.z) * lrelu_mask(xv.z); dz.w = (dqv * wv.w) * lrelu_mask(xv.w);
-      *reinterpret_cast<f32x4*>(a.dZ + x0 + k) = dz;
-    }
+    auto seed = [&](auto tag) {
+      for (int k = lane * 4; k < a.H; k += 256) {
+        const f32x4 xv = head_ld4t<decltype(tag)::value>(a.X, a.X16, x0 + k), wv = *reinterpret_cast<const f32x4*>(a.W + k);
+        // k_head_bwd<1>'s arithmetic: s0 = fma(d, w, 0) = d * w, then * lrelu'(x)
+        f32x4 dz;
+        dz.x = (dqv * wv.x) * lrelu_mask(xv.x); dz.y = (dqv * wv.y) * lrelu_mask(xv.y);
+        dz.z = (dqv * wv.z) * lrelu_mask(xv.z); dz.w = (dqv * wv.w) * lrelu_mask(xv.w);
+        if constexpr (decltype(tag)::value)
+          *reinterpret_cast<head_h4*>(a.dZ16 + x0 + k) = head_h4{(_Float16)(dz.x * a.scale16), (_Float16)(dz.y * a.scale16), (_Float16)(dz.z * a.scale16), (_Float16)(dz.w * a.scale16)};
+        else
+          *reinterpret_cast<f32x4*>(a.dZ + x0 + k) = dz;
+      }
+    };
+    HEAD_DISPATCH(a.X16 != nullptr, seed);
   }
   if (lane == 0) s_part[wave] = d2;
   __syncthreads();
@@ -1690,33 +1698,12 @@ static __global__ void k_shard_accumulate(float* total, const float* tail, int f
   total[0] = first ? tail[3] : total[0] + tail[3];
 }
 
-// Reduce the per-block loss / q partials into the gradient-arena tails
-// ([loss_sum, q_sum, 0, 0]) so they ride in the gradient all-reduce.
-// tail[2] carries this rank's non-finite-target flag (0 / 1): the flag is raised from the rank's OWN replay shard,
-// so without it one rank would stop with "Target not finite!" while the others walk into the next collective.
-static __global__ __launch_bounds__(256) void k_tails(const float* loss_partial, int n_loss, const double* q_partial, int n_q,
-                                               float inv_batch, float* critic_tail, float* actor_tail, const DevState* st) {
-  // one block, same reduction tree as k_tick (strided partials, butterfly, fixed cross-wave order)
+// Reduce the per-block loss / q partials into the gradient-arena tails (tails_block, gemm_common.hip.h) in a launch of its own: the
+// form for schedules without a carrier launch; otherwise the block rides in the net's last backward launch (TailsArgs::on).
+static __global__ __launch_bounds__(256) void k_tails(TailsArgs a) {
   __shared__ float sdot[4];
   __shared__ double sq[4];
-  const int t = threadIdx.x;
-  float dot = 0.0f; double qs = 0.0;
-  if (critic_tail != nullptr) for (int i = t; i < n_loss; i += 256) dot += loss_partial[i];
-  if (actor_tail != nullptr) for (int i = t; i < n_q; i += 256) qs += q_partial[i];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { dot += __shfl_xor(dot, off, 64); qs += __shfl_xor(qs, off, 64); }
-  if ((t & 63) == 0) { sdot[t >> 6] = dot; sq[t >> 6] = qs; }
-  __syncthreads();
-  if (t != 0) return;
-  if (critic_tail != nullptr) {
-    dot = (sdot[0] + sdot[1]) + (sdot[2] + sdot[3]);
-    critic_tail[0] = dot * inv_batch / 2.0f;   // EuclideanLoss: dot / num / 2
-    critic_tail[1] = 0.f; critic_tail[2] = (st->flags & kFlagTarget) ? 1.0f : 0.f; critic_tail[3] = 0.f;
-  }
-  if (actor_tail != nullptr) {
-    qs = (sq[0] + sq[1]) + (sq[2] + sq[3]);
-    actor_tail[0] = 0.f; actor_tail[1] = (float)qs; actor_tail[2] = 0.f; actor_tail[3] = 0.f;
-  }
+  tails_block(a, sdot, sq);
 }
 
 // End of update: publish (critic_loss, avg_q), advance both solver iterations

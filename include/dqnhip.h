@@ -254,14 +254,15 @@ int dqnhip_apply_update_sharded(dqnhip_handle h, int32_t net, int32_t world);
 #define DQNHIP_PLAN_DATA_PARALLEL 2             /* phases cut for an exchange: dp_world > 1, or a one-rank group with bf16 exchange / sharded optimiser */
 #define DQNHIP_PLAN_BWD_SHIFTED_CRITIC 4        /* the shifted backward schedule (see DQNHIP_TUNE_BWD_UNSHIFTED) in Step(1) */
 #define DQNHIP_PLAN_BWD_SHIFTED_ACTOR 8         /* ... in the actor's backward */
-#define DQNHIP_PLAN_HEAD_WGRAD_RIDES_CRITIC 16  /* the critic head's dW / db as rider blocks of the net's last backward launch */
+#define DQNHIP_PLAN_HEAD_WGRAD_RIDES_CRITIC 16  /* the critic head's dW / db as rider blocks of the net's last backward launch (both precisions) */
 #define DQNHIP_PLAN_HEAD_WGRAD_RIDES_ACTOR 32   /* ... the actor heads' */
-#define DQNHIP_PLAN_Q_TRAIN_IN_DGRAD 64         /* k_dgrad_qtrain (see DQNHIP_TUNE_SEPARATE_Q_TRAIN) */
+#define DQNHIP_PLAN_Q_TRAIN_IN_DGRAD 64         /* fp32: k_dgrad_qtrain (see DQNHIP_TUNE_SEPARATE_Q_TRAIN); fp16: k_head_q_train also writes the tower-top gradient — either way Step(1) has no head-backward launch */
 #define DQNHIP_PLAN_HEAD_SEED_FUSED 128         /* the dq = -1 seed from the top layer's forward epilogue (DQNHIP_TUNE_SEPARATE_HEAD_SEED) */
 #define DQNHIP_PLAN_DQDA_HEAD_BWD 256           /* k_dqda_head_bwd (DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) */
 #define DQNHIP_PLAN_CRITIC_L0_RIDES 512         /* critic(s, mu(s))'s first layer inside the critic's optimiser launch (DQNHIP_TUNE_SEPARATE_FIRST_LAYER) */
 #define DQNHIP_PLAN_FIRST_LAYERS_MERGED 1024    /* Step(1)'s four first layers in one launch (DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS) */
 #define DQNHIP_PLAN_EARLY_GATHER_L0 2048        /* multi-update graphs: next gather / next first layers ride in the two optimiser launches (DQNHIP_TUNE_LATE_GATHER) */
+#define DQNHIP_PLAN_DP_TAILS_RIDE 4096          /* data parallel: the [loss, q, flag] tails of the exchange ride in each net's last backward launch */
 typedef struct dqnhip_update_plan {
   int32_t struct_size;          /* in: sizeof(dqnhip_update_plan) */
   int32_t forms;                /* DQNHIP_PLAN_* bits */
