@@ -368,6 +368,52 @@ __device__ __forceinline__ f32x4 dgrad_narrow_tile(const GemmProblem& pr, int ti
   }
   return v;
 }
+// The same tile from the fp16 learner's operands (round 6): P = the fp16 weight mirror W16[n][k_in] (one column per lane), Q = the
+// scaled fp16 gradient panel dY16[rows][n].  fp16 x fp16 products are exact in fp32, so this is the fp16-MFMA dgrad's arithmetic up
+// to the order of the fp32 additions; the caller removes the loss scale.  No mask (the layer's input has no ReLU).
+struct NarrowTile16 { const _Float16* P; int ldp; const _Float16* Q; int ldq; int Kred; };
+template <int NS = 4>
+__device__ __forceinline__ f32x4 dgrad_narrow_tile16(const NarrowTile16& pr, int tile_q, float* smem) {
+  typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int q0 = tile_q * 16;
+  const int Kw = pr.Kred >> 2;
+  const int nkb = Kw >> 4;
+  const _Float16* pp = pr.P + (size_t)(wave * Kw + lg * 4) * pr.ldp + li;
+  const _Float16* qp = pr.Q + (size_t)(q0 + li) * pr.ldq + wave * Kw + lg * 4;
+  const size_t ldp = pr.ldp;
+  f32x4 acc[1];
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  _Float16 rp[NS][4]; h4 rq[NS];
+#define DN_LOAD(slot, kb)                                                               \
+  {                                                                                     \
+    rq[slot] = *reinterpret_cast<const h4*>(qp + ((kb) << 4));                         \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) rp[slot][s] = pp[(size_t)(((kb) << 4) + s) * ldp]; \
+  }
+#define DN_COMPUTE(slot)                                                                \
+  { _Pragma("unroll") for (int s = 0; s < 4; ++s) acc[0] = DQN_MFMA((float)rp[slot][s], (float)rq[slot][s], acc[0]); }
+  const int nkbN = nkb - nkb % NS;
+  if (nkbN > 0) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { DN_LOAD(i, i) DQN_PIN(); }
+    int kb = 0;
+    for (; kb + NS < nkbN; kb += NS) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) { DN_COMPUTE(i) DQN_PIN(); DN_LOAD(i, kb + NS + i) DQN_PIN(); }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { DN_COMPUTE(i) }
+  }
+  for (int kb = nkbN; kb < nkb; ++kb) { DN_LOAD(0, kb) DN_COMPUTE(0) }
+#undef DN_LOAD
+#undef DN_COMPUTE
+  park_accumulators<1>(smem, acc, wave, lane);
+  __syncthreads();
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave == 0) v = reduce_accumulator<1>(smem, 0, lane);
+  return v;
+}
 __device__ __forceinline__ void dgrad_narrow_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
   const f32x4 v = dgrad_narrow_tile<4>(pr, tile_p, tile_q, smem);
   if ((threadIdx.x >> 6) == 0) {
@@ -1068,6 +1114,7 @@ struct QHeadRider {
   const float* X4; const float* W; const float* bias;   // tower top [rows][H], head weights [H], head bias [1]
   float* q_out; double* qsum_partial;                   // [rows] each
   int H, rows, blocks;                                  // blocks = ceil(rows / 4) (0: none)
+  const _Float16* X416;                                 // fp16 learner: the tower top in fp16 (then X4 is null); last member (aggregate initialisers of the fp32 call sites leave it null)
 };
 __device__ __forceinline__ void q_head_rider(const QHeadRider& r, const int blk) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1075,6 +1122,13 @@ __device__ __forceinline__ void q_head_rider(const QHeadRider& r, const int blk)
   if (row >= r.rows) return;
   const size_t x0 = (size_t)row * r.H;
   float acc = 0.0f;
+  if (r.X416 != nullptr) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    for (int k = lane * 4; k < r.H; k += 256) {
+      const h4 xh = *reinterpret_cast<const h4*>(r.X416 + x0 + k); const f32x4 wv = *reinterpret_cast<const f32x4*>(r.W + k);
+      acc = fmaf((float)xh.x, wv.x, acc); acc = fmaf((float)xh.y, wv.y, acc); acc = fmaf((float)xh.z, wv.z, acc); acc = fmaf((float)xh.w, wv.w, acc);
+    }
+  } else
   for (int k = lane * 4; k < r.H; k += 256) {
     const f32x4 xv = *reinterpret_cast<const f32x4*>(r.X4 + x0 + k), wv = *reinterpret_cast<const f32x4*>(r.W + k);
     acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
@@ -1151,7 +1205,6 @@ struct HeadWgradRider {
   const float* X4; int H, rows;
   float* dW; float* db; float* partial;     // [NH][H], [NH], one sum-of-squares slot per rider block (H / 16)
   int blocks;                               // H / kRiderCW rider blocks, FIRST in the grid (0: none)
-  const _Float16* X416;                     // fp16 learner: the tower top in fp16 (then X4 is null).  Last member: aggregate initialisers of the fp32 call sites leave it null
 };
 constexpr int kRiderCW = 8;                    // columns per rider block (x 32 row groups)
 template <int NH>
@@ -1165,9 +1218,8 @@ __device__ __forceinline__ void head_wgrad_rider(const HeadWgradRider& r, const 
   constexpr int RB = 8;                        // every row of a 256-row minibatch in flight at once: the tower top was written
                                                // many launches ago (Infinity Cache / HBM latency, not L2)
   float xpre[RB];
-  auto ldx = [&](int m) -> float { return r.X416 != nullptr ? (float)r.X416[(size_t)m * r.H + k] : r.X4[(size_t)m * r.H + k]; };
 #pragma unroll
-  for (int u = 0; u < RB; ++u) xpre[u] = (m0 + u < m1) ? ldx(m0 + u) : 0.0f;
+  for (int u = 0; u < RB; ++u) xpre[u] = (m0 + u < m1) ? r.X4[(size_t)(m0 + u) * r.H + k] : 0.0f;
   for (int i = tid; i < r.rows * NH; i += 256) s_dy[i] = r.dy[(size_t)(i / NH) * r.lddy + (i % NH)];
   __syncthreads();
   float acc[NH];
@@ -1176,7 +1228,7 @@ __device__ __forceinline__ void head_wgrad_rider(const HeadWgradRider& r, const 
   for (int mb = m0; mb < m1; mb += RB) {
     float xb[RB];
 #pragma unroll
-    for (int u = 0; u < RB; ++u) xb[u] = (mb == m0) ? xpre[u] : ((mb + u < m1) ? ldx(mb + u) : 0.0f);
+    for (int u = 0; u < RB; ++u) xb[u] = (mb == m0) ? xpre[u] : ((mb + u < m1) ? r.X4[(size_t)(mb + u) * r.H + k] : 0.0f);
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
       const int m = mb + u;

@@ -38,7 +38,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#include "gemm_direct.hip.h"      // HeadWgradRider / head_wgrad_rider, TailsArgs: rider blocks of hgemm_group_db
+#include "gemm_common.hip.h"      // wave_sum64, TailsArgs (a rider block of hgemm_group_db)
 
 namespace dqnhip {
 
@@ -750,11 +750,108 @@ __global__ __launch_bounds__(256) void k_db16_cols(Db16Batch b) {
 // of the chip — or 256 of 64 x 64 at four times the operand bytes per FLOP (455 TF at 4096 rows, r02 profile);
 // once the dgrad chain has produced every dZ panel the L wgrads are independent, and together they are
 // 3 x 64 + 8 = 200 tiles of 128 x 128 (+ 48 column-sum workgroups) at 4 x 1024: one round on 256 CUs.
-// Round 6: the launch also carries the net's head dW / db as rider blocks (HeadWgradRider, rider_nh = 1 critic / 10 actor heads /
-// 0 none — the fp32 learner's arrangement: the head-backward kernel then only produces dZ, and Step(1)'s needs no launch at all) and,
-// for data-parallel learners, the tails block (TailsArgs).  Grid: tiles, column-sum blocks, riders, tails.
+// Round 6: the head's own gradients as column-sum workgroups of the same launch.  dWh[j][k] = sum_m dy[m][j] X[m][k] is a WEIGHTED
+// column sum of the tower top (the weights: the head diffs of row m), db_h[j] = sum_m dy[m][j]: the streaming pattern of
+// db16_cols_block — a block owns 64 columns, 8 lanes x 16 B cover them, 32 row groups stride the rows, fixed-order LDS reduction
+// over the row groups — with NH accumulator sets.  H / 64 short blocks (+ db in block 0) instead of the head-backward kernels'
+// slab / ticket tails (k_head_bwd) or a reduction launch of their own (k_head_wred); the head-backward kernel then only produces
+// dZ, and Step(1)'s needs no launch at all (k_head_q_train writes the tower-top gradient).
+// (First form, measured: the fp32 path's HeadWgradRider blocks — 8 columns x every row, H / 8 = 128 blocks — as riders of this
+// launch: with one 128-KiB workgroup per CU they queue behind the 200 wgrad tiles and gave back what the removed launch had saved:
+// 0.2626 against 0.263 ms per update at 512 rows.)
+struct HeadWsum {
+  const float* dy; int lddy;                // head diffs [rows][lddy] (critic: dq, lddy 1; actor: the post-invert diffs, lddy 16)
+  const h16* X16; int H, rows;              // tower top [rows][H]
+  float* dW; float* db; float* partial;     // [NH][H], [NH], one sum-of-squares slot per block
+  int nh;                                   // 1 / 10 (0: none)
+  int blocks;                               // H / 64
+};
+template <int NH>
+__device__ __forceinline__ void head_wsum_block(const HeadWsum& r, int blk, float* scratch /* 32 x 65 floats of LDS */) {
+  float (*sred)[65] = reinterpret_cast<float (*)[65]>(scratch);
+  const int col0 = blk * 64;
+  const int tid = threadIdx.x, c8 = tid & 7, rg = tid >> 3;
+  const h16* p = r.X16 + col0 + c8 * 8;
+  float acc[NH][8];
+#pragma unroll
+  for (int j = 0; j < NH; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+  auto weights = [&](int row, float (&w)[NH]) {
+    if constexpr (NH == 1) w[0] = r.dy[(size_t)row * r.lddy];
+    else {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const f4* q = reinterpret_cast<const f4*>(r.dy + (size_t)row * r.lddy);      // (lddy = 16: 64-B rows)
+#pragma unroll
+      for (int j4 = 0; j4 < (NH + 3) / 4; ++j4) {
+        const f4 v = q[j4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (j4 * 4 + c < NH) w[j4 * 4 + c] = v[c];
+      }
+    }
+  };
+  int row = rg;
+  for (; row + 32 < r.rows; row += 64) {       // two independent rows in flight
+    const h16x8 v0 = *reinterpret_cast<const h16x8*>(p + (size_t)row * r.H), v1 = *reinterpret_cast<const h16x8*>(p + (size_t)(row + 32) * r.H);
+    float w0[NH], w1[NH];
+    weights(row, w0); weights(row + 32, w1);
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { acc[j][e] = fmaf(w0[j], (float)v0[e], acc[j][e]); acc[j][e] = fmaf(w1[j], (float)v1[e], acc[j][e]); }
+  }
+  for (; row < r.rows; row += 32) {
+    const h16x8 v0 = *reinterpret_cast<const h16x8*>(p + (size_t)row * r.H);
+    float w0[NH];
+    weights(row, w0);
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(w0[j], (float)v0[e], acc[j][e]);
+  }
+  float ssq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    if (j > 0) __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sred[rg][c8 * 8 + e] = acc[j][e];
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) s += sred[g][tid];
+      r.dW[(size_t)j * r.H + col0 + tid] = s;
+      ssq = fmaf(s, s, ssq);
+    }
+  }
+  if (blk == 0) {                            // the head's bias gradient: rows strided over the threads, fixed-order reduction
+    float s[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) s[j] = 0.f;
+    for (int m = tid; m < r.rows; m += 256) {
+      float w[NH];
+      weights(m, w);
+#pragma unroll
+      for (int j = 0; j < NH; ++j) s[j] += w[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NH; ++j) { const float t = wave_sum64(s[j]); if ((tid & 63) == 0) sred[tid >> 6][j] = t; }
+    __syncthreads();
+    if (tid < NH) {
+      const float v = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+      r.db[tid] = v;
+      ssq = fmaf(v, v, ssq);
+    }
+  }
+  if (tid < 64 && r.partial != nullptr) {    // wave 0 holds every contribution of this block
+    ssq = wave_sum64(ssq);
+    if (tid == 0) r.partial[blk] = ssq;
+  }
+}
+// ... and, for data-parallel learners, the tails block (TailsArgs).  Grid: tiles, column-sum blocks, head blocks, tails.
 template <int WM, int WN>
-__global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_group_db(HGemmBatch batch, Db16Batch db, int db_blocks, HeadWgradRider rider, int rider_nh, TailsArgs tails) {
+__global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_group_db(HGemmBatch batch, Db16Batch db, int db_blocks, HeadWsum head, TailsArgs tails) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char hg_smem[];
   const int nt = batch.tile_end[batch.n - 1];
   int b = (int)blockIdx.x;
@@ -767,8 +864,8 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_group_db(HGemmBa
   b -= nt;
   if (b < db_blocks) { db16_cols_block(db, b, reinterpret_cast<float*>(hg_smem)); return; }
   b -= db_blocks;
-  if (rider_nh != 0 && b < rider.blocks) {
-    if (rider_nh == 1) head_wgrad_rider<1>(rider, b, reinterpret_cast<float*>(hg_smem)); else head_wgrad_rider<10>(rider, b, reinterpret_cast<float*>(hg_smem));
+  if (head.nh != 0 && b < head.blocks) {
+    if (head.nh == 1) head_wsum_block<1>(head, b, reinterpret_cast<float*>(hg_smem)); else head_wsum_block<10>(head, b, reinterpret_cast<float*>(hg_smem));
     return;
   }
   if (tails.on) tails_block(tails, reinterpret_cast<float*>(hg_smem), reinterpret_cast<double*>(hg_smem + 64));
@@ -781,23 +878,22 @@ inline hipError_t hgemm_group_db_prepare() {
 // gs: n reduction-major wgrads (mode 3); db_blocks = 64-column blocks of db (0: none).  big: 128 x 128 tiles
 // (every M, N a multiple of 128), else 64 x 64 split-K tiles.
 inline hipError_t hgemm_group_db_launch(const HGemm* gs, int n, bool big, const Db16Batch& db, int db_blocks, hipStream_t st,
-                                        hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, const HeadWgradRider* rider_in = nullptr, int rider_nh = 0,
-                                        const TailsArgs* tails_in = nullptr) {
+                                        hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, const HeadWsum* head_in = nullptr, const TailsArgs* tails_in = nullptr) {
   for (int i = 0; i < n; ++i) if (hgemm_mode(gs[i]) != 3) return hipErrorInvalidValue;
   HGemmBatch b; int wm, wn; long blocks;
   hipError_t e = hgemm_plan(gs, n, big ? 1 : 2, b, wm, wn, blocks);
   if (e != hipSuccess) return e;
-  HeadWgradRider rider{}; TailsArgs tails{};
-  if (rider_in != nullptr && rider_nh != 0) rider = *rider_in; else rider_nh = 0;
+  HeadWsum head{}; TailsArgs tails{};
+  if (head_in != nullptr) head = *head_in;
+  if (head.nh != 0 && head.nh != 1 && head.nh != 10) return hipErrorInvalidValue;
   if (tails_in != nullptr) { tails = *tails_in; tails.on = 1; }
-  if (rider_nh != 0 && (size_t)(rider.rows * rider_nh + 256 * rider_nh) * sizeof(float) > (size_t)(big ? HGCfg<2, 2>::LDS_BYTES : HGCfg<1, 1>::LDS_BYTES)) return hipErrorInvalidValue;
-  const unsigned grid = (unsigned)(blocks + db_blocks + (rider_nh ? rider.blocks : 0) + (tails.on ? 1 : 0));
+  const unsigned grid = (unsigned)(blocks + db_blocks + (head.nh ? head.blocks : 0) + (tails.on ? 1 : 0));
   if (big) {
-    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, b, db, db_blocks, rider, rider_nh, tails);
-    else hipLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, b, db, db_blocks, rider, rider_nh, tails);
+    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, t0, t1, 0, b, db, db_blocks, head, tails);
+    else hipLaunchKernelGGL((hgemm_group_db<2, 2>), dim3(grid), dim3(256), (HGCfg<2, 2>::LDS_BYTES), st, b, db, db_blocks, head, tails);
   } else {
-    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, b, db, db_blocks, rider, rider_nh, tails);
-    else hipLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, b, db, db_blocks, rider, rider_nh, tails);
+    if (t0) hipExtLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, t0, t1, 0, b, db, db_blocks, head, tails);
+    else hipLaunchKernelGGL((hgemm_group_db<1, 1>), dim3(grid), dim3(256), (HGCfg<1, 1>::LDS_BYTES), st, b, db, db_blocks, head, tails);
   }
   return hipGetLastError();
 }

@@ -342,12 +342,16 @@ UpdatePlan plan_of(const H* h) {
   p.dp = h->cfg.dp_world > 1 || h->dp_half || h->dp_shard;     // (a one-rank group with bf16 exchange / a sharded optimiser runs the N-rank code path)
   p.fused_seed = !(tf & DQNHIP_TUNE_SEPARATE_HEAD_SEED);
   if (h->fp16) {
-    // fp16 learner (round 6): the head's dW / db ride in the net's last backward launch (hgemm_group_db) when it exists and their
-    // staging fits its LDS; Step(1)'s k_head_q_train then also writes the scaled fp16 tower-top gradient — no head-backward launch
-    p.head_rides_c = bwd16_has_carrier(h, DQNHIP_CRITIC, B) && head_wgrad_can_ride(lc, B);
-    p.head_rides_a = bwd16_has_carrier(h, DQNHIP_ACTOR, B) && head_wgrad_can_ride(la, B) && !head_big_ok(h, B, Hh);
+    // fp16 learner (round 6): the head's dW / db are column-sum workgroups of the net's last backward launch (hgemm_group_db, HeadWsum)
+    // when that launch exists; Step(1)'s k_head_q_train then also writes the scaled fp16 tower-top gradient — no head-backward launch
+    p.head_rides_c = bwd16_has_carrier(h, DQNHIP_CRITIC, B) && Hc % 64 == 0;
+    p.head_rides_a = bwd16_has_carrier(h, DQNHIP_ACTOR, B) && Hh % 64 == 0;
     p.fuse_q = p.head_rides_c;
     p.tails_ride = p.dp && bwd16_has_carrier(h, DQNHIP_CRITIC, B) && bwd16_has_carrier(h, DQNHIP_ACTOR, B);
+    // the critic's layer-0 dgrad (only its ten action columns are consumed), the inverting gradients and the actor heads' backward in
+    // ONE launch (k_dqda_head_bwd<true>), as on the fp32 path; q(s, mu(s)) rides there
+    p.fuse_head = p.head_rides_a && p.fused_seed && !(tf & DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) && B % 16 == 0 && B < 1024 && Hh % 256 == 0 &&
+                  h->S + 16 <= h->k16[1][0] && L >= 1 && lc.dims[1] % 64 == 0;
     return p;
   }
   p.shifted_c = bwd_is_shifted(h, lc, B); p.shifted_a = bwd_is_shifted(h, la, B);
@@ -569,7 +573,7 @@ inline bool bwd16_has_carrier(const H* h, int net, int rows) {
   return hgemm_uses_small_tile(g) && g.K % 128 == 0 && g.M % 64 == 0 && g.N % 64 == 0;
 }
 int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float* dZ32_0, int rows,
-                     bool want_w, bool input_grad, float ls, float* partial = nullptr, const HeadWgradRider* rider = nullptr,
+                     bool want_w, bool input_grad, float ls, float* partial = nullptr, const HeadWsum* rider = nullptr,
                      const TailsArgs* tails = nullptr) {
   const NetLayout& l = layout_of(h, net);
   const int kind = net & 1;
@@ -626,10 +630,10 @@ int tower_backward16(H* h, hipStream_t st, int net, int p, float* garena, float*
   if (grouped) {
     // 128x128 tiles: a quarter of the operand bytes per FLOP of the 64x64 split-K tile (fp16 mode guarantees
     // hidden % 128 == 0, minibatch % 128 == 0 and a 128-wide first panel, so every wgrad tiles)
-    HIPCHK(hgemm_group_db_launch(gws, l.L, true, db, db_blocks, st, e0, e1, rider, l.NH, tails));
+    HIPCHK(hgemm_group_db_launch(gws, l.L, true, db, db_blocks, st, e0, e1, rider, tails));
   } else if (!input_grad && hgemm_uses_small_tile(gws[0]) && gws[0].K % 128 == 0) {
     // per-layer form: the first layer's wgrad (few tiles, long reduction) carries the column sums
-    HIPCHK(hgemm_group_db_launch(gws, 1, false, db, db_blocks, st, e0, e1, rider, l.NH, tails));
+    HIPCHK(hgemm_group_db_launch(gws, 1, false, db, db_blocks, st, e0, e1, rider, tails));
   } else {
     if (rider != nullptr || tails != nullptr) return fail("internal: the fp16 backward found no carrier launch for its riders");
     if (!input_grad) HIPCHK(hgemm_launch(gws[0], st, 0, e0, e1));
@@ -698,7 +702,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X416 = h->act16[3][L];
       a.H = Hc; a.rows = B; a.dZ = nullptr; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
-      HeadWgradRider r{h->dq, 1, nullptr, Hc, B, a.dW, a.db, a.partial, Hc / kRiderCW, h->act16[3][L]};
+      const HeadWsum r{h->dq, 1, h->act16[3][L], Hc, B, a.dW, a.db, a.partial, 1, Hc / 64};
       if (P.head_rides_c) {}                                       // (dZ16 came out of k_head_q_train, dW / db come from the riders)
       else if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->ls_c)); }
       else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_c; RC(head_backward<1>(h, st, a)); }
@@ -732,7 +736,15 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->ls_q)); }
       else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_q; RC(head_backward<1>(h, st, a)); }
     }
-    RC(tower_backward16(h, st, DQNHIP_CRITIC, 4, nullptr, h->dZc[0], B, false, true, h->ls_q));
+    RC(tower_backward16(h, st, DQNHIP_CRITIC, 4, nullptr, h->dZc[0], B, false, !P.fuse_head, h->ls_q));       // (fuse_head: layers L-1 .. 1 only)
+    if (P.fuse_head) {
+      DqdaHeadArgs fz{};
+      fz.aout16 = h->aout16; fz.dA16 = h->dA16; fz.W = wat(h, DQNHIP_ACTOR, la.hw_off); fz.H = Hh; fz.rows = B;
+      fz.t16 = NarrowTile16{h->w16[DQNHIP_CRITIC][0] + h->S, h->k16[1][0], h->dZ16[1][1], lc.dims[1], lc.dims[1]}; fz.inv_ls = 1.0f / h->ls_q;
+      fz.X416 = h->act16[1][L]; fz.dZ16 = h->dZ16[0][L]; fz.scale16 = h->ls_a;
+      const QHeadRider qr{nullptr, wat(h, DQNHIP_CRITIC, lc.hw_off), wat(h, DQNHIP_CRITIC, lc.hb_off), h->q2, h->q_partial, Hc, B, (B + 3) / 4, h->act16[4][L]};
+      HIPCHK(dqda_head_bwd_launch(fz, qr, st));
+    }
     {
       HeadBwdArgs a{}; a.dXc = h->dZc[0]; a.ldx = lc.kp[0]; a.S = h->S; a.aout16 = h->aout16; a.dA16 = h->dA16;
       a.W = wat(h, DQNHIP_ACTOR, la.hw_off); a.X416 = h->act16[1][L]; a.H = Hh; a.rows = B; a.dZ = nullptr;
@@ -741,9 +753,10 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
         a.qr_W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.qr_X416 = h->act16[4][L]; a.qr_H = Hc;
       }
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
-      const HeadWgradRider r{h->dA16, kAP, nullptr, Hh, B, a.dW, a.db, a.partial, Hh / kRiderCW, h->act16[1][L]};   // dA16: the post-invert diffs this launch leaves
+      const HeadWsum r{h->dA16, kAP, h->act16[1][L], Hh, B, a.dW, a.db, a.partial, kNO, Hh / 64};   // dA16: the post-invert diffs this launch leaves
       if (P.head_rides_a) { a.dW = nullptr; a.db = nullptr; a.partial = nullptr; }
-      if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->ls_a)); }
+      if (P.fuse_head) {}                                        // (k_dqda_head_bwd<true> above did all of it)
+      else if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->ls_a)); }
       else { a.dZ16 = h->dZ16[0][L]; a.scale16 = h->ls_a; RC(head_backward<kNO>(h, st, a)); }
       const TailsArgs tails_a{(const float*)nullptr, 0, (const double*)h->q_partial, B, inv_batch, (float*)nullptr, actor_tail, &h->st->flags, 0};
       RC(tower_backward16(h, st, DQNHIP_ACTOR, 1, h->g[0], nullptr, B, true, false, h->ls_a, part16 ? h->part[0] : nullptr, P.head_rides_a ? &r : nullptr,

@@ -896,8 +896,13 @@ struct DqdaHeadArgs {
   const float* W; const float* X4;         // actor head weights [10][H], actor tower top [rows][H]
   float* dZ;                               // actor tower-top gradient [rows][H]
   int H, rows, row_tiles;                  // row_tiles = rows / 16
+  // fp16 learner (F16 = true, round 6: its layer-0 dgrad launch + k_head_bwd<10> in one): the tile from the fp16 operands
+  // (dgrad_narrow_tile16; t16.P = W16_0 + S, t16.Q = the scaled dZ16_1), times inv_ls; the tower top read as fp16 (X416), the
+  // tower-top gradient written as the scaled fp16 panel dZ16 = (h16)(dZ * scale16)
+  NarrowTile16 t16; float inv_ls;
+  const _Float16* X416; _Float16* dZ16; float scale16;
 };
-template <int UNUSED = 0>
+template <bool F16 = false>
 __global__ __launch_bounds__(256) void k_dqda_head_bwd(const DqdaHeadArgs a, const QHeadRider rider) {
   extern __shared__ __attribute__((aligned(16))) float smem[];     // the narrow dgrad's parking area (4 waves x 64 lanes x 16 B)
   __shared__ float s_d[16][17];
@@ -912,10 +917,12 @@ __global__ __launch_bounds__(256) void k_dqda_head_bwd(const DqdaHeadArgs a, con
 #pragma unroll
   for (int j = 0; j < kNO; ++j) wh[j] = a.W[(size_t)j * a.H + k];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) xv[r] = a.X4[(size_t)(q0 + r) * a.H + k];
+  for (int r = 0; r < 16; ++r) xv[r] = F16 ? (float)a.X416[(size_t)(q0 + r) * a.H + k] : a.X4[(size_t)(q0 + r) * a.H + k];
   float out = 0.0f;
   if (tid < 16 * kNO) out = a.aout16[(size_t)(q0 + tid / kNO) * kAP + tid % kNO];
-  const f32x4 v = dgrad_narrow_tile<8>(a.pr, 0, rt, smem);
+  f32x4 v;
+  if constexpr (F16) { v = dgrad_narrow_tile16<8>(a.t16, rt, smem); v.x *= a.inv_ls; v.y *= a.inv_ls; v.z *= a.inv_ls; v.w *= a.inv_ls; }
+  else v = dgrad_narrow_tile<8>(a.pr, 0, rt, smem);
   if (tid < 64) {                          // wave 0 holds the tile: lane (li, lg), register r = dX[row q0 + li][column 4 lg + r]
     const int li = tid & 15, lg = tid >> 4;
     s_d[li][(lg << 2) + 0] = v.x; s_d[li][(lg << 2) + 1] = v.y; s_d[li][(lg << 2) + 2] = v.z; s_d[li][(lg << 2) + 3] = v.w;
@@ -943,7 +950,9 @@ __global__ __launch_bounds__(256) void k_dqda_head_bwd(const DqdaHeadArgs a, con
       if (j >= kNA) s1 = fmaf(d, wh[j], s1); else s0 = fmaf(d, wh[j], s0);
     }
     s0 += s1;
-    a.dZ[(size_t)(q0 + r) * a.H + k] = s0 * lrelu_mask(xv[r]);
+    const float dz = s0 * lrelu_mask(xv[r]);
+    if constexpr (F16) a.dZ16[(size_t)(q0 + r) * a.H + k] = (_Float16)(dz * a.scale16);
+    else a.dZ[(size_t)(q0 + r) * a.H + k] = dz;
   }
 }
 inline hipError_t dqda_head_bwd_launch(DqdaHeadArgs& a, const QHeadRider& rider, hipStream_t stream) {
@@ -951,8 +960,9 @@ inline hipError_t dqda_head_bwd_launch(DqdaHeadArgs& a, const QHeadRider& rider,
   a.pr.tiles_p = 1; a.pr.tiles_q = a.row_tiles; a.pr.tile_base = 0;
   const int grid = a.row_tiles * (a.H / 256) + rider.blocks;
   LaunchTimer& lt = launch_timer();
-  if (lt.start) { hipExtLaunchKernelGGL(k_dqda_head_bwd<0>, dim3(grid), dim3(256), 4 * 64 * 16, stream, lt.start, lt.stop, 0, a, rider); lt.start = lt.stop = nullptr; }
-  else hipLaunchKernelGGL(k_dqda_head_bwd<0>, dim3(grid), dim3(256), 4 * 64 * 16, stream, a, rider);
+  if (a.dZ16 != nullptr) hipLaunchKernelGGL(k_dqda_head_bwd<true>, dim3(grid), dim3(256), 4 * 64 * 16, stream, a, rider);
+  else if (lt.start) { hipExtLaunchKernelGGL(k_dqda_head_bwd<false>, dim3(grid), dim3(256), 4 * 64 * 16, stream, lt.start, lt.stop, 0, a, rider); lt.start = lt.stop = nullptr; }
+  else hipLaunchKernelGGL(k_dqda_head_bwd<false>, dim3(grid), dim3(256), 4 * 64 * 16, stream, a, rider);
   return hipGetLastError();
 }
 
