@@ -790,15 +790,20 @@ __device__ __forceinline__ void head_wsum_block(const HeadWsum& r, int blk, floa
       }
     }
   };
+  // U rows in flight per thread (a block streams rows x 128 B through 32 row groups: at 4096 rows a thread walks 128 rows, and with
+  // two in flight the actor's block outlasted the 40-us wgrad tiles beside it)
+  constexpr int U = NH == 1 ? 8 : 4;
   int row = rg;
-  for (; row + 32 < r.rows; row += 64) {       // two independent rows in flight
-    const h16x8 v0 = *reinterpret_cast<const h16x8*>(p + (size_t)row * r.H), v1 = *reinterpret_cast<const h16x8*>(p + (size_t)(row + 32) * r.H);
-    float w0[NH], w1[NH];
-    weights(row, w0); weights(row + 32, w1);
+  for (; row + 32 * (U - 1) < r.rows; row += 32 * U) {
+    h16x8 v[U]; float w[U][NH];
 #pragma unroll
-    for (int j = 0; j < NH; ++j)
+    for (int u = 0; u < U; ++u) { v[u] = *reinterpret_cast<const h16x8*>(p + (size_t)(row + 32 * u) * r.H); weights(row + 32 * u, w[u]); }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { acc[j][e] = fmaf(w0[j], (float)v0[e], acc[j][e]); acc[j][e] = fmaf(w1[j], (float)v1[e], acc[j][e]); }
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < NH; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(w[u][j], (float)v[u][e], acc[j][e]);
   }
   for (; row < r.rows; row += 32) {
     const h16x8 v0 = *reinterpret_cast<const h16x8*>(p + (size_t)row * r.H);

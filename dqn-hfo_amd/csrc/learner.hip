@@ -350,7 +350,7 @@ UpdatePlan plan_of(const H* h) {
     p.tails_ride = p.dp && bwd16_has_carrier(h, DQNHIP_CRITIC, B) && bwd16_has_carrier(h, DQNHIP_ACTOR, B);
     // the critic's layer-0 dgrad (only its ten action columns are consumed), the inverting gradients and the actor heads' backward in
     // ONE launch (k_dqda_head_bwd<true>), as on the fp32 path; q(s, mu(s)) rides there
-    p.fuse_head = p.head_rides_a && p.fused_seed && !(tf & DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) && B % 16 == 0 && B < 1024 && Hh % 256 == 0 &&
+    p.fuse_head = p.head_rides_a && !(tf & DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) && B % 16 == 0 && B < 1024 && Hh % 256 == 0 &&
                   h->S + 16 <= h->k16[1][0] && L >= 1 && lc.dims[1] % 64 == 0;
     return p;
   }
@@ -742,7 +742,8 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       fz.aout16 = h->aout16; fz.dA16 = h->dA16; fz.W = wat(h, DQNHIP_ACTOR, la.hw_off); fz.H = Hh; fz.rows = B;
       fz.t16 = NarrowTile16{h->w16[DQNHIP_CRITIC][0] + h->S, h->k16[1][0], h->dZ16[1][1], lc.dims[1], lc.dims[1]}; fz.inv_ls = 1.0f / h->ls_q;
       fz.X416 = h->act16[1][L]; fz.dZ16 = h->dZ16[0][L]; fz.scale16 = h->ls_a;
-      const QHeadRider qr{nullptr, wat(h, DQNHIP_CRITIC, lc.hw_off), wat(h, DQNHIP_CRITIC, lc.hb_off), h->q2, h->q_partial, Hc, B, (B + 3) / 4, h->act16[4][L]};
+      // (DQNHIP_TUNE_SEPARATE_HEAD_SEED: q(s, mu(s)) came out of the dq = -1 head launch — no rider blocks)
+      const QHeadRider qr{nullptr, wat(h, DQNHIP_CRITIC, lc.hw_off), wat(h, DQNHIP_CRITIC, lc.hb_off), h->q2, h->q_partial, Hc, B, fused_seed ? (B + 3) / 4 : 0, h->act16[4][L]};
       HIPCHK(dqda_head_bwd_launch(fz, qr, st));
     }
     {

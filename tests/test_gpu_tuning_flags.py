@@ -317,3 +317,23 @@ def test_early_gather_and_next_update_first_layers_equal_the_late_form(pkg, gpu,
     assert out[0][0] == out[1][0] and out[0][2] == out[1][2] == (n, n)
     for x, y in zip(out[0][1], out[1][1]):
         np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("B,hidden", [(128, (256, 128, 128)), (512, (1024, 1024, 1024, 1024)), (256, (256, 256))])
+def test_fp16_fused_dqda_head_bwd_against_separate_launches(pkg, gpu, B, hidden):
+    """fp16 learner (round 6): the critic's layer-0 input gradient (ten action columns), the inverting gradients and the actor heads'
+    backward in ONE launch (k_dqda_head_bwd<true>) against the fp16-MFMA layer-0 dgrad launch + k_head_bwd<10>
+    (DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD).  Same fp16 operands, exact products; the fp32 additions of the 16-column tile run in
+    another order (16x16x4 fp32 MFMA chains on converted operands against the 32x32x16 fp16 MFMA), so the two agree to fp32
+    round-off before the tower-top gradient is rounded to fp16 — not bit for bit."""
+    a = _run(pkg, 0, B, hidden)
+    b = _run(pkg, pkg.capi.TUNE_SEPARATE_ACTOR_HEAD_BWD, B, hidden)
+    assert np.allclose(a[0], b[0], rtol=1e-4, atol=1e-6), (a[0], b[0])
+    for it, ((ga, gc), (gb_a, gb_c)) in enumerate(zip(a[1], b[1])):
+        for x, y in ((ga, gb_a), (gc, gb_c)):
+            rel = np.linalg.norm(x.astype(np.float64) - y) / max(np.linalg.norm(y), 1e-30)
+            assert rel <= (3e-4 if it == 0 else 5e-3), (it, rel)
+    if B <= 512:
+        p = pkg.DQN(58, minibatch=B, hidden=hidden, memory=4096, seed=3, precision="fp16")
+        assert "dqda_head_bwd" in p.update_plan()["forms"]
+        p.close()
