@@ -197,8 +197,12 @@ def test_native_rccl_sharded_optimiser_one_rank(pkg, gpu, precision, half, use_g
     rng = np.random.default_rng(6)
     w = [torch_ref.init_params_np(rng, S, hid, act) * 5 for act in (True, False)]
     data = synth_replay(rng, 1024, S, mean_len=10)
+    # (like with like: a sharded pass covers 1/N of the arena and has no first-layer rider; the fp32 rider is bit-identical to the launch
+    # it replaces, the fp16 one — fp32 MFMA chains on converted operands against the fp16 MFMA — only to round-off, so the fp16 twins
+    # both keep the launch)
+    tuning = pkg.capi.TUNE_SEPARATE_FIRST_LAYER if precision == "fp16" else 0
     ds = [pkg.DQN(S, minibatch=B, hidden=hid, memory=4096, seed=2, dp_world=1, dp_rank=0, precision=precision, use_graph=use_graph,
-                  clip_grad=clip) for _ in range(2)]
+                  clip_grad=clip, tuning=tuning) for _ in range(2)]
     for d in ds:
         for net in (0, 1):
             d.set_params(net, w[net]); d.CloneNet(net)
@@ -212,7 +216,9 @@ def test_native_rccl_sharded_optimiser_one_rank(pkg, gpu, precision, half, use_g
     for u in range(4):
         ds[0].dp_update(None); ds[1].dp_update(None)
         s0, s1 = ds[0].read_stats(), ds[1].read_stats()
-        assert s0 == s1 if exact else np.allclose(s0, s1, rtol=1e-5, atol=1e-7), (s0, s1)
+        # (fp16 learner with the clip active: a weight that the ~1e-7 difference of the two clip scales moves across an fp16 rounding
+        # boundary changes by 1e-3 of itself in the mirror the GEMMs read — measured 5e-5 on avg_q by the fourth update)
+        assert s0 == s1 if exact else np.allclose(s0, s1, rtol=1e-5 if precision == "fp32" else 3e-4, atol=1e-7), (u, s0, s1)
     assert ds[0].dp_graph_active() == use_graph
     ds[0].dp_gather_state()
     same = np.testing.assert_array_equal if exact else (lambda a, b: np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-7))

@@ -337,7 +337,7 @@ def test_fp16_merged_launches_against_separate_ones(pkg, gpu, B, hidden, flag, f
         for x, y in ((ga, gb_a), (gc, gb_c)):
             rel = np.linalg.norm(x.astype(np.float64) - y) / max(np.linalg.norm(y), 1e-30)
             assert rel <= (1e-3 if it == 0 else 5e-3), (flag, it, rel)
-    for tuning, present in ((0, True), (getattr(pkg.capi, flag), False)):
+    for tuning, present in ((0, hidden[-1] % 256 == 0 or form != "dqda_head_bwd"), (getattr(pkg.capi, flag), False)):      # (k_dqda_head_bwd: a tower top of 256 k columns)
         p = pkg.DQN(58, minibatch=B, hidden=hidden, memory=4096, seed=3, precision="fp16", tuning=tuning)
         assert (form in p.update_plan()["forms"]) == present, (flag, tuning, p.update_plan())
         p.close()
