@@ -341,6 +341,14 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
                 r[name + "_ms"] = round(timed(step, torch.cuda.synchronize, 300, 30) * 1e3, 4)
                 if dp_kw is not None and kw["use_graph"]:
                     r[name + "_captured"] = d.dp_graph_active()
+                if name in ("plain_graph", "dp_graph"):
+                    # the form the headline enqueues: sixteen updates per graph launch (dqnhip_update_async_n / dqnhip_dp_update_n), the
+                    # next update's gather (and, where the riders fit, its first layers) riding in this update's optimiser launches
+                    step_n = (lambda k, d=d: d.dp_update_n(k)) if dp_kw is not None else (lambda k, d=d: d.update_async_n(k))
+                    step_n(64); torch.cuda.synchronize()
+                    t1 = time.perf_counter(); step_n(320); torch.cuda.synchronize()
+                    r[name + "_n_ms"] = round((time.perf_counter() - t1) / 320 * 1e3, 4)
+                    r[name + "_plan"] = d.update_plan()
                 if name == "plain_graph":
                     # the backward chain's launch durations at this rank shape: when each per-layer bucket becomes ready
                     d.set_kernel_timing(True)
@@ -894,7 +902,7 @@ def main():
     # collective the others never entered), and an exception only drops the side records.
     if not args.no_subrecords and not args.strong and args.precision == "fp32" and B == 256:
         import threading
-        dog = threading.Timer(240.0, emit_and_exit, kwargs={"note": "side records did not finish within 240 s"})
+        dog = threading.Timer(300.0, emit_and_exit, kwargs={"note": "side records did not finish within 300 s"})
         dog.daemon = True
         dog.start()
         try:

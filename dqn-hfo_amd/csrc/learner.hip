@@ -464,7 +464,7 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   else if (fl != nullptr) {
     if (blocks <= fl->blocks) return fail("adam_launch: no optimiser workgroups beside the first-layer riders");
     const bool timed = lt.start != nullptr;
-    if (h->fp16) hipLaunchKernelGGL((k_adam_soft_fwd1<2, true>), dim3(blocks), dim3(256), 0, st, a, *fl);
+    if (h->fp16) { if (timed) hipExtLaunchKernelGGL((k_adam_soft_fwd1<2, true>), dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL((k_adam_soft_fwd1<2, true>), dim3(blocks), dim3(256), 0, st, a, *fl); }
     else if (fl->Kp == 64) { if (timed) hipExtLaunchKernelGGL(k_adam_soft_fwd1<1>, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL(k_adam_soft_fwd1<1>, dim3(blocks), dim3(256), 0, st, a, *fl); }
     else { if (timed) hipExtLaunchKernelGGL(k_adam_soft_fwd1<2>, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL(k_adam_soft_fwd1<2>, dim3(blocks), dim3(256), 0, st, a, *fl); }
     if (timed) lt.start = lt.stop = nullptr;

@@ -972,7 +972,10 @@ inline hipError_t dqda_head_bwd_launch(DqdaHeadArgs& a, const QHeadRider& rider,
   a.pr.tiles_p = 1; a.pr.tiles_q = a.row_tiles; a.pr.tile_base = 0;
   const int grid = a.row_tiles * (a.H / 256) + rider.blocks;
   LaunchTimer& lt = launch_timer();
-  if (a.dZ16 != nullptr) hipLaunchKernelGGL(k_dqda_head_bwd<true>, dim3(grid), dim3(256), 4 * 64 * 16, stream, a, rider);
+  if (a.dZ16 != nullptr) {
+    if (lt.start) { hipExtLaunchKernelGGL(k_dqda_head_bwd<true>, dim3(grid), dim3(256), 4 * 64 * 16, stream, lt.start, lt.stop, 0, a, rider); lt.start = lt.stop = nullptr; }
+    else hipLaunchKernelGGL(k_dqda_head_bwd<true>, dim3(grid), dim3(256), 4 * 64 * 16, stream, a, rider);
+  }
   else if (lt.start) { hipExtLaunchKernelGGL(k_dqda_head_bwd<false>, dim3(grid), dim3(256), 4 * 64 * 16, stream, lt.start, lt.stop, 0, a, rider); lt.start = lt.stop = nullptr; }
   else hipLaunchKernelGGL(k_dqda_head_bwd<false>, dim3(grid), dim3(256), 4 * 64 * 16, stream, a, rider);
   return hipGetLastError();

@@ -296,33 +296,20 @@ int dqnhip_grad_buffer(dqnhip_handle h, int32_t net, void** dptr, size_t* nfloat
  *                         receive it.  Every waiter publishes <path>.req<rank> with a fresh nonce and accepts <path>
  *                         only if it carries that nonce, rank 0 clears leftovers first: a file from an earlier or a
  *                         crashed job can never hand out a dead id, and the same path can be reused.
- * flags: DQNHIP_DP_PER_LAYER buckets each all-reduce per tower layer on a communication stream,
- * started as soon as that layer's backward launch has run (backward order), head + tail last (fp32 learner only; the
- * fp16 learner produces all wgrads of a net in one launch and keeps one collective per net).
+ * flags: 0 — ONE sum all-reduce per net (arena + 4-float tail), the supported form, what bench.py --gpus N and the drop-in use.
  * DQNHIP_DP_HALF_GRADS: the gradient arenas cross the links as bf16 — half the bytes (6.4 instead of 12.9 MB per
  * net at 4x1024); the [loss, q, flag] tails stay fp32 and travel once, with the actor's gradients.  The reduced
  * gradient then carries 8 significant bits (tests/test_gpu_dp_hip.py bounds the effect); meant for the fp16 learner.
  * cfg.use_graph: dqnhip_dp_update captures phase 0 / all-reduce / phase 1 / all-reduce / phase 2 ONCE and replays
  * it as a hipGraph (eager if RCCL refuses the capture: dqnhip_dp_graph_active tells).
- * DQNHIP_DP_SHARD_OPT: the optimiser is sharded over the group (ZeRO-1 style) instead of replicated: per net, a
- * reduce-scatter leaves rank r with slice r of the summed gradient, the ranks all-reduce a 4-float tail {loss, q, target
- * flag, sum of squares of their slice} — the clip norm — each rank runs clip + Adam + soft update on its 1/N slice only, and
- * the updated online AND target weights (the targets move every update, src/dqn.cpp:967-970; fp16 learner: the fp16 mirrors
- * too) are all-gathered.  What SURVEY 8(e) calls "identical Adam on every rank" is relaxed to "every parameter's Adam on
- * exactly one rank, identical weights everywhere afterwards".  m and v of foreign slices go stale: dqnhip_dp_gather_state
- * (collective) brings them back before a snapshot / dqnhip_get_params(KIND_M, KIND_V); dqnhip_dp_destroy refuses until it has
- * been called since the last update (a teardown never blocks on peers: dqnhip_destroy itself just frees).
- * Combines with DQNHIP_DP_HALF_GRADS, not with DQNHIP_DP_PER_LAYER.  Priced in DESIGN.md 6: it does not pay at 4 x 1024
- * (the target nets double the all-gather, the clip norm needs its own latency-bound collective); off by default.
- * The arena must be divisible by 4 x dp_world. */
+ * Since round 6 a data-parallel learner runs the single learner's merged launches (dqnhip_get_update_plan): the riders sit
+ * between the exchange points, the tails of the exchange ride in each net's last backward launch.
+ * (Two further exchange forms exist behind DQNHIP_DP_UNVERIFIED_OK — see the end of this header.) */
 #define DQNHIP_DP_ID_BYTES 128
 #define DQNHIP_DP_PER_LAYER 1
 #define DQNHIP_DP_HALF_GRADS 2
 #define DQNHIP_DP_SHARD_OPT 4
-/* DQNHIP_DP_PER_LAYER and DQNHIP_DP_SHARD_OPT have only ever run on one-rank groups (no box with more than one GPU has been
- * available): dqnhip_dp_init refuses them for dp_world > 1 unless this bit says the caller knows.  The replicated
- * one-bucket exchange (flags 0, optionally DQNHIP_DP_HALF_GRADS) is the supported form. */
-#define DQNHIP_DP_UNVERIFIED_OK 256
+#define DQNHIP_DP_UNVERIFIED_OK 256     /* lets DQNHIP_DP_PER_LAYER / DQNHIP_DP_SHARD_OPT through for dp_world > 1 (see the end of this header) */
 /* ncclGetVersion() and the shared object RCCL was resolved from in this process (a PyTorch host process resolves torch's
  * bundled librccl, a bare host /opt/rocm's); dqnhip_dp_init cross-checks the version over the group and fails on a mix. */
 int dqnhip_dp_info(int32_t* rccl_version, char* path, size_t path_bytes);
@@ -540,6 +527,20 @@ int dqnhip_get_stream(dqnhip_handle h, void** stream);
 int dqnhip_set_kernel_timing(dqnhip_handle h, int32_t enable);
 int dqnhip_get_kernel_timing(dqnhip_handle h, const char* family, float* avg_ms,
                              int64_t* launches, int32_t reset);
+
+/* ---- data parallelism: exchange forms that are NOT part of the supported surface -----------------------------------------
+ * Built in rounds 3-4, priced net-negative by this library's own model and never run on more than one rank (no box
+ * with more than one GPU has been available): dqnhip_dp_init refuses them for dp_world > 1 unless DQNHIP_DP_UNVERIFIED_OK says the
+ * caller knows.  One-rank groups stay open (tests pin their launch sequences).
+ * DQNHIP_DP_PER_LAYER buckets each all-reduce per tower layer on a communication stream, started as soon as that layer's backward
+ * launch has run (backward order), head + tail last (fp32 learner only).
+ * DQNHIP_DP_SHARD_OPT: the optimiser sharded over the group (ZeRO-1 style) instead of replicated: per net, a reduce-scatter leaves
+ * rank r with slice r of the summed gradient, the ranks all-reduce a 4-float tail {loss, q, target flag, sum of squares of their
+ * slice} — the clip norm — each rank runs clip + Adam + soft update on its 1/N slice only, and the updated online AND target weights
+ * (the targets move every update, src/dqn.cpp:967-970; fp16 learner: the fp16 mirrors too) are all-gathered.  m and v of foreign
+ * slices go stale: dqnhip_dp_gather_state (collective) brings them back before a snapshot / dqnhip_get_params(KIND_M, KIND_V);
+ * dqnhip_dp_destroy refuses until it has been called since the last update.  Combines with DQNHIP_DP_HALF_GRADS, not with
+ * DQNHIP_DP_PER_LAYER; the arena must be divisible by 4 x dp_world.  dqnhip_apply_update_sharded pins its slice arithmetic on one GPU. */
 
 /* ---- batched env front-end (HFOGameState reward shaping, N workers) ----- */
 
