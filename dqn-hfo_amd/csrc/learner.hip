@@ -350,13 +350,6 @@ UpdatePlan plan_of(const H* h) {
     p.tails_ride = p.dp && bwd16_has_carrier(h, DQNHIP_CRITIC, B) && bwd16_has_carrier(h, DQNHIP_ACTOR, B);
     // the critic's layer-0 dgrad (only its ten action columns are consumed), the inverting gradients and the actor heads' backward in
     // ONE launch (k_dqda_head_bwd<true>), as on the fp32 path; q(s, mu(s)) rides there
-    // Step(1)'s four first layers in ONE launch (critic_target's as its state half into fp32, finished by the target actor's head
-    // kernel: rows < 1024, at most 1024 outputs)
-    p.first_layers_merged = h->Zs != nullptr && !(tf & DQNHIP_TUNE_SEPARATE_CRITIC_FIRST_LAYERS) && L >= 2 && B < 1024 && lc.dims[1] <= 1024 && lc.dims[1] % 4 == 0 &&
-                            h->k16[0][0] == h->k16[1][0] && la.dims[1] == lc.dims[1];
-    // the first layer of critic(s, mu(s)) inside the critic's optimiser launch (FirstLayerWork<2, true>)
-    p.critic_l0 = !h->dp_shard && !(tf & DQNHIP_TUNE_SEPARATE_FIRST_LAYER) && lc.kp[0] == 128 && lc.dims[1] % 16 == 0 && B % 16 == 0 && B <= 512 && L >= 2 &&
-                  lc.w_off[0] == 0 && lc.b_off[0] == (size_t)lc.dims[1] * lc.kp[0];
     p.fuse_head = p.head_rides_a && !(tf & DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) && B % 16 == 0 && B < 1024 && Hh % 256 == 0 &&
                   h->S + 16 <= h->k16[1][0] && L >= 1 && lc.dims[1] % 64 == 0;
     return p;
@@ -443,8 +436,7 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   // same-box A/B gives 18.4 us per launch against 19.3 at 2048 (a second, short round of blocks), 19.4 at 1792, 18.7 at
   // 1280, 21.5 at 4096 (round 2, before the hoist: 512 .. 8192 within +-3 %, profiles/r02_adam_probe.txt)
   if (fl != nullptr || next_l0 != nullptr) {
-    if (begin != 0 || (fl && tick != nullptr) || a.w_sh != nullptr || (h->fp16 && (next_l0 != nullptr || early_gather != nullptr || fl->Kp != 128)) || !corr_pre)
-      return fail("adam_launch: a first-layer rider needs the whole, unshared arena inside an update");
+    if (begin != 0 || (fl && tick != nullptr) || a.w_sh != nullptr || h->fp16 || !corr_pre) return fail("adam_launch: a first-layer rider needs the whole, unshared fp32 arena inside an update");
     a.skip4 = layout_of(h, net).w_off[1] / 4;
   }
   const int blocks = (int)std::min<size_t>((a.n4 - a.skip4 + 255) / 256 + (fl ? fl->blocks : 0), (size_t)1536);   // riders + the strided pass: what is resident at once
@@ -464,8 +456,7 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
   else if (fl != nullptr) {
     if (blocks <= fl->blocks) return fail("adam_launch: no optimiser workgroups beside the first-layer riders");
     const bool timed = lt.start != nullptr;
-    if (h->fp16) { if (timed) hipExtLaunchKernelGGL((k_adam_soft_fwd1<2, true>), dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL((k_adam_soft_fwd1<2, true>), dim3(blocks), dim3(256), 0, st, a, *fl); }
-    else if (fl->Kp == 64) { if (timed) hipExtLaunchKernelGGL(k_adam_soft_fwd1<1>, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL(k_adam_soft_fwd1<1>, dim3(blocks), dim3(256), 0, st, a, *fl); }
+    if (fl->Kp == 64) { if (timed) hipExtLaunchKernelGGL(k_adam_soft_fwd1<1>, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL(k_adam_soft_fwd1<1>, dim3(blocks), dim3(256), 0, st, a, *fl); }
     else { if (timed) hipExtLaunchKernelGGL(k_adam_soft_fwd1<2>, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL(k_adam_soft_fwd1<2>, dim3(blocks), dim3(256), 0, st, a, *fl); }
     if (timed) lt.start = lt.stop = nullptr;
   }
@@ -549,16 +540,16 @@ HGemm fwd16_problem(H* h, int p, int net, int rows, int i) {
   g.bias = h->w[net] + l.b_off[i]; g.relu = 1; g.scale32 = 1.0f;
   return g;
 }
-int tower_forward16(H* h, hipStream_t st, int p, int net, int rows, int first_layer = 0) {
+int tower_forward16(H* h, hipStream_t st, int p, int net, int rows) {
   const NetLayout& l = layout_of(h, net);
-  for (int i = first_layer; i < l.L; ++i) RC(hgemm_timed(h, st, fwd16_problem(h, p, net, rows, i), 7));
+  for (int i = 0; i < l.L; ++i) RC(hgemm_timed(h, st, fwd16_problem(h, p, net, rows, i), 7));
   return 0;
 }
 // two independent passes of the same net kind, layer by layer in ONE launch each (the target and
 // the online net: same shapes, different weights and inputs)
-int tower_forward16_pair(H* h, hipStream_t st, int p0, int net0, int p1, int net1, int rows, int first_layer = 0) {
+int tower_forward16_pair(H* h, hipStream_t st, int p0, int net0, int p1, int net1, int rows) {
   const NetLayout& l = layout_of(h, net0);
-  for (int i = first_layer; i < l.L; ++i) {
+  for (int i = 0; i < l.L; ++i) {
     const HGemm gs[2] = {fwd16_problem(h, p0, net0, rows, i), fwd16_problem(h, p1, net1, rows, i)};
     RC(hgemm_timed(h, st, gs, 2, 7));
   }
@@ -681,21 +672,8 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       hipLaunchKernelGGL(k_gather, dim3(g.blocks), dim3(256), 0, st, g);
       HIPCHK(hipGetLastError());
     }
-    const bool merged_l0 = P.first_layers_merged;
-    if (merged_l0) {
-      // all of Step(1)'s first layers in one launch: actor_target(s'), actor(s) (unless split), critic(s, a) and the STATE half of
-      // critic_target(s', mu'(s'))'s (its panel's action columns are still the zeros the gather wrote; fp32, no bias, no ReLU)
-      HGemm gs[4]; int n = 0;
-      gs[n++] = fwd16_problem(h, 0, DQNHIP_ACTOR_TARGET, B, 0);
-      if (!split) gs[n++] = fwd16_problem(h, 1, DQNHIP_ACTOR, B, 0);
-      gs[n++] = fwd16_problem(h, 3, DQNHIP_CRITIC, B, 0);
-      HGemm zs = fwd16_problem(h, 2, DQNHIP_CRITIC_TARGET, B, 0);
-      zs.C16 = nullptr; zs.C32 = h->Zs; zs.ldc32 = lc.kp[1]; zs.n_valid32 = lc.dims[1]; zs.bias = nullptr; zs.relu = 0; zs.scale32 = 1.0f;
-      gs[n++] = zs;
-      RC(hgemm_timed(h, st, gs, n, 7));
-    }
-    if (split) RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B, merged_l0 ? 1 : 0));
-    else RC(tower_forward16_pair(h, st, 0, DQNHIP_ACTOR_TARGET, 1, DQNHIP_ACTOR, B, merged_l0 ? 1 : 0));
+    if (split) RC(tower_forward16(h, st, 0, DQNHIP_ACTOR_TARGET, B));
+    else RC(tower_forward16_pair(h, st, 0, DQNHIP_ACTOR_TARGET, 1, DQNHIP_ACTOR, B));
     HeadArgs hAT{}; hAT.X16 = h->act16[0][L]; hAT.ldx = Hh; hAT.H = Hh; hAT.rows = B;
     hAT.W = wat(h, DQNHIP_ACTOR_TARGET, la.hw_off); hAT.b = wat(h, DQNHIP_ACTOR_TARGET, la.hb_off);
     hAT.out16 = h->aout_t16; hAT.xc = nullptr; hAT.ldxc = lc.kp[0]; hAT.xc_col = h->S;     // (fp32 panels: unused in fp16 mode)
@@ -703,13 +681,9 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
     hA.W = wat(h, DQNHIP_ACTOR, la.hw_off); hA.b = wat(h, DQNHIP_ACTOR, la.hb_off);
     hA.out16 = h->aout16; hA.xc = nullptr; hA.ldxc = lc.kp[0]; hA.xc_col = h->S;
     hAT.xc16 = h->act16[2][0]; hAT.ldxc16 = h->k16[1][0]; hA.xc16 = h->act16[4][0]; hA.ldxc16 = h->k16[1][0];
-    if (merged_l0) {      // the target actor's head kernel finishes critic_target's first layer for its row (HeadArgs::l1_*)
-      hAT.l1_zs = h->Zs; hAT.l1_b = wat(h, DQNHIP_CRITIC_TARGET, lc.b_off[0]); hAT.l1_ld = lc.kp[1]; hAT.l1_n = lc.dims[1];
-      hAT.l1_w16 = h->w16[DQNHIP_CRITIC_TARGET][0] + h->S; hAT.l1_ldw = h->k16[1][0]; hAT.l1_y16 = h->act16[2][1];
-    }
     if (split) RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT)));
     else RC((head_forward<kNO, HEAD_ACTOR>(h, st, hAT, &hA)));
-    RC(tower_forward16_pair(h, st, 2, DQNHIP_CRITIC_TARGET, 3, DQNHIP_CRITIC, B, merged_l0 ? 1 : 0));
+    RC(tower_forward16_pair(h, st, 2, DQNHIP_CRITIC_TARGET, 3, DQNHIP_CRITIC, B));
     {
       HeadTrainArgs t{};
       t.Xt16 = h->act16[2][L]; t.Wt = wat(h, DQNHIP_CRITIC_TARGET, lc.hw_off); t.bt = wat(h, DQNHIP_CRITIC_TARGET, lc.hb_off);
@@ -743,19 +717,13 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
   }
   if (phase == 1) {
     // the Adam pass writes the fp16 mirrors of the critic and its target itself
-    if (P.critic_l0) {
-      // the first layer of critic(s, mu(s)) rides in this launch: the workgroups that own W1 run it on the weights they have just stepped
-      const FirstLayerRider fl{nullptr, h->k16[1][0], nullptr, lc.dims[1], B, lc.kp[0], lc.dims[1], lc.dims[1] / 16, h->act16[4][0], h->act16[4][1]};
-      if (part16) RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena, nullptr, true, &fl));
-      else RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr, &fl));
-    }
-    else if (part16) RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
+    if (part16) RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena));
     else RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr));
     // As on the fp32 path: the seed of the dq = -1 pass comes out of the top layer's forward epilogue (HGemm::seed_w, the
     // scaled fp16 panel the dgrad chain reads) and q(s, mu(s)) rides in a later launch-floor launch — here the actor heads'
     // backward (HeadBwdArgs::qr_*).  DQNHIP_TUNE_SEPARATE_HEAD_SEED: the head-backward launch of their own.
     const bool fused_seed = P.fused_seed;
-    for (int i = P.critic_l0 ? 1 : 0; i < L; ++i) {
+    for (int i = 0; i < L; ++i) {
       HGemm g = fwd16_problem(h, 4, DQNHIP_CRITIC, B, i);
       if (fused_seed && i == L - 1) { g.seed_w = wat(h, DQNHIP_CRITIC, lc.hw_off); g.CS16 = h->dZ16[1][L]; g.ldcs16 = Hc; g.seed_scale = h->ls_q; }
       RC(hgemm_timed(h, st, g, 7));

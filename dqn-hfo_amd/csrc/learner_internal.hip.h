@@ -263,7 +263,7 @@ int head_forward(H* h, hipStream_t st, const HeadArgs& a, const HeadArgs* b = nu
   HeadArgs2 a2{}; a2.p[0] = a; if (b) a2.p[1] = *b;
   if (NH > 1 && a.rows >= 1024 && a.H <= 1024 && a.H % 4 == 0)   // (single-head: the block-per-row form measured faster, 6.6 vs 8.8 us)
     hipLaunchKernelGGL((k_head_fwd_rows<NH, MODE>), dim3(256, b ? 2 : 1), dim3(256), 0, st, a2);
-  else if (a.l1_y != nullptr || a.l1_y16 != nullptr || (b && (b->l1_y != nullptr || b->l1_y16 != nullptr)))      // Step(1): the target actor's head also finishes critic_target's first layer
+  else if (a.l1_y != nullptr || (b && b->l1_y != nullptr))      // Step(1): the target actor's head also finishes critic_target's first layer
     hipLaunchKernelGGL((k_head_fwd<NH, MODE, true>), dim3(std::min(a.rows, 1024), b ? 2 : 1), dim3(256), 0, st, a2);
   else
     hipLaunchKernelGGL((k_head_fwd<NH, MODE, false>), dim3(std::min(a.rows, 1024), b ? 2 : 1), dim3(256), 0, st, a2);

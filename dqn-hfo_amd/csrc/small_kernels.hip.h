@@ -310,9 +310,6 @@ struct HeadArgs {
   // l1_y[row][n] = lrelu((l1_zs[row][n] + sum_a W1[n][S + a] mu'[a]) + b1[n]), a in action order (an fma chain on l1_zs).
   // (With the action-column weights read in place — 40 dwords 512 B apart per thread — this kernel took 6.8 instead of 4.9 us.)
   const float* l1_zs; const float* l1_wt; const float* l1_b; float* l1_y; int l1_ld; int l1_n;   // l1_wt[a][n] = W1[n][S + a] (GemmProblem::xcopy_dst); l1_n <= 1024, % 4 == 0
-  // fp16 learner (round 6): the action-column weights read in place from the fp16 mirror, l1_w16[n * l1_ldw + a] = fp16(W1[n][S + a])
-  // (20 B per output row), mu'(s') rounded to fp16 as the panel holds it, the finished layer written as fp16 (l1_y16; l1_y, l1_wt null)
-  const _Float16* l1_w16; int l1_ldw; _Float16* l1_y16;
   // HEAD_Q*
   float* q;                            // [rows]
   // HEAD_Q_TRAIN: TD target + Euclidean loss
@@ -348,21 +345,13 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
   __shared__ float s_mu[kAP];
   float l1w[kL1 ? 4 : 1][kL1 ? kNO : 1];
   f32x4 l1b = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool l1_any = kL1 && (a.l1_y != nullptr || a.l1_y16 != nullptr);
-  const bool l1_on = l1_any && (int)threadIdx.x * 4 < a.l1_n;
+  const bool l1_on = kL1 && a.l1_y != nullptr && (int)threadIdx.x * 4 < a.l1_n;
   if constexpr (kL1) {
     if (l1_on) {
-      if (a.l1_w16 != nullptr) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int j = 0; j < kNO; ++j) l1w[e][j] = (float)a.l1_w16[(size_t)(threadIdx.x * 4 + e) * a.l1_ldw + j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < kNO; ++j) {
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.l1_wt + (size_t)j * a.l1_n + threadIdx.x * 4);
-          l1w[0][j] = w4.x; l1w[1][j] = w4.y; l1w[2][j] = w4.z; l1w[3][j] = w4.w;
-        }
+      for (int j = 0; j < kNO; ++j) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.l1_wt + (size_t)j * a.l1_n + threadIdx.x * 4);
+        l1w[0][j] = w4.x; l1w[1][j] = w4.y; l1w[2][j] = w4.z; l1w[3][j] = w4.w;
       }
       l1b = *reinterpret_cast<const f32x4*>(a.l1_b + threadIdx.x * 4);
     }
@@ -400,7 +389,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
         a.out16[(size_t)row * kAP + j] = v;
         if (a.xc != nullptr && j < NH) a.xc[(size_t)row * a.ldxc + a.xc_col + j] = v;
         if (a.xc16 != nullptr && j < NH) a.xc16[(size_t)row * a.ldxc16 + a.xc_col + j] = (_Float16)v;
-        if constexpr (kL1) s_mu[j] = a.l1_y16 != nullptr ? (float)(_Float16)v : v;
+        if constexpr (kL1) s_mu[j] = v;
       } else {
         if (j == 0) {
           a.q[row] = v;
@@ -410,7 +399,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
     }
     __syncthreads();                       // s_acc is rewritten by the next row
     if constexpr (kL1) {
-      if (l1_any) {                        // (uniform)
+      if (a.l1_y != nullptr) {             // (uniform)
         if (l1_on) {
           float o[4] = {zs.x, zs.y, zs.z, zs.w};
 #pragma unroll
@@ -420,8 +409,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs2 a2) {
           }
           f32x4 y;
           y.x = lrelu_fwd(o[0] + l1b.x); y.y = lrelu_fwd(o[1] + l1b.y); y.z = lrelu_fwd(o[2] + l1b.z); y.w = lrelu_fwd(o[3] + l1b.w);
-          if (a.l1_y16 != nullptr) *reinterpret_cast<head_h4*>(a.l1_y16 + (size_t)row * a.l1_ld + threadIdx.x * 4) = head_h4{(_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
-          else *reinterpret_cast<f32x4*>(a.l1_y + (size_t)row * a.l1_ld + threadIdx.x * 4) = y;
+          *reinterpret_cast<f32x4*>(a.l1_y + (size_t)row * a.l1_ld + threadIdx.x * 4) = y;
         }
         __syncthreads();                   // s_mu is rewritten by the next row
       }
@@ -1440,24 +1428,15 @@ struct FirstLayerRider {
   float* Y; int ldy;            // [rows][N] out
   int rows, Kp, N;              // Kp = 64 G, rows % 16 == 0, N % 16 == 0; W1 = arena float4 [0, N Kp / 4), b1 behind it
   int blocks;                   // N / 16
-  // fp16 learner (round 6; F16 instantiation): the input / output panels in fp16 (then X / Y are null).  The riders then also write
-  // their slice of the fp16 weight mirrors and run the layer on the fp16-ROUNDED new weights and inputs with fp32 MFMAs (exact
-  // products, fp32 accumulation: the fp16-MFMA layer's arithmetic up to the order of the additions), rounding the output to fp16.
-  const _Float16* X16; _Float16* Y16;
 };
 // One step of a first-layer rider: the four 16-row tiles [t4, t4 + 4) of outputs [out0, out0 + 16) — fwd_direct_body's arithmetic,
 // element for element (the reduction split over the four waves, its step order, (w0 + w1) + (w2 + w3)).  pw: this lane's weight
 // fragments (row li of the 16, k = wave Kw + 16 kb + 4 lg; LDS or global); qf: the tiles' operands, requested earlier; the
 // operands of step t4 + 4 are requested into qf behind the MFMAs; wave w reduces tile t4 + w.  bias16: the 16 outputs' biases
 // (LDS or global; null: none).  One 16-KB parking area per workgroup (six workgroups per CU must keep fitting the LDS).
-template <bool F16>
-__device__ __forceinline__ f32x4 l0_ldq(const float* x32, const _Float16* x16, size_t off) {
-  if constexpr (F16) { const head_h4 v = *reinterpret_cast<const head_h4*>(x16 + off); return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w}; }
-  else return *reinterpret_cast<const f32x4*>(x32 + off);
-}
-template <int G, bool F16 = false>
+template <int G>
 __device__ __forceinline__ void l0_step(const float* pw, const float* xq, int ldx, f32x4 (&qf)[4][G], int t4, int T, const float* bias16, bool relu,
-                                        float* Y, int ldy, int out0, float* park, bool first, const _Float16* xq16 = nullptr, _Float16* Y16 = nullptr) {
+                                        float* Y, int ldy, int out0, float* park, bool first) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
   f32x4 acc[4], pf[G];
 #pragma unroll
@@ -1474,7 +1453,7 @@ __device__ __forceinline__ void l0_step(const float* pw, const float* xq, int ld
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int kb = 0; kb < G; ++kb)
-      qf[j][kb] = l0_ldq<F16>(xq, xq16, (size_t)(t4 + 4 + j < T ? t4 + 4 + j : T - 1) * 16 * ldx + kb * 16);   // (beyond the last tile: a valid row, unused)
+      qf[j][kb] = *reinterpret_cast<const f32x4*>(xq + (size_t)(t4 + 4 + j < T ? t4 + 4 + j : T - 1) * 16 * ldx + kb * 16);   // (beyond the last tile: a valid row, unused)
   f32x4* pk = reinterpret_cast<f32x4*>(park);
   if (!first) __syncthreads();
 #pragma unroll
@@ -1491,11 +1470,10 @@ __device__ __forceinline__ void l0_step(const float* pw, const float* xq, int ld
       o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w;
     }
     if (relu) { o.x = lrelu_fwd(o.x); o.y = lrelu_fwd(o.y); o.z = lrelu_fwd(o.z); o.w = lrelu_fwd(o.w); }
-    if constexpr (F16) *reinterpret_cast<head_h4*>(Y16 + (size_t)((t4 + wave) * 16 + li) * ldy + out0 + (lg << 2)) = head_h4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
-    else *reinterpret_cast<f32x4*>(Y + (size_t)((t4 + wave) * 16 + li) * ldy + out0 + (lg << 2)) = o;
+    *reinterpret_cast<f32x4*>(Y + (size_t)((t4 + wave) * 16 + li) * ldy + out0 + (lg << 2)) = o;
   }
 }
-template <int G, bool F16 = false>
+template <int G>
 struct FirstLayerWork {
   const AdamArgs& a; const FirstLayerRider& r; const int blk; float* sW; float* sB; float* park;
   __device__ __forceinline__ FirstLayerWork(const AdamArgs& a_, const FirstLayerRider& r_, int blk_, float* sW_, float* sB_, float* park_)
@@ -1518,11 +1496,11 @@ struct FirstLayerWork {
     // ... and the first row tiles' operands of the layer (as many as the 80-register budget holds beside the step's operands)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int T = r.rows >> 4;
-    const size_t x0 = (size_t)li * r.ldx + wave * (r.Kp >> 2) + lg * 4;
+    const float* xq = r.X + (size_t)li * r.ldx + wave * (r.Kp >> 2) + lg * 4;
 #pragma unroll
     for (int j = 0; j < NH; ++j)
 #pragma unroll
-      for (int kb = 0; kb < G; ++kb) qf[j][kb] = l0_ldq<F16>(r.X, r.X16, x0 + (size_t)(j < T ? j : T - 1) * 16 * r.ldx + kb * 16);
+      for (int kb = 0; kb < G; ++kb) qf[j][kb] = *reinterpret_cast<const f32x4*>(xq + (size_t)(j < T ? j : T - 1) * 16 * r.ldx + kb * 16);
   }
   __device__ __forceinline__ void run(float scale, float step, bool soft, bool apply) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
@@ -1539,16 +1517,6 @@ struct FirstLayerWork {
         reinterpret_cast<f32x4*>(a.m)[i] = m[u]; reinterpret_cast<f32x4*>(a.v)[i] = v[u]; reinterpret_cast<f32x4*>(a.w)[i] = w[u];
         if (soft) reinterpret_cast<f32x4*>(a.wt)[i] = wt[u];
       }
-      if constexpr (F16) {
-        // the fp16 mirrors of this slice (the strided pass, which writes them elsewhere, starts behind it), and the layer runs on
-        // what the mirror holds
-        const head_h4 wh = head_h4{(_Float16)w[u].x, (_Float16)w[u].y, (_Float16)w[u].z, (_Float16)w[u].w};
-        if (apply) {
-          reinterpret_cast<head_h4*>(a.w16)[i] = wh;
-          if (soft) reinterpret_cast<head_h4*>(a.wt16)[i] = head_h4{(_Float16)wt[u].x, (_Float16)wt[u].y, (_Float16)wt[u].z, (_Float16)wt[u].w};
-        }
-        reinterpret_cast<f32x4*>(sW)[u * 256 + threadIdx.x] = f32x4{(float)wh.x, (float)wh.y, (float)wh.z, (float)wh.w};
-      } else
       reinterpret_cast<f32x4*>(sW)[u * 256 + threadIdx.x] = w[u];
     }
     if (threadIdx.x < 16) {
@@ -1556,26 +1524,25 @@ struct FirstLayerWork {
       if (apply) { a.m[i] = bm; a.v[i] = bv; a.w[i] = bw; if (soft) a.wt[i] = bwt; }
       sB[threadIdx.x] = bw;
     }
-    const size_t x0 = (size_t)li * r.ldx + wave * Kw + lg * 4;
+    const float* xq = r.X + (size_t)li * r.ldx + wave * Kw + lg * 4;
 #pragma unroll
     for (int j = NH; j < 4; ++j)          // (the rest of the first group: behind the step's stores, whose registers they take over)
 #pragma unroll
-      for (int kb = 0; kb < G; ++kb) qf[j][kb] = l0_ldq<F16>(r.X, r.X16, x0 + (size_t)(j < T ? j : T - 1) * 16 * r.ldx + kb * 16);
+      for (int kb = 0; kb < G; ++kb) qf[j][kb] = *reinterpret_cast<const f32x4*>(xq + (size_t)(j < T ? j : T - 1) * 16 * r.ldx + kb * 16);
     __syncthreads();
     // the layer: outputs [16 blk, +16) x every row, four row tiles per step (l0_step)
     const float* pw = sW + li * r.Kp + wave * Kw + lg * 4;
-    for (int t4 = 0; t4 < T; t4 += 4)
-      l0_step<G, F16>(pw, F16 ? nullptr : r.X + x0, r.ldx, qf, t4, T, sB, true, r.Y, r.ldy, blk * 16, park, t4 == 0, F16 ? r.X16 + x0 : nullptr, r.Y16);
+    for (int t4 = 0; t4 < T; t4 += 4) l0_step<G>(pw, xq, r.ldx, qf, t4, T, sB, true, r.Y, r.ldy, blk * 16, park, t4 == 0);
   }
 };
-template <int G, bool F16 = false>
+template <int G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_adam_soft_fwd1(AdamArgs a, FirstLayerRider r) {   // (six workgroups per CU, as k_adam_soft: 1536 resident at once)
   __shared__ float s[8];
   __shared__ __attribute__((aligned(16))) float sW[16 * 64 * G];
   __shared__ __attribute__((aligned(16))) float sB[16];
   __shared__ __attribute__((aligned(16))) float park[4096];
   if ((int)blockIdx.x < r.blocks) {
-    FirstLayerWork<G, F16> work(a, r, (int)blockIdx.x, sW, sB, park);
+    FirstLayerWork<G> work(a, r, (int)blockIdx.x, sW, sB, park);
     work.request();
     adam_scalars<true>(a, -1, s);          // (-1: the strided pass's first workgroup reports a skipped step)
     // (a skipped step — non-finite gradient norm — still runs the layer, on the weights as they are)

@@ -197,12 +197,8 @@ def test_native_rccl_sharded_optimiser_one_rank(pkg, gpu, precision, half, use_g
     rng = np.random.default_rng(6)
     w = [torch_ref.init_params_np(rng, S, hid, act) * 5 for act in (True, False)]
     data = synth_replay(rng, 1024, S, mean_len=10)
-    # (like with like: a sharded pass covers 1/N of the arena and has no first-layer rider; the fp32 rider is bit-identical to the launch
-    # it replaces, the fp16 one — fp32 MFMA chains on converted operands against the fp16 MFMA — only to round-off, so the fp16 twins
-    # both keep the launch)
-    tuning = pkg.capi.TUNE_SEPARATE_FIRST_LAYER if precision == "fp16" else 0
     ds = [pkg.DQN(S, minibatch=B, hidden=hid, memory=4096, seed=2, dp_world=1, dp_rank=0, precision=precision, use_graph=use_graph,
-                  clip_grad=clip, tuning=tuning) for _ in range(2)]
+                  clip_grad=clip) for _ in range(2)]
     for d in ds:
         for net in (0, 1):
             d.set_params(net, w[net]); d.CloneNet(net)

@@ -319,25 +319,21 @@ def test_early_gather_and_next_update_first_layers_equal_the_late_form(pkg, gpu,
         np.testing.assert_array_equal(x, y)
 
 
-@pytest.mark.parametrize("flag,form", [("TUNE_SEPARATE_ACTOR_HEAD_BWD", "dqda_head_bwd"), ("TUNE_SEPARATE_FIRST_LAYER", "critic_l0_rides"),
-                                       ("TUNE_SEPARATE_CRITIC_FIRST_LAYERS", "first_layers_merged")])
 @pytest.mark.parametrize("B,hidden", [(128, (256, 128, 128)), (512, (1024, 1024, 1024, 1024)), (256, (256, 256))])
-def test_fp16_merged_launches_against_separate_ones(pkg, gpu, B, hidden, flag, form):
-    """fp16 learner (round 6), the fp32 learner's round-5 merges: (i) the critic's layer-0 input gradient (ten action columns), the
-    inverting gradients and the actor heads' backward in ONE launch (k_dqda_head_bwd<true>) against the fp16-MFMA layer-0 dgrad launch
-    + k_head_bwd<10>; (ii) the first layer of critic(s, mu(s)) inside the critic's optimiser launch (FirstLayerWork<2, true>) against
-    a launch of its own; (iii) Step(1)'s four first layers in one launch, critic_target's finished by the target actor's head kernel,
-    against the critics' pair launch behind the heads.  Same fp16 operands and rounding points, exact products; the fp32 additions run
-    in another order (16x16x4 fp32 MFMA chains on converted operands / a rank-10 fma chain against the 32x32x16 fp16 MFMA), so the two
-    sides agree to fp32 round-off before the next rounding to fp16 — not bit for bit."""
+def test_fp16_fused_dqda_head_bwd_against_separate_launches(pkg, gpu, B, hidden):
+    """fp16 learner (round 6): the critic's layer-0 input gradient (ten action columns), the inverting gradients and the actor heads'
+    backward in ONE launch (k_dqda_head_bwd<true>) against the fp16-MFMA layer-0 dgrad launch + k_head_bwd<10>
+    (DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD).  Same fp16 operands, exact products; the fp32 additions of the 16-column tile run in
+    another order (16x16x4 fp32 MFMA chains on converted operands against the 32x32x16 fp16 MFMA), so the two agree to fp32
+    round-off before the tower-top gradient is rounded to fp16 — not bit for bit."""
     a = _run(pkg, 0, B, hidden)
-    b = _run(pkg, getattr(pkg.capi, flag), B, hidden)
+    b = _run(pkg, pkg.capi.TUNE_SEPARATE_ACTOR_HEAD_BWD, B, hidden)
     assert np.allclose(a[0], b[0], rtol=2e-4, atol=2e-6), (a[0], b[0])
     for it, ((ga, gc), (gb_a, gb_c)) in enumerate(zip(a[1], b[1])):
         for x, y in ((ga, gb_a), (gc, gb_c)):
             rel = np.linalg.norm(x.astype(np.float64) - y) / max(np.linalg.norm(y), 1e-30)
-            assert rel <= (1e-3 if it == 0 else 5e-3), (flag, it, rel)
-    for tuning, present in ((0, hidden[-1] % 256 == 0 or form != "dqda_head_bwd"), (getattr(pkg.capi, flag), False)):      # (k_dqda_head_bwd: a tower top of 256 k columns)
+            assert rel <= (1e-3 if it == 0 else 5e-3), (it, rel)
+    for tuning, present in ((0, hidden[-1] % 256 == 0), (pkg.capi.TUNE_SEPARATE_ACTOR_HEAD_BWD, False)):      # (k_dqda_head_bwd: a tower top of 256 k columns)
         p = pkg.DQN(58, minibatch=B, hidden=hidden, memory=4096, seed=3, precision="fp16", tuning=tuning)
-        assert (form in p.update_plan()["forms"]) == present, (flag, tuning, p.update_plan())
+        assert ("dqda_head_bwd" in p.update_plan()["forms"]) == present, (tuning, p.update_plan())
         p.close()
