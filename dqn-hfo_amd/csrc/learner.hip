@@ -460,7 +460,7 @@ int adam_launch(H* h, hipStream_t st, int net, const float* partial, int n_parti
     else { if (timed) hipExtLaunchKernelGGL(k_adam_soft_fwd1<2>, dim3(blocks), dim3(256), 0, st, lt.start, lt.stop, 0, a, *fl); else hipLaunchKernelGGL(k_adam_soft_fwd1<2>, dim3(blocks), dim3(256), 0, st, a, *fl); }
     if (timed) lt.start = lt.stop = nullptr;
   }
-  else if (tick && h->cap_u >= 0 && h->cap_u + 1 < kMultiU && !early_l0(h)) {
+  else if (tick && h->cap_u >= 0 && h->cap_u + 1 < h->cap_n && !early_l0(h)) {
     // inside a multi-update graph: the next update's gather rides in this, the update's last launch (k_adam_soft_gather).
     // At small minibatches the grid stays at what is resident at once; a large minibatch's gather (1025 workgroups at 4096
     // rows) must not thin the optimiser's own grid — its blocks drain within a few us and the rest of the grid moves in
@@ -927,7 +927,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
       const FirstLayerRider fl{h->Xc_pl, lc.kp[0], h->act[4][1], lc.kp[1], B, lc.kp[0], lc.dims[1], lc.dims[1] / 16};
       // inside a multi-update graph the NEXT update's gather rides here too (its panels: the other parity), so that its first layers
       // can ride in the actor's launch
-      const bool eg = early_l0(h) && h->cap_u + 1 < kMultiU;
+      const bool eg = early_l0(h) && h->cap_u + 1 < h->cap_n;
       const GatherArgs g = eg ? gather_args(h, nullptr, h->cap_u + 1) : GatherArgs{};
       if (dp) RC(dp_optimiser_step(h, st, 1, critic_tail, nullptr, &fl, eg ? &g : nullptr));
       else RC(adam_launch(h, st, 1, h->part[1], lc.n_part, 0, lc.arena, nullptr, true, &fl, eg ? &g : nullptr));
@@ -983,7 +983,7 @@ int run_phase(H* h, int phase, const int* idx_dev) {
     // (critic_loss, avg_q) and advances the iteration / sampling counters
     const TickArgs tick{h->st, critic_tail, actor_tail, (const float*)h->loss_partial, h->n_head_blocks,
                         dp ? (const double*)nullptr : (const double*)h->q_partial, B, (float)(B * h->cfg.dp_world), h->stats_dev};
-    if (early_l0(h) && h->cap_u + 1 < kMultiU) {
+    if (early_l0(h) && h->cap_u + 1 < h->cap_n) {
       // the next update's first layers ride here: its panels (gathered in this update's critic launch) are those of the other parity
       const int pn = (h->cap_u + 1) & 1;
       NextL0 n{};
@@ -1053,6 +1053,7 @@ int ensure_act(H* h, int rows) {
 
 void drop_graphs(H* h) {
   for (auto& g : h->graph_exec) if (g) { hipGraphExecDestroy(g); g = nullptr; }
+  for (auto& g : h->graph_small) if (g) { hipGraphExecDestroy(g); g = nullptr; }
   if (h->dp_graph) { hipGraphExecDestroy(h->dp_graph); h->dp_graph = nullptr; }
   if (h->dp_graph_n) { hipGraphExecDestroy(h->dp_graph_n); h->dp_graph_n = nullptr; }
   h->dp_graph_failed = false; h->dp_graph_n_failed = false; h->graph_failed = false;
@@ -1277,6 +1278,7 @@ int dqnhip_destroy(dqnhip_handle h) {
   hipStreamSynchronize(h->stream);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (auto& g : h->graph_exec) if (g) hipGraphExecDestroy(g);
+  for (auto& g : h->graph_small) if (g) hipGraphExecDestroy(g);
   for (int i = 0; i < 2; ++i) {
     if (h->pipe_ev[i]) hipEventDestroy(h->pipe_ev[i]);
     if (h->pipe_idx_pinned[i]) hipHostFree(h->pipe_idx_pinned[i]);
@@ -1311,7 +1313,7 @@ int dqnhip_destroy(dqnhip_handle h) {
 // last kernel of one and the first kernel of the next (kernel trace, profiles/r04_graph_gap.txt; two instances of the
 // graph launched alternately: the same) - 2.8 % of a 300-us update; inside a graph the same boundary is a plain kernel boundary.
 // Inside it the gather of update u + 1 rides in update u's last launch (adam_launch, DevState::gbase).
-static int capture_graph(H* h, int which, const int* idx_fixed = nullptr) {
+static int capture_graph(H* h, int which, const int* idx_fixed = nullptr, int n_multi = kMultiU, hipGraphExec_t* out = nullptr) {
   // Capture phases 0,1,2 once; replays re-read every changing scalar from DevState
   // and (which == 1) the indices from the fixed pinned buffer through a memcpy node; which == 2, 3: the indices
   // are already in the given device buffer (dqnhip_update_pipelined's two slots).
@@ -1321,20 +1323,21 @@ static int capture_graph(H* h, int which, const int* idx_fixed = nullptr) {
   const int* idx_dev = idx_fixed;
   if (which == 1 || which == 5) idx_dev = h->idx_pinned_dev;
   const int it_a = h->h_actor_iter, it_c = h->h_critic_iter;
-  for (int u = 0; u < (which == 4 ? kMultiU : 1); ++u) {
+  h->cap_n = which == 4 ? n_multi : kMultiU;       // (chain graphs: always a successor's riders)
+  for (int u = 0; u < (which == 4 ? n_multi : 1); ++u) {
     // which >= 5 (dqnhip_update_chained): ONE update captured as position 0 (head: own gather), 1 or 2 (continued at parity 1 / 0) of
     // a multi-update graph, its riders reading the next update's explicit indices
     h->cap_u = which == 4 ? u : which >= 5 ? which - 5 : -1;
     h->chain_cap = which >= 5;
     for (int p = 0; p < 3 && !rc; ++p) rc = run_phase(h, p, idx_dev);
   }
-  h->cap_u = -1; h->chain_cap = false;
+  h->cap_u = -1; h->chain_cap = false; h->cap_n = kMultiU;
   select_panels(h, 0);
   h->h_actor_iter = it_a; h->h_critic_iter = it_c;   // capture does not execute
   hipError_t e = hipStreamEndCapture(h->stream, &graph);
   if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
   if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
-  e = hipGraphInstantiate(&h->graph_exec[which], graph, nullptr, nullptr, 0);
+  e = hipGraphInstantiate(out != nullptr ? out : &h->graph_exec[which], graph, nullptr, nullptr, 0);
   hipGraphDestroy(graph);
   if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
   return 0;
@@ -1457,6 +1460,14 @@ int dqnhip_update_async_n(dqnhip_handle h, int32_t n) {
     while (n >= kMultiU && h->graph_exec[4]) {
       HIPCHK(hipGraphLaunch(h->graph_exec[4], h->stream));
       h->h_actor_iter += kMultiU; h->h_critic_iter += kMultiU; n -= kMultiU;
+    }
+    // the remainder as graphs of 8 / 4 / 2 updates (the same launch sequence as the sixteen-update graph, cut shorter), then one
+    for (int k = 0; k < 3 && !h->graph_failed; ++k) {
+      const int sz = 8 >> k;
+      if (n < sz) continue;
+      if (!h->graph_small[k] && capture_graph(h, 4, nullptr, sz, &h->graph_small[k])) { h->graph_failed = true; break; }
+      HIPCHK(hipGraphLaunch(h->graph_small[k], h->stream));
+      h->h_actor_iter += sz; h->h_critic_iter += sz; n -= sz;
     }
     if (n > 0 && !h->graph_failed && !h->graph_exec[0] && capture_graph(h, 0)) h->graph_failed = true;
     while (n > 0 && h->graph_exec[0]) {

@@ -181,6 +181,11 @@ struct dqnhip_learner {
   std::vector<TimingRec> recs;
   // graph
   int cap_u = -1;              // while capturing a multi-update graph: the position of the update being captured (else -1)
+  int cap_n = 16;              // ... and the number of updates of that graph (the last one carries no riders for a successor)
+  // dqnhip_update_async_n: graphs of 8 / 4 / 2 updates for what is left after the sixteen-update graphs (round 6: a remainder of r
+  // updates used to be r one-update graphs, each with its own gather, its own first-layer launch and the 8-us gap between two graph
+  // launches — the driver's 20 timed steps are 16 + 4)
+  hipGraphExec_t graph_small[3] = {nullptr, nullptr, nullptr};
   // [0]: device-sampled, [1]: explicit idx (pinned buffer), [2], [3]: explicit idx in the pipelined slots, [4]: kMultiU device-sampled
   // updates (dqnhip_update_async_n), [5] .. [7]: dqnhip_update_chained — head of a chain (own gather, parity 0), continued at parity 1 / 0
   hipGraphExec_t graph_exec[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
