@@ -217,7 +217,10 @@ def test_native_rccl_sharded_optimiser_one_rank(pkg, gpu, precision, half, use_g
         assert s0 == s1 if exact else np.allclose(s0, s1, rtol=1e-5 if precision == "fp32" else 3e-4, atol=1e-7), (u, s0, s1)
     assert ds[0].dp_graph_active() == use_graph
     ds[0].dp_gather_state()
-    same = np.testing.assert_array_equal if exact else (lambda a, b: np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-7))
+    # (fp16 with the clip active, see above: a few weights sit on the other side of an fp16 rounding boundary in the mirrors -> 1e-4-level
+    # relative differences in what four updates made of them)
+    rt, at = (2e-5, 1e-7) if precision == "fp32" else (5e-4, 2e-6)
+    same = np.testing.assert_array_equal if exact else (lambda a, b: np.testing.assert_allclose(a, b, rtol=rt, atol=at))
     for net in range(4):
         same(ds[0].get_params(net), ds[1].get_params(net))
     for kind in (pkg.KIND_M, pkg.KIND_V):
