@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-PMC_SUMMARY = "profiles/r05_pmc_summary.json"
+PMC_SUMMARY = "profiles/r06_pmc_summary.json"
 
 
 def pmc_traffic(kernel):
