@@ -764,13 +764,17 @@ struct HeadWsum {
   const h16* X16; int H, rows;              // tower top [rows][H]
   float* dW; float* db; float* partial;     // [NH][H], [NH], one sum-of-squares slot per block
   int nh;                                   // 1 / 10 (0: none)
-  int blocks;                               // H / 64
+  int cw;                                   // columns per block: 64 (8 lanes x 16 B per row, 32 row groups) or, from 1024 rows, 16 (2 lanes, 128 row groups)
+  int blocks;                               // H / cw
 };
-template <int NH>
-__device__ __forceinline__ void head_wsum_block(const HeadWsum& r, int blk, float* scratch /* 32 x 65 floats of LDS */) {
-  float (*sred)[65] = reinterpret_cast<float (*)[65]>(scratch);
-  const int col0 = blk * 64;
-  const int tid = threadIdx.x, c8 = tid & 7, rg = tid >> 3;
+// (cw = 16 for long minibatches: with 64-column blocks a thread walks rows / 32 rows behind the chip-wide traffic of the wgrad
+// tiles beside it — at 4096 rows the 16 blocks took 55 us and extended the 40-us launch they ride in: profiles/r06_fp16_b4096_kernel_stats.md, first run)
+template <int NH, int CW>
+__device__ __forceinline__ void head_wsum_block(const HeadWsum& r, int blk, float* scratch /* (2048 / CW) x (CW + 1) floats of LDS */) {
+  constexpr int LPR = CW / 8, RG = 256 / LPR;      // lanes per row, row groups
+  float (*sred)[CW + 1] = reinterpret_cast<float (*)[CW + 1]>(scratch);
+  const int col0 = blk * CW;
+  const int tid = threadIdx.x, c8 = tid % LPR, rg = tid / LPR;
   const h16* p = r.X16 + col0 + c8 * 8;
   float acc[NH][8];
 #pragma unroll
@@ -790,14 +794,13 @@ __device__ __forceinline__ void head_wsum_block(const HeadWsum& r, int blk, floa
       }
     }
   };
-  // U rows in flight per thread (a block streams rows x 128 B through 32 row groups: at 4096 rows a thread walks 128 rows, and with
-  // two in flight the actor's block outlasted the 40-us wgrad tiles beside it)
+  // U rows in flight per thread
   constexpr int U = NH == 1 ? 8 : 4;
   int row = rg;
-  for (; row + 32 * (U - 1) < r.rows; row += 32 * U) {
+  for (; row + RG * (U - 1) < r.rows; row += RG * U) {
     h16x8 v[U]; float w[U][NH];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { v[u] = *reinterpret_cast<const h16x8*>(p + (size_t)(row + 32 * u) * r.H); weights(row + 32 * u, w[u]); }
+    for (int u = 0; u < U; ++u) { v[u] = *reinterpret_cast<const h16x8*>(p + (size_t)(row + RG * u) * r.H); weights(row + RG * u, w[u]); }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -805,7 +808,7 @@ __device__ __forceinline__ void head_wsum_block(const HeadWsum& r, int blk, floa
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(w[u][j], (float)v[u][e], acc[j][e]);
   }
-  for (; row < r.rows; row += 32) {
+  for (; row < r.rows; row += RG) {
     const h16x8 v0 = *reinterpret_cast<const h16x8*>(p + (size_t)row * r.H);
     float w0[NH];
     weights(row, w0);
@@ -821,10 +824,10 @@ __device__ __forceinline__ void head_wsum_block(const HeadWsum& r, int blk, floa
 #pragma unroll
     for (int e = 0; e < 8; ++e) sred[rg][c8 * 8 + e] = acc[j][e];
     __syncthreads();
-    if (tid < 64) {
+    if (tid < CW) {
       float s = 0.f;
-#pragma unroll
-      for (int g = 0; g < 32; ++g) s += sred[g][tid];
+#pragma unroll 8
+      for (int g = 0; g < RG; ++g) s += sred[g][tid];
       r.dW[(size_t)j * r.H + col0 + tid] = s;
       ssq = fmaf(s, s, ssq);
     }
@@ -870,7 +873,9 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_group_db(HGemmBa
   if (b < db_blocks) { db16_cols_block(db, b, reinterpret_cast<float*>(hg_smem)); return; }
   b -= db_blocks;
   if (head.nh != 0 && b < head.blocks) {
-    if (head.nh == 1) head_wsum_block<1>(head, b, reinterpret_cast<float*>(hg_smem)); else head_wsum_block<10>(head, b, reinterpret_cast<float*>(hg_smem));
+    float* sc = reinterpret_cast<float*>(hg_smem);
+    if (head.cw == 16) { if (head.nh == 1) head_wsum_block<1, 16>(head, b, sc); else head_wsum_block<10, 16>(head, b, sc); }
+    else { if (head.nh == 1) head_wsum_block<1, 64>(head, b, sc); else head_wsum_block<10, 64>(head, b, sc); }
     return;
   }
   if (tails.on) tails_block(tails, reinterpret_cast<float*>(hg_smem), reinterpret_cast<double*>(hg_smem + 64));
@@ -890,7 +895,7 @@ inline hipError_t hgemm_group_db_launch(const HGemm* gs, int n, bool big, const 
   if (e != hipSuccess) return e;
   HeadWsum head{}; TailsArgs tails{};
   if (head_in != nullptr) head = *head_in;
-  if (head.nh != 0 && head.nh != 1 && head.nh != 10) return hipErrorInvalidValue;
+  if (head.nh != 0 && ((head.nh != 1 && head.nh != 10) || (head.cw != 16 && head.cw != 64) || head.blocks * head.cw != head.H)) return hipErrorInvalidValue;
   if (tails_in != nullptr) { tails = *tails_in; tails.on = 1; }
   const unsigned grid = (unsigned)(blocks + db_blocks + (head.nh ? head.blocks : 0) + (tails.on ? 1 : 0));
   if (big) {

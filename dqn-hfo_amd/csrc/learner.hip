@@ -702,7 +702,8 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X416 = h->act16[3][L];
       a.H = Hc; a.rows = B; a.dZ = nullptr; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
-      const HeadWsum r{h->dq, 1, h->act16[3][L], Hc, B, a.dW, a.db, a.partial, 1, Hc / 64};
+      const int cw = B >= 1024 && Hc % 16 == 0 ? 16 : 64;          // (long minibatches: four times the blocks, a quarter of the rows per thread)
+      const HeadWsum r{h->dq, 1, h->act16[3][L], Hc, B, a.dW, a.db, a.partial, 1, cw, Hc / cw};
       if (P.head_rides_c) {}                                       // (dZ16 came out of k_head_q_train, dW / db come from the riders)
       else if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->ls_c)); }
       else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_c; RC(head_backward<1>(h, st, a)); }
@@ -754,7 +755,8 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
         a.qr_W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.qr_X416 = h->act16[4][L]; a.qr_H = Hc;
       }
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
-      const HeadWsum r{h->dA16, kAP, h->act16[1][L], Hh, B, a.dW, a.db, a.partial, kNO, Hh / 64};   // dA16: the post-invert diffs this launch leaves
+      const int cw = B >= 1024 && Hh % 16 == 0 ? 16 : 64;
+      const HeadWsum r{h->dA16, kAP, h->act16[1][L], Hh, B, a.dW, a.db, a.partial, kNO, cw, Hh / cw};   // dA16: the post-invert diffs this launch leaves
       if (P.head_rides_a) { a.dW = nullptr; a.db = nullptr; a.partial = nullptr; }
       if (P.fuse_head) {}                                        // (k_dqda_head_bwd<true> above did all of it)
       else if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->ls_a)); }
