@@ -764,15 +764,15 @@ struct HeadWsum {
   const h16* X16; int H, rows;              // tower top [rows][H]
   float* dW; float* db; float* partial;     // [NH][H], [NH], one sum-of-squares slot per block
   int nh;                                   // 1 / 10 (0: none)
-  int cw;                                   // columns per block: 64 (8 lanes x 16 B per row, 32 row groups) or, from 1024 rows, 16 (2 lanes, 128 row groups)
-  int blocks;                               // H / cw
+  int blocks;                               // H / 64
 };
-// (cw = 16 for long minibatches: with 64-column blocks a thread walks rows / 32 rows behind the chip-wide traffic of the wgrad
-// tiles beside it — at 4096 rows the 16 blocks took 55 us and extended the 40-us launch they ride in: profiles/r06_fp16_b4096_kernel_stats.md, first run)
-template <int NH, int CW>
-__device__ __forceinline__ void head_wsum_block(const HeadWsum& r, int blk, float* scratch /* (2048 / CW) x (CW + 1) floats of LDS */) {
+// (Minibatches below 1024 rows only.  At 4096 rows the blocks extend the 43-us grouped wgrad launch they ride in — one 128-KiB workgroup
+// per CU: what does not fit beside the 200 tiles queues — by 9 us (critic) / 14 us (actor heads), more than the head-backward launches
+// they replace cost; 64- and 16-column blocks, either order in the grid, 2 to 8 rows in flight: same-box A/B 0.607-0.614 against
+// 0.597-0.605 ms per update without them, profiles/r06_fp16_merges_ab.txt.)
+template <int NH, int CW = 64>
+__device__ __forceinline__ void head_wsum_block(const HeadWsum& r, int blk, float* scratch /* < 100 KB of LDS: NH x (2048 / CW) x (CW + 1) + NH x 256 floats */) {
   constexpr int LPR = CW / 8, RG = 256 / LPR;      // lanes per row, row groups
-  float (*sred)[CW + 1] = reinterpret_cast<float (*)[CW + 1]>(scratch);
   const int col0 = blk * CW;
   const int tid = threadIdx.x, c8 = tid % LPR, rg = tid / LPR;
   const h16* p = r.X16 + col0 + c8 * 8;
@@ -817,47 +817,67 @@ __device__ __forceinline__ void head_wsum_block(const HeadWsum& r, int blk, floa
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(w0[j], (float)v0[e], acc[j][e]);
   }
-  float ssq = 0.f;
+  // Reduction over the row groups, all NH sets at once (three barriers): every set to LDS, PARTS = 256 / CW partial sums per (head,
+  // column) over RG / PARTS consecutive row groups each, then the partials in index order — a fixed order.
+  // (First form: per head, CW threads summing all RG row groups serially — 10 x 128 dependent LDS reads at 4096 rows = 18 us that
+  // extended the 40-us launch this block rides in.)
+  constexpr int PARTS = 256 / CW, PER = RG / PARTS, LD = CW + 1;
+  float* S = scratch;                                  // [NH][RG][LD]
+  float* S2 = scratch + NH * RG * LD;                  // [NH][PARTS][CW]
 #pragma unroll
-  for (int j = 0; j < NH; ++j) {
-    if (j > 0) __syncthreads();
+  for (int j = 0; j < NH; ++j)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sred[rg][c8 * 8 + e] = acc[j][e];
-    __syncthreads();
-    if (tid < CW) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int g = 0; g < RG; ++g) s += sred[g][tid];
-      r.dW[(size_t)j * r.H + col0 + tid] = s;
-      ssq = fmaf(s, s, ssq);
+    for (int e = 0; e < 8; ++e) S[(j * RG + rg) * LD + c8 * 8 + e] = acc[j][e];
+  __syncthreads();
+  {
+    const int col = tid % CW, part = tid / CW;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < PER; ++g) t += S[(j * RG + part * PER + g) * LD + col];
+      S2[(j * PARTS + part) * CW + col] = t;
     }
   }
-  if (blk == 0) {                            // the head's bias gradient: rows strided over the threads, fixed-order reduction
-    float s[NH];
+  __syncthreads();
+  float ssq = 0.f;
+  for (int o = tid; o < NH * CW; o += 256) {
+    const int j = o / CW, c = o % CW;
+    float t = 0.f;
 #pragma unroll
-    for (int j = 0; j < NH; ++j) s[j] = 0.f;
+    for (int q = 0; q < PARTS; ++q) t += S2[(j * PARTS + q) * CW + c];
+    r.dW[(size_t)j * r.H + col0 + c] = t;
+    ssq = fmaf(t, t, ssq);
+  }
+  if (blk == 0) {                            // the head's bias gradient: rows strided over the threads, fixed-order reduction
+    float sb[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) sb[j] = 0.f;
     for (int m = tid; m < r.rows; m += 256) {
       float w[NH];
       weights(m, w);
 #pragma unroll
-      for (int j = 0; j < NH; ++j) s[j] += w[j];
+      for (int j = 0; j < NH; ++j) sb[j] += w[j];
     }
-    __syncthreads();
+    __syncthreads();                         // (S is free again)
 #pragma unroll
-    for (int j = 0; j < NH; ++j) { const float t = wave_sum64(s[j]); if ((tid & 63) == 0) sred[tid >> 6][j] = t; }
+    for (int j = 0; j < NH; ++j) { const float t = wave_sum64(sb[j]); if ((tid & 63) == 0) S[(tid >> 6) * 16 + j] = t; }
     __syncthreads();
     if (tid < NH) {
-      const float v = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+      const float v = (S[0 * 16 + tid] + S[1 * 16 + tid]) + (S[2 * 16 + tid] + S[3 * 16 + tid]);
       r.db[tid] = v;
       ssq = fmaf(v, v, ssq);
     }
   }
-  if (tid < 64 && r.partial != nullptr) {    // wave 0 holds every contribution of this block
+  if (r.partial != nullptr) {                // one slot per block: the four waves' sums in fixed order
     ssq = wave_sum64(ssq);
-    if (tid == 0) r.partial[blk] = ssq;
+    __syncthreads();
+    if ((tid & 63) == 0) S2[tid >> 6] = ssq;
+    __syncthreads();
+    if (tid == 0) r.partial[blk] = (S2[0] + S2[1]) + (S2[2] + S2[3]);
   }
 }
-// ... and, for data-parallel learners, the tails block (TailsArgs).  Grid: tiles, column-sum blocks, head blocks, tails.
+// ... and, for data-parallel learners, the tails block (TailsArgs).  Grid: tiles, head blocks, column-sum blocks, tails.
 template <int WM, int WN>
 __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_group_db(HGemmBatch batch, Db16Batch db, int db_blocks, HeadWsum head, TailsArgs tails) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char hg_smem[];
@@ -870,14 +890,14 @@ __global__ __launch_bounds__((HGCfg<WM, WN>::NT), 1) void hgemm_group_db(HGemmBa
     return;
   }
   b -= nt;
-  if (b < db_blocks) { db16_cols_block(db, b, reinterpret_cast<float*>(hg_smem)); return; }
-  b -= db_blocks;
-  if (head.nh != 0 && b < head.blocks) {
+  const int nhb = head.nh != 0 ? head.blocks : 0;     // (the head blocks before the shorter column-sum blocks: with one workgroup per CU what does not fit beside the tiles queues)
+  if (b < nhb) {
     float* sc = reinterpret_cast<float*>(hg_smem);
-    if (head.cw == 16) { if (head.nh == 1) head_wsum_block<1, 16>(head, b, sc); else head_wsum_block<10, 16>(head, b, sc); }
-    else { if (head.nh == 1) head_wsum_block<1, 64>(head, b, sc); else head_wsum_block<10, 64>(head, b, sc); }
+    if (head.nh == 1) head_wsum_block<1>(head, b, sc); else head_wsum_block<10>(head, b, sc);
     return;
   }
+  b -= nhb;
+  if (b < db_blocks) { db16_cols_block(db, b, reinterpret_cast<float*>(hg_smem)); return; }
   if (tails.on) tails_block(tails, reinterpret_cast<float*>(hg_smem), reinterpret_cast<double*>(hg_smem + 64));
 }
 inline hipError_t hgemm_group_db_prepare() {
@@ -895,7 +915,7 @@ inline hipError_t hgemm_group_db_launch(const HGemm* gs, int n, bool big, const 
   if (e != hipSuccess) return e;
   HeadWsum head{}; TailsArgs tails{};
   if (head_in != nullptr) head = *head_in;
-  if (head.nh != 0 && ((head.nh != 1 && head.nh != 10) || (head.cw != 16 && head.cw != 64) || head.blocks * head.cw != head.H)) return hipErrorInvalidValue;
+  if (head.nh != 0 && ((head.nh != 1 && head.nh != 10) || head.blocks * 64 != head.H)) return hipErrorInvalidValue;
   if (tails_in != nullptr) { tails = *tails_in; tails.on = 1; }
   const unsigned grid = (unsigned)(blocks + db_blocks + (head.nh ? head.blocks : 0) + (tails.on ? 1 : 0));
   if (big) {

@@ -344,8 +344,9 @@ UpdatePlan plan_of(const H* h) {
   if (h->fp16) {
     // fp16 learner (round 6): the head's dW / db are column-sum workgroups of the net's last backward launch (hgemm_group_db, HeadWsum)
     // when that launch exists; Step(1)'s k_head_q_train then also writes the scaled fp16 tower-top gradient — no head-backward launch
-    p.head_rides_c = bwd16_has_carrier(h, DQNHIP_CRITIC, B) && Hc % 64 == 0;
-    p.head_rides_a = bwd16_has_carrier(h, DQNHIP_ACTOR, B) && Hh % 64 == 0;
+    // (below 1024 rows: beside the grouped wgrad's 200 one-per-CU tiles at 4096 rows the blocks cost more than the launches they replace)
+    p.head_rides_c = bwd16_has_carrier(h, DQNHIP_CRITIC, B) && Hc % 64 == 0 && B < 1024;
+    p.head_rides_a = bwd16_has_carrier(h, DQNHIP_ACTOR, B) && Hh % 64 == 0 && B < 1024;
     p.fuse_q = p.head_rides_c;
     p.tails_ride = p.dp && bwd16_has_carrier(h, DQNHIP_CRITIC, B) && bwd16_has_carrier(h, DQNHIP_ACTOR, B);
     // the critic's layer-0 dgrad (only its ten action columns are consumed), the inverting gradients and the actor heads' backward in
@@ -702,8 +703,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
       HeadBwdArgs a{}; a.dyh = h->dq; a.lddy = 1; a.W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.X416 = h->act16[3][L];
       a.H = Hc; a.rows = B; a.dZ = nullptr; a.dW = h->g[1] + lc.hw_off; a.db = h->g[1] + lc.hb_off;
       a.partial = h->part[1] + lc.part_off[L];
-      const int cw = B >= 1024 && Hc % 16 == 0 ? 16 : 64;          // (long minibatches: four times the blocks, a quarter of the rows per thread)
-      const HeadWsum r{h->dq, 1, h->act16[3][L], Hc, B, a.dW, a.db, a.partial, 1, cw, Hc / cw};
+      const HeadWsum r{h->dq, 1, h->act16[3][L], Hc, B, a.dW, a.db, a.partial, 1, Hc / 64};
       if (P.head_rides_c) {}                                       // (dZ16 came out of k_head_q_train, dW / db come from the riders)
       else if (head_big_ok(h, B, Hc)) { a.dZ = nullptr; RC(head_backward_big<1>(h, st, a, h->dZ16[1][L], h->ls_c)); }
       else { a.dZ16 = h->dZ16[1][L]; a.scale16 = h->ls_c; RC(head_backward<1>(h, st, a)); }
@@ -755,8 +755,7 @@ int run_phase16(H* h, int phase, const int* idx_dev) {
         a.qr_W = wat(h, DQNHIP_CRITIC, lc.hw_off); a.qr_X416 = h->act16[4][L]; a.qr_H = Hc;
       }
       a.dW = h->g[0] + la.hw_off; a.db = h->g[0] + la.hb_off; a.partial = h->part[0] + la.part_off[L];
-      const int cw = B >= 1024 && Hh % 16 == 0 ? 16 : 64;
-      const HeadWsum r{h->dA16, kAP, h->act16[1][L], Hh, B, a.dW, a.db, a.partial, kNO, cw, Hh / cw};   // dA16: the post-invert diffs this launch leaves
+      const HeadWsum r{h->dA16, kAP, h->act16[1][L], Hh, B, a.dW, a.db, a.partial, kNO, Hh / 64};   // dA16: the post-invert diffs this launch leaves
       if (P.head_rides_a) { a.dW = nullptr; a.db = nullptr; a.partial = nullptr; }
       if (P.fuse_head) {}                                        // (k_dqda_head_bwd<true> above did all of it)
       else if (head_big_ok(h, B, Hh)) { a.dZ = nullptr; RC(head_backward_big<kNO>(h, st, a, h->dZ16[0][L], h->ls_a)); }

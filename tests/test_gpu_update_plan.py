@@ -71,8 +71,9 @@ def test_plan_fp16(pkg, gpu, B):
     d.add_transitions_arrays(*synth_replay(np.random.default_rng(5), 4096, 58))
     p = d.update_plan()
     print("fp16", B, p)
-    assert {"fp16", "head_seed_fused", "head_wgrad_rides_critic", "head_wgrad_rides_actor", "q_train_in_dgrad"} <= set(p["forms"]), p
-    assert ("dqda_head_bwd" in p["forms"]) == (B == 512)          # (>= 1024 rows: the bandwidth-tiled head kernels)
+    assert {"fp16", "head_seed_fused"} <= set(p["forms"]), p
+    for form in ("head_wgrad_rides_critic", "head_wgrad_rides_actor", "q_train_in_dgrad", "dqda_head_bwd"):      # (>= 1024 rows: the bandwidth-tiled head kernels)
+        assert (form in p["forms"]) == (B == 512), (form, p)
     assert 0 < p["launches_in_graph"] < p["launches_single"]       # the gather rides in the previous update's last launch
     assert p["launches_in_graph"] <= FP16_LAUNCHES[B], p
     d.update_async_n(17)
@@ -81,7 +82,7 @@ def test_plan_fp16(pkg, gpu, B):
 
 
 # kernels per update inside a sixteen-update graph (a regression bound: fewer is fine, more is a schedule that fell back)
-FP16_LAUNCHES = {512: 28, 4096: 29}
+FP16_LAUNCHES = {512: 28, 4096: 32}
 
 
 def test_tuning_bits_show_in_the_plan(pkg, gpu):
