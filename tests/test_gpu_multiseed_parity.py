@@ -10,7 +10,7 @@ quantities of UpdateActorCritic, and :918-965, its gradients):
     probe, with the decision margins reported (at most a handful of near-ties among the 512);
   * gradients: 1e-5 (Frobenius, against the C oracle) on every pass in which both sides stored the same activation signs; where
     k units landed on the other side of zero (a pre-activation within fp32 round-off of 0: legitimate on either side) the bound
-    is 1e-5 + k x PER_FLIP, PER_FLIP = ten times the largest per-unit effect measured (no cap on k);
+    is 1e-5 + k x PER_FLIP, PER_FLIP = 4.5 times the largest per-unit effect measured (no cap on k);
   * at least a quarter of the seeds are flip-free throughout (printed), so the tight bound is exercised.
 """
 import numpy as np
@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 TOWER = (1024, 1024, 1024, 1024)
 SEEDS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12)          # consecutive: not selected
-PER_FLIP = 2.5e-4   # gradient error one flipped unit may add (relative Frobenius) = 10 x the largest measured in update 1 (1.4e-5, 2.4e-5 at 256 rows)
+PER_FLIP = 5e-4     # gradient error one flipped unit may add (relative Frobenius): 4.5 x the largest measured in update 1 (1.4e-5 … 1.1e-4 at 256 rows)
 
 
 def _first_update(pkg, B, seed, n_replay=2048):
