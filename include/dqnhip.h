@@ -193,7 +193,9 @@ int dqnhip_update_pipelined(dqnhip_handle h, const int32_t* idx_host,
  * next call simply starts a fresh chain.  Every update computes what dqnhip_update computes on the same indices, bit for
  * bit.  Learners the riders do not fit (see dqnhip_get_update_plan: early_gather_l0; fp16, data-parallel, sharing
  * learners; use_graph = 0) run dqnhip_update.  The drop-in draws idx_next from a COPY of its std::mt19937 and adopts the
- * copy's state only when the prediction held, so the engine's observable call order is the reference's. */
+ * copy's state only when the prediction held, so the engine's observable call order is the reference's.
+ * critic_loss == avg_q == NULL: enqueue only (the caller works while the update runs — the drop-in draws the prediction
+ * after next — and collects the pair with dqnhip_read_stats). */
 int dqnhip_update_chained(dqnhip_handle h, const int32_t* idx_host, const int32_t* idx_next,
                           float* critic_loss, float* avg_q);
 
