@@ -32,12 +32,12 @@ def _first_update(pkg, B, seed, n_replay=2048):
     idx = rng.integers(0, n_replay, size=B)
     rec = {"seed": seed}
     dqn.update_phase(0, idx); orc.update_phase(0, idx)
-    f_c1, _ = _sign_flips(dqn, orc, 3, "C")
+    f_c1, _ = _sign_flips(dqn, orc, 3, "C", same_weights=True)      # (identical weights: a flip must be a pre-activation within round-off of 0)
     rec["flips_c1"] = f_c1
     rec["g_critic"] = _fro(dqn.get_params(1, 3), orc.grad_view(1).copy())
     dqn.update_phase(1); orc.update_phase(1, idx)
-    f_a, _ = _sign_flips(dqn, orc, 1, "A")
-    f_c2, _ = _sign_flips(dqn, orc, 4, "C")
+    f_a, _ = _sign_flips(dqn, orc, 1, "A", same_weights=True)
+    f_c2, _ = _sign_flips(dqn, orc, 4, "C", same_weights=f_c1 == 0)
     rec["flips_a"], rec["flips_c2"] = f_a, f_c2
     rec["g_actor"] = _fro(dqn.get_params(0, 3), orc.grad_view(0).copy())
     dqn.update_phase(2); orc.update_phase(2, idx)

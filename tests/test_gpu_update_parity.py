@@ -21,7 +21,7 @@ def _fro(a, b):
 FLIP_TOL = 5e-3   # gradient bound when the two sides provably differentiated a different ReLU branch somewhere (see _sign_flips)
 
 
-def _sign_flips(dqn, orc, p, which):
+def _sign_flips(dqn, orc, p, which, same_weights=False):
     """(mismatches, rows) between the SIGNS of the stored tower activations of the learner's pass p and the oracle's last
     actor ('A') / critic ('C') forward.  ReLU is applied in place (src/dqn.cpp:409-410), so ReLU' is taken from the sign of
     the stored output; a pre-activation within fp32 round-off of zero can land on either side — on this library about once
@@ -32,6 +32,13 @@ def _sign_flips(dqn, orc, p, which):
     for i in range(1, len(orc.hidden) + 1):
         a, b = dqn.debug_read("act%d_%d" % (p, i)), orc.debug_read("act%s_%d" % (which, i))
         bad = (a > 0) != (b > 0)
+        if bad.any() and same_weights:
+            # both sides evaluated this pass with IDENTICAL weights: a legitimate flip is then a pre-activation within fp32 round-off
+            # of zero on BOTH sides (the stored value is x or 0.01 x) — anything larger with the wrong sign is a bug, not round-off.
+            # (Not applicable to a pass whose weights already differ by an Adam step, e.g. the policy pass after a flip in Step(1).)
+            scale = float(np.abs(b).max())
+            assert float(np.abs(a[bad]).max()) <= 2e-5 * scale and float(np.abs(b[bad]).max()) <= 2e-5 * scale, \
+                (p, i, float(np.abs(a[bad]).max()), float(np.abs(b[bad]).max()), scale)
         n += int(bad.sum()); rows.update(np.nonzero(bad.any(axis=1))[0].tolist())
     return n, rows
 
@@ -60,11 +67,11 @@ def _check_update(dqn, orc, idx, t64=None, data=None):
         t64.update(s[idx], a[idx], r[idx], mc[idx], nx[idx], term[idx])
         g64 = [t64.g[0].numpy(), t64.g[1].numpy()]
     dqn.update_phase(0, idx); orc.update_phase(0, idx)
-    f_c1, _ = _sign_flips(dqn, orc, 3, "C")         # critic(s, a): the training forward
+    f_c1, _ = _sign_flips(dqn, orc, 3, "C", same_weights=True)         # critic(s, a): the training forward
     _check_grads(dqn, orc, 1, g64[1], f_c1)        # critic dW/db of Step(1)
     dqn.update_phase(1); orc.update_phase(1, idx)
-    f_a, rows_a = _sign_flips(dqn, orc, 1, "A")     # actor(s)
-    f_c2, rows_c2 = _sign_flips(dqn, orc, 4, "C")   # critic(s, mu(s)) with the updated critic
+    f_a, rows_a = _sign_flips(dqn, orc, 1, "A", same_weights=True)     # actor(s)
+    f_c2, rows_c2 = _sign_flips(dqn, orc, 4, "C", same_weights=f_c1 == 0)   # critic(s, mu(s)) with the updated critic
     _check_grads(dqn, orc, 0, g64[0], f_c1 + f_a + f_c2)        # actor dW/db (a flip in the critic's step moves its weights, hence everything after)
     dqn.update_phase(2); orc.update_phase(2, idx)
     l1, q1 = dqn.read_stats()
@@ -109,15 +116,13 @@ def _check_update(dqn, orc, idx, t64=None, data=None):
     # BASELINE.json config #2.  wscale 2 (weights N(0, 0.02^2)): at 5x the 4x1024 critic's loss
     # explodes to 5e4 after one lr=1e-3 Adam step and HIP, the C oracle and a float64 reference
     # then differ from each other by ReLU-mask flips in different rows (all three measured).
-    # seed: the first one for which learner and oracle take the same ReLU branch in every unit of all three updates with the default
-    # build (profiles/r05_flip_scan_b256.txt: 13 of 40 seeds; an update has a ~25 % chance of a round-off flip at this size whatever
-    # the summation order — seed 1, flip-free in rounds 1-4, flips one unit in update 2 since q', q are summed from 16-column pieces)
-    dict(B=256, S=58, hidden=(1024, 1024, 1024, 1024), wscale=2.0, f64=True, seed=10),
-    # minibatches above 256 rows on seeds for which learner and oracle take the same ReLU branch in every unit of every pass
-    # of every update (scanned on the MI355X, scripts/_scratch: 6 of 8 seeds at 1024 x 256-256, 4 of 8 at 512 x 1024-1024):
-    # the 1e-5 gradient bound applies throughout and nothing is ever re-synchronised
-    dict(B=1024, S=58, hidden=(256, 256), wscale=3.0, seed=2, no_flips=True),
-    dict(B=512, S=58, hidden=(1024, 1024), wscale=2.0, seed=2, no_flips=True, f64=True),
+    # No seed is picked here any more (rounds 4-5 scanned for a flip-free one): an update at this size has a ~25 % chance of a
+    # round-off flip whatever the summation order; flips are counted, checked to be round-off (|x| <= 2e-5 of the layer's scale on
+    # both sides, _sign_flips) and bounded per update; the statement over MANY seeds is tests/test_gpu_multiseed_parity.py
+    dict(B=256, S=58, hidden=(1024, 1024, 1024, 1024), wscale=2.0, f64=True),
+    # minibatches above 256 rows on a second seed each
+    dict(B=1024, S=58, hidden=(256, 256), wscale=3.0, seed=2),
+    dict(B=512, S=58, hidden=(1024, 1024), wscale=2.0, seed=2, f64=True),
 ])
 def test_update_matches_oracle(pkg, gpu, shape):
     shape = dict(shape)
@@ -146,8 +151,9 @@ def test_update_matches_oracle(pkg, gpu, shape):
                 for kind in (1, 2):
                     for net in (0, 1):
                         ref.set_params(net, dqn.get_params(net, kind), kind)
-    if B <= 256 or no_flips:
-        assert flips == 0, flips          # (so the 1e-5 bound was the one applied at BASELINE's and the reference's shapes)
+    print("flipped units over %d updates: %d" % (n_it, flips))
+    if B <= 128 or no_flips:
+        assert flips == 0, flips          # (small shapes: so the 1e-5 bound was the one applied, e.g. at the reference's shape)
     # Adam's normalised step m/(sqrt(v)+eps) is O(1) whatever |g| is, so an element whose gradient
     # is at fp32-roundoff level may legitimately move differently by up to lr per update; on
     # average the parameters must agree to 1% of a step.
