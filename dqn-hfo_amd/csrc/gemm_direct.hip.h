@@ -308,6 +308,79 @@ __device__ __forceinline__ void dgrad_direct_body(const GemmProblem& pr, int til
   }
 }
 
+// ---- DGRAD, half-width tiles: 32 input columns x 16 rows (round 6 experiment) ---------------------------
+// Twice the workgroups of dgrad_direct_body<1, 1> (512 for a 256 x 1024 x 1024 layer), each with half the MFMA chain and a quarter
+// of the LDS: two (or more) co-resident per CU.  P = W read as 8-byte pieces (two columns per lane), Q = dY as in dgrad_direct_body.
+// Harness variant 8 of dqnhip_test_gemm mode 1; measured against variants 1 (64 x 16 direct) and 5 (64 x 16, dY through the LDS
+// transpose — the learner's): profiles/r06_dgrad_half_tiles.txt.
+__device__ __forceinline__ void dgrad_direct32_body(const GemmProblem& pr, int tile_p, int tile_q, float* smem) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int NACC = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int p0 = tile_p * 32, q0 = tile_q * 16;
+  const int Kw = pr.Kred >> 2;
+  const int nkb = Kw >> 4;
+  const float* pp = pr.P + (size_t)(wave * Kw + lg * 4) * pr.ldp + p0 + li * 2;
+  const float* qp = pr.Q + (size_t)(q0 + li) * pr.ldq + wave * Kw + lg * 4;
+  const size_t ldp = pr.ldp;
+  f32x4 acc[NACC];
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+  f32x2 rp[4][4]; f32x4 rq[4];
+#define D32_LOAD(slot, kb)                                                              \
+  {                                                                                     \
+    rq[slot] = *reinterpret_cast<const f32x4*>(qp + ((kb) << 4));                      \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
+        rp[slot][s] = *reinterpret_cast<const f32x2*>(pp + (size_t)(((kb) << 4) + s) * ldp); \
+  }
+#define D32_COMPUTE(slot)                                                               \
+  {                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
+    _Pragma("unroll") for (int pc = 0; pc < 2; ++pc)                                    \
+        acc[pc] = DQN_MFMA(rp[slot][s][pc], rq[slot][s], acc[pc]);                      \
+  }
+  const int nkb4 = nkb & ~3;
+  if (nkb4 > 0) {
+    D32_LOAD(0, 0) D32_LOAD(1, 1) D32_LOAD(2, 2) D32_LOAD(3, 3)
+    int kb = 0;
+    for (; kb + 4 < nkb4; kb += 4) {
+      D32_COMPUTE(0) DQN_PIN(); D32_LOAD(0, kb + 4) DQN_PIN();
+      D32_COMPUTE(1) DQN_PIN(); D32_LOAD(1, kb + 5) DQN_PIN();
+      D32_COMPUTE(2) DQN_PIN(); D32_LOAD(2, kb + 6) DQN_PIN();
+      D32_COMPUTE(3) DQN_PIN(); D32_LOAD(3, kb + 7) DQN_PIN();
+    }
+    D32_COMPUTE(0) D32_COMPUTE(1) D32_COMPUTE(2) D32_COMPUTE(3)
+  }
+  for (int kb = nkb4; kb < nkb; ++kb) { D32_LOAD(0, kb) D32_COMPUTE(0) }
+#undef D32_LOAD
+#undef D32_COMPUTE
+  // C/D map of acc[pc]: lane (li, lg), register r = dX[row q0 + li][column p0 + 2 (4 lg + r) + pc]: 8 consecutive columns per lane
+  f32x4 m0 = f32x4{1.f, 1.f, 1.f, 1.f}, m1 = m0;
+  if (wave == 0 && pr.mask != nullptr) {
+    const float* mp = pr.mask + (size_t)(q0 + li) * pr.ldm + p0 + (lg << 3);
+    m0 = *reinterpret_cast<const f32x4*>(mp); m1 = *reinterpret_cast<const f32x4*>(mp + 4);
+  }
+  park_accumulators<NACC>(smem, acc, wave, lane);
+  __syncthreads();
+  if (wave == 0) {
+    const f32x4 a0 = reduce_accumulator<NACC>(smem, 0, lane), a1 = reduce_accumulator<NACC>(smem, 1, lane);
+    f32x4 v0 = f32x4{a0.x, a1.x, a0.y, a1.y}, v1 = f32x4{a0.z, a1.z, a0.w, a1.w};
+    if (pr.mask != nullptr) {
+      v0.x *= lrelu_mask(m0.x); v0.y *= lrelu_mask(m0.y); v0.z *= lrelu_mask(m0.z); v0.w *= lrelu_mask(m0.w);
+      v1.x *= lrelu_mask(m1.x); v1.y *= lrelu_mask(m1.y); v1.z *= lrelu_mask(m1.z); v1.w *= lrelu_mask(m1.w);
+    }
+    float* c = pr.C + (size_t)(q0 + li) * pr.ldc + p0 + (lg << 3);
+    *reinterpret_cast<f32x4*>(c) = v0; *reinterpret_cast<f32x4*>(c + 4) = v1;
+  }
+}
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void gemm_dgrad_direct32(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int pi, tile_p, tile_q;
+  tile_of_block(batch, pi, tile_p, tile_q);
+  dgrad_direct32_body(batch.prob[pi], tile_p, tile_q, smem);
+}
+
 // ---- DGRAD, narrow: 16 input columns per workgroup ------------------------------------------
 // The critic's first-layer input gradient is consumed only in the 10 action columns (inverting
 // gradients, src/dqn.cpp:924-957): instead of 64-wide tiles over the whole 128-column panel (32
@@ -1337,6 +1410,7 @@ template <int TPB, int TQ>
 inline hipError_t dgrad_direct_launch(GemmBatch& b, hipStream_t s) {
   return direct_launch(gemm_dgrad_direct<TPB, TQ>, b, 64 * TPB, 16 * TQ, 4 * TPB * 4 * TQ * 64 * 16, s);
 }
+inline hipError_t dgrad_direct32_launch(GemmBatch& b, hipStream_t s) { return direct_launch(gemm_dgrad_direct32<0>, b, 32, 16, 4 * 2 * 64 * 16, s); }
 template <int TPB, int TQ>
 constexpr int dgrad_lds_bytes() { return 4 * ((2 * TQ * 512 > TPB * 4 * TQ * 256) ? 2 * TQ * 512 : TPB * 4 * TQ * 256) * 4; }
 template <int TPB, int TQ>

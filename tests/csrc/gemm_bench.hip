@@ -139,6 +139,7 @@ hipError_t launch_variant(int mode, int variant, GemmBatch& b, hipStream_t s) {
       case 5: return dgrad_lds_launch<1, 1>(b, s);     // 64x16, dY through the LDS transpose
       case 6: return dgrad_lds_launch<1, 2>(b, s);     // 64x32
       case 7: return dgrad_narrow_launch(b, s);        // 16 input columns x 16 rows
+      case 8: return dgrad_direct32_launch(b, s);      // 32 x 16 tiles: twice the workgroups, co-resident (round 6 experiment)
     }
   } else {
     switch (variant) {
