@@ -351,7 +351,7 @@ UpdatePlan plan_of(const H* h) {
     p.tails_ride = p.dp && bwd16_has_carrier(h, DQNHIP_CRITIC, B) && bwd16_has_carrier(h, DQNHIP_ACTOR, B);
     // the critic's layer-0 dgrad (only its ten action columns are consumed), the inverting gradients and the actor heads' backward in
     // ONE launch (k_dqda_head_bwd<true>), as on the fp32 path; q(s, mu(s)) rides there
-    p.fuse_head = p.head_rides_a && !(tf & DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) && B % 16 == 0 && B < 1024 && Hh % 256 == 0 &&
+    p.fuse_head = p.head_rides_a && !(tf & DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) && B % 16 == 0 && B < 1024 &&
                   h->S + 16 <= h->k16[1][0] && L >= 1 && lc.dims[1] % 64 == 0;
     return p;
   }
@@ -363,8 +363,8 @@ UpdatePlan plan_of(const H* h) {
   // Step(1)'s head arithmetic inside the critic's top-layer dgrad launch (k_dgrad_qtrain; one 16-column piece per lane: H / 16 <= 64)
   p.fuse_q = h->U3 != nullptr && !(tf & DQNHIP_TUNE_SEPARATE_Q_TRAIN) && p.head_rides_c && p.shifted_c && Hc >= 512 && Hc <= 1024 && Hc % 256 == 0;
   // dQ/da's last step, the inverting gradients and the actor heads' backward in ONE launch (k_dqda_head_bwd): 16 columns from the first
-  // action column inside the panel row, H a multiple of 256, fewer than 1024 rows
-  p.fuse_head = p.head_rides_a && !(tf & DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) && B % 16 == 0 && B < 1024 && Hh % 256 == 0 &&
+  // action column inside the panel row, fewer than 1024 rows (any tower-top width since round 6)
+  p.fuse_head = p.head_rides_a && !(tf & DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD) && B % 16 == 0 && B < 1024 &&
                 h->S + 16 <= lc.kp[0] && L >= 1 && lc.dims[1] % 64 == 0;
   // the first layer of critic(s, mu(s)) rides in the critic's optimiser launch (FirstLayerRider).  Data-parallel learners too (round 6):
   // the launch sits behind the critic's exchange point, its norm then comes from k_sumsq's partials; only a SHARDED optimiser — whose

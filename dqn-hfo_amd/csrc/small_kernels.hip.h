@@ -907,10 +907,14 @@ __global__ __launch_bounds__(256) void k_dqda_head_bwd(const DqdaHeadArgs a, con
   extern __shared__ __attribute__((aligned(16))) float smem[];     // the narrow dgrad's parking area (4 waves x 64 lanes x 16 B)
   __shared__ float s_d[16][17];
   __shared__ float s_dy[16 * kNO];
-  const int tiles = a.row_tiles * (a.H >> 8);
+  const int tiles = a.row_tiles * ((a.H + 255) >> 8);
   if ((int)blockIdx.x >= tiles) { q_head_rider(rider, (int)blockIdx.x - tiles); return; }
   const int rt = (int)blockIdx.x % a.row_tiles, cc = (int)blockIdx.x / a.row_tiles;
-  const int tid = threadIdx.x, q0 = rt * 16, k = (cc << 8) + tid;
+  const int tid = threadIdx.x, q0 = rt * 16;
+  // (round 6: any tower-top width — the reference's own tower ends in 128 units; threads beyond it keep column H - 1's loads, take
+  // part in the tile and the barriers, and store nothing)
+  const bool live = (cc << 8) + tid < a.H;
+  const int k = live ? (cc << 8) + tid : a.H - 1;
   // everything the head part needs that does not depend on dQ/da goes out first: this thread's ten head weights, its column of
   // the 16 tower-top rows, and (160 threads) one output of mu(s)
   float wh[kNO], xv[16];
@@ -951,6 +955,7 @@ __global__ __launch_bounds__(256) void k_dqda_head_bwd(const DqdaHeadArgs a, con
     }
     s0 += s1;
     const float dz = s0 * lrelu_mask(xv[r]);
+    if (!live) continue;
     if constexpr (F16) a.dZ16[(size_t)(q0 + r) * a.H + k] = (_Float16)(dz * a.scale16);
     else a.dZ[(size_t)(q0 + r) * a.H + k] = dz;
   }
@@ -958,7 +963,7 @@ __global__ __launch_bounds__(256) void k_dqda_head_bwd(const DqdaHeadArgs a, con
 inline hipError_t dqda_head_bwd_launch(DqdaHeadArgs& a, const QHeadRider& rider, hipStream_t stream) {
   a.row_tiles = a.rows / 16;
   a.pr.tiles_p = 1; a.pr.tiles_q = a.row_tiles; a.pr.tile_base = 0;
-  const int grid = a.row_tiles * (a.H / 256) + rider.blocks;
+  const int grid = a.row_tiles * ((a.H + 255) / 256) + rider.blocks;
   LaunchTimer& lt = launch_timer();
   if (a.dZ16 != nullptr) {
     if (lt.start) { hipExtLaunchKernelGGL(k_dqda_head_bwd<true>, dim3(grid), dim3(256), 4 * 64 * 16, stream, lt.start, lt.stop, 0, a, rider); lt.start = lt.stop = nullptr; }

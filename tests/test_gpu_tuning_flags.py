@@ -151,7 +151,8 @@ def test_fp16_fused_head_seed_equals_separate_launch(pkg, gpu, B, hidden):
 @pytest.mark.parametrize("B,hidden,S", [
     (256, (1024, 1024, 1024, 1024), 58),       # BASELINE configs[1]: 16 row tiles x 4 column chunks + 64 q-rider blocks
     (32, (1024, 512, 256, 256), 59),           # 2 row tiles, one column chunk
-    (64, (256, 128, 64, 64), 59),              # H = 64: not a multiple of 256 -> both sides take the separate launches
+    (64, (256, 128, 64, 64), 59),              # H = 64: a quarter of the workgroup's 256 column threads live (round 6: any tower-top width)
+    (32, (1024, 512, 256, 128), 59),           # the reference's compile-time defaults (src/dqn.hpp:19, src/dqn.cpp:425): H = 128
     (512, (1024, 1024), 68),                   # 1v1 state size: the action columns start at 68 (panel 128 wide)
     (128, (512,), 58),                         # one tower layer: the fused launch reads the seed the forward epilogue left
     (96, (256, 256, 256), 77),                 # 2v1 state size, a row count that is not a multiple of 64
@@ -333,7 +334,7 @@ def test_fp16_fused_dqda_head_bwd_against_separate_launches(pkg, gpu, B, hidden)
         for x, y in ((ga, gb_a), (gc, gb_c)):
             rel = np.linalg.norm(x.astype(np.float64) - y) / max(np.linalg.norm(y), 1e-30)
             assert rel <= (1e-3 if it == 0 else 5e-3), (it, rel)
-    for tuning, present in ((0, hidden[-1] % 256 == 0), (pkg.capi.TUNE_SEPARATE_ACTOR_HEAD_BWD, False)):      # (k_dqda_head_bwd: a tower top of 256 k columns)
+    for tuning, present in ((0, True), (pkg.capi.TUNE_SEPARATE_ACTOR_HEAD_BWD, False)):
         p = pkg.DQN(58, minibatch=B, hidden=hidden, memory=4096, seed=3, precision="fp16", tuning=tuning)
         assert ("dqda_head_bwd" in p.update_plan()["forms"]) == present, (tuning, p.update_plan())
         p.close()

@@ -18,10 +18,10 @@ FP32_ALL = {"bwd_shifted_critic", "bwd_shifted_actor", "head_wgrad_rides_critic"
 CASES = [
     # BASELINE configs[1]: every merged form, 26 launches stand-alone, 24 inside a sixteen-update graph (gather and first layers ride)
     ("configs1_b256_4x1024", dict(state_size=58, minibatch=256, hidden=TOWER), None, FP32_ALL, (26, 26, 24)),
-    # the reference's compile-time defaults (configs[0] on the GPU): 128-wide tower top -> no k_dgrad_qtrain / k_dqda_head_bwd
-    # (both need a tower top that is a multiple of 256); layers narrower than 512 take the pair launches, not the shifted schedule
+    # the reference's compile-time defaults (configs[0] on the GPU): layers narrower than 512 take the pair launches, not the shifted
+    # schedule -> no k_dgrad_qtrain (it is the shifted schedule's first launch); k_dqda_head_bwd takes any tower-top width since round 6
     ("configs0_b32_ref_tower", dict(state_size=59, minibatch=32, hidden=REF_TOWER), None,
-     {"head_wgrad_rides_critic", "head_wgrad_rides_actor", "head_seed_fused", "critic_l0_rides", "first_layers_merged", "early_gather_l0"}, (28, 28, 26)),
+     {"head_wgrad_rides_critic", "head_wgrad_rides_actor", "head_seed_fused", "dqda_head_bwd", "critic_l0_rides", "first_layers_merged", "early_gather_l0"}, (27, 27, 25)),
     # configs[2]'s learner (S = 68: both first panels are 128 wide — the actor's first-layer riders of k_adam_soft_l0 are built for 64)
     ("configs2_b256_s68", dict(state_size=68, minibatch=256, hidden=TOWER), None, FP32_ALL - {"early_gather_l0"}, (26, 26, 25)),
     # configs[3] / weak scaling: a rank of a replicated data-parallel group at 256 rows runs the same merged forms (round 6)
