@@ -119,8 +119,10 @@ typedef struct dqnhip_config {
 /* fp32 learner: a tower's backward as wgrad(i) + dgrad(i) per layer and a last launch with the first layer's wgrad alone,
  * instead of the shifted schedule dgrad(L-1) | wgrad(i+1) + dgrad(i) ... | wgrad(1) + wgrad(0) (same launch count). */
 #define DQNHIP_TUNE_BWD_UNSHIFTED 4
-/* fp32 learner: the critic's first-layer action-column input gradient in a launch of its own (+ the q riders) and the inverting
- * gradients + actor heads' backward in another (k_head_bwd<10>), instead of all three in one launch (k_dqda_head_bwd, round 5). */
+/* The critic's first-layer action-column input gradient in a launch of its own (+ the q riders) and the inverting gradients + actor
+ * heads' backward in another (k_head_bwd<10>), instead of all three in one launch (k_dqda_head_bwd, round 5; any tower-top width and
+ * the fp16 learner below 1024 rows since round 6 — there the separate form is the fp16-MFMA layer-0 dgrad launch, and the two agree
+ * to fp32 round-off instead of bit for bit). */
 #define DQNHIP_TUNE_SEPARATE_ACTOR_HEAD_BWD 8
 /* fp32 learner: Step(1)'s head arithmetic (q', q, TD target, loss, dq, the tower-top gradient) in a launch of its own
  * (k_head_q_train) instead of inside the critic's top-layer dgrad launch (k_dgrad_qtrain, round 5: the two head dot products
