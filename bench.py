@@ -268,10 +268,11 @@ def sub_records(pkg, par, args, rank, world, local_rank, native, barrier):
         from synth import synth_replay
         d.add_transitions_arrays(*synth_replay(np.random.default_rng(3), 50000, 59))
         dt = timed_n(d, torch.cuda.synchronize, 1000, 104)
-        ms_b = d.BenchmarkBlocking(1000, 100, seed=1, pipelined=False)
+        ms_b = d.BenchmarkBlocking(1000, 100, seed=1, pipelined=2)
         out["configs0_ref_defaults_b32"] = {"ms_per_update": round(dt * 1e3, 4), "updates_per_s": round(1 / dt, 1),
                                             "blocking_ms_per_update": round(ms_b, 4), "blocking_updates_per_s": round(1e3 / ms_b, 1),
-                                            "note": "launch-bound: ~29 launches per update, each at its ~5-us floor"}
+                                            "plan": d.update_plan(),
+                                            "note": "launch-bound: every launch of the plan at its ~5-us floor"}
         d.read_stats(); d.close()
         # configs[2]: 1v1 (S = 68), 64 parallel workers feeding one replay buffer
         d = pkg.DQN(68, minibatch=B, hidden=HIDDEN, memory=200000, seed=1, device=local_rank, use_graph=True)
